@@ -1,0 +1,156 @@
+/*
+ * phi_amd.h -- C ABI of the MI355X-native PHI hot path (libphi_amd.so).
+ *
+ * The reference (at-cg/PHI) has no FFI seam: its hot path is the C++ member function
+ * ILP_index::ILP_function (src/ILP_index.cpp:528-1601) reading public fields that
+ * ILP_index::read_gfa (src/ILP_index.cpp:20-155) fills.  This header is the seam a maintainer
+ * binds instead (INTEGRATION.md shows the patch to src/main.cpp:114-140): plain pointers and
+ * sizes, no C++ or torch types.  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 (PHI_OK) or a negative phi_status; nothing calls exit();
+ *   - host pointers are borrowed for the duration of the call and copied;
+ *   - result buffers are owned by the context and stay valid until the next phi_solve /
+ *     phi_ctx_destroy;
+ *   - one context per process per GPU, calls serialised by the caller (the reference is not
+ *     re-entrant either: src/main.cpp:136-140).
+ */
+#ifndef PHI_AMD_H
+#define PHI_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct phi_ctx phi_ctx;
+
+typedef enum {
+    PHI_OK = 0,
+    PHI_ERR_INVALID = -1,      /* bad argument (null pointer, k/w out of range, offsets not monotone) */
+    PHI_ERR_NOMEM = -2,        /* host or device allocation failed */
+    PHI_ERR_DEVICE = -3,       /* HIP runtime error, kernel fault, no gfx950 device */
+    PHI_ERR_STATE = -4,        /* call order violated (e.g. phi_solve before phi_set_graph) */
+    PHI_ERR_UNSUPPORTED = -5,  /* input the path does not handle: see phi_last_error() */
+    PHI_ERR_WALK = -6,         /* walk does not follow graph edges / reverse-strand vertex:
+                                  the reference exit(1)s at ILP_index.cpp:104-107, :1568-1572 */
+    PHI_ERR_OVERFLOW = -7      /* an internal table overflowed its capacity */
+} phi_status;
+
+const char *phi_strerror(int status);
+/* Human-readable detail of the last failure on this context ("" if none). */
+const char *phi_last_error(const phi_ctx *ctx);
+
+/* ILP_index::ILP_index(gfa_t*) (ILP_index.cpp:4-6).  device_id = HIP device ordinal. */
+int phi_ctx_create(int device_id, phi_ctx **out);
+void phi_ctx_destroy(phi_ctx *ctx);
+
+/* Run all work of this context on the caller's HIP stream (hipStream_t passed as void*);
+ * NULL restores the context's private stream. */
+int phi_set_stream(phi_ctx *ctx, void *hip_stream);
+
+/* Flags of phi_set_params. */
+#define PHI_FLAG_QCLP 1u       /* -q1 (main.cpp:66): accepted; both programs have the same optimum */
+#define PHI_FLAG_MIXED 2u      /* -m1 (main.cpp:62): accepted; integral optimum of equal value exists */
+
+/* main.cpp:118-131: k_mer, window, threshold, recombination, is_qclp/is_mixed.
+ * k in [1,32], w in [1,256].  Must precede phi_set_graph. */
+int phi_set_params(phi_ctx *ctx, int32_t k, int32_t w, float threshold, int32_t recombination,
+                   uint32_t flags);
+
+/*
+ * ILP_index::read_gfa's outputs (ILP_index.h:53-61) as flat arrays, then stage 1a of
+ * ILP_function (:559-573): the graph goes to HBM, every walk is sketched on the GPU and the
+ * minimiser table is built.
+ *   seq_concat/seq_off[n_vtx+1]  node_seq, original case
+ *   adj_off[n_vtx+1]/adj         adj_list (forward strand)
+ *   walk_off[n_walks+1]/walk_vtx paths
+ *   topo_rank[n_vtx]             top_order_map
+ */
+int phi_set_graph(phi_ctx *ctx, int32_t n_vtx, const char *seq_concat, const int64_t *seq_off,
+                  const int64_t *adj_off, const int32_t *adj, int32_t n_walks,
+                  const int64_t *walk_off, const int32_t *walk_vtx, const int32_t *topo_rank);
+
+/*
+ * Stage 1b/2a of ILP_function (:617-655) for one batch of reads: sketch, spectrum insert,
+ * match against the walk minimiser table.  Streaming: may be called repeatedly.
+ * bases = raw ASCII (upper/lower case; any byte), read r = bases[read_off[r], read_off[r+1]).
+ */
+int phi_add_reads(phi_ctx *ctx, const char *bases, const int64_t *read_off, int64_t n_reads);
+/* Same, with both arrays already resident in this GPU's HBM (n_bases = read_off[n_reads]). */
+int phi_add_reads_device(phi_ctx *ctx, const void *d_bases, const void *d_read_off, int64_t n_reads,
+                         int64_t n_bases);
+/* Forget all reads seen so far (graph index is kept). */
+int phi_reset_reads(phi_ctx *ctx);
+
+/*
+ * Multi-GPU exchange (no reference counterpart: the reference is one process).  Each rank holds
+ * a shard of the reads; before phi_solve the caller all-reduces (MAX) the hit vector in place
+ * and tells every rank the size of the union spectrum.
+ *   phi_hits_buffer     device pointer to uint32 hit[n], n = number of distinct walk minimisers
+ *   phi_spectrum_export this rank's distinct read hashes: device pointer to uint64[n]
+ *   phi_spectrum_set_size  global |Sp_R| (ILP_index.cpp:641) to use in the log counters
+ */
+int phi_hits_buffer(phi_ctx *ctx, void **d_hits, int64_t *n);
+int phi_spectrum_export(phi_ctx *ctx, void **d_hashes, int64_t *n);
+int phi_spectrum_set_size(phi_ctx *ctx, int64_t global_size);
+
+typedef struct {
+    /* ---- solve (ILP_index.cpp:776-1418) */
+    int64_t objective;          /* max  #covered minimisers - 2*(R/2)*#recombinations          */
+    int64_t upper_bound;        /* proven bound; optimal iff upper_bound == objective           */
+    int32_t optimal;            /* 1 when proven optimal                                        */
+    int32_t n_dp_runs;          /* DP launches used (1 = certificate closed at the root)        */
+    int64_t n_covered;          /* minimisers with >=1 anchor fully traversed (sum of z_i)      */
+    /* ---- decode (:1431-1525) */
+    int64_t n_path;
+    const int32_t *path_vtx;    /* [n_path] vertices in topological order                       */
+    const int32_t *path_hap;    /* [n_path] haplotype label of each vertex                      */
+    int32_t recombination_count;/* :1519 adjacent label changes                                 */
+    int32_t n_switches;         /* w-node traversals (each costs 2*(R/2))                       */
+    int64_t hap_len;            /* length of the inferred sequence                              */
+    /* ---- log counters (:563, :641, :734, :738-743, :883) */
+    int32_t n_walks;
+    const int64_t *n_minimizers;/* [n_walks] "Number of Minimizers"                             */
+    const int64_t *n_anchors;   /* [n_walks] "Number of Anchors" (after the filter)             */
+    int64_t spectrum_size;      /* |Sp_R|                                                       */
+    int64_t filtered;           /* minimisers dropped by the shared-anchor filter               */
+    int64_t retained;           /* spectrum_size - filtered                                     */
+    int64_t n_in_model;         /* minimisers with a z_i ("% Minimizers are in ILP")            */
+} phi_result;
+
+/* Stages 2b-3 of ILP_function (:670-1525): filter, exact solve, decode.  Replaces
+ * model.optimize() (:1418) with a max-plus DP + optimality certificate. */
+int phi_solve(phi_ctx *ctx, phi_result *out);
+
+/* ILP_index.cpp:1577-1581: concatenated original-case node sequences of the path.
+ * buf must hold result.hap_len bytes. */
+int phi_path_sequence(phi_ctx *ctx, char *buf, int64_t cap);
+
+/*
+ * Introspection used by the parity tests (tests/ compare these with oracle/).
+ * phi_sketch: stand-alone (w,k)-minimiser sketch of arbitrary sequences on the GPU
+ * (compute_hashes / index_kmers minus the vertex map).  Records come back sorted by
+ * (sequence, position).  Pass cap = 0 to query *n_out.
+ */
+int phi_sketch(phi_ctx *ctx, const char *bases, const int64_t *seq_off, int64_t n_seq, int32_t k,
+               int32_t w, uint64_t *out_hash, int64_t *out_pos, int32_t *out_seq, int64_t cap,
+               int64_t *n_out);
+/* Minimisers of walk h found by phi_set_graph, sorted by position. */
+int phi_walk_minimizers(phi_ctx *ctx, int32_t walk, uint64_t *out_hash, int64_t *out_pos,
+                        int64_t cap, int64_t *n_out);
+/* Kept anchors after the filter (valid after phi_solve): hash, walk, first/last walk index. */
+int phi_kept_anchors(phi_ctx *ctx, uint64_t *out_hash, int32_t *out_walk, int32_t *out_t0,
+                     int32_t *out_t1, int64_t cap, int64_t *n_out);
+
+/* Timing of the dominant kernel (the sketch kernel), measured with HIP events on the stream
+ * the kernel is launched on.  phi_prof_enable(1) starts bracketing every sketch launch;
+ * phi_prof_read returns the number of bracketed launches and their summed duration. */
+int phi_prof_enable(phi_ctx *ctx, int on);
+int phi_prof_read(phi_ctx *ctx, int64_t *n_launches, double *total_ms, int64_t *total_bases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,124 @@
+// phi_dev.h -- k-mer and hash primitives shared by the gfx950 kernels.
+//
+// Layout of packed sequences in HBM: uint64 words, 32 bases per word, 2 bits per base
+// (A=0 C=1 G=2 T=3: ASCII order, so unsigned integer order of a left-aligned k-mer equals the
+// std::string order the reference uses, ILP_index.cpp:394), base j of a word at bits
+// [62-2j, 64-2j): a 64-bit load returns 32 bases with the first base most significant.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PHI_HD __host__ __device__ __forceinline__
+#else
+#define PHI_HD static inline
+#endif
+
+#define PHI_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull   // also the reference's initial prev_hash (:383, :455)
+
+// 2-bit code of an ASCII base; valid iff the upper-cased byte is one of ACGT.
+PHI_HD uint32_t phi_code(uint32_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }
+PHI_HD bool phi_is_acgt(uint32_t c)
+{
+    c &= 0xDFu;
+    return c == 'A' || c == 'C' || c == 'G' || c == 'T';
+}
+
+// 32 bases starting at base i, left-aligned (bases beyond the buffer read as the padding word).
+PHI_HD uint64_t phi_extract64(const uint64_t *words, int64_t i)
+{
+    const int64_t wi = i >> 5;
+    const int s = (int)(i & 31) * 2;
+    const uint64_t hi = words[wi];
+    if (s == 0) return hi;
+    return (hi << s) | (words[wi + 1] >> (64 - s));
+}
+
+PHI_HD uint64_t phi_kmask(int k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1); }
+
+// reverse complement of a right-aligned k-mer value
+PHI_HD uint64_t phi_revcomp(uint64_t f, int k)
+{
+    uint64_t x = ~f;
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = __builtin_bswap64(x);
+    return x >> (64 - 2 * k);
+}
+
+PHI_HD uint64_t phi_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+PHI_HD uint64_t phi_fmix64(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+// 4 bases (8 bits, first base in the top two bits) -> 4 ASCII bytes, first base in byte 0.
+PHI_HD uint32_t phi_ascii4(uint32_t x)
+{
+    uint32_t t = x | (x << 10);
+    t = t | (x << 20);
+    const uint32_t sel = ((t << 4) | (x >> 6)) & 0x03030303u;      // byte j = code of base j
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0x54474341u, 0x54474341u, sel);    // "ACGT" byte lookup
+#else
+    uint32_t r = 0;
+    for (int j = 0; j < 4; j++) r |= ((0x54474341u >> (8 * ((sel >> (8 * j)) & 3))) & 0xFFu) << (8 * j);
+    return r;
+#endif
+}
+
+// 8 bases (16 bits, first base in the top two bits) -> 8 ASCII bytes as a little-endian u64.
+PHI_HD uint64_t phi_ascii8(uint32_t x16)
+{
+    return (uint64_t)phi_ascii4((x16 >> 8) & 0xFFu) | ((uint64_t)phi_ascii4(x16 & 0xFFu) << 32);
+}
+
+// hash128_to_64 (ILP_index.cpp:10-18) of the k ASCII bytes spelled by a right-aligned k-mer
+// value: MurmurHash3_x64_128 (MurmurHash3.cpp:255-332), seed 0, h1 ^ h2.  1 <= k <= 32.
+PHI_HD uint64_t phi_kmer_hash(uint64_t val, int k)
+{
+    const uint64_t c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
+    const uint64_t L = val << (64 - 2 * k);                        // base i at bits [62-2i]
+    uint64_t e[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint64_t a = phi_ascii8((uint32_t)(L >> (48 - 16 * g)) & 0xFFFFu);
+        const int nb = k - 8 * g;                                   // bytes of this lane in use
+        if (nb <= 0) a = 0;
+        else if (nb < 8) a &= (1ull << (8 * nb)) - 1;
+        e[g] = a;
+    }
+    uint64_t h1 = 0, h2 = 0;
+    const int nblocks = k >> 4;
+    uint64_t t1, t2;                                               // tail lanes
+    if (nblocks >= 1) {
+        uint64_t k1 = e[0], k2 = e[1];
+        k1 *= c1; k1 = phi_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = phi_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = phi_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = phi_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+        t1 = e[2]; t2 = e[3];
+    } else {
+        t1 = e[0]; t2 = e[1];
+    }
+    if (nblocks == 2) {                                            // k == 32: second full block
+        uint64_t k1 = t1, k2 = t2;
+        k1 *= c1; k1 = phi_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = phi_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = phi_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = phi_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    } else {
+        const int rem = k & 15;
+        if (rem > 8) { uint64_t k2 = t2; k2 *= c2; k2 = phi_rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+        if (rem > 0) { uint64_t k1 = t1; k1 *= c1; k1 = phi_rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+    }
+    h1 ^= (uint64_t)k; h2 ^= (uint64_t)k;
+    h1 += h2; h2 += h1;
+    h1 = phi_fmix64(h1); h2 = phi_fmix64(h2);
+    h1 += h2; h2 += h1;
+    return h1 ^ h2;
+}
