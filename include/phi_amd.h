@@ -88,12 +88,19 @@ int phi_reset_reads(phi_ctx *ctx);
  * Multi-GPU exchange (no reference counterpart: the reference is one process).  Each rank holds
  * a shard of the reads; before phi_solve the caller all-reduces (MAX) the hit vector in place
  * and tells every rank the size of the union spectrum.
- *   phi_hits_buffer     device pointer to uint32 hit[n], n = number of distinct walk minimisers
+ *   phi_hits_buffer     device pointer to uint8 hit[n], n = number of walk minimiser records
+ *                       (same on every rank: records are in deterministic position order and a
+ *                       hit is stored at the first record carrying that hash)
  *   phi_spectrum_export this rank's distinct read hashes: device pointer to uint64[n]
- *   phi_spectrum_set_size  global |Sp_R| (ILP_index.cpp:641) to use in the log counters
+ *                       (valid until the next call on this context)
+ *   phi_spectrum_import insert another rank's exported hashes (a device buffer the caller owns)
+ *                       so that the local set becomes the union; |Sp_R| (ILP_index.cpp:641)
+ *                       is then the same on every rank
+ *   phi_spectrum_set_size  alternatively, override |Sp_R| used in the log counters
  */
 int phi_hits_buffer(phi_ctx *ctx, void **d_hits, int64_t *n);
 int phi_spectrum_export(phi_ctx *ctx, void **d_hashes, int64_t *n);
+int phi_spectrum_import(phi_ctx *ctx, const void *d_hashes, int64_t n);
 int phi_spectrum_set_size(phi_ctx *ctx, int64_t global_size);
 
 typedef struct {

@@ -1,0 +1,162 @@
+"""Thin object wrapper over the C ABI: one Context == one phi_ctx (one GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class PhiError(RuntimeError):
+    def __init__(self, status, detail):
+        self.status = status
+        self.detail = detail
+        super().__init__(f"{_capi.load().phi_strerror(status).decode()} ({status}): {detail}")
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None and a.size else None
+
+
+class Context:
+    def __init__(self, device=0):
+        self._L = _capi.load()
+        self._h = C.c_void_p()
+        rc = self._L.phi_ctx_create(device, C.byref(self._h))
+        if rc:
+            raise PhiError(rc, "phi_ctx_create failed (no HIP device?)")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._L.phi_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise PhiError(rc, self._L.phi_last_error(self._h).decode())
+
+    # ------------------------------------------------------------------ configuration
+    def set_stream(self, hip_stream):
+        self._chk(self._L.phi_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_params(self, k=31, w=25, threshold=1.0, recombination=100, flags=_capi.PHI_FLAG_QCLP | _capi.PHI_FLAG_MIXED):
+        self._chk(self._L.phi_set_params(self._h, k, w, C.c_float(threshold), recombination, flags))
+        self.k, self.w = k, w
+
+    def set_graph(self, seq_concat, seq_off, adj_off, adj, walk_off, walk_vtx, top_rank):
+        """Arrays of phi_set_graph: bytes + int64/int32 numpy arrays."""
+        seq_off = np.ascontiguousarray(seq_off, np.int64)
+        adj_off = np.ascontiguousarray(adj_off, np.int64)
+        adj = np.ascontiguousarray(adj, np.int32)
+        walk_off = np.ascontiguousarray(walk_off, np.int64)
+        walk_vtx = np.ascontiguousarray(walk_vtx, np.int32)
+        top_rank = np.ascontiguousarray(top_rank, np.int32)
+        buf = np.frombuffer(seq_concat, np.uint8) if not isinstance(seq_concat, np.ndarray) else seq_concat
+        self.n_vtx, self.n_walks = len(seq_off) - 1, len(walk_off) - 1
+        self._chk(self._L.phi_set_graph(self._h, self.n_vtx, _ptr(buf), _ptr(seq_off), _ptr(adj_off), _ptr(adj),
+                                        self.n_walks, _ptr(walk_off), _ptr(walk_vtx), _ptr(top_rank)))
+
+    # ------------------------------------------------------------------ reads
+    def add_reads(self, seqs):
+        """seqs: list of bytes, or (concat bytes/uint8 array, int64 offsets)."""
+        if isinstance(seqs, tuple):
+            concat, off = seqs
+            concat = np.frombuffer(concat, np.uint8) if not isinstance(concat, np.ndarray) else concat
+            off = np.ascontiguousarray(off, np.int64)
+        else:
+            off = np.zeros(len(seqs) + 1, np.int64)
+            np.cumsum([len(s) for s in seqs], out=off[1:])
+            concat = np.frombuffer(b"".join(seqs), np.uint8)
+        self._chk(self._L.phi_add_reads(self._h, _ptr(concat), _ptr(off), len(off) - 1))
+
+    def add_reads_device(self, d_bases, d_read_off, n_reads, n_bases):
+        self._chk(self._L.phi_add_reads_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_read_off), n_reads, n_bases))
+
+    def reset_reads(self):
+        self._chk(self._L.phi_reset_reads(self._h))
+
+    # ------------------------------------------------------------------ multi-GPU hooks
+    def hits_buffer(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self._L.phi_hits_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def spectrum_export(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self._L.phi_spectrum_export(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def spectrum_import(self, d_hashes, n):
+        self._chk(self._L.phi_spectrum_import(self._h, C.c_void_p(d_hashes), n))
+
+    def spectrum_set_size(self, n):
+        self._chk(self._L.phi_spectrum_set_size(self._h, n))
+
+    # ------------------------------------------------------------------ solve
+    def solve(self):
+        r = _capi.PhiResult()
+        self._chk(self._L.phi_solve(self._h, C.byref(r)))
+        nw, npth = r.n_walks, r.n_path
+        out = {f: getattr(r, f) for f in ("objective", "upper_bound", "optimal", "n_dp_runs", "n_covered", "n_path",
+                                           "recombination_count", "n_switches", "hap_len", "n_walks", "spectrum_size",
+                                           "filtered", "retained", "n_in_model")}
+        out["path_vtx"] = np.ctypeslib.as_array(r.path_vtx, shape=(npth,)).copy() if npth else np.zeros(0, np.int32)
+        out["path_hap"] = np.ctypeslib.as_array(r.path_hap, shape=(npth,)).copy() if npth else np.zeros(0, np.int32)
+        out["n_minimizers"] = np.ctypeslib.as_array(r.n_minimizers, shape=(nw,)).copy()
+        out["n_anchors"] = np.ctypeslib.as_array(r.n_anchors, shape=(nw,)).copy()
+        return out
+
+    def path_sequence(self, hap_len):
+        buf = C.create_string_buffer(max(int(hap_len), 1))
+        self._chk(self._L.phi_path_sequence(self._h, buf, hap_len))
+        return buf.raw[:hap_len]
+
+    # ------------------------------------------------------------------ introspection
+    def sketch(self, seqs, k, w):
+        """Stand-alone minimiser sketch: (hash[], pos[], seq[]) sorted by (seq, pos)."""
+        off = np.zeros(len(seqs) + 1, np.int64)
+        np.cumsum([len(s) for s in seqs], out=off[1:])
+        concat = np.frombuffer(b"".join(seqs), np.uint8)
+        n = C.c_int64()
+        self._chk(self._L.phi_sketch(self._h, _ptr(concat), _ptr(off), len(seqs), k, w, None, None, None, 0, C.byref(n)))
+        h = np.zeros(n.value, np.uint64)
+        p = np.zeros(n.value, np.int64)
+        s = np.zeros(n.value, np.int32)
+        if n.value:
+            self._chk(self._L.phi_sketch(self._h, _ptr(concat), _ptr(off), len(seqs), k, w, _ptr(h), _ptr(p), _ptr(s),
+                                         n.value, C.byref(n)))
+        return h, p, s
+
+    def walk_minimizers(self, walk):
+        n = C.c_int64()
+        self._chk(self._L.phi_walk_minimizers(self._h, walk, None, None, 0, C.byref(n)))
+        h = np.zeros(n.value, np.uint64)
+        p = np.zeros(n.value, np.int64)
+        if n.value:
+            self._chk(self._L.phi_walk_minimizers(self._h, walk, _ptr(h), _ptr(p), n.value, C.byref(n)))
+        return h, p
+
+    def kept_anchors(self):
+        n = C.c_int64()
+        self._chk(self._L.phi_kept_anchors(self._h, None, None, None, None, 0, C.byref(n)))
+        h = np.zeros(n.value, np.uint64)
+        wk = np.zeros(n.value, np.int32)
+        t0 = np.zeros(n.value, np.int32)
+        t1 = np.zeros(n.value, np.int32)
+        if n.value:
+            self._chk(self._L.phi_kept_anchors(self._h, _ptr(h), _ptr(wk), _ptr(t0), _ptr(t1), n.value, C.byref(n)))
+        return h, wk, t0, t1
+
+    def prof_enable(self, on=True):
+        self._chk(self._L.phi_prof_enable(self._h, int(on)))
+
+    def prof_read(self):
+        n, ms, b = C.c_int64(), C.c_double(), C.c_int64()
+        self._chk(self._L.phi_prof_read(self._h, C.byref(n), C.byref(ms), C.byref(b)))
+        return n.value, ms.value, b.value

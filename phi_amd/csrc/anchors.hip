@@ -1,0 +1,313 @@
+// anchors.hip -- anchor extraction and the shared-anchor filter on the GPU.
+//
+// Replaces, from the reference:
+//   the base->vertex map and unique-vertex list of index_kmers   src/ILP_index.cpp:374-381, 416-438
+//   compute_anchors                                              src/ILP_index.cpp:495-526, 643-655
+//   the shared-anchor filter                                     src/ILP_index.cpp:670-743
+//
+// A walk follows graph edges of a DAG, so the unique vertices under a k-mer, sorted by
+// topological rank (:432-435), are consecutive walk entries: an anchor is (walk, first entry,
+// last entry) and its "v1_v2_..._" key (:680-683) is the vertex sequence walk_vtx[e0..e1].
+// Groups of equal keys are counted in an open-addressed table keyed by a seeded 64-bit
+// fingerprint of (minimiser, vertex list); every hit is verified against the group's
+// representative anchor, so a fingerprint collision is detected (PHI_KERR_FP_COLLISION, the
+// caller reseeds) instead of merging two groups.
+#include <hip/hip_runtime.h>
+#include "phi_dev.h"
+#include "phi_kernels.h"
+
+static inline unsigned grid_for(int64_t n, int tpb)
+{
+    int64_t nb = (n + tpb - 1) / tpb;
+    if (nb > 256 * 16) nb = 256 * 16;
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}
+
+#define GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------------- locate
+// rec_e0/rec_e1: walk entries owning the first / last base of each minimiser's k-mer.
+__global__ void __launch_bounds__(256) phi_locate_kernel(const int64_t *__restrict__ rec_pos, int64_t n_rec,
+                                                         const int64_t *__restrict__ ebase, int64_t n_entries,
+                                                         int32_t k, int32_t *__restrict__ rec_e0,
+                                                         int32_t *__restrict__ rec_e1)
+{
+    GRID_STRIDE(i, n_rec) {
+        const int64_t g = rec_pos[i];
+        int64_t lo = 0, hi = n_entries;                 // ebase[lo] <= g < ebase[hi]
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (ebase[mid] <= g) lo = mid; else hi = mid;
+        }
+        int64_t e1 = lo;
+        const int64_t last = g + k - 1;
+        while (ebase[e1 + 1] <= last) e1++;
+        rec_e0[i] = (int32_t)lo;
+        rec_e1[i] = (int32_t)e1;
+    }
+}
+
+void phi_launch_locate(hipStream_t st, const int64_t *rec_pos, int64_t n_rec, const int64_t *ebase,
+                       int64_t n_entries, int32_t k, int32_t *rec_e0, int32_t *rec_e1)
+{
+    if (n_rec > 0)
+        hipLaunchKernelGGL(phi_locate_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, st, rec_pos, n_rec, ebase,
+                           n_entries, k, rec_e0, rec_e1);
+}
+
+// out[j] = number of elements of the sorted array a[0..n) that are < keys[j]
+__global__ void phi_lower_bound_kernel(const int64_t *__restrict__ a, int64_t n, const int64_t *__restrict__ keys,
+                                       int64_t m, int64_t *__restrict__ out)
+{
+    GRID_STRIDE(j, m) {
+        const int64_t key = keys[j];
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        out[j] = lo;
+    }
+}
+
+void phi_launch_lower_bound(hipStream_t st, const int64_t *a, int64_t n, const int64_t *keys, int64_t m,
+                            int64_t *out)
+{
+    if (m > 0)
+        hipLaunchKernelGGL(phi_lower_bound_kernel, dim3(grid_for(m, 64)), dim3(64), 0, st, a, n, keys, m, out);
+}
+
+// ------------------------------------------------------------------------- ordered compaction
+// flags[n] (0/1) -> ascending list of the flagged indices.  2048 items per workgroup.
+#define CMP_ITEMS 8
+__global__ void __launch_bounds__(256) phi_flag_count_kernel(const uint8_t *__restrict__ flags, int64_t n,
+                                                             int32_t *__restrict__ block_cnt)
+{
+    __shared__ int s_w[4];
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * CMP_ITEMS;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < CMP_ITEMS; j++)
+        if (base + j < n) c += flags[base + j] != 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ void __launch_bounds__(256) phi_flag_write_kernel(const uint8_t *__restrict__ flags, int64_t n,
+                                                             const int64_t *__restrict__ block_off,
+                                                             int32_t *__restrict__ out)
+{
+    __shared__ int s_w[4];
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * CMP_ITEMS;
+    uint32_t f = 0;
+#pragma unroll
+    for (int j = 0; j < CMP_ITEMS; j++)
+        if (base + j < n && flags[base + j]) f |= 1u << j;
+    const int c = __popc(f);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int v = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    if (lane == 63) s_w[wid] = v;
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < wid; i++) woff += s_w[i];
+    int64_t o = block_off[blockIdx.x] + woff + v - c;
+#pragma unroll
+    for (int j = 0; j < CMP_ITEMS; j++)
+        if (f & (1u << j)) out[o++] = (int32_t)(base + j);
+}
+
+int64_t phi_compact_num_blocks(int64_t n) { return (n + 256 * CMP_ITEMS - 1) / (256 * CMP_ITEMS); }
+
+void phi_launch_flag_count(hipStream_t st, const uint8_t *flags, int64_t n, int32_t *block_cnt)
+{
+    const int64_t nb = phi_compact_num_blocks(n);
+    if (nb > 0) hipLaunchKernelGGL(phi_flag_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, flags, n, block_cnt);
+}
+void phi_launch_flag_write(hipStream_t st, const uint8_t *flags, int64_t n, const int64_t *block_off, int32_t *out)
+{
+    const int64_t nb = phi_compact_num_blocks(n);
+    if (nb > 0)
+        hipLaunchKernelGGL(phi_flag_write_kernel, dim3((unsigned)nb), dim3(256), 0, st, flags, n, block_off, out);
+}
+
+// ------------------------------------------------------------------------- match
+// compute_anchors: a walk minimiser is an anchor iff its hash is in the read spectrum.
+__global__ void __launch_bounds__(256) phi_match_flags_kernel(const uint32_t *__restrict__ rec_slot, int64_t n_rec,
+                                                              const uint32_t *__restrict__ u_rep,
+                                                              const uint8_t *__restrict__ hit,
+                                                              uint8_t *__restrict__ flags)
+{
+    GRID_STRIDE(i, n_rec) flags[i] = hit[u_rep[rec_slot[i]]];
+}
+
+void phi_launch_match_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_rec, const uint32_t *u_rep,
+                            const uint8_t *hit, uint8_t *flags)
+{
+    if (n_rec > 0)
+        hipLaunchKernelGGL(phi_match_flags_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, st, rec_slot, n_rec,
+                           u_rep, hit, flags);
+}
+
+// ------------------------------------------------------------------------- filter groups
+__device__ __forceinline__ uint64_t group_key(uint32_t slot, const int32_t *__restrict__ walk_vtx, int32_t e0,
+                                              int32_t e1, uint64_t seed)
+{
+    uint64_t h = seed ^ ((uint64_t)slot * 0x9E3779B97F4A7C15ull);
+    h = phi_fmix64(h ^ (uint64_t)(e1 - e0 + 1));
+    for (int32_t e = e0; e <= e1; e++) h = phi_fmix64(h ^ (uint64_t)(uint32_t)walk_vtx[e]) + 0x632BE59BD9B4E019ull;
+    return h == PHI_EMPTY_KEY ? 0 : h;
+}
+
+__device__ __forceinline__ bool same_group(const PhiFilterArgs &A, int32_t ra, int32_t rb)
+{
+    if (A.rec_slot[ra] != A.rec_slot[rb]) return false;
+    const int32_t a0 = A.rec_e0[ra], a1 = A.rec_e1[ra], b0 = A.rec_e0[rb], b1 = A.rec_e1[rb];
+    if (a1 - a0 != b1 - b0) return false;
+    for (int32_t d = 0; d <= a1 - a0; d++)
+        if (A.walk_vtx[a0 + d] != A.walk_vtx[b0 + d]) return false;
+    return true;
+}
+
+// pass 1: claim a table slot per fingerprint; representative = smallest record index
+__global__ void __launch_bounds__(256) phi_group_insert_kernel(PhiFilterArgs A, int64_t n_matched)
+{
+    GRID_STRIDE(j, n_matched) {
+        const int32_t r = A.m_rec[j];
+        const uint64_t key = group_key(A.rec_slot[r], A.walk_vtx, A.rec_e0[r], A.rec_e1[r], A.seed);
+        uint64_t gs = key & A.g_mask;
+        int probes = 0;
+        for (;;) {
+            const unsigned long long prev = atomicCAS((unsigned long long *)&A.g_keys[gs], PHI_EMPTY_KEY, key);
+            if (prev == PHI_EMPTY_KEY || prev == key) break;
+            gs = (gs + 1) & A.g_mask;
+            if (++probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
+        }
+        atomicMin((uint32_t *)&A.g_rep[gs], (uint32_t)r);
+        A.m_group[j] = (int32_t)gs;
+    }
+}
+
+// pass 2: verify against the representative, count the group (the map's .first, :686-689)
+__global__ void __launch_bounds__(256) phi_group_count_kernel(PhiFilterArgs A, int64_t n_matched)
+{
+    GRID_STRIDE(j, n_matched) {
+        const int32_t r = A.m_rec[j];
+        const int32_t gs = A.m_group[j];
+        if (!same_group(A, r, A.g_rep[gs])) { atomicOr(A.err, PHI_KERR_FP_COLLISION); continue; }
+        atomicAdd(&A.g_cnt[gs], 1u);
+    }
+}
+
+// pass 3: per minimiser, the largest group and whether any anchor spans >= 2 vertices
+__global__ void __launch_bounds__(256) phi_group_max_kernel(PhiFilterArgs A, int64_t n_matched)
+{
+    GRID_STRIDE(j, n_matched) {
+        const int32_t r = A.m_rec[j];
+        const uint32_t slot = A.rec_slot[r];
+        atomicMax(&A.slot_maxcnt[slot], A.g_cnt[A.m_group[j]]);
+        if (A.rec_e1[r] > A.rec_e0[r]) A.slot_multi[slot] = 1;
+    }
+}
+
+// pass 4: filtered / in-model counters over the table (ILP_index.cpp:698, :711, :822/:868)
+__global__ void __launch_bounds__(256) phi_slot_count_kernel(PhiFilterArgs A, int64_t u_cap)
+{
+    int n_filtered = 0, n_model = 0;
+    GRID_STRIDE(s, u_cap) {
+        const uint32_t c = A.slot_maxcnt[s];
+        if (c == 0) continue;                               // no anchor for this minimiser
+        if ((float)c >= A.limit) n_filtered++;
+        else if (A.slot_multi[s]) n_model++;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        n_filtered += __shfl_xor(n_filtered, d, 64);
+        n_model += __shfl_xor(n_model, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_filtered) atomicAdd(&A.counters[0], (unsigned long long)n_filtered);
+        if (n_model) atomicAdd(&A.counters[1], (unsigned long long)n_model);
+    }
+}
+
+// pass 5: kept anchors (:704-709); dp anchors additionally span >= 2 vertices (:795/:846)
+__global__ void __launch_bounds__(256) phi_kept_flags_kernel(PhiFilterArgs A, int64_t n_matched,
+                                                             uint8_t *__restrict__ kept, uint8_t *__restrict__ dp)
+{
+    GRID_STRIDE(j, n_matched) {
+        const int32_t r = A.m_rec[j];
+        const bool keep = !((float)A.slot_maxcnt[A.rec_slot[r]] >= A.limit);
+        kept[j] = keep;
+        dp[j] = keep && A.rec_e1[r] > A.rec_e0[r];
+    }
+}
+
+void phi_launch_group_insert(hipStream_t st, const PhiFilterArgs &A, int64_t n)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_group_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, A, n);
+}
+void phi_launch_group_count(hipStream_t st, const PhiFilterArgs &A, int64_t n)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_group_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, A, n);
+}
+void phi_launch_group_max(hipStream_t st, const PhiFilterArgs &A, int64_t n)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_group_max_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, A, n);
+}
+void phi_launch_slot_count(hipStream_t st, const PhiFilterArgs &A, int64_t u_cap)
+{
+    if (u_cap > 0) hipLaunchKernelGGL(phi_slot_count_kernel, dim3(grid_for(u_cap, 256)), dim3(256), 0, st, A, u_cap);
+}
+void phi_launch_kept_flags(hipStream_t st, const PhiFilterArgs &A, int64_t n, uint8_t *kept, uint8_t *dp)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_kept_flags_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, A, n, kept, dp);
+}
+
+// ------------------------------------------------------------------------- gathers for the DP
+// out[j] = src[idx[j]]
+__global__ void phi_gather_i32_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int64_t n,
+                                      int32_t *__restrict__ out)
+{
+    GRID_STRIDE(j, n) out[j] = src[idx[j]];
+}
+void phi_launch_gather_i32(hipStream_t st, const int32_t *src, const int32_t *idx, int64_t n, int32_t *out)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_gather_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, src, idx, n, out);
+}
+
+__global__ void phi_gather_u64_kernel(const uint64_t *__restrict__ src, const int32_t *__restrict__ idx, int64_t n,
+                                      uint64_t *__restrict__ out)
+{
+    GRID_STRIDE(j, n) out[j] = src[idx[j]];
+}
+void phi_launch_gather_u64(hipStream_t st, const uint64_t *src, const int32_t *idx, int64_t n, uint64_t *out)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_gather_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, src, idx, n, out);
+}
+
+// CSR over walk entries of the dp anchors, which arrive sorted by their last entry e1:
+// g_off[e] = first anchor with e1 >= e.
+__global__ void phi_entry_csr_kernel(const int32_t *__restrict__ a_e1, int64_t n_a, int64_t n_entries,
+                                     int64_t *__restrict__ g_off)
+{
+    GRID_STRIDE(j, n_a + 1) {
+        const int64_t lo = j == 0 ? 0 : (int64_t)a_e1[j - 1] + 1;
+        const int64_t hi = j == n_a ? n_entries : (int64_t)a_e1[j];
+        for (int64_t e = lo; e <= hi; e++) g_off[e] = j;
+    }
+}
+void phi_launch_entry_csr(hipStream_t st, const int32_t *a_e1, int64_t n_a, int64_t n_entries, int64_t *g_off)
+{
+    hipLaunchKernelGGL(phi_entry_csr_kernel, dim3(grid_for(n_a + 1, 256)), dim3(256), 0, st, a_e1, n_a, n_entries,
+                       g_off);
+}

@@ -1,0 +1,655 @@
+// phi_abi.hip -- C ABI of include/phi_amd.h: context, graph index build, read batches.
+// Host-side orchestration only; all per-base work runs in the kernels of sketch.hip, table.hip,
+// anchors.hip and dp.hip.  There is no CPU fallback: without a HIP device every entry point
+// that needs one returns PHI_ERR_DEVICE.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include "phi_ctx.h"
+#include "phi_dev.h"
+
+// scalar slots in d_scalars (8 bytes each)
+enum { S_ERR = 0, S_NBAD = 1, S_SPCOUNT = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_N = 8 };
+
+int phi_fail(phi_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->last_error = buf;
+    return code;
+}
+
+int phi_hip_check(phi_ctx *c, hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return PHI_OK;
+    const int code = (e == hipErrorOutOfMemory) ? PHI_ERR_NOMEM : PHI_ERR_DEVICE;
+    return phi_fail(c, code, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIPCHK(call) do { int rc_ = phi_hip_check(c, (call), #call); if (rc_) return rc_; } while (0)
+#define PHICHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return PHI_OK;
+    if (b.p) { hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return phi_hip_check(c, e, "hipFree"); }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; return phi_fail(c, PHI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e)); }
+    b.cap = want;
+    return PHI_OK;
+}
+
+static void dev_free(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+template <class T> static int upload(phi_ctx *c, DevBuf &b, const T *src, size_t n)
+{
+    PHICHK(phi_dev_ensure(c, b, (n ? n : 1) * sizeof(T)));
+    if (n) HIPCHK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return PHI_OK;
+}
+
+static uint64_t *scalar(phi_ctx *c, int i) { return c->d_scalars.as<uint64_t>() + i; }
+
+// wait for the stream and translate the device error word
+int phi_sync_check(phi_ctx *c)
+{
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint64_t s[S_N];
+    HIPCHK(hipMemcpy(s, c->d_scalars.p, sizeof s, hipMemcpyDeviceToHost));
+    const uint32_t err = (uint32_t)s[S_ERR];
+    if (err & PHI_KERR_TABLE_FULL) return phi_fail(c, PHI_ERR_OVERFLOW, "open-addressed table overflow (probe bound %d)", PHI_MAX_PROBE);
+    if (err & PHI_KERR_SENTINEL) return phi_fail(c, PHI_ERR_UNSUPPORTED, "a minimiser hashes to UINT64_MAX (table sentinel)");
+    if (s[S_NBAD]) return phi_fail(c, PHI_ERR_UNSUPPORTED, "%llu bases outside ACGTacgt: the 2-bit path does not handle them yet", (unsigned long long)s[S_NBAD]);
+    return PHI_OK;
+}
+
+static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
+
+extern "C" {
+
+const char *phi_strerror(int status)
+{
+    switch (status) {
+    case PHI_OK: return "ok";
+    case PHI_ERR_INVALID: return "invalid argument";
+    case PHI_ERR_NOMEM: return "out of memory";
+    case PHI_ERR_DEVICE: return "HIP device error";
+    case PHI_ERR_STATE: return "call order violated";
+    case PHI_ERR_UNSUPPORTED: return "unsupported input";
+    case PHI_ERR_WALK: return "walk does not follow the graph";
+    case PHI_ERR_OVERFLOW: return "internal table overflow";
+    default: return "unknown status";
+    }
+}
+
+const char *phi_last_error(const phi_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int phi_ctx_create(int device_id, phi_ctx **out)
+{
+    if (!out) return PHI_ERR_INVALID;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return PHI_ERR_DEVICE;
+    if (device_id < 0 || device_id >= n_dev) return PHI_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return PHI_ERR_DEVICE;
+    phi_ctx *c = new (std::nothrow) phi_ctx();
+    if (!c) return PHI_ERR_NOMEM;
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PHI_ERR_DEVICE; }
+    c->stream = c->own_stream;
+    if (phi_dev_ensure(c, c->d_scalars, S_N * 8) || hipMemset(c->d_scalars.p, 0, S_N * 8) != hipSuccess) {
+        (void)hipStreamDestroy(c->own_stream); delete c; return PHI_ERR_DEVICE;
+    }
+    *out = c;
+    return PHI_OK;
+}
+
+void phi_ctx_destroy(phi_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
+                     &c->d_in_src, &c->d_wwords, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
+                     &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
+                     &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_blk_cnt,
+                     &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_m_rec, &c->d_m_group,
+                     &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
+                     &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_qbest, &c->d_lent, &c->d_top,
+                     &c->d_ent};
+    for (DevBuf *b : all) dev_free(*b);
+    for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int phi_set_stream(phi_ctx *c, void *hip_stream)
+{
+    if (!c) return PHI_ERR_INVALID;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PHI_OK;
+}
+
+int phi_set_params(phi_ctx *c, int32_t k, int32_t w, float threshold, int32_t recombination, uint32_t flags)
+{
+    if (!c) return PHI_ERR_INVALID;
+    if (c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_set_params must precede phi_set_graph");
+    if (k < 1 || k > PHI_MAX_K) return phi_fail(c, PHI_ERR_INVALID, "k=%d outside [1,%d] (2-bit k-mers are held in 64 bits)", k, PHI_MAX_K);
+    if (w < 1 || w > PHI_MAX_W) return phi_fail(c, PHI_ERR_INVALID, "w=%d outside [1,%d]", w, PHI_MAX_W);
+    if (recombination < 0) return phi_fail(c, PHI_ERR_INVALID, "recombination penalty must be >= 0");
+    c->k = k; c->w = w; c->threshold = threshold; c->recombination = recombination; c->flags = flags;
+    return PHI_OK;
+}
+
+// count pass -> scan -> ordered write of the minimiser records of one packed flat sequence
+static int sketch_records(phi_ctx *c, const uint64_t *words, const unsigned long long *starts, int64_t n_bases,
+                          int32_t k, int32_t w, DevBuf &out_hash, DevBuf &out_pos, int64_t *n_out)
+{
+    *n_out = 0;
+    const int64_t nb = phi_sketch_num_blocks(n_bases);
+    if (nb == 0) return PHI_OK;
+    PHICHK(phi_dev_ensure(c, c->d_blk_cnt, (size_t)nb * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_off, (size_t)(nb + 1) * 8));
+    PhiSketchArgs A{};
+    A.words = words; A.starts = starts; A.n_bases = n_bases; A.k = k; A.w = w;
+    A.block_cnt = c->d_blk_cnt.as<int32_t>();
+    A.err = (uint32_t *)scalar(c, S_ERR);
+    phi_launch_sketch(c->stream, PHI_MODE_COUNT, A);
+    phi_launch_scan_counts(c->stream, c->d_blk_cnt.as<int32_t>(), nb, c->d_blk_off.as<int64_t>());
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, c->d_blk_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    PHICHK(phi_dev_ensure(c, out_hash, (size_t)std::max<int64_t>(total, 1) * 8));
+    PHICHK(phi_dev_ensure(c, out_pos, (size_t)std::max<int64_t>(total, 1) * 8));
+    A.block_off = c->d_blk_off.as<int64_t>();
+    A.out_hash = out_hash.as<uint64_t>();
+    A.out_pos = out_pos.as<int64_t>();
+    phi_launch_sketch(c->stream, PHI_MODE_WRITE, A);
+    HIPCHK(hipGetLastError());
+    *n_out = total;
+    return PHI_OK;
+}
+
+int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64_t *seq_off, const int64_t *adj_off,
+                  const int32_t *adj, int32_t n_walks, const int64_t *walk_off, const int32_t *walk_vtx,
+                  const int32_t *topo_rank)
+{
+    if (!c) return PHI_ERR_INVALID;
+    if (n_vtx <= 0 || n_walks <= 0 || !seq_concat || !seq_off || !adj_off || !walk_off || !walk_vtx || !topo_rank)
+        return phi_fail(c, PHI_ERR_INVALID, "phi_set_graph: null pointer or empty graph");
+    if (adj_off[n_vtx] > 0 && !adj) return phi_fail(c, PHI_ERR_INVALID, "phi_set_graph: adj is null");
+    HIPCHK(hipSetDevice(c->device));
+    c->have_graph = false;
+    c->solved = false;
+
+    // ---- validate and keep host copies
+    if (seq_off[0] != 0 || adj_off[0] != 0 || walk_off[0] != 0) return phi_fail(c, PHI_ERR_INVALID, "offset arrays must start at 0");
+    for (int32_t v = 0; v < n_vtx; v++)
+        if (seq_off[v + 1] < seq_off[v] || adj_off[v + 1] < adj_off[v]) return phi_fail(c, PHI_ERR_INVALID, "offsets not monotone at vertex %d", v);
+    for (int32_t h = 0; h < n_walks; h++)
+        if (walk_off[h + 1] <= walk_off[h]) return phi_fail(c, PHI_ERR_INVALID, "walk %d is empty", h);
+    const int64_t n_edges = adj_off[n_vtx], n_entries = walk_off[n_walks];
+    if (n_entries >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk entries");
+    c->n_vtx = n_vtx; c->n_walks = n_walks; c->n_entries = n_entries;
+    c->h_seq.assign(seq_concat, seq_concat + seq_off[n_vtx]);
+    c->h_seq_off.assign(seq_off, seq_off + n_vtx + 1);
+    c->h_adj_off.assign(adj_off, adj_off + n_vtx + 1);
+    c->h_adj.assign(adj, adj + n_edges);
+    c->h_walk_off.assign(walk_off, walk_off + n_walks + 1);
+    c->h_walk_vtx.assign(walk_vtx, walk_vtx + n_entries);
+    c->h_topo_rank.assign(topo_rank, topo_rank + n_vtx);
+
+    // topological order from the ranks; every edge must go forward (acyclic GFA, README.md:70-75)
+    c->h_topo.assign(n_vtx, -1);
+    for (int32_t v = 0; v < n_vtx; v++) {
+        const int32_t r = topo_rank[v];
+        if (r < 0 || r >= n_vtx || c->h_topo[r] != -1) return phi_fail(c, PHI_ERR_INVALID, "topo_rank is not a permutation (vertex %d): is the graph cyclic?", v);
+        c->h_topo[r] = v;
+    }
+    std::vector<int64_t> indeg(n_vtx, 0);
+    for (int32_t u = 0; u < n_vtx; u++)
+        for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) {
+            const int32_t v = adj[x];
+            if (v < 0 || v >= n_vtx) return phi_fail(c, PHI_ERR_INVALID, "edge target %d out of range", v);
+            if (topo_rank[u] >= topo_rank[v]) return phi_fail(c, PHI_ERR_INVALID, "edge %d->%d goes backwards in topo_rank: graph must be acyclic", u, v);
+            indeg[v]++;
+        }
+    // walks follow edges of forward vertices (ILP_index.cpp:104-107 exits on reverse strand; an
+    // edge-less step would make the anchor's edge variables unconstrained, :799-815)
+    bool start_interior = false, end_interior = false;
+    for (int32_t h = 0; h < n_walks; h++) {
+        for (int64_t e = walk_off[h]; e < walk_off[h + 1]; e++) {
+            const int32_t v = walk_vtx[e];
+            if (v < 0 || v >= n_vtx) return phi_fail(c, PHI_ERR_WALK, "walk %d holds vertex %d out of range", h, v);
+            if (seq_off[v + 1] == seq_off[v]) return phi_fail(c, PHI_ERR_UNSUPPORTED, "walk %d passes through empty segment %d", h, v);
+            if (e > walk_off[h]) {
+                const int32_t u = walk_vtx[e - 1];
+                bool ok = false;
+                for (int64_t x = adj_off[u]; x < adj_off[u + 1] && !ok; x++) ok = adj[x] == v;
+                if (!ok) return phi_fail(c, PHI_ERR_WALK, "walk %d steps %d->%d without a graph edge", h, u, v);
+            }
+        }
+        if (indeg[walk_vtx[walk_off[h]]] > 0) start_interior = true;
+        const int32_t last = walk_vtx[walk_off[h + 1] - 1];
+        if (adj_off[last + 1] > adj_off[last]) end_interior = true;
+    }
+    if (start_interior && end_interior)
+        return phi_fail(c, PHI_ERR_UNSUPPORTED, "walks both start and end at interior vertices: the reference model "
+                        "admits flow leak/spawn artefacts there (ILP_index.cpp:1330) that are not emulated");
+
+    // flat base offset of every walk entry; walk of every entry
+    c->h_ebase.resize(n_entries + 1);
+    c->h_entry_walk.resize(n_entries);
+    int64_t run = 0;
+    for (int32_t h = 0; h < n_walks; h++)
+        for (int64_t e = walk_off[h]; e < walk_off[h + 1]; e++) {
+            c->h_ebase[e] = run;
+            c->h_entry_walk[e] = h;
+            run += seq_off[walk_vtx[e] + 1] - seq_off[walk_vtx[e]];
+        }
+    c->h_ebase[n_entries] = run;
+    c->walk_bases = run;
+    // entries on each vertex, ascending walk id (host side: backtracking)
+    c->h_vh_off.assign(n_vtx + 1, 0);
+    for (int64_t e = 0; e < n_entries; e++) c->h_vh_off[walk_vtx[e] + 1]++;
+    for (int32_t v = 0; v < n_vtx; v++) c->h_vh_off[v + 1] += c->h_vh_off[v];
+    c->h_vh_entry.resize(n_entries);
+    {
+        std::vector<int64_t> cur(c->h_vh_off.begin(), c->h_vh_off.end() - 1);
+        for (int64_t e = 0; e < n_entries; e++) c->h_vh_entry[cur[walk_vtx[e]]++] = (int32_t)e;
+    }
+    // reverse adjacency
+    c->h_in_off.assign(n_vtx + 1, 0);
+    for (int32_t v = 0; v < n_vtx; v++) c->h_in_off[v + 1] = c->h_in_off[v] + indeg[v];
+    c->h_in_src.resize(n_edges);
+    {
+        std::vector<int64_t> cur(c->h_in_off.begin(), c->h_in_off.end() - 1);
+        for (int32_t u = 0; u < n_vtx; u++)
+            for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) c->h_in_src[cur[adj[x]]++] = u;
+    }
+
+    // ---- device copies
+    PHICHK(upload(c, c->d_seq, c->h_seq.data(), c->h_seq.size()));
+    PHICHK(upload(c, c->d_seq_off, c->h_seq_off.data(), c->h_seq_off.size()));
+    PHICHK(upload(c, c->d_walk_vtx, c->h_walk_vtx.data(), c->h_walk_vtx.size()));
+    PHICHK(upload(c, c->d_walk_off, c->h_walk_off.data(), c->h_walk_off.size()));
+    PHICHK(upload(c, c->d_ebase, c->h_ebase.data(), c->h_ebase.size()));
+    PHICHK(upload(c, c->d_topo, c->h_topo.data(), c->h_topo.size()));
+    PHICHK(upload(c, c->d_in_off, c->h_in_off.data(), c->h_in_off.size()));
+    PHICHK(upload(c, c->d_in_src, c->h_in_src.data(), c->h_in_src.size()));
+
+    // ---- stage 1a on the GPU: pack the walks, sketch them, build the minimiser table
+    HIPCHK(hipMemsetAsync(c->d_scalars.p, 0, S_N * 8, c->stream));
+    const int64_t n_words = (run + 31) / 32;
+    PHICHK(phi_dev_ensure(c, c->d_wwords, (size_t)(n_words + 2) * 8));
+    HIPCHK(hipMemsetAsync(c->d_wwords.as<uint64_t>() + n_words, 0, 16, c->stream));
+    phi_launch_pack_walks(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(),
+                          c->d_ebase.as<int64_t>(), n_entries, c->d_wwords.as<uint64_t>(), n_words,
+                          (unsigned long long *)scalar(c, S_NBAD));
+    const size_t n_sw = (size_t)(run / 64 + 2);
+    PHICHK(phi_dev_ensure(c, c->d_wstarts, n_sw * 8));
+    HIPCHK(hipMemsetAsync(c->d_wstarts.p, 0, n_sw * 8, c->stream));
+    std::vector<int64_t> wstart(n_walks + 1);
+    for (int32_t h = 0; h <= n_walks; h++) wstart[h] = c->h_ebase[walk_off[h]];
+    PHICHK(upload(c, c->d_list, wstart.data(), wstart.size()));
+    phi_launch_mark_starts(c->stream, c->d_list.as<int64_t>(), n_walks, c->d_wstarts.as<unsigned long long>());
+
+    PHICHK(sketch_records(c, c->d_wwords.as<uint64_t>(), c->d_wstarts.as<unsigned long long>(), run, c->k, c->w,
+                          c->d_rec_hash, c->d_rec_pos, &c->n_rec));
+    if (c->n_rec >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk minimisers");
+    const int64_t nr = std::max<int64_t>(c->n_rec, 1);
+    PHICHK(phi_dev_ensure(c, c->d_rec_slot, (size_t)nr * 4));
+    PHICHK(phi_dev_ensure(c, c->d_rec_e0, (size_t)nr * 4));
+    PHICHK(phi_dev_ensure(c, c->d_rec_e1, (size_t)nr * 4));
+    c->u_cap = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)c->n_rec));
+    PHICHK(phi_dev_ensure(c, c->d_u_keys, c->u_cap * 8));
+    PHICHK(phi_dev_ensure(c, c->d_u_rep, c->u_cap * 4));
+    phi_launch_fill_u64(c->stream, c->d_u_keys.as<uint64_t>(), (int64_t)c->u_cap, PHI_EMPTY_KEY);
+    phi_launch_fill_u32(c->stream, c->d_u_rep.as<uint32_t>(), (int64_t)c->u_cap, 0xFFFFFFFFu);
+    phi_launch_table_build(c->stream, c->d_rec_hash.as<uint64_t>(), c->n_rec, c->d_u_keys.as<uint64_t>(),
+                           c->d_u_rep.as<uint32_t>(), c->u_cap - 1, c->d_rec_slot.as<uint32_t>(),
+                           (uint32_t *)scalar(c, S_ERR));
+    phi_launch_locate(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_ebase.as<int64_t>(), n_entries, c->k,
+                      c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>());
+    // records of each walk ("Number of Minimizers", ILP_index.cpp:563)
+    PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)(n_walks + 1) * 8));
+    phi_launch_lower_bound(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_list.as<int64_t>(), n_walks + 1,
+                           c->d_list2.as<int64_t>());
+    c->h_walk_rec_off.resize(n_walks + 1);
+    HIPCHK(hipMemcpyAsync(c->h_walk_rec_off.data(), c->d_list2.p, (size_t)(n_walks + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    PHICHK(phi_dev_ensure(c, c->d_hit, (size_t)nr));
+    HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)nr, c->stream));
+    HIPCHK(hipGetLastError());
+    PHICHK(phi_sync_check(c));
+    c->h_n_minimizers.resize(n_walks);
+    for (int32_t h = 0; h < n_walks; h++) c->h_n_minimizers[h] = c->h_walk_rec_off[h + 1] - c->h_walk_rec_off[h];
+
+    c->sp_cap = 0; c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
+    c->have_graph = true;
+    return PHI_OK;
+}
+
+// make room in the read-spectrum set for the minimisers of add_bases more read bases
+static int sp_ensure(phi_ctx *c, int64_t add_bases)
+{
+    const int64_t est = add_bases / 4 + 16;
+    uint64_t need = pow2_at_least(std::max<uint64_t>(1u << 16, 2 * (uint64_t)(c->sp_bound + est)));
+    if (c->sp_cap == 0) {
+        PHICHK(phi_dev_ensure(c, c->d_sp_keys, need * 8));
+        c->sp_cap = need;
+        phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)need, PHI_EMPTY_KEY);
+        HIPCHK(hipMemsetAsync(scalar(c, S_SPCOUNT), 0, 8, c->stream));
+    } else if (need > c->sp_cap) {
+        // the bound is pessimistic: look at the real size before growing
+        HIPCHK(hipStreamSynchronize(c->stream));
+        uint64_t cnt = 0;
+        HIPCHK(hipMemcpy(&cnt, scalar(c, S_SPCOUNT), 8, hipMemcpyDeviceToHost));
+        c->sp_bound = (int64_t)cnt;
+        need = pow2_at_least(std::max<uint64_t>(1u << 16, 2 * (uint64_t)(c->sp_bound + est)));
+        if (need > c->sp_cap) {
+            PHICHK(phi_dev_ensure(c, c->d_export, (size_t)std::max<uint64_t>(cnt, 1) * 8));
+            HIPCHK(hipMemsetAsync(scalar(c, S_EXPORT), 0, 8, c->stream));
+            phi_launch_spectrum_export(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap,
+                                       c->d_export.as<uint64_t>(), (unsigned long long *)scalar(c, S_EXPORT));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            dev_free(c->d_sp_keys);
+            PHICHK(phi_dev_ensure(c, c->d_sp_keys, need * 8));
+            c->sp_cap = need;
+            phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)need, PHI_EMPTY_KEY);
+            HIPCHK(hipMemsetAsync(scalar(c, S_SPCOUNT), 0, 8, c->stream));
+            phi_launch_spectrum_insert(c->stream, c->d_export.as<uint64_t>(), (int64_t)cnt, c->d_sp_keys.as<uint64_t>(),
+                                       c->sp_cap - 1, (unsigned long long *)scalar(c, S_SPCOUNT),
+                                       (uint32_t *)scalar(c, S_ERR));
+        }
+    }
+    c->sp_bound += est;
+    return PHI_OK;
+}
+
+int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases)
+{
+    if (!c) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads before phi_set_graph");
+    if (n_reads < 0 || n_bases < 0 || (n_bases > 0 && (!d_bases || !d_read_off))) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads: bad arguments");
+    if (n_reads == 0 || n_bases == 0) { c->reads_count += n_reads; return PHI_OK; }
+    HIPCHK(hipSetDevice(c->device));
+    c->solved = false;
+    PHICHK(sp_ensure(c, n_bases));
+    const int64_t n_words = (n_bases + 31) / 32;
+    PHICHK(phi_dev_ensure(c, c->d_rwords, (size_t)(n_words + 2) * 8));
+    HIPCHK(hipMemsetAsync(c->d_rwords.as<uint64_t>() + n_words, 0, 16, c->stream));
+    const size_t n_sw = (size_t)(n_bases / 64 + 2);
+    PHICHK(phi_dev_ensure(c, c->d_rstarts, n_sw * 8));
+    HIPCHK(hipMemsetAsync(c->d_rstarts.p, 0, n_sw * 8, c->stream));
+    phi_launch_mark_starts(c->stream, (const int64_t *)d_read_off, n_reads, c->d_rstarts.as<unsigned long long>());
+    phi_launch_pack_ascii(c->stream, (const uint8_t *)d_bases, n_bases, c->d_rwords.as<uint64_t>(), n_words,
+                          (unsigned long long *)scalar(c, S_NBAD));
+    PhiSketchArgs A{};
+    A.words = c->d_rwords.as<uint64_t>();
+    A.starts = c->d_rstarts.as<unsigned long long>();
+    A.n_bases = n_bases; A.k = c->k; A.w = c->w;
+    A.sp_keys = c->d_sp_keys.as<uint64_t>(); A.sp_mask = c->sp_cap - 1;
+    A.sp_count = (unsigned long long *)scalar(c, S_SPCOUNT);
+    A.n_emitted = (unsigned long long *)scalar(c, S_NEMIT);
+    A.u_keys = c->d_u_keys.as<uint64_t>(); A.u_rep = c->d_u_rep.as<uint32_t>(); A.u_mask = c->u_cap - 1;
+    A.hit = c->d_hit.as<uint8_t>();
+    A.err = (uint32_t *)scalar(c, S_ERR);
+    if (c->prof) {
+        if (c->prof_used == c->prof_events.size()) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            c->prof_events.emplace_back(a, b);
+        }
+        HIPCHK(hipEventRecord(c->prof_events[c->prof_used].first, c->stream));
+    }
+    phi_launch_sketch(c->stream, PHI_MODE_PROBE, A);
+    if (c->prof) {
+        HIPCHK(hipEventRecord(c->prof_events[c->prof_used].second, c->stream));
+        c->prof_used++;
+        c->prof_bases += n_bases;
+    }
+    HIPCHK(hipGetLastError());
+    c->reads_bases += n_bases;
+    c->reads_count += n_reads;
+    return PHI_OK;
+}
+
+int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_t n_reads)
+{
+    if (!c) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads before phi_set_graph");
+    if (n_reads < 0 || (n_reads > 0 && !read_off)) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads: bad arguments");
+    if (n_reads == 0) return PHI_OK;
+    if (read_off[0] != 0) return phi_fail(c, PHI_ERR_INVALID, "read_off must start at 0");
+    for (int64_t r = 0; r < n_reads; r++)
+        if (read_off[r + 1] < read_off[r]) return phi_fail(c, PHI_ERR_INVALID, "read_off not monotone at read %lld", (long long)r);
+    const int64_t n_bases = read_off[n_reads];
+    if (n_bases > 0 && !bases) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads: bases is null");
+    HIPCHK(hipSetDevice(c->device));
+    // the previous batch may still be reading the staging buffers
+    HIPCHK(hipStreamSynchronize(c->stream));
+    PHICHK(phi_dev_ensure(c, c->d_rbases, (size_t)std::max<int64_t>(n_bases, 1)));
+    PHICHK(phi_dev_ensure(c, c->d_roff, (size_t)(n_reads + 1) * 8));
+    if (n_bases) HIPCHK(hipMemcpyAsync(c->d_rbases.p, bases, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_roff.p, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    PHICHK(phi_add_reads_device(c, c->d_rbases.p, c->d_roff.p, n_reads, n_bases));
+    // host buffers are borrowed for the call only
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PHI_OK;
+}
+
+int phi_reset_reads(phi_ctx *c)
+{
+    if (!c) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reset_reads before phi_set_graph");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->sp_cap) phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, PHI_EMPTY_KEY);
+    HIPCHK(hipMemsetAsync(scalar(c, S_SPCOUNT), 0, 16, c->stream));       // sp_count and n_emitted
+    HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)std::max<int64_t>(c->n_rec, 1), c->stream));
+    c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
+    c->solved = false;
+    return PHI_OK;
+}
+
+int phi_hits_buffer(phi_ctx *c, void **d_hits, int64_t *n)
+{
+    if (!c || !d_hits || !n) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_hits_buffer before phi_set_graph");
+    *d_hits = c->d_hit.p;
+    *n = c->n_rec;
+    return PHI_OK;
+}
+
+int phi_spectrum_export(phi_ctx *c, void **d_hashes, int64_t *n)
+{
+    if (!c || !d_hashes || !n) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_spectrum_export before phi_set_graph");
+    HIPCHK(hipSetDevice(c->device));
+    *d_hashes = nullptr; *n = 0;
+    if (c->sp_cap == 0) return PHI_OK;
+    PHICHK(phi_sync_check(c));
+    uint64_t cnt = 0;
+    HIPCHK(hipMemcpy(&cnt, scalar(c, S_SPCOUNT), 8, hipMemcpyDeviceToHost));
+    PHICHK(phi_dev_ensure(c, c->d_export, (size_t)std::max<uint64_t>(cnt, 1) * 8));
+    HIPCHK(hipMemsetAsync(scalar(c, S_EXPORT), 0, 8, c->stream));
+    phi_launch_spectrum_export(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_export.as<uint64_t>(),
+                               (unsigned long long *)scalar(c, S_EXPORT));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *d_hashes = c->d_export.p;
+    *n = (int64_t)cnt;
+    return PHI_OK;
+}
+
+int phi_spectrum_import(phi_ctx *c, const void *d_hashes, int64_t n)
+{
+    if (!c || n < 0 || (n > 0 && !d_hashes)) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_spectrum_import before phi_set_graph");
+    if (n == 0) return PHI_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (d_hashes == c->d_export.p) return phi_fail(c, PHI_ERR_INVALID, "phi_spectrum_import: pass a copy, not the export buffer");
+    PHICHK(sp_ensure(c, n * 4));
+    phi_launch_spectrum_insert(c->stream, (const uint64_t *)d_hashes, n, c->d_sp_keys.as<uint64_t>(), c->sp_cap - 1,
+                               (unsigned long long *)scalar(c, S_SPCOUNT), (uint32_t *)scalar(c, S_ERR));
+    HIPCHK(hipGetLastError());
+    c->solved = false;
+    return PHI_OK;
+}
+
+int phi_spectrum_set_size(phi_ctx *c, int64_t global_size)
+{
+    if (!c || global_size < 0) return PHI_ERR_INVALID;
+    c->spectrum_override = global_size;
+    return PHI_OK;
+}
+
+int phi_solve(phi_ctx *c, phi_result *out)
+{
+    if (!c || !out) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_solve before phi_set_graph");
+    HIPCHK(hipSetDevice(c->device));
+    PHICHK(phi_solve_impl(c));
+    *out = c->result;
+    return PHI_OK;
+}
+
+int phi_path_sequence(phi_ctx *c, char *buf, int64_t cap)
+{
+    if (!c || (!buf && cap > 0)) return PHI_ERR_INVALID;
+    if (!c->solved) return phi_fail(c, PHI_ERR_STATE, "phi_path_sequence before phi_solve");
+    if (cap < c->result.hap_len) return phi_fail(c, PHI_ERR_INVALID, "buffer too small: need %lld bytes", (long long)c->result.hap_len);
+    int64_t o = 0;
+    for (int32_t v : c->h_path_vtx) {
+        const int64_t len = c->h_seq_off[v + 1] - c->h_seq_off[v];
+        memcpy(buf + o, c->h_seq.data() + c->h_seq_off[v], (size_t)len);      // original case, :1580
+        o += len;
+    }
+    return PHI_OK;
+}
+
+int phi_sketch(phi_ctx *c, const char *bases, const int64_t *seq_off, int64_t n_seq, int32_t k, int32_t w,
+               uint64_t *out_hash, int64_t *out_pos, int32_t *out_seq, int64_t cap, int64_t *n_out)
+{
+    if (!c || !n_out || n_seq < 0 || (n_seq > 0 && !seq_off)) return PHI_ERR_INVALID;
+    if (k < 1 || k > PHI_MAX_K || w < 1 || w > PHI_MAX_W) return phi_fail(c, PHI_ERR_INVALID, "k or w out of range");
+    *n_out = 0;
+    if (n_seq == 0) return PHI_OK;
+    for (int64_t r = 0; r < n_seq; r++)
+        if (seq_off[r + 1] < seq_off[r]) return phi_fail(c, PHI_ERR_INVALID, "seq_off not monotone");
+    const int64_t n_bases = seq_off[n_seq] - seq_off[0];
+    if (n_bases == 0) return PHI_OK;
+    if (!bases) return PHI_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    DevBuf dB, dO, dW, dS, dH, dP;
+    int rc = PHI_OK;
+    std::vector<int64_t> off(seq_off, seq_off + n_seq + 1);
+    for (auto &o : off) o -= seq_off[0];
+    do {
+        if ((rc = phi_dev_ensure(c, dB, (size_t)n_bases))) break;
+        if ((rc = phi_dev_ensure(c, dO, (size_t)(n_seq + 1) * 8))) break;
+        const int64_t n_words = (n_bases + 31) / 32;
+        if ((rc = phi_dev_ensure(c, dW, (size_t)(n_words + 2) * 8))) break;
+        const size_t n_sw = (size_t)(n_bases / 64 + 2);
+        if ((rc = phi_dev_ensure(c, dS, n_sw * 8))) break;
+        if ((rc = phi_hip_check(c, hipMemcpyAsync(dB.p, bases + seq_off[0], (size_t)n_bases, hipMemcpyHostToDevice, c->stream), "H2D bases"))) break;
+        if ((rc = phi_hip_check(c, hipMemcpyAsync(dO.p, off.data(), (size_t)(n_seq + 1) * 8, hipMemcpyHostToDevice, c->stream), "H2D offsets"))) break;
+        if ((rc = phi_hip_check(c, hipMemsetAsync(dW.as<uint64_t>() + n_words, 0, 16, c->stream), "memset"))) break;
+        if ((rc = phi_hip_check(c, hipMemsetAsync(dS.p, 0, n_sw * 8, c->stream), "memset"))) break;
+        if ((rc = phi_hip_check(c, hipMemsetAsync(scalar(c, S_NBAD), 0, 8, c->stream), "memset"))) break;
+        phi_launch_mark_starts(c->stream, dO.as<int64_t>(), n_seq, dS.as<unsigned long long>());
+        phi_launch_pack_ascii(c->stream, dB.as<uint8_t>(), n_bases, dW.as<uint64_t>(), n_words,
+                              (unsigned long long *)scalar(c, S_NBAD));
+        int64_t total = 0;
+        if ((rc = sketch_records(c, dW.as<uint64_t>(), dS.as<unsigned long long>(), n_bases, k, w, dH, dP, &total))) break;
+        if ((rc = phi_sync_check(c))) break;
+        *n_out = total;
+        if (cap >= total && total > 0) {
+            std::vector<int64_t> gpos((size_t)total);
+            if (out_hash && (rc = phi_hip_check(c, hipMemcpy(out_hash, dH.p, (size_t)total * 8, hipMemcpyDeviceToHost), "D2H hash"))) break;
+            if ((rc = phi_hip_check(c, hipMemcpy(gpos.data(), dP.p, (size_t)total * 8, hipMemcpyDeviceToHost), "D2H pos"))) break;
+            int64_t s = 0;
+            for (int64_t i = 0; i < total; i++) {
+                while (off[s + 1] <= gpos[i]) s++;
+                if (out_pos) out_pos[i] = gpos[i] - off[s];
+                if (out_seq) out_seq[i] = (int32_t)s;
+            }
+        }
+    } while (0);
+    dev_free(dB); dev_free(dO); dev_free(dW); dev_free(dS); dev_free(dH); dev_free(dP);
+    // a failed stand-alone sketch must not poison later calls on this context
+    (void)hipMemset(c->d_scalars.p, 0, 16);
+    return rc;
+}
+
+int phi_walk_minimizers(phi_ctx *c, int32_t walk, uint64_t *out_hash, int64_t *out_pos, int64_t cap, int64_t *n_out)
+{
+    if (!c || !n_out) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_walk_minimizers before phi_set_graph");
+    if (walk < 0 || walk >= c->n_walks) return phi_fail(c, PHI_ERR_INVALID, "walk out of range");
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t lo = c->h_walk_rec_off[walk], n = c->h_walk_rec_off[walk + 1] - lo;
+    *n_out = n;
+    if (cap < n || n == 0) return PHI_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (out_hash) HIPCHK(hipMemcpy(out_hash, c->d_rec_hash.as<uint64_t>() + lo, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (out_pos) {
+        HIPCHK(hipMemcpy(out_pos, c->d_rec_pos.as<int64_t>() + lo, (size_t)n * 8, hipMemcpyDeviceToHost));
+        const int64_t base = c->h_ebase[c->h_walk_off[walk]];
+        for (int64_t i = 0; i < n; i++) out_pos[i] -= base;
+    }
+    return PHI_OK;
+}
+
+int phi_kept_anchors(phi_ctx *c, uint64_t *out_hash, int32_t *out_walk, int32_t *out_t0, int32_t *out_t1, int64_t cap,
+                     int64_t *n_out)
+{
+    if (!c || !n_out) return PHI_ERR_INVALID;
+    if (!c->solved) return phi_fail(c, PHI_ERR_STATE, "phi_kept_anchors before phi_solve");
+    const int64_t n = (int64_t)c->h_kept.size();
+    *n_out = n;
+    if (cap < n) return PHI_OK;
+    for (int64_t i = 0; i < n; i++) {
+        const PhiAnchorHost &a = c->h_kept[i];
+        const int32_t h = c->h_entry_walk[a.e0];
+        if (out_hash) out_hash[i] = c->h_kept_hash[i];
+        if (out_walk) out_walk[i] = h;
+        if (out_t0) out_t0[i] = a.e0 - (int32_t)c->h_walk_off[h];
+        if (out_t1) out_t1[i] = a.e1 - (int32_t)c->h_walk_off[h];
+    }
+    return PHI_OK;
+}
+
+int phi_prof_enable(phi_ctx *c, int on)
+{
+    if (!c) return PHI_ERR_INVALID;
+    c->prof = on != 0;
+    return PHI_OK;
+}
+
+int phi_prof_read(phi_ctx *c, int64_t *n_launches, double *total_ms, int64_t *total_bases)
+{
+    if (!c) return PHI_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->prof_used; i++) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
+        c->prof_ms_done += ms;
+        c->prof_n_done++;
+    }
+    c->prof_used = 0;
+    if (n_launches) *n_launches = c->prof_n_done;
+    if (total_ms) *total_ms = c->prof_ms_done;
+    if (total_bases) *total_bases = c->prof_bases;
+    c->prof_n_done = 0; c->prof_ms_done = 0.0; c->prof_bases = 0;
+    return PHI_OK;
+}
+
+}  // extern "C"

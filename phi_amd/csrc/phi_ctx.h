@@ -1,0 +1,89 @@
+// phi_ctx.h -- the context behind the opaque phi_ctx handle of include/phi_amd.h.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "../../include/phi_amd.h"
+#include "phi_kernels.h"
+
+// growable device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct PhiAnchorHost {       // one dp anchor on the host (certificate / branch-and-bound)
+    uint32_t slot;           // minimiser identity: slot of the walk-minimiser table
+    int32_t e0, e1;          // first / last walk entry
+};
+
+struct phi_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string last_error;
+
+    // params (main.cpp:118-131)
+    int32_t k = 31, w = 25, recombination = 100;
+    float threshold = 1.0f;
+    uint32_t flags = PHI_FLAG_QCLP | PHI_FLAG_MIXED;
+
+    // ---- graph, host side (decode, validation)
+    bool have_graph = false;
+    int32_t n_vtx = 0, n_walks = 0;
+    std::vector<char> h_seq;
+    std::vector<int64_t> h_seq_off, h_adj_off, h_walk_off, h_ebase, h_vh_off, h_in_off;
+    std::vector<int32_t> h_adj, h_walk_vtx, h_topo_rank, h_topo, h_vh_entry, h_in_src, h_entry_walk;
+    int64_t n_entries = 0, walk_bases = 0;
+
+    // ---- graph, device side
+    DevBuf d_seq, d_seq_off, d_walk_vtx, d_walk_off, d_ebase, d_topo, d_in_off, d_in_src;
+    DevBuf d_wwords, d_wstarts;                       // packed walk sequences + start bitmap
+    DevBuf d_rec_hash, d_rec_pos, d_rec_slot, d_rec_e0, d_rec_e1;   // walk minimiser records
+    int64_t n_rec = 0;
+    std::vector<int64_t> h_walk_rec_off;              // record range of each walk
+    DevBuf d_u_keys, d_u_rep;                         // walk-minimiser table
+    uint64_t u_cap = 0;
+    DevBuf d_hit;                                     // uint8 per record (set at representatives)
+
+    // ---- reads
+    DevBuf d_sp_keys;                                 // read spectrum set
+    uint64_t sp_cap = 0;
+    int64_t sp_bound = 0;                             // host-side upper bound of the set size
+    int64_t reads_bases = 0, reads_count = 0;
+    int64_t spectrum_override = -1;
+    DevBuf d_rbases, d_roff, d_rwords, d_rstarts, d_export;
+    // device scalars: [0] err(u32 in low half) [1] n_bad [2] sp_count [3] n_emitted [4..] scratch
+    DevBuf d_scalars;
+
+    // ---- scratch for sketch passes and compaction
+    DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2;
+
+    // ---- solve state
+    DevBuf d_m_rec, d_m_group, d_g_keys, d_g_rep, d_g_cnt, d_slot_maxcnt, d_slot_multi;
+    DevBuf d_a_e1, d_g_off, d_g_span, d_a_weight;
+    DevBuf d_dmax, d_qbest, d_lent, d_top, d_ent;
+    std::vector<PhiAnchorHost> h_kept, h_dp;          // kept anchors; dp anchors (span >= 1 edge)
+    std::vector<uint64_t> h_kept_hash;
+    std::vector<int32_t> h_path_vtx, h_path_hap;
+    std::vector<int64_t> h_n_minimizers, h_n_anchors;
+    phi_result result{};
+    bool solved = false;
+
+    // ---- profiling of the sketch kernel
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+    int64_t prof_bases = 0;
+    double prof_ms_done = 0.0;
+    int64_t prof_n_done = 0;
+};
+
+// phi_solve.cpp: host orchestration of the exact solve on top of the DP kernel
+int phi_solve_impl(phi_ctx *c);
+// helpers shared between phi_abi.hip and phi_solve.hip
+int phi_fail(phi_ctx *c, int code, const char *fmt, ...);
+int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes);
+int phi_hip_check(phi_ctx *c, hipError_t e, const char *what);
+int phi_sync_check(phi_ctx *c);

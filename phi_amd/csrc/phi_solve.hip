@@ -1,0 +1,439 @@
+// phi_solve.hip -- stages 2b-3 of ILP_function (src/ILP_index.cpp:670-1525) behind phi_solve().
+//
+// Host orchestration of GPU kernels:
+//   1. match + shared-anchor filter                      (anchors.hip)    <- :643-743
+//   2. exact solve replacing model.optimize() (:1418):   (dp.hip)
+//        The reference objective counts each minimiser at most once (z_i, :830/:876):
+//            true(P) = #{i : some anchor of i traversed by P} - 2*(R/2) * #recombinations(P).
+//        The DP maximises an ADDITIVE score sum_a w_a [a traversed] - cost.  Used three ways:
+//          upper bound   for any set S of minimisers:  true(P) <= |S| + DP(w = 1 outside S, 0 on S)
+//          lower bound   true(P) of any path the DP returns
+//          branching     OPT = max over "minimiser i is counted only at cluster c of its anchors"
+//                        (clusters = groups of pairwise mutually exclusive anchors), each child
+//                        again solved by the DP with the other clusters' weights set to 0.
+//        The root closes with one DP run when the optimal path traverses no minimiser twice and
+//        typically with two or three otherwise (S := the doubly-counted minimisers).
+//   3. decode (:1431-1525): path vertices / haplotype labels, recombination count.
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <set>
+#include <unordered_map>
+#include "phi_ctx.h"
+#include "phi_dev.h"
+
+#define HIPCHK(call) do { int rc_ = phi_hip_check(c, (call), #call); if (rc_) return rc_; } while (0)
+#define PHICHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+enum { S_ERR = 0, S_NBAD = 1, S_SPCOUNT = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_N = 8 };
+static uint64_t *scalar(phi_ctx *c, int i) { return c->d_scalars.as<uint64_t>() + i; }
+static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
+
+struct Seg { int32_t h; int32_t es, ee; };     // path segment: walk h, entries es..ee (inclusive)
+
+// flags[n] -> ascending indices in out; *n_out = count
+static int compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_t *n_out)
+{
+    *n_out = 0;
+    const int64_t nb = phi_compact_num_blocks(n);
+    if (nb == 0) return PHI_OK;
+    PHICHK(phi_dev_ensure(c, c->d_blk_cnt, (size_t)nb * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_off, (size_t)(nb + 1) * 8));
+    phi_launch_flag_count(c->stream, flags, n, c->d_blk_cnt.as<int32_t>());
+    phi_launch_scan_counts(c->stream, c->d_blk_cnt.as<int32_t>(), nb, c->d_blk_off.as<int64_t>());
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, c->d_blk_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    PHICHK(phi_dev_ensure(c, out, (size_t)std::max<int64_t>(total, 1) * 4));
+    phi_launch_flag_write(c->stream, flags, n, c->d_blk_off.as<int64_t>(), out.as<int32_t>());
+    *n_out = total;
+    return PHI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ DP
+struct DpHost {
+    std::vector<int32_t> dmax, lent, ent_u, ent_h;
+    std::vector<uint8_t> qbest;
+};
+
+// one DP launch with the given anchor weights; returns its value and the argmax path
+static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_t *value, std::vector<Seg> *segs)
+{
+    const int64_t n_dp = (int64_t)c->h_dp.size();
+    const int64_t ne = c->n_entries;
+    const int32_t nv = c->n_vtx;
+    if (n_dp) HIPCHK(hipMemcpyAsync(c->d_a_weight.p, wgt.data(), (size_t)n_dp, hipMemcpyHostToDevice, c->stream));
+    PhiDpArgs A{};
+    A.n_vtx = nv; A.n_walks = c->n_walks;
+    A.topo = c->d_topo.as<int32_t>();
+    A.in_off = c->d_in_off.as<int64_t>(); A.in_src = c->d_in_src.as<int32_t>();
+    A.walk_off = c->d_walk_off.as<int64_t>(); A.walk_vtx = c->d_walk_vtx.as<int32_t>();
+    A.g_off = c->d_g_off.as<int64_t>(); A.g_span = c->d_g_span.as<uint8_t>(); A.a_weight = c->d_a_weight.as<uint8_t>();
+    A.cost = 2 * (c->recombination / 2);                       // (c_1/2) twice, ILP_index.cpp:1276,1299
+    A.dmax = c->d_dmax.as<int32_t>(); A.qbest = c->d_qbest.as<uint8_t>(); A.lent = c->d_lent.as<int32_t>();
+    int32_t *top = c->d_top.as<int32_t>();
+    A.top1v = top; A.top1h = top + nv; A.top1n = top + 2 * (int64_t)nv; A.top2v = top + 3 * (int64_t)nv; A.top2h = top + 4 * (int64_t)nv;
+    int32_t *ent = c->d_ent.as<int32_t>();
+    A.ent_v = ent; A.ent_u = ent + nv; A.ent_h = ent + 2 * (int64_t)nv;
+    phi_launch_dp(c->stream, A);
+    HIPCHK(hipGetLastError());
+    H.dmax.resize(ne); H.lent.resize(ne); H.qbest.resize(ne); H.ent_u.resize(nv); H.ent_h.resize(nv);
+    HIPCHK(hipMemcpyAsync(H.dmax.data(), A.dmax, (size_t)ne * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(H.lent.data(), A.lent, (size_t)ne * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(H.qbest.data(), A.qbest, (size_t)ne, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(H.ent_u.data(), A.ent_u, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(H.ent_h.data(), A.ent_h, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+
+    // end at (last(h), h) for the best h; ties go to the lowest walk id
+    int32_t bh = -1;
+    int64_t best = INT64_MIN;
+    for (int32_t h = 0; h < c->n_walks; h++) {
+        const int32_t d = H.dmax[c->h_walk_off[h + 1] - 1];
+        if (d > -(1 << 28) && d > best) { best = d; bh = h; }
+    }
+    if (bh < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP found no s->e path (internal error)");
+    *value = best;
+    segs->clear();
+    int32_t h = bh;
+    int64_t e = c->h_walk_off[h + 1] - 1;
+    for (int64_t guard = 0; guard <= (int64_t)nv; guard++) {
+        const int32_t q = H.qbest[e];
+        const int64_t es = (q < PHI_RCAP - 1) ? e - q : c->h_walk_off[h] + H.lent[e];
+        if (es < c->h_walk_off[h] || es > e) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack left the walk (internal error)");
+        segs->push_back(Seg{h, (int32_t)es, (int32_t)e});
+        if (es == c->h_walk_off[h]) break;                     // reached s_{first(h),h}
+        const int32_t v = c->h_walk_vtx[es];
+        const int32_t u = H.ent_u[v], h2 = H.ent_h[v];
+        if (u < 0 || h2 < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack hit a vertex without an entry (internal error)");
+        int64_t e2 = -1;
+        for (int64_t x = c->h_vh_off[u]; x < c->h_vh_off[u + 1]; x++)
+            if (c->h_entry_walk[c->h_vh_entry[x]] == h2) { e2 = c->h_vh_entry[x]; break; }
+        if (e2 < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack: walk %d is not on vertex %d (internal error)", h2, u);
+        h = h2; e = e2;
+    }
+    std::reverse(segs->begin(), segs->end());
+    return PHI_OK;
+}
+
+// dp anchors traversed by a path: calls f(anchor index)
+template <class F> static void for_covered(const phi_ctx *c, const std::vector<Seg> &segs, F f)
+{
+    const std::vector<PhiAnchorHost> &A = c->h_dp;            // sorted by e1
+    for (const Seg &s : segs) {
+        auto lo = std::lower_bound(A.begin(), A.end(), s.es, [](const PhiAnchorHost &a, int32_t e) { return a.e1 < e; });
+        for (auto it = lo; it != A.end() && it->e1 <= s.ee; ++it)
+            if (it->e0 >= s.es) f((int64_t)(it - A.begin()));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ solve
+struct Node {
+    std::vector<std::pair<uint32_t, int32_t>> assign;          // minimiser slot -> chosen cluster
+};
+
+int phi_solve_impl(phi_ctx *c)
+{
+    c->solved = false;
+    PHICHK(phi_sync_check(c));
+    uint64_t sc[S_N];
+    HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
+    const int64_t spectrum = c->spectrum_override >= 0 ? c->spectrum_override : (c->sp_cap ? (int64_t)sc[S_SPCOUNT] : 0);
+    const int64_t n_rec = c->n_rec;
+    const int32_t nw = c->n_walks;
+
+    // ---- 1. anchors = walk minimisers whose hash is in the read spectrum (:495-526)
+    int64_t n_matched = 0;
+    PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)std::max<int64_t>(n_rec, 1)));
+    phi_launch_match_flags(c->stream, c->d_rec_slot.as<uint32_t>(), n_rec, c->d_u_rep.as<uint32_t>(),
+                           c->d_hit.as<uint8_t>(), c->d_flags.as<uint8_t>());
+    PHICHK(compact(c, c->d_flags.as<uint8_t>(), n_rec, c->d_m_rec, &n_matched));
+
+    // ---- 2. shared-anchor filter (:670-743)
+    PhiFilterArgs F{};
+    F.rec_slot = c->d_rec_slot.as<uint32_t>(); F.rec_e0 = c->d_rec_e0.as<int32_t>(); F.rec_e1 = c->d_rec_e1.as<int32_t>();
+    F.walk_vtx = c->d_walk_vtx.as<int32_t>();
+    F.m_rec = c->d_m_rec.as<int32_t>();
+    const uint64_t g_cap = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)n_matched));
+    PHICHK(phi_dev_ensure(c, c->d_g_keys, g_cap * 8));
+    PHICHK(phi_dev_ensure(c, c->d_g_rep, g_cap * 4));
+    PHICHK(phi_dev_ensure(c, c->d_g_cnt, g_cap * 4));
+    PHICHK(phi_dev_ensure(c, c->d_m_group, (size_t)std::max<int64_t>(n_matched, 1) * 4));
+    PHICHK(phi_dev_ensure(c, c->d_slot_maxcnt, c->u_cap * 4));
+    PHICHK(phi_dev_ensure(c, c->d_slot_multi, c->u_cap));
+    F.g_keys = c->d_g_keys.as<uint64_t>(); F.g_rep = c->d_g_rep.as<int32_t>(); F.g_cnt = c->d_g_cnt.as<uint32_t>();
+    F.g_mask = g_cap - 1;
+    F.m_group = c->d_m_group.as<int32_t>();
+    F.slot_maxcnt = c->d_slot_maxcnt.as<uint32_t>(); F.slot_multi = c->d_slot_multi.as<uint8_t>();
+    F.limit = c->threshold * (float)(uint32_t)nw;              // threshold * num_walks, float (:698)
+    F.counters = (unsigned long long *)scalar(c, S_FILTERED);
+    F.err = (uint32_t *)scalar(c, S_ERR);
+    for (int attempt = 0;; attempt++) {
+        F.seed = 0x243F6A8885A308D3ull + 0x9E3779B97F4A7C15ull * (uint64_t)attempt;
+        phi_launch_fill_u64(c->stream, F.g_keys, (int64_t)g_cap, PHI_EMPTY_KEY);
+        phi_launch_fill_u32(c->stream, (uint32_t *)F.g_rep, (int64_t)g_cap, 0xFFFFFFFFu);
+        HIPCHK(hipMemsetAsync(F.g_cnt, 0, g_cap * 4, c->stream));
+        phi_launch_group_insert(c->stream, F, n_matched);
+        phi_launch_group_count(c->stream, F, n_matched);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        uint32_t err = 0;
+        HIPCHK(hipMemcpy(&err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
+        if (err & PHI_KERR_TABLE_FULL) return phi_fail(c, PHI_ERR_OVERFLOW, "anchor group table overflow");
+        if (!(err & PHI_KERR_FP_COLLISION)) break;
+        if (attempt == 7) return phi_fail(c, PHI_ERR_DEVICE, "anchor fingerprints collide under 8 seeds (internal error)");
+        HIPCHK(hipMemset(scalar(c, S_ERR), 0, 4));
+    }
+    HIPCHK(hipMemsetAsync(F.slot_maxcnt, 0, c->u_cap * 4, c->stream));
+    HIPCHK(hipMemsetAsync(F.slot_multi, 0, c->u_cap, c->stream));
+    HIPCHK(hipMemsetAsync(scalar(c, S_FILTERED), 0, 16, c->stream));
+    phi_launch_group_max(c->stream, F, n_matched);
+    phi_launch_slot_count(c->stream, F, (int64_t)c->u_cap);
+    PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)std::max<int64_t>(std::max(n_matched, n_rec), 1)));
+    PHICHK(phi_dev_ensure(c, c->d_flags2, (size_t)std::max<int64_t>(n_matched, 1)));
+    phi_launch_kept_flags(c->stream, F, n_matched, c->d_flags.as<uint8_t>(), c->d_flags2.as<uint8_t>());
+    int64_t n_kept = 0;
+    PHICHK(compact(c, c->d_flags.as<uint8_t>(), n_matched, c->d_list, &n_kept));
+    // kept anchors to the host: record index -> (slot, e0, e1, hash)
+    std::vector<int32_t> k_slot(n_kept), k_e0(n_kept), k_e1(n_kept);
+    c->h_kept_hash.resize(n_kept);
+    if (n_kept) {
+        PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)n_kept * 8));
+        int32_t *k_rec = c->d_list2.as<int32_t>();
+        phi_launch_gather_i32(c->stream, c->d_m_rec.as<int32_t>(), c->d_list.as<int32_t>(), n_kept, k_rec);
+        PHICHK(phi_dev_ensure(c, c->d_a_e1, (size_t)n_kept * 8));
+        int32_t *tmp = c->d_a_e1.as<int32_t>();
+        phi_launch_gather_i32(c->stream, (const int32_t *)c->d_rec_slot.p, k_rec, n_kept, tmp);
+        HIPCHK(hipMemcpyAsync(k_slot.data(), tmp, (size_t)n_kept * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        phi_launch_gather_i32(c->stream, c->d_rec_e0.as<int32_t>(), k_rec, n_kept, tmp);
+        HIPCHK(hipMemcpyAsync(k_e0.data(), tmp, (size_t)n_kept * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        phi_launch_gather_i32(c->stream, c->d_rec_e1.as<int32_t>(), k_rec, n_kept, tmp);
+        HIPCHK(hipMemcpyAsync(k_e1.data(), tmp, (size_t)n_kept * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        phi_launch_gather_u64(c->stream, c->d_rec_hash.as<uint64_t>(), k_rec, n_kept, (uint64_t *)tmp);
+        HIPCHK(hipMemcpyAsync(c->h_kept_hash.data(), tmp, (size_t)n_kept * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
+    const int64_t filtered = (int64_t)sc[S_FILTERED], in_model = (int64_t)sc[S_INMODEL];
+
+    c->h_kept.resize(n_kept);
+    c->h_dp.clear();
+    c->h_n_anchors.assign(nw, 0);
+    for (int64_t i = 0; i < n_kept; i++) {
+        c->h_kept[i] = PhiAnchorHost{(uint32_t)k_slot[i], k_e0[i], k_e1[i]};
+        c->h_n_anchors[c->h_entry_walk[k_e0[i]]]++;
+        if (k_e1[i] > k_e0[i]) c->h_dp.push_back(c->h_kept[i]);     // single-vertex anchors are ignored (:795/:846)
+    }
+    const int64_t n_dp = (int64_t)c->h_dp.size();
+
+    // ---- 3. DP inputs
+    {
+        std::vector<int32_t> a_e1(n_dp);
+        std::vector<uint8_t> a_span(n_dp);
+        for (int64_t i = 0; i < n_dp; i++) {
+            a_e1[i] = c->h_dp[i].e1;
+            a_span[i] = (uint8_t)(c->h_dp[i].e1 - c->h_dp[i].e0);
+            if (i && a_e1[i] < a_e1[i - 1]) return phi_fail(c, PHI_ERR_DEVICE, "dp anchors not sorted by last entry (internal error)");
+            if (c->h_dp[i].e1 - c->h_dp[i].e0 >= PHI_RCAP) return phi_fail(c, PHI_ERR_DEVICE, "anchor spans %d edges (internal error)", c->h_dp[i].e1 - c->h_dp[i].e0);
+        }
+        PHICHK(phi_dev_ensure(c, c->d_a_e1, (size_t)std::max<int64_t>(n_dp, 1) * 4));
+        PHICHK(phi_dev_ensure(c, c->d_g_span, (size_t)std::max<int64_t>(n_dp, 1)));
+        PHICHK(phi_dev_ensure(c, c->d_a_weight, (size_t)std::max<int64_t>(n_dp, 1)));
+        PHICHK(phi_dev_ensure(c, c->d_g_off, (size_t)(c->n_entries + 1) * 8));
+        if (n_dp) {
+            HIPCHK(hipMemcpyAsync(c->d_a_e1.p, a_e1.data(), (size_t)n_dp * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->d_g_span.p, a_span.data(), (size_t)n_dp, hipMemcpyHostToDevice, c->stream));
+        }
+        phi_launch_entry_csr(c->stream, c->d_a_e1.as<int32_t>(), n_dp, c->n_entries, c->d_g_off.as<int64_t>());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        PHICHK(phi_dev_ensure(c, c->d_dmax, (size_t)c->n_entries * 4));
+        PHICHK(phi_dev_ensure(c, c->d_lent, (size_t)c->n_entries * 4));
+        PHICHK(phi_dev_ensure(c, c->d_qbest, (size_t)c->n_entries));
+        PHICHK(phi_dev_ensure(c, c->d_top, (size_t)c->n_vtx * 5 * 4));
+        PHICHK(phi_dev_ensure(c, c->d_ent, (size_t)c->n_vtx * 3 * 4));
+    }
+
+    // ---- 4. exact solve
+    const int64_t cost = 2 * (int64_t)(c->recombination / 2);
+    std::unordered_map<uint32_t, std::vector<int32_t>> slot_anchors;     // minimisers with >= 2 dp anchors
+    {
+        std::unordered_map<uint32_t, int32_t> cnt;
+        for (const PhiAnchorHost &a : c->h_dp) cnt[a.slot]++;
+        for (int64_t i = 0; i < n_dp; i++)
+            if (cnt[c->h_dp[i].slot] >= 2) slot_anchors[c->h_dp[i].slot].push_back((int32_t)i);
+    }
+    // clusters of pairwise mutually exclusive anchors of one minimiser: anchors on different walks
+    // whose topological-rank intervals overlap cannot both be traversed (a path holds one
+    // haplotype label per vertex).  Anything else becomes a singleton cluster.
+    auto clusters_of = [&](uint32_t slot) {
+        const std::vector<int32_t> &idx = slot_anchors[slot];
+        struct Iv { int32_t lo, hi, h, a; };
+        std::vector<Iv> iv;
+        for (int32_t a : idx) {
+            const PhiAnchorHost &A = c->h_dp[a];
+            iv.push_back(Iv{c->h_topo_rank[c->h_walk_vtx[A.e0]], c->h_topo_rank[c->h_walk_vtx[A.e1]], c->h_entry_walk[A.e0], a});
+        }
+        std::sort(iv.begin(), iv.end(), [](const Iv &x, const Iv &y) { return x.lo != y.lo ? x.lo < y.lo : x.a < y.a; });
+        std::vector<std::vector<int32_t>> out;
+        std::vector<Iv> cur;
+        auto flush = [&]() {
+            if (cur.empty()) return;
+            bool ok = true;
+            for (size_t i = 0; i < cur.size() && ok; i++)
+                for (size_t j = i + 1; j < cur.size() && ok; j++)
+                    ok = cur[i].h != cur[j].h && cur[i].lo <= cur[j].hi && cur[j].lo <= cur[i].hi;
+            if (ok) { out.emplace_back(); for (const Iv &x : cur) out.back().push_back(x.a); }
+            else for (const Iv &x : cur) out.push_back({x.a});
+            cur.clear();
+        };
+        int32_t reach = -1;
+        for (const Iv &x : iv) {
+            if (!cur.empty() && x.lo > reach) flush();
+            cur.push_back(x);
+            reach = std::max(reach, x.hi);
+        }
+        flush();
+        return out;
+    };
+
+    DpHost H;
+    std::vector<uint8_t> wgt(n_dp, 1);
+    std::vector<Seg> best_segs;
+    int64_t incumbent = INT64_MIN, global_ub = INT64_MIN;
+    int n_runs = 0;
+    const int max_runs = 256;
+    bool exhausted = false;
+    std::vector<Node> stack;
+    stack.push_back(Node{});
+    std::vector<int64_t> open_ub;                              // bounds of nodes given up on
+    std::vector<int32_t> cov_cnt;                              // scratch: per dp anchor slot counts
+    while (!stack.empty()) {
+        Node node = stack.back();
+        stack.pop_back();
+        std::map<uint32_t, int32_t> assign(node.assign.begin(), node.assign.end());
+        std::map<uint32_t, std::vector<std::vector<int32_t>>> assign_clusters;
+        for (auto &kv : assign) assign_clusters[kv.first] = clusters_of(kv.first);
+        std::set<uint32_t> S;
+        std::set<std::set<uint32_t>> seenS;
+        bool closed = false;
+        int64_t node_ub = INT64_MAX;
+        uint32_t branch_slot = 0;
+        bool have_branch = false;
+        for (int iter = 0; iter < 8 && !closed; iter++) {
+            if (n_runs >= max_runs) { exhausted = true; break; }
+            // weights of this relaxation
+            std::fill(wgt.begin(), wgt.end(), 1);
+            for (uint32_t s : S) for (int32_t a : slot_anchors[s]) wgt[a] = 0;
+            for (auto &kv : assign) {
+                if (S.count(kv.first)) continue;
+                const auto &cl = assign_clusters[kv.first];
+                for (size_t ci = 0; ci < cl.size(); ci++)
+                    if ((int32_t)ci != kv.second) for (int32_t a : cl[ci]) wgt[a] = 0;
+            }
+            int64_t val = 0;
+            std::vector<Seg> segs;
+            PHICHK(run_dp(c, wgt, H, &val, &segs));
+            n_runs++;
+            // exact value of this path and its additive value under wgt
+            std::unordered_map<uint32_t, int32_t> cov_all, cov_w;
+            int64_t add_w = 0;
+            for_covered(c, segs, [&](int64_t a) {
+                cov_all[c->h_dp[a].slot]++;
+                if (wgt[a]) { cov_w[c->h_dp[a].slot]++; add_w++; }
+            });
+            const int64_t n_sw = (int64_t)segs.size() - 1;
+            add_w -= cost * n_sw;
+            if (add_w != val) return phi_fail(c, PHI_ERR_DEVICE, "DP value %lld != value %lld of its own path (internal error)", (long long)val, (long long)add_w);
+            const int64_t true_val = (int64_t)cov_all.size() - cost * n_sw;
+            if (true_val > incumbent) { incumbent = true_val; best_segs = segs; }
+            const int64_t ub = val + (int64_t)S.size();
+            node_ub = std::min(node_ub, ub);
+            if (n_runs == 1) global_ub = ub;
+            if (node_ub <= incumbent) { closed = true; break; }
+            // tighten: bound doubly-counted minimisers by the constant 1, release unused constants
+            std::set<uint32_t> D, Z;
+            for (auto &kv : cov_w) if (kv.second >= 2) D.insert(kv.first);
+            for (uint32_t s : S) {
+                // is any anchor this node still allows for s traversed?
+                bool covered = false;
+                if (cov_all.count(s)) {
+                    auto it = assign.find(s);
+                    if (it == assign.end()) covered = true;
+                    else {
+                        const auto &cl = assign_clusters[s][it->second];
+                        for_covered(c, segs, [&](int64_t a) {
+                            if (c->h_dp[a].slot == s && std::find(cl.begin(), cl.end(), (int32_t)a) != cl.end()) covered = true;
+                        });
+                    }
+                }
+                if (!covered) Z.insert(s);
+            }
+            if (D.empty() && Z.empty()) { closed = true; break; }   // bound attained by this path
+            // remember a branching candidate in canonical (first anchor) order
+            {
+                int32_t best_a = INT32_MAX;
+                for (uint32_t s : D) if (slot_anchors[s][0] < best_a) { best_a = slot_anchors[s][0]; branch_slot = s; }
+                if (D.empty()) for (uint32_t s : Z) if (!assign.count(s) && slot_anchors[s][0] < best_a) { best_a = slot_anchors[s][0]; branch_slot = s; }
+                have_branch = best_a != INT32_MAX;
+            }
+            std::set<uint32_t> S2 = S;
+            for (uint32_t s : D) S2.insert(s);
+            for (uint32_t s : Z) S2.erase(s);
+            if (S2 == S || seenS.count(S2)) break;
+            seenS.insert(S);
+            S = S2;
+        }
+        if (closed) continue;
+        if (exhausted || !have_branch) { open_ub.push_back(node_ub); if (exhausted) break; continue; }
+        const auto cl = clusters_of(branch_slot);
+        for (int32_t ci = (int32_t)cl.size() - 1; ci >= 0; ci--) {
+            Node ch = node;
+            ch.assign.emplace_back(branch_slot, ci);
+            stack.push_back(ch);
+        }
+    }
+    for (const Node &n : stack) { (void)n; open_ub.push_back(global_ub); }
+    int64_t ub = incumbent;
+    for (int64_t u : open_ub) ub = std::max(ub, u);
+
+    // ---- 5. decode (:1431-1525)
+    c->h_path_vtx.clear();
+    c->h_path_hap.clear();
+    int64_t hap_len = 0;
+    for (const Seg &s : best_segs)
+        for (int32_t e = s.es; e <= s.ee; e++) {
+            const int32_t v = c->h_walk_vtx[e];
+            c->h_path_vtx.push_back(v);
+            c->h_path_hap.push_back(s.h);
+            hap_len += c->h_seq_off[v + 1] - c->h_seq_off[v];
+        }
+    int32_t recomb = 0;
+    for (size_t i = 1; i < c->h_path_hap.size(); i++) recomb += c->h_path_hap[i] != c->h_path_hap[i - 1];   // :1517-1519
+    std::unordered_map<uint32_t, int32_t> cov;
+    for_covered(c, best_segs, [&](int64_t a) { cov[c->h_dp[a].slot]++; });
+
+    phi_result &R = c->result;
+    R.objective = incumbent;
+    R.upper_bound = ub;
+    R.optimal = ub == incumbent;
+    R.n_dp_runs = n_runs;
+    R.n_covered = (int64_t)cov.size();
+    R.n_path = (int64_t)c->h_path_vtx.size();
+    R.path_vtx = c->h_path_vtx.data();
+    R.path_hap = c->h_path_hap.data();
+    R.recombination_count = recomb;
+    R.n_switches = (int32_t)best_segs.size() - 1;
+    R.hap_len = hap_len;
+    R.n_walks = nw;
+    R.n_minimizers = c->h_n_minimizers.data();
+    R.n_anchors = c->h_n_anchors.data();
+    R.spectrum_size = spectrum;
+    R.filtered = filtered;
+    R.retained = spectrum - filtered;
+    R.n_in_model = in_model;
+    c->solved = true;
+    return PHI_OK;
+}

@@ -1,0 +1,124 @@
+// table.hip -- open-addressed hash tables in HBM (linear probing, 64-bit keys, atomicCAS).
+//
+// Replaces the reference's std::map<uint64_t,int32_t> Sp_R (src/ILP_index.cpp:616-635) and the
+// per-minimiser std::map::find of compute_anchors (:495-526).  Roles are swapped with respect to
+// the reference so that reads can stream and shard across GPUs: the table is built once from
+// the walk minimisers (the "index"), reads probe it; a second set holds the distinct read
+// hashes only to report |Sp_R| (:641).
+#include <hip/hip_runtime.h>
+#include "phi_dev.h"
+#include "phi_kernels.h"
+
+__global__ void phi_fill_u64_kernel(uint64_t *p, int64_t n, uint64_t v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+__global__ void phi_fill_u32_kernel(uint32_t *p, int64_t n, uint32_t v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+static inline unsigned grid_for(int64_t n, int tpb)
+{
+    int64_t nb = (n + tpb - 1) / tpb;
+    if (nb > 256 * 16) nb = 256 * 16;        // grid-stride beyond 16 workgroups per CU
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}
+
+void phi_launch_fill_u64(hipStream_t st, uint64_t *p, int64_t n, uint64_t v)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_fill_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, n, v);
+}
+void phi_launch_fill_u32(hipStream_t st, uint32_t *p, int64_t n, uint32_t v)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_fill_u32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, n, v);
+}
+
+__global__ void __launch_bounds__(256) phi_table_build_kernel(const uint64_t *__restrict__ rec_hash, int64_t n_rec,
+                                                              uint64_t *__restrict__ u_keys,
+                                                              uint32_t *__restrict__ u_rep, uint64_t u_mask,
+                                                              uint32_t *__restrict__ rec_slot,
+                                                              uint32_t *__restrict__ err)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = rec_hash[i];
+        if (h == PHI_EMPTY_KEY) { atomicOr(err, PHI_KERR_SENTINEL); rec_slot[i] = 0; continue; }
+        uint64_t slot = h & u_mask;
+        int probes = 0;
+        for (;;) {
+            const unsigned long long prev = atomicCAS((unsigned long long *)&u_keys[slot], PHI_EMPTY_KEY, h);
+            if (prev == PHI_EMPTY_KEY || prev == h) break;
+            slot = (slot + 1) & u_mask;
+            if (++probes > PHI_MAX_PROBE) { atomicOr(err, PHI_KERR_TABLE_FULL); break; }
+        }
+        atomicMin(&u_rep[slot], (uint32_t)i);     // smallest record index: same on every rank
+        rec_slot[i] = (uint32_t)slot;
+    }
+}
+
+void phi_launch_table_build(hipStream_t st, const uint64_t *rec_hash, int64_t n_rec, uint64_t *u_keys,
+                            uint32_t *u_rep, uint64_t u_mask, uint32_t *rec_slot, uint32_t *err)
+{
+    if (n_rec > 0)
+        hipLaunchKernelGGL(phi_table_build_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, st, rec_hash, n_rec,
+                           u_keys, u_rep, u_mask, rec_slot, err);
+}
+
+__global__ void __launch_bounds__(256) phi_spectrum_insert_kernel(const uint64_t *__restrict__ hashes, int64_t n,
+                                                                  uint64_t *__restrict__ sp_keys, uint64_t sp_mask,
+                                                                  unsigned long long *__restrict__ sp_count,
+                                                                  uint32_t *__restrict__ err)
+{
+    int n_new = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = hashes[i];
+        if (h == PHI_EMPTY_KEY) continue;
+        uint64_t slot = h & sp_mask;
+        int probes = 0;
+        for (;;) {
+            const unsigned long long prev = atomicCAS((unsigned long long *)&sp_keys[slot], PHI_EMPTY_KEY, h);
+            if (prev == PHI_EMPTY_KEY) { n_new++; break; }
+            if (prev == h) break;
+            slot = (slot + 1) & sp_mask;
+            if (++probes > PHI_MAX_PROBE) { atomicOr(err, PHI_KERR_TABLE_FULL); break; }
+        }
+    }
+    if (n_new) atomicAdd(sp_count, (unsigned long long)n_new);
+}
+
+void phi_launch_spectrum_insert(hipStream_t st, const uint64_t *hashes, int64_t n, uint64_t *sp_keys,
+                                uint64_t sp_mask, unsigned long long *sp_count, uint32_t *err)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(phi_spectrum_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, hashes, n, sp_keys,
+                           sp_mask, sp_count, err);
+}
+
+__global__ void __launch_bounds__(256) phi_spectrum_export_kernel(const uint64_t *__restrict__ sp_keys, int64_t cap,
+                                                                  uint64_t *__restrict__ out,
+                                                                  unsigned long long *__restrict__ n_out)
+{
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < cap; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = i0 + threadIdx.x;
+        const uint64_t key = i < cap ? sp_keys[i] : PHI_EMPTY_KEY;
+        const bool occ = key != PHI_EMPTY_KEY;
+        const unsigned long long bal = __ballot(occ);
+        const int lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == 0 && bal) base = atomicAdd(n_out, (unsigned long long)__popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (occ) out[base + __popcll(bal & ((1ull << lane) - 1))] = key;
+    }
+}
+
+void phi_launch_spectrum_export(hipStream_t st, const uint64_t *sp_keys, int64_t cap, uint64_t *out,
+                                unsigned long long *n_out)
+{
+    if (cap > 0)
+        hipLaunchKernelGGL(phi_spectrum_export_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, st, sp_keys, cap, out,
+                           n_out);
+}

@@ -1,0 +1,59 @@
+"""Regenerates the golden fixtures under tests/golden/ (run in the build container, where
+/root/reference exists and oracle/_ref/libphi_ref.so has been built by `make -C oracle`).
+
+  murmur_vectors.json   inputs + outputs of the REFERENCE's MurmurHash3_x64_128 (folded h1^h2 as in
+                        ILP_index.cpp:10-18), produced by the reference's own MurmurHash3.cpp
+  gfa_flatten.json      segments / arcs / walks of test/test.gfa as the REFERENCE's gfa_read() parses
+                        them, flattened as ILP_index::read_gfa does; plus digests for test/MHC_4.gfa.gz
+  hap_names.json        outputs of the reference's get_hap_name() (misc.cpp:58-87)
+  counters.json         NOT regenerated here: the counters the reference logged on its own fixtures,
+                        recorded in SURVEY.md section 8(c) (the ILP_index.cpp TU needs gurobi_c++.h,
+                        absent from this image, so it cannot be rebuilt)
+"""
+import hashlib
+import json
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    R = O.ref()
+    rnd = random.Random(20251003)
+    vec = []
+    for n in list(range(0, 49)) + [63, 64, 65, 127, 255]:
+        for _ in range(3):
+            b = bytes(rnd.choice(b"ACGT") for _ in range(n)) if rnd.random() < 0.7 else bytes(rnd.randrange(256) for _ in range(n))
+            vec.append({"hex": b.hex(), "hash": str(R.ref_hash128_to_64(b, n))})
+    json.dump(vec, open(os.path.join(HERE, "murmur_vectors.json"), "w"), indent=0)
+
+    data = os.path.join(HERE, "data")
+    g = O.ref_parse_gfa(os.path.join(data, "test.gfa"))
+    out = {"test.gfa": {"seg_names": g.seg_names, "node_seq": [s.decode() for s in g.node_seq],
+                         "adj": [sorted(a) for a in g.adj], "paths": g.paths, "hap_names": g.hap_names}}
+    g = O.ref_parse_gfa(os.path.join(data, "MHC_4.gfa.gz"))
+    A = g.arrays()
+    adj_sorted = [sorted(a) for a in g.adj]
+    out["MHC_4.gfa.gz"] = {
+        "n_vtx": g.n_vtx, "n_edges": int(A["adj_off"][-1]), "hap_names": g.hap_names,
+        "walk_len": [len(p) for p in g.paths],
+        "sha256_seq": hashlib.sha256(A["seq_concat"]).hexdigest(),
+        "sha256_seq_off": hashlib.sha256(A["seq_off"].tobytes()).hexdigest(),
+        "sha256_adj_sorted": hashlib.sha256(json.dumps(adj_sorted).encode()).hexdigest(),
+        "sha256_walk_vtx": hashlib.sha256(A["walk_vtx"].tobytes()).hexdigest(),
+    }
+    json.dump(out, open(os.path.join(HERE, "gfa_flatten.json"), "w"))
+
+    names = []
+    for gfa, rd in [("test/MHC_4.gfa.gz", "test/CHM13_reads.fq.gz"), ("a.gfa", "r.fa"), ("/x/y/z.v1.gfa", "../q/reads.fastq.gz"),
+                    ("graph", "reads"), ("dir.d/graph.gfa", "dir.e/reads")]:
+        names.append({"gfa": gfa, "reads": rd, "name": O.ref_hap_name(gfa, rd)})
+    json.dump(names, open(os.path.join(HERE, "hap_names.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,221 @@
+"""GPU parity tests: the HIP path, through the C ABI, against the CPU oracle and the golden counters.
+
+Bit-exact bar: hashes, positions, counters, anchors and objective values are integers and must be
+equal.  Run on the GPU box with `pytest -m gpu`.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLDEN
+from graphgen import mosaic_reads, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _set_graph(ctx, g):
+    A = g.arrays()
+    ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
+
+
+# --------------------------------------------------------------------------- sketch kernel
+
+@pytest.mark.parametrize("k,w", [(31, 25), (3, 2), (15, 10), (32, 1), (1, 1), (21, 64), (31, 200), (5, 9)])
+def test_sketch_random_sequences(oracle, ctx_factory, k, w):
+    rng = np.random.default_rng(1000 * k + w)
+    ctx = ctx_factory()
+    seqs = []
+    for L in [0, 1, k - 1, k, k + w - 2, k + w - 1, k + w, 150, 151, 2047, 2048, 2049, 5000, 0, 33, 12345]:
+        L = max(L, 0)
+        seqs.append(bytes(rng.choice(list(b"ACGT"), size=L).tolist()))
+    # low-complexity and mixed-case sequences exercise ties and upper-casing
+    seqs.append(b"A" * 300)
+    seqs.append(b"ACACACACACACACACACACACACACACACACACACACACACACACACACACACACACACACAC" * 5)
+    seqs.append(bytes(rng.choice(list(b"acgtACGT"), size=700).tolist()))
+    seqs.append((b"ACGTTGCA" * 40 + b"T" * 50) * 3)
+    h, p, s = ctx.sketch(seqs, k, w)
+    eh, ep, es = [], [], []
+    for i, q in enumerate(seqs):
+        a, b = oracle.sketch(q, k, w)
+        eh.append(a); ep.append(b); es.append(np.full(len(a), i, np.int32))
+    eh, ep, es = np.concatenate(eh), np.concatenate(ep), np.concatenate(es)
+    assert len(h) == len(eh)
+    assert np.array_equal(s, es)
+    assert np.array_equal(p, ep)
+    assert np.array_equal(h, eh)
+
+
+def test_sketch_many_short_reads(oracle, ctx_factory):
+    """Ragged 150-bp-like reads crossing many chunk seams."""
+    rng = np.random.default_rng(7)
+    ctx = ctx_factory()
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=int(L)).tolist()) for L in rng.integers(40, 260, size=400)]
+    h, p, s = ctx.sketch(seqs, 31, 25)
+    eh = np.concatenate([oracle.sketch(q, 31, 25)[0] for q in seqs])
+    ep = np.concatenate([oracle.sketch(q, 31, 25)[1] for q in seqs])
+    assert np.array_equal(h, eh) and np.array_equal(p, ep)
+
+
+def test_sketch_empty_and_errors(ctx_factory):
+    import phi_amd
+    ctx = ctx_factory()
+    h, p, s = ctx.sketch([], 31, 25)
+    assert len(h) == 0
+    h, p, s = ctx.sketch([b"", b""], 31, 25)
+    assert len(h) == 0
+    with pytest.raises(phi_amd.PhiError) as e:
+        ctx.sketch([b"ACGT"], 33, 25)
+    assert e.value.status == phi_amd.PHI_ERR_INVALID
+    with pytest.raises(phi_amd.PhiError) as e:
+        ctx.sketch([b"ACGTNACGT" * 20], 5, 3)
+    assert e.value.status == phi_amd.PHI_ERR_UNSUPPORTED
+    # the context stays usable after a failed call
+    h, p, s = ctx.sketch([b"ACGTACGTAGCTAGCTAGCTAGCATCGATCGATCAGCTAGCTAGCATCGAT"], 5, 3)
+    assert len(h) > 0
+
+
+# --------------------------------------------------------------------------- full path, small
+
+def _check_against_oracle(oracle, ctx, g, reads, k, w, T, R):
+    from oracle import solve_oracle as S
+    st = oracle.run_stage12(g, reads, k, w, T)
+    res = ctx.solve()
+    # stage 1: walk minimisers (hash, position)
+    for hh in range(g.n_walks):
+        gh, gp = ctx.walk_minimizers(hh)
+        lo, hi = st.m_off[hh], st.m_off[hh + 1]
+        assert np.array_equal(gh, st.m_hash[lo:hi]), f"walk {hh} hashes"
+        assert np.array_equal(gp, st.m_pos[lo:hi]), f"walk {hh} positions"
+    assert np.array_equal(res["n_minimizers"], st.n_minimizers)
+    # stage 2: counters and kept anchors
+    assert res["spectrum_size"] == len(st.spectrum)
+    assert res["filtered"] == st.filtered
+    assert res["retained"] == st.retained
+    assert res["n_in_model"] == st.n_in_model
+    assert np.array_equal(res["n_anchors"], st.n_anchors)
+    kh, kw, k0, k1 = ctx.kept_anchors()
+    exp = sorted(zip(st.spectrum[st.a_r].tolist(), st.a_h.tolist(), st.a_t0.tolist(), st.a_t1.tolist()))
+    got = sorted(zip(kh.tolist(), kw.tolist(), k0.tolist(), k1.tolist()))
+    assert got == exp
+    # stage 3: the decoded path is feasible on the restated model and attains the reported objective
+    m = S.Model(g, st, R)
+    states = S.states_from_path(res["path_vtx"], res["path_hap"])
+    obj, cov, nsw = m.objective(states)
+    assert obj == res["objective"]
+    assert cov == res["n_covered"]
+    assert nsw == res["n_switches"]
+    assert res["optimal"] == 1 and res["upper_bound"] == res["objective"]
+    seq = ctx.path_sequence(res["hap_len"])
+    assert seq == b"".join(g.node_seq[v] for v in res["path_vtx"])
+    return st, res, m
+
+
+def test_reference_toy_graph(oracle, ctx_factory):
+    """test/test.gfa + test/read.fa at -k3 -w2: the reference's counters."""
+    g = oracle.parse_gfa(os.path.join(DATA, "test.gfa"))
+    reads = [s for _, s in oracle.read_reads(os.path.join(DATA, "read.fa"))]
+    gold = json.load(open(os.path.join(GOLDEN, "counters.json")))["test_gfa_k3_w2"]
+    for R in (100, 2, 0):
+        ctx = ctx_factory(k=3, w=2, threshold=1.0, recombination=R)
+        _set_graph(ctx, g)
+        ctx.add_reads(reads)
+        st, res, m = _check_against_oracle(oracle, ctx, g, reads, 3, 2, 1.0, R)
+        assert res["n_minimizers"].tolist() == gold["n_minimizers"]
+        assert res["spectrum_size"] == gold["spectrum_size"]
+        assert res["n_anchors"].tolist() == gold["n_anchors"]
+        assert res["filtered"] == gold["filtered"] and res["n_in_model"] == gold["n_in_model"]
+        best, arg = m.brute_force()
+        assert res["objective"] == best
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_small_graphs_vs_brute_force(oracle, ctx_factory, seed):
+    rng = np.random.default_rng(seed)
+    k, w = int(rng.integers(3, 8)), int(rng.integers(1, 5))
+    rep = bytes(rng.choice(list(b"ACGT"), size=k + 3).tolist()) if seed % 2 else None
+    g = random_graph(rng, n_sites=int(rng.integers(3, 6)), n_walks=int(rng.integers(2, 5)), repeat=rep)
+    reads = mosaic_reads(rng, g, n_reads=25, read_len=k + w + 8, n_seg=2)
+    R = int(rng.choice([0, 1, 2, 3, 100]))
+    T = float(rng.choice([1.0, 0.5, 2.0]))
+    ctx = ctx_factory(k=k, w=w, threshold=T, recombination=R)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads)
+    st, res, m = _check_against_oracle(oracle, ctx, g, reads, k, w, T, R)
+    best, arg = m.brute_force()
+    assert res["objective"] == best, (seed, k, w, R, T)
+
+
+def test_streaming_batches_equal_one_batch(oracle, ctx_factory):
+    rng = np.random.default_rng(5)
+    g = random_graph(rng, n_sites=8, n_walks=4, seg_len=(8, 30))
+    reads = mosaic_reads(rng, g, n_reads=60, read_len=30, n_seg=3, err=0.02)
+    a = ctx_factory(k=7, w=4, threshold=1.0, recombination=5)
+    _set_graph(a, g)
+    a.add_reads(reads)
+    ra = a.solve()
+    b = ctx_factory(k=7, w=4, threshold=1.0, recombination=5)
+    _set_graph(b, g)
+    for i in range(0, len(reads), 7):
+        b.add_reads(reads[i:i + 7])
+    b.add_reads([])
+    rb = b.solve()
+    for key in ("objective", "spectrum_size", "filtered", "n_in_model", "n_covered"):
+        assert ra[key] == rb[key]
+    assert np.array_equal(ra["path_vtx"], rb["path_vtx"]) and np.array_equal(ra["path_hap"], rb["path_hap"])
+    # reset forgets the reads but keeps the index
+    b.reset_reads()
+    b.add_reads(reads)
+    rc = b.solve()
+    assert rc["objective"] == ra["objective"] and rc["spectrum_size"] == ra["spectrum_size"]
+
+
+def test_bad_inputs(oracle, ctx_factory):
+    import phi_amd
+    g = oracle.parse_gfa(os.path.join(DATA, "test.gfa"))
+    A = g.arrays()
+    ctx = ctx_factory(k=3, w=2)
+    with pytest.raises(phi_amd.PhiError) as e:
+        ctx.solve()
+    assert e.value.status == phi_amd.PHI_ERR_STATE
+    # a walk that jumps over a missing edge (the reference exits at ILP_index.cpp:1568-1572)
+    wv = A["walk_vtx"].copy()
+    wv[1] = 2 if wv[1] == 1 else 1
+    wv[2] = 7
+    with pytest.raises(phi_amd.PhiError) as e:
+        ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], wv, A["top_rank"])
+    assert e.value.status == phi_amd.PHI_ERR_WALK
+    # a rank array that is not a topological order
+    tr = A["top_rank"].copy()
+    tr[[0, 7]] = tr[[7, 0]]
+    with pytest.raises(phi_amd.PhiError) as e:
+        ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], tr)
+    assert e.value.status == phi_amd.PHI_ERR_INVALID
+    # and the context still works afterwards
+    _set_graph(ctx, g)
+    ctx.add_reads([b"ATCGATCATACTTACCATG"])
+    assert ctx.solve()["objective"] == 4
+
+
+# --------------------------------------------------------------------------- config 1 (reference fixtures)
+
+def test_config1_mhc4(oracle, ctx_factory):
+    """test/MHC_4.gfa.gz + test/CHM13_reads.fq.gz, defaults: every counter the reference logs."""
+    gold = json.load(open(os.path.join(GOLDEN, "counters.json")))["mhc4_chm13_k31_w25"]
+    g = oracle.parse_gfa(os.path.join(DATA, "MHC_4.gfa.gz"))
+    reads = [s for _, s in oracle.read_reads(os.path.join(DATA, "CHM13_reads.fq.gz"))]
+    ctx = ctx_factory(k=31, w=25, threshold=1.0, recombination=100)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads)
+    st, res, m = _check_against_oracle(oracle, ctx, g, reads, 31, 25, 1.0, 100)
+    assert g.hap_names == gold["hap_names"]
+    assert res["n_minimizers"].tolist() == gold["n_minimizers"]
+    assert res["spectrum_size"] == gold["spectrum_size"]
+    assert res["n_anchors"].tolist() == gold["n_anchors"]
+    assert res["n_in_model"] == gold["n_in_model"]
+    assert "%.2f/%.2f" % (res["filtered"] / res["spectrum_size"] * 100, res["retained"] / res["spectrum_size"] * 100) == gold["filtered_retained_pct"]
+    assert "%.2f" % (res["n_in_model"] * 100.0 / res["spectrum_size"]) == gold["pct_in_model"]
+    print("config1 objective", res["objective"], "dp runs", res["n_dp_runs"], "recomb", res["recombination_count"])
+    if "objective_highs" in gold:
+        assert res["objective"] == gold["objective_highs"]
