@@ -83,14 +83,17 @@ int phi_add_reads_device(phi_ctx *ctx, const void *d_bases, const void *d_read_o
                          int64_t n_bases);
 /* Forget all reads seen so far (graph index is kept). */
 int phi_reset_reads(phi_ctx *ctx);
+/* Totals since the last reset (waits for the stream): reads, bases, emitted read minimisers
+ * (with multiplicity) and distinct read hashes so far. */
+int phi_reads_stats(phi_ctx *ctx, int64_t *n_reads, int64_t *n_bases, int64_t *n_emitted, int64_t *n_distinct);
 
 /*
  * Multi-GPU exchange (no reference counterpart: the reference is one process).  Each rank holds
  * a shard of the reads; before phi_solve the caller all-reduces (MAX) the hit vector in place
  * and tells every rank the size of the union spectrum.
- *   phi_hits_buffer     device pointer to uint8 hit[n], n = number of walk minimiser records
- *                       (same on every rank: records are in deterministic position order and a
- *                       hit is stored at the first record carrying that hash)
+ *   phi_hits_buffer     device pointer to uint8 hit[n], n = number of distinct walk minimisers;
+ *                       index = dense minimiser id (rank of the hash's first occurrence in walk
+ *                       position order), identical on every rank for the same graph
  *   phi_spectrum_export this rank's distinct read hashes: device pointer to uint64[n]
  *                       (valid until the next call on this context)
  *   phi_spectrum_import insert another rank's exported hashes (a device buffer the caller owns)

@@ -17,7 +17,7 @@ PHI_FLAG_QCLP, PHI_FLAG_MIXED = 1, 2
 # every symbol include/phi_amd.h declares
 SYMBOLS = [
     "phi_strerror", "phi_last_error", "phi_ctx_create", "phi_ctx_destroy", "phi_set_stream", "phi_set_params",
-    "phi_set_graph", "phi_add_reads", "phi_add_reads_device", "phi_reset_reads", "phi_hits_buffer",
+    "phi_set_graph", "phi_add_reads", "phi_add_reads_device", "phi_reset_reads", "phi_reads_stats", "phi_hits_buffer",
     "phi_spectrum_export", "phi_spectrum_import", "phi_spectrum_set_size", "phi_solve", "phi_path_sequence",
     "phi_sketch", "phi_walk_minimizers", "phi_kept_anchors", "phi_prof_enable", "phi_prof_read",
 ]
@@ -60,6 +60,7 @@ def load():
     L.phi_add_reads.argtypes = [vp, vp, vp, i64]
     L.phi_add_reads_device.argtypes = [vp, vp, vp, i64, i64]
     L.phi_reset_reads.argtypes = [vp]
+    L.phi_reads_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.phi_hits_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.phi_spectrum_export.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.phi_spectrum_import.argtypes = [vp, vp, i64]

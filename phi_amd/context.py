@@ -81,6 +81,11 @@ class Context:
     def reset_reads(self):
         self._chk(self._L.phi_reset_reads(self._h))
 
+    def reads_stats(self):
+        a, b, e, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._L.phi_reads_stats(self._h, C.byref(a), C.byref(b), C.byref(e), C.byref(d)))
+        return dict(n_reads=a.value, n_bases=b.value, n_emitted=e.value, n_distinct=d.value)
+
     # ------------------------------------------------------------------ multi-GPU hooks
     def hits_buffer(self):
         p, n = C.c_void_p(), C.c_int64()

@@ -143,19 +143,19 @@ void phi_launch_flag_write(hipStream_t st, const uint8_t *flags, int64_t n, cons
 // ------------------------------------------------------------------------- match
 // compute_anchors: a walk minimiser is an anchor iff its hash is in the read spectrum.
 __global__ void __launch_bounds__(256) phi_match_flags_kernel(const uint32_t *__restrict__ rec_slot, int64_t n_rec,
-                                                              const uint32_t *__restrict__ u_rep,
+                                                              const uint32_t *__restrict__ u_uid,
                                                               const uint8_t *__restrict__ hit,
                                                               uint8_t *__restrict__ flags)
 {
-    GRID_STRIDE(i, n_rec) flags[i] = hit[u_rep[rec_slot[i]]];
+    GRID_STRIDE(i, n_rec) flags[i] = hit[u_uid[rec_slot[i]]];
 }
 
-void phi_launch_match_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_rec, const uint32_t *u_rep,
+void phi_launch_match_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_rec, const uint32_t *u_uid,
                             const uint8_t *hit, uint8_t *flags)
 {
     if (n_rec > 0)
         hipLaunchKernelGGL(phi_match_flags_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, st, rec_slot, n_rec,
-                           u_rep, hit, flags);
+                           u_uid, hit, flags);
 }
 
 // ------------------------------------------------------------------------- filter groups

@@ -116,7 +116,7 @@ void phi_ctx_destroy(phi_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_wwords, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
-                     &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
+                     &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
                      &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_blk_cnt,
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
@@ -315,6 +315,14 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     phi_launch_table_build(c->stream, c->d_rec_hash.as<uint64_t>(), c->n_rec, c->d_u_keys.as<uint64_t>(),
                            c->d_u_rep.as<uint32_t>(), c->u_cap - 1, c->d_rec_slot.as<uint32_t>(),
                            (uint32_t *)scalar(c, S_ERR));
+    // dense, rank-independent minimiser ids: rank of the first record of each hash in position order
+    PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)nr));
+    phi_launch_rep_flags(c->stream, c->d_rec_slot.as<uint32_t>(), c->n_rec, c->d_u_rep.as<uint32_t>(),
+                         c->d_flags.as<uint8_t>());
+    PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), c->n_rec, c->d_m_rec, &c->n_unique));
+    PHICHK(phi_dev_ensure(c, c->d_u_uid, c->u_cap * 4));
+    phi_launch_slot_uid(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_slot.as<uint32_t>(),
+                        c->d_u_uid.as<uint32_t>());
     phi_launch_locate(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_ebase.as<int64_t>(), n_entries, c->k,
                       c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>());
     // records of each walk ("Number of Minimizers", ILP_index.cpp:563)
@@ -323,8 +331,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                            c->d_list2.as<int64_t>());
     c->h_walk_rec_off.resize(n_walks + 1);
     HIPCHK(hipMemcpyAsync(c->h_walk_rec_off.data(), c->d_list2.p, (size_t)(n_walks + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    PHICHK(phi_dev_ensure(c, c->d_hit, (size_t)nr));
-    HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)nr, c->stream));
+    PHICHK(phi_dev_ensure(c, c->d_hit, (size_t)std::max<int64_t>(c->n_unique, 1)));
+    HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)std::max<int64_t>(c->n_unique, 1), c->stream));
     HIPCHK(hipGetLastError());
     PHICHK(phi_sync_check(c));
     c->h_n_minimizers.resize(n_walks);
@@ -397,7 +405,7 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     A.sp_keys = c->d_sp_keys.as<uint64_t>(); A.sp_mask = c->sp_cap - 1;
     A.sp_count = (unsigned long long *)scalar(c, S_SPCOUNT);
     A.n_emitted = (unsigned long long *)scalar(c, S_NEMIT);
-    A.u_keys = c->d_u_keys.as<uint64_t>(); A.u_rep = c->d_u_rep.as<uint32_t>(); A.u_mask = c->u_cap - 1;
+    A.u_keys = c->d_u_keys.as<uint64_t>(); A.u_uid = c->d_u_uid.as<uint32_t>(); A.u_mask = c->u_cap - 1;
     A.hit = c->d_hit.as<uint8_t>();
     A.err = (uint32_t *)scalar(c, S_ERR);
     if (c->prof) {
@@ -452,9 +460,24 @@ int phi_reset_reads(phi_ctx *c)
     HIPCHK(hipSetDevice(c->device));
     if (c->sp_cap) phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, PHI_EMPTY_KEY);
     HIPCHK(hipMemsetAsync(scalar(c, S_SPCOUNT), 0, 16, c->stream));       // sp_count and n_emitted
-    HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)std::max<int64_t>(c->n_rec, 1), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)std::max<int64_t>(c->n_unique, 1), c->stream));
     c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
     c->solved = false;
+    return PHI_OK;
+}
+
+int phi_reads_stats(phi_ctx *c, int64_t *n_reads, int64_t *n_bases, int64_t *n_emitted, int64_t *n_distinct)
+{
+    if (!c) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reads_stats before phi_set_graph");
+    HIPCHK(hipSetDevice(c->device));
+    PHICHK(phi_sync_check(c));
+    uint64_t s[S_N];
+    HIPCHK(hipMemcpy(s, c->d_scalars.p, sizeof s, hipMemcpyDeviceToHost));
+    if (n_reads) *n_reads = c->reads_count;
+    if (n_bases) *n_bases = c->reads_bases;
+    if (n_emitted) *n_emitted = (int64_t)s[S_NEMIT];
+    if (n_distinct) *n_distinct = c->sp_cap ? (int64_t)s[S_SPCOUNT] : 0;
     return PHI_OK;
 }
 
@@ -463,7 +486,7 @@ int phi_hits_buffer(phi_ctx *c, void **d_hits, int64_t *n)
     if (!c || !d_hits || !n) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_hits_buffer before phi_set_graph");
     *d_hits = c->d_hit.p;
-    *n = c->n_rec;
+    *n = c->n_unique;
     return PHI_OK;
 }
 

@@ -43,9 +43,10 @@ struct phi_ctx {
     DevBuf d_rec_hash, d_rec_pos, d_rec_slot, d_rec_e0, d_rec_e1;   // walk minimiser records
     int64_t n_rec = 0;
     std::vector<int64_t> h_walk_rec_off;              // record range of each walk
-    DevBuf d_u_keys, d_u_rep;                         // walk-minimiser table
+    DevBuf d_u_keys, d_u_rep, d_u_uid;                // walk-minimiser table: keys, first record, dense id
+    int64_t n_unique = 0;                             // distinct walk minimisers
     uint64_t u_cap = 0;
-    DevBuf d_hit;                                     // uint8 per record (set at representatives)
+    DevBuf d_hit;                                     // uint8 per distinct walk minimiser
 
     // ---- reads
     DevBuf d_sp_keys;                                 // read spectrum set
@@ -87,3 +88,5 @@ int phi_fail(phi_ctx *c, int code, const char *fmt, ...);
 int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes);
 int phi_hip_check(phi_ctx *c, hipError_t e, const char *what);
 int phi_sync_check(phi_ctx *c);
+// flags[n] (0/1) -> ascending list of flagged indices (int32) in out
+int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_t *n_out);

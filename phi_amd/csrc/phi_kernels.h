@@ -31,8 +31,8 @@ struct PhiSketchArgs {
     uint64_t *sp_keys; uint64_t sp_mask;   // read spectrum set
     unsigned long long *sp_count;
     unsigned long long *n_emitted;
-    const uint64_t *u_keys; const uint32_t *u_rep; uint64_t u_mask;   // walk-minimiser table
-    uint8_t *hit;                          // per walk-minimiser record, set at representatives
+    const uint64_t *u_keys; const uint32_t *u_uid; uint64_t u_mask;   // walk-minimiser table: slot -> dense id
+    uint8_t *hit;                          // per distinct walk minimiser (dense id)
     uint32_t *err;
 };
 
@@ -52,6 +52,10 @@ void phi_launch_scan_counts(hipStream_t st, const int32_t *cnt, int64_t n, int64
 // (deterministic on every rank); rec_slot[i] = slot of record i.
 void phi_launch_table_build(hipStream_t st, const uint64_t *rec_hash, int64_t n_rec, uint64_t *u_keys,
                             uint32_t *u_rep, uint64_t u_mask, uint32_t *rec_slot, uint32_t *err);
+void phi_launch_rep_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_rec, const uint32_t *u_rep,
+                          uint8_t *flags);
+void phi_launch_slot_uid(hipStream_t st, const int32_t *rep_list, int64_t n_unique, const uint32_t *rec_slot,
+                         uint32_t *u_uid);
 void phi_launch_fill_u64(hipStream_t st, uint64_t *p, int64_t n, uint64_t v);
 void phi_launch_fill_u32(hipStream_t st, uint32_t *p, int64_t n, uint32_t v);
 // insert a list of hashes into the spectrum set (multi-GPU spectrum merge)
@@ -70,7 +74,7 @@ void phi_launch_lower_bound(hipStream_t st, const int64_t *a, int64_t n, const i
 int64_t phi_compact_num_blocks(int64_t n);
 void phi_launch_flag_count(hipStream_t st, const uint8_t *flags, int64_t n, int32_t *block_cnt);
 void phi_launch_flag_write(hipStream_t st, const uint8_t *flags, int64_t n, const int64_t *block_off, int32_t *out);
-void phi_launch_match_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_rec, const uint32_t *u_rep,
+void phi_launch_match_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_rec, const uint32_t *u_uid,
                             const uint8_t *hit, uint8_t *flags);
 
 struct PhiFilterArgs {

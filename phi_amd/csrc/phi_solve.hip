@@ -33,7 +33,7 @@ static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 
 struct Seg { int32_t h; int32_t es, ee; };     // path segment: walk h, entries es..ee (inclusive)
 
 // flags[n] -> ascending indices in out; *n_out = count
-static int compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_t *n_out)
+int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_t *n_out)
 {
     *n_out = 0;
     const int64_t nb = phi_compact_num_blocks(n);
@@ -146,9 +146,9 @@ int phi_solve_impl(phi_ctx *c)
     // ---- 1. anchors = walk minimisers whose hash is in the read spectrum (:495-526)
     int64_t n_matched = 0;
     PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)std::max<int64_t>(n_rec, 1)));
-    phi_launch_match_flags(c->stream, c->d_rec_slot.as<uint32_t>(), n_rec, c->d_u_rep.as<uint32_t>(),
+    phi_launch_match_flags(c->stream, c->d_rec_slot.as<uint32_t>(), n_rec, c->d_u_uid.as<uint32_t>(),
                            c->d_hit.as<uint8_t>(), c->d_flags.as<uint8_t>());
-    PHICHK(compact(c, c->d_flags.as<uint8_t>(), n_rec, c->d_m_rec, &n_matched));
+    PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_rec, c->d_m_rec, &n_matched));
 
     // ---- 2. shared-anchor filter (:670-743)
     PhiFilterArgs F{};
@@ -193,7 +193,7 @@ int phi_solve_impl(phi_ctx *c)
     PHICHK(phi_dev_ensure(c, c->d_flags2, (size_t)std::max<int64_t>(n_matched, 1)));
     phi_launch_kept_flags(c->stream, F, n_matched, c->d_flags.as<uint8_t>(), c->d_flags2.as<uint8_t>());
     int64_t n_kept = 0;
-    PHICHK(compact(c, c->d_flags.as<uint8_t>(), n_matched, c->d_list, &n_kept));
+    PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_matched, c->d_list, &n_kept));
     // kept anchors to the host: record index -> (slot, e0, e1, hash)
     std::vector<int32_t> k_slot(n_kept), k_e0(n_kept), k_e1(n_kept);
     c->h_kept_hash.resize(n_kept);

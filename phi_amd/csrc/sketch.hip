@@ -347,11 +347,11 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
                         slot = (slot + 1) & A.sp_mask;
                         if (++probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
                     }
-                    // walk-minimiser table: lookup, mark the representative record as hit
+                    // walk-minimiser table: lookup, mark the minimiser as hit
                     slot = h & A.u_mask;
                     for (probes = 0; probes <= PHI_MAX_PROBE; probes++) {
                         const uint64_t key = A.u_keys[slot];
-                        if (key == h) { A.hit[A.u_rep[slot]] = 1; break; }
+                        if (key == h) { A.hit[A.u_uid[slot]] = 1; break; }
                         if (key == PHI_EMPTY_KEY) break;
                         slot = (slot + 1) & A.u_mask;
                     }

@@ -68,6 +68,38 @@ void phi_launch_table_build(hipStream_t st, const uint64_t *rec_hash, int64_t n_
                            u_keys, u_rep, u_mask, rec_slot, err);
 }
 
+// flags[i] = record i is the representative (first record) of its hash
+__global__ void __launch_bounds__(256) phi_rep_flags_kernel(const uint32_t *__restrict__ rec_slot, int64_t n_rec,
+                                                            const uint32_t *__restrict__ u_rep,
+                                                            uint8_t *__restrict__ flags)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (int64_t)gridDim.x * blockDim.x)
+        flags[i] = u_rep[rec_slot[i]] == (uint32_t)i;
+}
+// dense minimiser ids: uid = rank of the representative record in position order, identical on
+// every rank because the records are
+__global__ void __launch_bounds__(256) phi_slot_uid_kernel(const int32_t *__restrict__ rep_list, int64_t n_unique,
+                                                           const uint32_t *__restrict__ rec_slot,
+                                                           uint32_t *__restrict__ u_uid)
+{
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_unique; j += (int64_t)gridDim.x * blockDim.x)
+        u_uid[rec_slot[rep_list[j]]] = (uint32_t)j;
+}
+void phi_launch_rep_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_rec, const uint32_t *u_rep,
+                          uint8_t *flags)
+{
+    if (n_rec > 0)
+        hipLaunchKernelGGL(phi_rep_flags_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, st, rec_slot, n_rec, u_rep,
+                           flags);
+}
+void phi_launch_slot_uid(hipStream_t st, const int32_t *rep_list, int64_t n_unique, const uint32_t *rec_slot,
+                         uint32_t *u_uid)
+{
+    if (n_unique > 0)
+        hipLaunchKernelGGL(phi_slot_uid_kernel, dim3(grid_for(n_unique, 256)), dim3(256), 0, st, rep_list, n_unique,
+                           rec_slot, u_uid);
+}
+
 __global__ void __launch_bounds__(256) phi_spectrum_insert_kernel(const uint64_t *__restrict__ hashes, int64_t n,
                                                                   uint64_t *__restrict__ sp_keys, uint64_t sp_mask,
                                                                   unsigned long long *__restrict__ sp_count,

@@ -1,0 +1,252 @@
+"""Deterministic synthetic stand-ins for the benchmark configurations of BASELINE.json.
+
+The real 49-haplotype MHC Minigraph-Cactus graph (reference: data/preprocess.py:34-55,
+data/chop_graph.sh) needs network downloads and external tools, so the benchmark uses the
+generators specified in SURVEY.md section 8(d):
+
+  synMHC-49   backbone of uniform ACGT; bi-allelic variant sites every ~250 bp (80 % SNP, 15 %
+              indel 1-50 bp, 5 % SV 50-5000 bp, some SV insertions copied from elsewhere on the
+              backbone to create true repeats); walks pick alleles through a block model (founder
+              haplotypes per ~20 kb block, so sharing resembles LD blocks); nodes chopped to
+              <= 30 bp as chop_graph.sh:62 does; every walk runs source -> sink.
+  reads       drawn from a mosaic of walks, substitution / indel errors, both strands.
+
+PRNG: numpy PCG64 seeded per SURVEY 8(d) (graph 4901, 1x reads 4902, 10x reads 4903, ...).
+Output = the flat arrays of phi_set_graph (include/phi_amd.h) and (concat, offsets) reads.
+"""
+import numpy as np
+
+_COMP = np.zeros(256, np.uint8)
+for _a, _b in zip(b"ACGTacgt", b"TGCAtgca"):
+    _COMP[_a] = _b
+_ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
+def _rand_seq(rng, n):
+    return _ACGT[rng.integers(0, 4, size=n)]
+
+
+class SynGraph:
+    """Flat arrays + per-walk unit choices (kept so reads can be drawn without re-walking nodes)."""
+
+    def __init__(self):
+        self.seq_concat = None      # uint8
+        self.seq_off = None         # int64 [n_vtx+1]
+        self.adj_off = None
+        self.adj = None
+        self.walk_off = None
+        self.walk_vtx = None
+        self.top_rank = None
+        self.n_vtx = 0
+        self.n_walks = 0
+        self.hap_names = []
+
+    def arrays(self):
+        return dict(seq_concat=self.seq_concat, seq_off=self.seq_off, adj_off=self.adj_off, adj=self.adj,
+                    walk_off=self.walk_off, walk_vtx=self.walk_vtx, top_rank=self.top_rank)
+
+    def walk_sequence(self, h):
+        v = self.walk_vtx[self.walk_off[h]:self.walk_off[h + 1]]
+        lens = (self.seq_off[v + 1] - self.seq_off[v]).astype(np.int64)
+        starts = self.seq_off[v]
+        idx = np.repeat(starts - np.concatenate(([0], np.cumsum(lens)[:-1])), lens) + np.arange(int(lens.sum()))
+        return self.seq_concat[idx]
+
+
+def make_graph(backbone_len=5_000_000, n_walks=49, seed=4901, site_spacing=250, chop=30, block_len=20_000,
+               n_founders=6, max_sv=5000):
+    rng = np.random.default_rng(seed)
+    backbone = _rand_seq(rng, backbone_len)
+    # variant sites: position on the backbone, type, alleles
+    n_sites = max(1, backbone_len // site_spacing)
+    pos = np.sort(rng.choice(np.arange(chop + 1, backbone_len - max_sv - chop - 1), size=n_sites, replace=False))
+    # keep sites apart so that a backbone segment of >= 1 base separates the ref alleles
+    units = []          # list of (ref_seq or None, alt_seq or None) per site; backbone pieces between
+    pieces = []         # backbone pieces (uint8 arrays), len = n_kept_sites + 1
+    site_alleles = []   # (ref uint8 array possibly empty, alt uint8 array possibly empty)
+    cur = 0
+    kept_pos = []
+    for p in pos.tolist():
+        if p < cur + 1:
+            continue
+        u = rng.random()
+        if u < 0.80:                                   # SNP
+            ref = backbone[p:p + 1]
+            alt = _ACGT[[(int(np.searchsorted(_ACGT, ref[0])) + int(rng.integers(1, 4))) % 4]]
+            ref_len = 1
+        elif u < 0.95:                                 # indel 1-50 bp
+            L = int(rng.integers(1, 51))
+            if rng.random() < 0.5:                     # deletion of L ref bases
+                ref, alt, ref_len = backbone[p:p + L], backbone[0:0], L
+            else:                                      # insertion of L new bases
+                ref, alt, ref_len = backbone[0:0], _rand_seq(rng, L), 0
+        else:                                          # SV 50-5000 bp
+            L = int(rng.integers(50, max_sv + 1))
+            r = rng.random()
+            if r < 0.4:
+                ref, alt, ref_len = backbone[p:p + L], backbone[0:0], L
+            elif r < 0.7:
+                ref, alt, ref_len = backbone[0:0], _rand_seq(rng, L), 0
+            else:                                      # duplicated segment: copy from elsewhere
+                q = int(rng.integers(0, backbone_len - L))
+                ref, alt, ref_len = backbone[0:0], backbone[q:q + L].copy(), 0
+        if p + ref_len >= backbone_len - chop:
+            break
+        pieces.append(backbone[cur:p])
+        site_alleles.append((ref, alt))
+        kept_pos.append(p)
+        cur = p + ref_len
+    pieces.append(backbone[cur:])
+    n_sites = len(site_alleles)
+
+    # nodes: chop every unit into <= chop bp nodes with consecutive ids; record id ranges per unit
+    seqs = []
+    node_count = 0
+    piece_rng = np.zeros((n_sites + 1, 2), np.int64)
+    allele_rng = np.zeros((n_sites, 2, 2), np.int64)     # [site][allele] -> [first, end)
+
+    def add_unit(arr):
+        nonlocal node_count
+        first = node_count
+        for a in range(0, len(arr), chop):
+            seqs.append(arr[a:a + chop])
+            node_count += 1
+        return first, node_count
+    for i in range(n_sites + 1):
+        piece_rng[i] = add_unit(pieces[i])
+        if i < n_sites:
+            allele_rng[i, 0] = add_unit(site_alleles[i][0])
+            allele_rng[i, 1] = add_unit(site_alleles[i][1])
+    n_vtx = node_count
+    lens = np.fromiter((len(s) for s in seqs), np.int64, n_vtx)
+    seq_off = np.zeros(n_vtx + 1, np.int64)
+    np.cumsum(lens, out=seq_off[1:])
+    seq_concat = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
+
+    # edges: inside units consecutive ids; unit ends -> next unit starts (alleles may be empty)
+    src, dst = [], []
+    inner = np.ones(n_vtx, bool)
+    ends = np.concatenate([piece_rng[:, 1], allele_rng[:, :, 1].ravel()])
+    inner[ends[ends > 0] - 1] = False
+    inner_src = np.nonzero(inner)[0]
+    src.append(inner_src)
+    dst.append(inner_src + 1)
+    pe = piece_rng[:-1, 1] - 1                          # last node of piece i
+    pn = piece_rng[1:, 0]                               # first node of piece i+1
+    for al in (0, 1):
+        first, end = allele_rng[:, al, 0], allele_rng[:, al, 1]
+        nonempty = end > first
+        src.append(pe[nonempty]); dst.append(first[nonempty])
+        src.append(end[nonempty] - 1); dst.append(pn[nonempty])
+        empty = ~nonempty
+        src.append(pe[empty]); dst.append(pn[empty])
+    src = np.concatenate(src)
+    dst = np.concatenate(dst)
+    e = np.unique(np.stack([src, dst], 1), axis=0)
+    adj_off = np.zeros(n_vtx + 1, np.int64)
+    np.cumsum(np.bincount(e[:, 0], minlength=n_vtx), out=adj_off[1:])
+    adj = e[:, 1].astype(np.int32)
+
+    # walks: founder haplotypes per block, walks follow a founder and sometimes hop at block seams
+    block_id = np.asarray(kept_pos, np.int64) // block_len
+    n_blocks = int(block_id.max()) + 1 if n_sites else 1
+    founder_alleles = rng.random((n_founders, n_sites)) < 0.35        # alt-allele frequency per founder
+    choice = np.zeros((n_walks, n_sites), np.int8)
+    for h in range(n_walks):
+        f = int(rng.integers(0, n_founders))
+        fb = np.zeros(n_blocks, np.int64)
+        for b in range(n_blocks):
+            if rng.random() < 0.3:
+                f = int(rng.integers(0, n_founders))
+            fb[b] = f
+        ch = founder_alleles[fb[block_id], np.arange(n_sites)]
+        priv = rng.random(n_sites) < 0.01                             # private mutations
+        choice[h] = (ch ^ priv).astype(np.int8)
+    walk_list = []
+    for h in range(n_walks):
+        first = np.empty(2 * n_sites + 1, np.int64)
+        end = np.empty(2 * n_sites + 1, np.int64)
+        first[0::2], end[0::2] = piece_rng[:, 0], piece_rng[:, 1]
+        first[1::2] = allele_rng[np.arange(n_sites), choice[h], 0]
+        end[1::2] = allele_rng[np.arange(n_sites), choice[h], 1]
+        n = end - first
+        tot = int(n.sum())
+        base = np.repeat(first - np.concatenate(([0], np.cumsum(n)[:-1])), n)
+        walk_list.append((base + np.arange(tot)).astype(np.int32))
+    walk_off = np.zeros(n_walks + 1, np.int64)
+    np.cumsum([len(w) for w in walk_list], out=walk_off[1:])
+    walk_vtx = np.concatenate(walk_list)
+
+    g = SynGraph()
+    g.seq_concat, g.seq_off, g.adj_off, g.adj = seq_concat, seq_off, adj_off, adj
+    g.walk_off, g.walk_vtx = walk_off, walk_vtx
+    g.top_rank = np.arange(n_vtx, dtype=np.int32)        # ids were issued left to right
+    g.n_vtx, g.n_walks = n_vtx, n_walks
+    g.hap_names = [f"syn{h:03d}.{h % 2}" for h in range(n_walks)]
+    g.choice = choice
+    return g
+
+
+def make_reads(g, coverage=1.0, read_len=150, seed=4902, sub_err=0.005, n_mosaic=3, long_reads=False,
+               indel_err=0.0):
+    """Reads from a mosaic of n_mosaic walks.  Returns (uint8 concat, int64 offsets, truth dict)."""
+    rng = np.random.default_rng(seed)
+    hs = rng.choice(g.n_walks, size=n_mosaic, replace=False)
+    seqs = [g.walk_sequence(int(h)) for h in hs]
+    cuts = np.sort(rng.random(n_mosaic - 1))
+    parts = []
+    for i, s in enumerate(seqs):
+        a = 0 if i == 0 else int(cuts[i - 1] * len(s))
+        b = len(s) if i == n_mosaic - 1 else int(cuts[i] * len(s))
+        parts.append(s[a:b])
+    hap = np.concatenate(parts)
+    L = len(hap)
+    target = int(coverage * L)
+    if long_reads:
+        lens = np.minimum(np.maximum(rng.lognormal(np.log(8000), 0.6, size=max(1, target // 6000)).astype(np.int64), 500), L)
+        lens = lens[np.cumsum(lens) <= max(target, int(lens[0]))]
+    else:
+        lens = np.full(max(1, (target + read_len - 1) // read_len), read_len, np.int64)
+    starts = (rng.random(len(lens)) * (L - lens + 1)).astype(np.int64)
+    off = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    idx = np.repeat(starts - off[:-1], lens) + np.arange(int(off[-1]))
+    bases = hap[idx].copy()
+    # substitution errors
+    e = rng.random(len(bases)) < sub_err
+    ne = int(e.sum())
+    if ne:
+        cur = np.searchsorted(_ACGT, bases[e])
+        bases[e] = _ACGT[(cur + rng.integers(1, 4, size=ne)) % 4]
+    # reverse-complement half of the reads
+    rc = rng.random(len(lens)) < 0.5
+    if rc.any():
+        rid = np.repeat(np.arange(len(lens)), lens)
+        within = np.arange(int(off[-1])) - off[:-1][rid]
+        src = np.where(rc[rid], off[:-1][rid] + lens[rid] - 1 - within, np.arange(int(off[-1])))
+        out = bases[src]
+        out = np.where(rc[rid], _COMP[out], out)
+        bases = out.astype(np.uint8)
+    if indel_err > 0:                                   # ONT-like indels: drop / duplicate bases
+        keep = rng.random(len(bases)) >= indel_err / 2
+        dup = rng.random(len(bases)) < indel_err / 2
+        rid = np.repeat(np.arange(len(lens)), lens)
+        rep = keep.astype(np.int64) + (keep & dup)
+        bases = np.repeat(bases, rep)
+        newlen = np.bincount(rid, weights=rep, minlength=len(lens)).astype(np.int64)
+        off = np.zeros(len(lens) + 1, np.int64)
+        np.cumsum(newlen, out=off[1:])
+    return bases, off, dict(walks=hs.tolist(), cuts=cuts.tolist(), hap_len=L)
+
+
+CONFIGS = {
+    # name: (graph kwargs, reads kwargs) -- SURVEY.md 8(d) table
+    "C2": (dict(backbone_len=5_000_000, n_walks=49, seed=4901), dict(coverage=1.0, seed=4902)),
+    "C3": (dict(backbone_len=5_000_000, n_walks=49, seed=4901), dict(coverage=10.0, seed=4903)),
+    "C4": (dict(backbone_len=5_000_000, n_walks=49, seed=4901),
+           dict(coverage=5.0, seed=4904, long_reads=True, sub_err=0.03, indel_err=0.02)),
+    "C5": (dict(backbone_len=170_000_000, n_walks=200, seed=20001), dict(coverage=30.0, seed=20002)),
+    # small variants for tests and smoke runs
+    "tiny": (dict(backbone_len=60_000, n_walks=7, seed=11, max_sv=800), dict(coverage=2.0, seed=12)),
+    "small": (dict(backbone_len=400_000, n_walks=16, seed=21, max_sv=2000), dict(coverage=1.0, seed=22)),
+}
