@@ -115,7 +115,7 @@ void phi_ctx_destroy(phi_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
-                     &c->d_in_src, &c->d_wwords, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
+                     &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
                      &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_blk_cnt,
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_m_rec, &c->d_m_group,
@@ -274,7 +274,60 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) c->h_in_src[cur[adj[x]]++] = u;
     }
 
+    // ---- DP step stream (dp.hip): per step the live in-edges as (steps back, out-edge index),
+    //      per step and wave the mask of walks on the vertex, per entry the out-edge index
+    if (n_walks > PHI_DP_MAX_WALKS) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than %d walks", PHI_DP_MAX_WALKS);
+    c->dp_nw = phi_dp_num_waves(n_walks);
+    std::vector<uint8_t> e_out(n_entries, 255);
+    std::vector<int32_t> cnt_edge(std::max<int64_t>(n_edges, 1), 0), cont_total(n_vtx, 0);
+    for (int32_t h = 0; h < n_walks; h++)
+        for (int64_t e = walk_off[h]; e + 1 < walk_off[h + 1]; e++) {
+            const int32_t u = walk_vtx[e], v = walk_vtx[e + 1];
+            int64_t x = adj_off[u];
+            while (adj[x] != v) x++;
+            if (x - adj_off[u] >= 255) return phi_fail(c, PHI_ERR_UNSUPPORTED, "vertex %d has more than 254 out-edges", u);
+            e_out[e] = (uint8_t)(x - adj_off[u]);
+            cnt_edge[x]++;
+            cont_total[u]++;
+        }
+    std::vector<int32_t> st_rec((size_t)n_vtx * 8, 0), in_packed;
+    std::vector<unsigned long long> st_mask((size_t)n_vtx * c->dp_nw, 0ull);
+    {
+        // live in-edges of v: (u, x) with some walk on u continuing along another edge than x
+        std::vector<std::vector<int32_t>> live(n_vtx);
+        std::vector<uint8_t> tops(n_vtx, 0);
+        for (int32_t u = 0; u < n_vtx; u++)
+            for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++)
+                if (cont_total[u] - cnt_edge[x] > 0) {
+                    const int64_t back = (int64_t)topo_rank[adj[x]] - topo_rank[u];
+                    if (back >= (1 << 23)) return phi_fail(c, PHI_ERR_UNSUPPORTED, "edge spans more than 2^23 topological steps");
+                    live[adj[x]].push_back((int32_t)(back << 8) | (int32_t)(x - adj_off[u]));
+                    tops[u] = 1;
+                }
+        for (int32_t s = 0; s < n_vtx; s++) {
+            const int32_t v = c->h_topo[s];
+            int32_t *r = &st_rec[(size_t)s * 8];
+            const int n_in = (int)live[v].size();
+            if (n_in > 255) return phi_fail(c, PHI_ERR_UNSUPPORTED, "vertex %d has more than 255 in-edges", v);
+            r[0] = (n_in ? PHI_DP_NEED_ENTRY : 0) | (tops[v] ? PHI_DP_NEED_TOPS : 0) | (n_in << 8);
+            r[1] = (int32_t)in_packed.size();
+            for (int j = 0; j < n_in; j++) {
+                if (j < 3) r[2 + j] = live[v][j];
+                else in_packed.push_back(live[v][j]);
+            }
+            r[5] = v;
+            for (int64_t x = c->h_vh_off[v]; x < c->h_vh_off[v + 1]; x++) {
+                const int32_t h = c->h_entry_walk[c->h_vh_entry[x]];
+                st_mask[(size_t)s * c->dp_nw + (h >> 6)] |= 1ull << (h & 63);
+            }
+        }
+    }
+
     // ---- device copies
+    PHICHK(upload(c, c->d_e_out, e_out.data(), e_out.size()));
+    PHICHK(upload(c, c->d_st_rec, st_rec.data(), st_rec.size()));
+    PHICHK(upload(c, c->d_st_mask, st_mask.data(), st_mask.size()));
+    PHICHK(upload(c, c->d_in_packed, in_packed.data(), in_packed.size()));
     PHICHK(upload(c, c->d_seq, c->h_seq.data(), c->h_seq.size()));
     PHICHK(upload(c, c->d_seq_off, c->h_seq_off.data(), c->h_seq_off.size()));
     PHICHK(upload(c, c->d_walk_vtx, c->h_walk_vtx.data(), c->h_walk_vtx.size()));

@@ -39,6 +39,8 @@ struct phi_ctx {
 
     // ---- graph, device side
     DevBuf d_seq, d_seq_off, d_walk_vtx, d_walk_off, d_ebase, d_topo, d_in_off, d_in_src;
+    DevBuf d_e_out, d_st_rec, d_st_mask, d_in_packed;  // DP step stream (dp.hip)
+    int dp_nw = 1;                                    // waves of the DP workgroup
     DevBuf d_wwords, d_wstarts;                       // packed walk sequences + start bitmap
     DevBuf d_rec_hash, d_rec_pos, d_rec_slot, d_rec_e0, d_rec_e1;   // walk minimiser records
     int64_t n_rec = 0;
@@ -64,7 +66,7 @@ struct phi_ctx {
     // ---- solve state
     DevBuf d_m_rec, d_m_group, d_g_keys, d_g_rep, d_g_cnt, d_slot_maxcnt, d_slot_multi;
     DevBuf d_a_e1, d_g_off, d_g_span, d_a_weight;
-    DevBuf d_dmax, d_qbest, d_lent, d_top, d_ent;
+    DevBuf d_dmax, d_qbest, d_lent, d_top, d_ent, d_word;
     std::vector<PhiAnchorHost> h_kept, h_dp;          // kept anchors; dp anchors (span >= 1 edge)
     std::vector<uint64_t> h_kept_hash;
     std::vector<int32_t> h_path_vtx, h_path_hap;

@@ -99,20 +99,31 @@ void phi_launch_gather_u64(hipStream_t st, const uint64_t *src, const int32_t *i
 void phi_launch_entry_csr(hipStream_t st, const int32_t *a_e1, int64_t n_a, int64_t n_entries, int64_t *g_off);
 
 // dp.hip
+#define PHI_DP_CHUNK 128        // steps staged through LDS at a time
+#define PHI_DP_RING 2048        // steps whose leaving states are kept in LDS
+#define PHI_DP_NEED_ENTRY 1     // step flag: a recombination can enter this vertex
+#define PHI_DP_NEED_TOPS 2      // step flag: a recombination can leave this vertex
+#define PHI_DP_MAX_WALKS 512
+
 struct PhiDpArgs {
     int32_t n_vtx, n_walks;
-    const int32_t *topo;                 // vertices in topological order
-    const int64_t *in_off; const int32_t *in_src;   // reverse adjacency (by vertex)
-    const int64_t *walk_off; const int32_t *walk_vtx;
-    // dp anchors sorted by last entry: CSR over walk entries
-    const int64_t *g_off; const uint8_t *g_span;
-    const uint8_t *a_weight;             // weight (0/1) of each dp anchor in this run
+    // step stream (static per graph, built by phi_set_graph)
+    const int32_t *st_rec;               // [n_vtx][8]: flags | n_in<<8, overflow start, 3 inline in-edges, vertex, -, -
+    const unsigned long long *st_mask;   // [n_vtx][NW]: walks on the vertex of each step
+    const int32_t *in_packed;            // in-edges beyond the third of a step: back<<8 | out-edge index
+    const int64_t *walk_off;
+    // per run
+    const uint64_t *word;                // per walk entry: out-edge index + spans of weight-1 anchors ending there
+    const int64_t *g_off; const uint8_t *g_span; const uint8_t *a_weight;   // CSR, only for overflowing entries
     int32_t cost;                        // 2 * (R / 2)
     // outputs
-    int32_t *dmax;                       // per entry: best score of a path ending there
-    uint8_t *qbest;                      // per entry: run length attaining it (ties: longest)
-    int32_t *lent;                       // per entry: walk index where the capped run began
-    int32_t *top1v, *top1h, *top1n, *top2v, *top2h;   // per vertex: best leaving states by next vertex
-    int32_t *ent_v, *ent_u, *ent_h;      // per vertex: recombination entry value and its source
+    int32_t *dmax;                       // per entry (only where a path can end or leave): best score
+    uint8_t *qbest;                      // per entry: run length attaining it (31 = 31 or more; ties: longest)
+    int32_t *lent;                       // per entry: walk index where the >=31 run began
+    int32_t *tops;                       // [n_vtx][5] by step: top1 value/walk/out-edge, top2 value/walk
+    int32_t *ent_src, *ent_h;            // per step: source step and walk of the best recombination entry
 };
 void phi_launch_dp(hipStream_t st, const PhiDpArgs &A);
+int phi_dp_num_waves(int n_walks);
+void phi_launch_dp_words(hipStream_t st, const uint8_t *e_out, const int64_t *g_off, const uint8_t *g_span,
+                         const uint8_t *a_weight, int64_t n_entries, uint64_t *word);

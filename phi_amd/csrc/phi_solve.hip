@@ -64,25 +64,26 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
     const int64_t ne = c->n_entries;
     const int32_t nv = c->n_vtx;
     if (n_dp) HIPCHK(hipMemcpyAsync(c->d_a_weight.p, wgt.data(), (size_t)n_dp, hipMemcpyHostToDevice, c->stream));
+    phi_launch_dp_words(c->stream, c->d_e_out.as<uint8_t>(), c->d_g_off.as<int64_t>(), c->d_g_span.as<uint8_t>(),
+                        c->d_a_weight.as<uint8_t>(), ne, c->d_word.as<uint64_t>());
     PhiDpArgs A{};
     A.n_vtx = nv; A.n_walks = c->n_walks;
-    A.topo = c->d_topo.as<int32_t>();
-    A.in_off = c->d_in_off.as<int64_t>(); A.in_src = c->d_in_src.as<int32_t>();
-    A.walk_off = c->d_walk_off.as<int64_t>(); A.walk_vtx = c->d_walk_vtx.as<int32_t>();
+    A.st_rec = c->d_st_rec.as<int32_t>(); A.st_mask = c->d_st_mask.as<unsigned long long>();
+    A.in_packed = c->d_in_packed.as<int32_t>();
+    A.walk_off = c->d_walk_off.as<int64_t>();
+    A.word = c->d_word.as<uint64_t>();
     A.g_off = c->d_g_off.as<int64_t>(); A.g_span = c->d_g_span.as<uint8_t>(); A.a_weight = c->d_a_weight.as<uint8_t>();
     A.cost = 2 * (c->recombination / 2);                       // (c_1/2) twice, ILP_index.cpp:1276,1299
     A.dmax = c->d_dmax.as<int32_t>(); A.qbest = c->d_qbest.as<uint8_t>(); A.lent = c->d_lent.as<int32_t>();
-    int32_t *top = c->d_top.as<int32_t>();
-    A.top1v = top; A.top1h = top + nv; A.top1n = top + 2 * (int64_t)nv; A.top2v = top + 3 * (int64_t)nv; A.top2h = top + 4 * (int64_t)nv;
-    int32_t *ent = c->d_ent.as<int32_t>();
-    A.ent_v = ent; A.ent_u = ent + nv; A.ent_h = ent + 2 * (int64_t)nv;
+    A.tops = c->d_top.as<int32_t>();
+    A.ent_src = c->d_ent.as<int32_t>(); A.ent_h = c->d_ent.as<int32_t>() + nv;
     phi_launch_dp(c->stream, A);
     HIPCHK(hipGetLastError());
     H.dmax.resize(ne); H.lent.resize(ne); H.qbest.resize(ne); H.ent_u.resize(nv); H.ent_h.resize(nv);
     HIPCHK(hipMemcpyAsync(H.dmax.data(), A.dmax, (size_t)ne * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(H.lent.data(), A.lent, (size_t)ne * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(H.qbest.data(), A.qbest, (size_t)ne, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(H.ent_u.data(), A.ent_u, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(H.ent_u.data(), A.ent_src, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(H.ent_h.data(), A.ent_h, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
 
@@ -105,7 +106,8 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
         segs->push_back(Seg{h, (int32_t)es, (int32_t)e});
         if (es == c->h_walk_off[h]) break;                     // reached s_{first(h),h}
         const int32_t v = c->h_walk_vtx[es];
-        const int32_t u = H.ent_u[v], h2 = H.ent_h[v];
+        const int32_t src = H.ent_u[c->h_topo_rank[v]], h2 = H.ent_h[c->h_topo_rank[v]];   // by step
+        const int32_t u = src >= 0 ? c->h_topo[src] : -1;
         if (u < 0 || h2 < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack hit a vertex without an entry (internal error)");
         int64_t e2 = -1;
         for (int64_t x = c->h_vh_off[u]; x < c->h_vh_off[u + 1]; x++)
@@ -253,7 +255,8 @@ int phi_solve_impl(phi_ctx *c)
         PHICHK(phi_dev_ensure(c, c->d_lent, (size_t)c->n_entries * 4));
         PHICHK(phi_dev_ensure(c, c->d_qbest, (size_t)c->n_entries));
         PHICHK(phi_dev_ensure(c, c->d_top, (size_t)c->n_vtx * 5 * 4));
-        PHICHK(phi_dev_ensure(c, c->d_ent, (size_t)c->n_vtx * 3 * 4));
+        PHICHK(phi_dev_ensure(c, c->d_ent, (size_t)c->n_vtx * 2 * 4));
+        PHICHK(phi_dev_ensure(c, c->d_word, (size_t)c->n_entries * 8));
     }
 
     // ---- 4. exact solve

@@ -219,3 +219,39 @@ def test_config1_mhc4(oracle, ctx_factory):
     print("config1 objective", res["objective"], "dp runs", res["n_dp_runs"], "recomb", res["recombination_count"])
     if "objective_highs" in gold:
         assert res["objective"] == gold["objective_highs"]
+
+
+# --------------------------------------------------------------------------- mid-scale solve parity
+
+def _syn_oracle_graph(oracle, g):
+    G = oracle.Graph(seg_names=[str(i) for i in range(g.n_vtx)],
+                     node_seq=[bytes(g.seq_concat[g.seq_off[v]:g.seq_off[v + 1]]) for v in range(g.n_vtx)],
+                     adj=[g.adj[g.adj_off[v]:g.adj_off[v + 1]].tolist() for v in range(g.n_vtx)],
+                     paths=[g.walk_vtx[g.walk_off[h]:g.walk_off[h + 1]].tolist() for h in range(g.n_walks)],
+                     hap_names=g.hap_names)
+    oracle.kahn(G)
+    return G
+
+
+def test_synthetic_vs_highs_golden(oracle, ctx_factory):
+    """Objective equality with HiGHS on the reference's restated -q0 program (tests/golden/
+    solve_golden.json, made by tests/golden/make_solve_golden.py), at sizes brute force cannot reach."""
+    from phi_amd import synth
+    gold = json.load(open(os.path.join(GOLDEN, "solve_golden.json")))
+    cache = {}
+    for case in gold:
+        name = case["config"]
+        if name not in cache:
+            gk, rk = synth.CONFIGS[name]
+            g = synth.make_graph(**gk)
+            bases, off, _ = synth.make_reads(g, **rk)
+            cache[name] = (g, _syn_oracle_graph(oracle, g), bases, off)
+        g, G, bases, off = cache[name]
+        ctx = ctx_factory(k=case["k"], w=case["w"], threshold=case["T"], recombination=case["R"])
+        A = g.arrays()
+        ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
+        ctx.add_reads((bases, off))
+        reads = [bytes(bases[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+        st, res, m = _check_against_oracle(oracle, ctx, G, reads, case["k"], case["w"], case["T"], case["R"])
+        assert res["spectrum_size"] == case["spectrum_size"] and res["n_in_model"] == case["n_in_model"]
+        assert res["objective"] == case["objective"], (case, res["objective"], res["n_dp_runs"])
