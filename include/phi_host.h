@@ -1,0 +1,68 @@
+/*
+ * phi_host.h -- C ABI of the host-side feeders of the hot path (libphi_host.so, CPU only).
+ *
+ * These are the steps on either side of the GPU path (SURVEY.md section 8f "next"):
+ *   phi_gfa_read     gfa_read() + ILP_index::read_gfa()   src/gfa-io.cpp:462-508, src/ILP_index.cpp:20-155
+ *   phi_reads_read   ILP_index::read_ip_reads()           src/ILP_index.cpp:313-328 (kseq FASTA/FASTQ, gz)
+ *   phi_hap_name     get_hap_name()                       src/misc.cpp:58-87
+ *   phi_write_fasta  the FASTA writer                     src/ILP_index.cpp:1590-1598
+ * The arrays phi_gfa_read returns are exactly the arguments of phi_set_graph (phi_amd.h).
+ * All functions return 0 or a negative code and never call exit(); *err receives a message.
+ */
+#ifndef PHI_HOST_H
+#define PHI_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct phi_graph phi_graph;
+typedef struct phi_reads phi_reads;
+
+enum {
+    PHI_HOST_OK = 0,
+    PHI_HOST_ERR_IO = -1,       /* file cannot be opened / read (main.cpp:102-105 returns 1) */
+    PHI_HOST_ERR_WALK = -2,     /* a walk holds a reverse-strand vertex (ILP_index.cpp:104-107 exits) */
+    PHI_HOST_ERR_CYCLE = -3,    /* Kahn's algorithm did not reach every vertex: graph is not acyclic */
+    PHI_HOST_ERR_INVALID = -4
+};
+
+/* Parse S/L/W lines (plain or gzip), flip walks as gfa_walk_flip does, complete arcs with their
+ * complements, keep forward-strand arcs, build walks / names / Kahn topological order. */
+int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap);
+void phi_graph_free(phi_graph *g);
+
+int32_t phi_graph_n_vtx(const phi_graph *g);
+int32_t phi_graph_n_walks(const phi_graph *g);
+int64_t phi_graph_n_edges(const phi_graph *g);
+const char *phi_graph_seq_concat(const phi_graph *g);      /* node_seq, original case */
+const int64_t *phi_graph_seq_off(const phi_graph *g);      /* [n_vtx+1] */
+const int64_t *phi_graph_adj_off(const phi_graph *g);      /* [n_vtx+1] */
+const int32_t *phi_graph_adj(const phi_graph *g);
+const int64_t *phi_graph_walk_off(const phi_graph *g);     /* [n_walks+1] */
+const int32_t *phi_graph_walk_vtx(const phi_graph *g);
+const int32_t *phi_graph_topo_rank(const phi_graph *g);    /* top_order_map */
+const char *phi_graph_hap_name(const phi_graph *g, int32_t walk);   /* sample + "." + hap (:98) */
+const char *phi_graph_seg_name(const phi_graph *g, int32_t vtx);
+
+/* FASTA/FASTQ reader with kseq's record rules (multi-line FASTA, '+' quality blocks). */
+int phi_reads_read(const char *path, phi_reads **out, char *err, int err_cap);
+void phi_reads_free(phi_reads *r);
+int64_t phi_reads_count(const phi_reads *r);
+const char *phi_reads_bases(const phi_reads *r);           /* concatenated sequences */
+const int64_t *phi_reads_off(const phi_reads *r);          /* [count+1] */
+const char *phi_reads_name(const phi_reads *r, int64_t i);
+
+/* Record id of the output: basename(gfa) minus extension + "_" + basename(reads), minus the last
+ * extension of the whole string.  Returns the length or -1 if cap is too small. */
+int phi_hap_name(const char *gfa_path, const char *reads_path, char *out, int cap);
+
+/* ">" name " LN:" len, then the sequence in 80-column lines. */
+int phi_write_fasta(const char *path, const char *name, const char *seq, int64_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+// phi_main.cpp -- the `PHI` command-line driver: same flags, stderr log lines and FASTA output as
+// the reference's src/main.cpp + the logging of ILP_index::ILP_function, with the hot path behind
+// the C ABI of include/phi_amd.h (HIP kernels on one MI355X).  Own implementation.
+//
+//   ./PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta> [-k -w -R -q -m -T -t -d -N -c]
+//
+// Flag semantics (main.cpp:38-95): -q (IQP/ILP), -m (mixed/integer), -N (naive expanded graph)
+// choose between formulations with the same optimum; they are accepted and mapped onto the one
+// exact solver.  -t only sized OpenMP/Gurobi thread pools and is accepted and ignored.  The log
+// lines scraped by the reference's evaluation scripts (data/postprocessing_2_MIQP.py:55-79) keep
+// their exact formats.
+#include <getopt.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/resource.h>
+#include <sys/time.h>
+#include <string>
+#include <vector>
+#include "../../../include/phi_amd.h"
+#include "../../../include/phi_host.h"
+
+#define PHI_VERSION "1.0-mi355x"
+
+static double t0_real;
+static double realtime()
+{
+    struct timeval tp;
+    gettimeofday(&tp, nullptr);
+    return tp.tv_sec + tp.tv_usec * 1e-6;
+}
+static double cputime()
+{
+    struct rusage r;
+    getrusage(RUSAGE_SELF, &r);
+    return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+}
+static long peakrss()
+{
+    struct rusage r;
+    getrusage(RUSAGE_SELF, &r);
+    return r.ru_maxrss * 1024;
+}
+// "[M::func::<wall>*<cpu/wall>] " stamp of the reference (sys.cpp:92-117 users)
+static void stamp(const char *func)
+{
+    const double w = realtime() - t0_real;
+    fprintf(stderr, "[M::%s::%.3f*%.2f] ", func, w, cputime() / (w > 0 ? w : 1e-9));
+}
+
+static void usage(FILE *fp, int k, int w, int R, int q, int m, float T, int t, const char *g, const char *r, const char *o, int d)
+{
+    fprintf(fp, "Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta> \n");
+    fprintf(fp, "Options:\n");
+    fprintf(fp, "    -k INT       K-mer size [%d]\n", k);
+    fprintf(fp, "    -w INT       Minimizer window size [%d]\n", w);
+    fprintf(fp, "    -R INT       Recombination penalty [%d]\n", R);
+    fprintf(fp, "    -q INT       Mode QP/ILP (default IQP i.e q1, use q0 for ILP) [%d]\n", q);
+    fprintf(fp, "    -m INT       Mixed/Interger programming (default Mixed i.e -m1, use -m0 for Integer) [%d]\n", m);
+    fprintf(fp, "    -T FLOAT     Threshold for minimizer filtering [%.3f]\n", T);
+    fprintf(fp, "    -t INT       Threads [%d]\n", t);
+    fprintf(fp, "    -g INT       GFA file [%s]\n", g);
+    fprintf(fp, "    -r INT       Read [%s]\n", r);
+    fprintf(fp, "    -o INT       Output haplotype [%s]\n", o);
+    fprintf(fp, "    -d bool      Debug mode [%d]\n", d);
+}
+
+int main(int argc, char *argv[])
+{
+    int k = 31, w = 25, n_threads = 4, recombination = 100, is_qclp = 1, is_naive = 0, is_mixed = 1, debug = 0, help = 0;
+    int device = 0, max_occ = 5000;
+    float threshold = 1.0f;
+    std::string gfa_file, reads_file, hap_file;
+    static struct option long_options[] = {{"version", no_argument, 0, 300}, {"device", required_argument, 0, 301}, {0, 0, 0, 0}};
+    int c;
+    // main.cpp:38 declares -h with an argument; a bare -h falls into the usage branch either way
+    while ((c = getopt_long(argc, argv, "x:d:c:l:s:m:R:q:T:N:h:k:w:t:g:r:o:DS", long_options, nullptr)) >= 0) {
+        if (c == 'w') w = atoi(optarg);
+        else if (c == 'k') k = atoi(optarg);
+        else if (c == 't') n_threads = atoi(optarg);
+        else if (c == 'm') is_mixed = atoi(optarg);
+        else if (c == 'g') gfa_file = optarg;
+        else if (c == 'R') recombination = atoi(optarg);
+        else if (c == 'q') is_qclp = atoi(optarg);
+        else if (c == 'N') is_naive = atoi(optarg);
+        else if (c == 'T') threshold = (float)atof(optarg);
+        else if (c == 'r') reads_file = optarg;
+        else if (c == 'o') hap_file = optarg;
+        else if (c == 'c') max_occ = atoi(optarg);
+        else if (c == 'd') debug = atoi(optarg);
+        else if (c == 'h' || c == '?') help = 1;
+        else if (c == 300) { fprintf(stderr, "PHI version: %s\n", PHI_VERSION); return 0; }
+        else if (c == 301) device = atoi(optarg);
+    }
+    (void)max_occ; (void)is_naive; (void)n_threads;
+    if (argc < 2 || gfa_file.empty() || reads_file.empty() || hap_file.empty() || help) {
+        usage(stderr, k, w, recombination, is_qclp, is_mixed, threshold, n_threads, gfa_file.c_str(), reads_file.c_str(), hap_file.c_str(), debug);
+        return 1;
+    }
+    t0_real = realtime();
+    char err[512] = "";
+
+    // ---- graph (main.cpp:101-115)
+    phi_graph *g = nullptr;
+    if (phi_gfa_read(gfa_file.c_str(), &g, err, sizeof err) != PHI_HOST_OK) {
+        if (err[0] == 'E') fprintf(stderr, "%s\n", err);            // walk error text of ILP_index.cpp:105
+        else fprintf(stderr, "[E::%s] failed to load the GFA file\n", __func__);
+        if (err[0] && err[0] != 'E') fprintf(stderr, "[E::%s] %s\n", __func__, err);
+        return 1;
+    }
+    stamp(__func__);
+    fprintf(stderr, "Loaded graph from: %s\n", gfa_file.c_str());
+    char hap_name[4096];
+    if (phi_hap_name(gfa_file.c_str(), reads_file.c_str(), hap_name, sizeof hap_name) < 0) { fprintf(stderr, "[E::%s] output name too long\n", __func__); return 1; }
+
+    phi_ctx *ctx = nullptr;
+    int rc = phi_ctx_create(device, &ctx);
+    if (rc) { fprintf(stderr, "[E::%s] no usable MI355X (HIP) device %d: %s\n", __func__, device, phi_strerror(rc)); return 1; }
+    auto die = [&](const char *what, int code) {
+        fprintf(stderr, "[E::%s] %s: %s: %s\n", "main", what, phi_strerror(code), phi_last_error(ctx));
+        return 1;
+    };
+    const uint32_t flags = (is_qclp ? PHI_FLAG_QCLP : 0) | (is_mixed ? PHI_FLAG_MIXED : 0);
+    if ((rc = phi_set_params(ctx, k, w, threshold, recombination, flags))) return die("parameters", rc);
+
+    // ---- reads (main.cpp:136-137)
+    phi_reads *rd = nullptr;
+    if (phi_reads_read(reads_file.c_str(), &rd, err, sizeof err) != PHI_HOST_OK) { fprintf(stderr, "[E::%s] %s\n", __func__, err); return 1; }
+    const int32_t n_walks = phi_graph_n_walks(g);
+    stamp("ILP_function");
+    fprintf(stderr, "Graph has %d vertices, %d walks and read has %d reads\n", phi_graph_n_vtx(g), n_walks, (int)phi_reads_count(rd));
+
+    // ---- stage 1a: walks (ILP_index.cpp:556-611)
+    if ((rc = phi_set_graph(ctx, phi_graph_n_vtx(g), phi_graph_seq_concat(g), phi_graph_seq_off(g), phi_graph_adj_off(g),
+                            phi_graph_adj(g), n_walks, phi_graph_walk_off(g), phi_graph_walk_vtx(g), phi_graph_topo_rank(g)))) {
+        if (rc == PHI_ERR_WALK) fprintf(stderr, "Error: %s\n", phi_last_error(ctx));
+        return die("graph", rc);
+    }
+    // ---- stage 1b/2a: reads (:615-655)
+    if ((rc = phi_add_reads(ctx, phi_reads_bases(rd), phi_reads_off(rd), phi_reads_count(rd)))) return die("reads", rc);
+    // ---- stages 2b-3 (:670-1525)
+    phi_result res;
+    if ((rc = phi_solve(ctx, &res))) return die("solve", rc);
+
+    fprintf(stderr, "Number of Minimizers\n");
+    for (int32_t h = 0; h < n_walks; h++) fprintf(stderr, "%s : %d\n", phi_graph_hap_name(g, h), (int)res.n_minimizers[h]);
+    stamp("ILP_function");
+    fprintf(stderr, "Haplotypes sketched\n");
+    stamp("ILP_function");
+    fprintf(stderr, "Indexed reads with spectrum size: %d\n", (int)res.spectrum_size);
+    fprintf(stderr, "Number of Anchors\n");
+    for (int32_t h = 0; h < n_walks; h++) fprintf(stderr, "%s : %d\n", phi_graph_hap_name(g, h), (int)res.n_anchors[h]);
+    stamp("ILP_function");
+    fprintf(stderr, "Filtered/Retained Minimizers: %.2f/%.2f%%\n", (float)res.filtered / (float)res.spectrum_size * 100,
+            (float)res.retained / (float)res.spectrum_size * 100);
+    stamp("ILP_function");
+    fprintf(stderr, "%s model started\n", is_qclp ? "QP" : "ILP");
+    stamp("ILP_function");
+    fprintf(stderr, "%.2f%% Minimizers are in ILP\n", (res.n_in_model * 100.0) / res.spectrum_size);
+    stamp("ILP_function");
+    fprintf(stderr, "Minimizer constraints added to the model\n");
+    stamp("ILP_function");
+    fprintf(stderr, "%s\n", is_mixed ? "Using Mixed Integer Programming" : "Using Integer Programming");
+    stamp("ILP_function");
+    fprintf(stderr, "Optimized expanded graph constructed\n");
+    stamp("ILP_function");
+    fprintf(stderr, "Model optimized\n");
+    if (debug || !res.optimal)
+        fprintf(stderr, "[M::%s] objective %lld (upper bound %lld, %s) after %d DP run(s); %lld minimisers covered, %d w-node(s)\n", "solve",
+                (long long)res.objective, (long long)res.upper_bound, res.optimal ? "proven optimal" : "NOT proven optimal", res.n_dp_runs,
+                (long long)res.n_covered, res.n_switches);
+
+    // ---- recombination report (:1508-1550): segments in output coordinates
+    fprintf(stderr, "Recombination count: %d\n", res.recombination_count);
+    fprintf(stderr, "Recombined haplotypes: ");
+    {
+        const int64_t *so = phi_graph_seq_off(g);
+        int64_t str_id = 0, prev_str_id = 0;
+        int32_t prev_hap = res.n_path ? res.path_hap[0] : 0;
+        for (int64_t i = 0; i < res.n_path; i++) {
+            const int32_t v = res.path_vtx[i];
+            if (i > 0 && res.path_hap[i] != prev_hap) {
+                // the reference adds the vertex length before testing the label (:1515-1523)
+                str_id += so[v + 1] - so[v];
+                fprintf(stderr, ">(%s,[%lld,%lld])", phi_graph_hap_name(g, prev_hap), (long long)prev_str_id, (long long)(str_id - 1));
+                prev_hap = res.path_hap[i];
+                prev_str_id = str_id;
+            } else {
+                str_id += so[v + 1] - so[v];
+            }
+        }
+        if (res.n_path) fprintf(stderr, ">(%s,[%lld,%lld])", phi_graph_hap_name(g, prev_hap), (long long)prev_str_id, (long long)(str_id - 1));
+        fprintf(stderr, "\n");
+    }
+
+    // ---- FASTA (:1577-1598)
+    std::vector<char> seq((size_t)(res.hap_len > 0 ? res.hap_len : 1));
+    if ((rc = phi_path_sequence(ctx, seq.data(), res.hap_len))) return die("sequence", rc);
+    if (phi_write_fasta(hap_file.c_str(), hap_name, seq.data(), res.hap_len) != PHI_HOST_OK) {
+        fprintf(stderr, "[E::%s] cannot write %s\n", __func__, hap_file.c_str());
+        return 1;
+    }
+    stamp("ILP_function");
+    fprintf(stderr, "Haplotype of size: %d written to: %s\n", (int)res.hap_len, hap_file.c_str());
+
+    fprintf(stderr, "[M::%s] PHI Version: %s\n", __func__, PHI_VERSION);
+    fprintf(stderr, "[M::%s] CMD:", __func__);
+    for (int i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
+    fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", __func__, realtime() - t0_real, cputime(),
+            peakrss() / 1024.0 / 1024.0 / 1024.0);
+    phi_reads_free(rd);
+    phi_graph_free(g);
+    phi_ctx_destroy(ctx);
+    return 0;
+}
