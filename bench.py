@@ -34,13 +34,6 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-class _DevArray:
-    """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface)."""
-
-    def __init__(self, ptr, n, typestr="|u1"):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
-
-
 def cpu_baseline(reads_concat, read_off, k, w, budget_s=12.0):
     """Oracle (scalar string-based port of compute_hashes) on the host cores: checker code timed as
     the CPU baseline, never part of the measured GPU path."""
@@ -75,6 +68,7 @@ def main():
 
     import torch
     import phi_amd
+    from phi_amd import dist as pdist
     from phi_amd import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,13 +114,13 @@ def main():
     d_bases = torch.from_numpy(bases).to(dev)
     d_off = torch.from_numpy(off).to(dev)
     hit_ptr, n_unique = ctx.hits_buffer()
-    hit_t = torch.as_tensor(_DevArray(hit_ptr, n_unique), device=dev) if world > 1 else None
+    hit_t = torch.as_tensor(pdist.DevArray(hit_ptr, n_unique), device=dev) if world > 1 else None
 
     def step():
         ctx.reset_reads()
         ctx.add_reads_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases)
         if world > 1:
-            dist.all_reduce(hit_t, op=dist.ReduceOp.MAX)
+            pdist.allreduce_hits(hit_t)
 
     for _ in range(args.warmup):
         step()
@@ -157,19 +151,7 @@ def main():
     if not args.no_solve:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if world > 1:
-            p, n = ctx.spectrum_export()
-            mine = torch.as_tensor(_DevArray(p, n, "<i8"), device=dev).clone() if n else torch.zeros(0, dtype=torch.int64, device=dev)
-            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev))
-            mx = int(max(int(s.item()) for s in sizes))
-            pad = torch.zeros(max(mx, 1), dtype=torch.int64, device=dev)
-            pad[:n] = mine
-            bufs = [torch.zeros_like(pad) for _ in range(world)]
-            dist.all_gather(bufs, pad)
-            for r in range(world):
-                if r != rank and int(sizes[r].item()):
-                    ctx.spectrum_import(bufs[r].data_ptr(), int(sizes[r].item()))
+        pdist.merge_spectrum_into(ctx, dev)
         res = ctx.solve()
         torch.cuda.synchronize()
         t_solve = time.perf_counter() - t0

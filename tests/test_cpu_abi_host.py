@@ -1,0 +1,202 @@
+"""CPU tests: the C-ABI libraries load and export what the headers declare (no GPU compute), the
+host-side readers agree with the reference parser's goldens and with the oracle, and the device
+k-mer / hash primitives (phi_dev.h compiled for the host) agree with the known answers."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import DATA, GOLDEN, ROOT
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(phi_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from phi_amd import build as B
+    B.build_device()
+    B.build_host()
+    return True
+
+
+def test_phi_amd_abi_exports_every_declared_symbol(built):
+    from phi_amd import _capi
+    names = _declared("phi_amd.h")
+    assert len(names) >= 20
+    assert sorted(_capi.SYMBOLS) == names            # the binding covers the header exactly
+    L = C.CDLL(_capi.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
+    L2 = _capi.load()
+    assert L2.phi_strerror(0) == b"ok" and L2.phi_strerror(-6) == b"walk does not follow the graph"
+
+
+def test_phi_amd_fails_loudly_without_gpu(built):
+    """No CPU fallback: without a HIP device the context cannot be created."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import phi_amd
+    with pytest.raises(phi_amd.PhiError) as e:
+        phi_amd.Context(0)
+    assert e.value.status == phi_amd.PHI_ERR_DEVICE
+
+
+def test_product_never_imports_the_oracle():
+    """The checker must not leak into the product path."""
+    pkg = os.path.join(ROOT, "phi_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f == "build.py":
+                continue        # only runs `make -C oracle` (building the checker is not using it)
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt and "phi_oracle" not in txt, f
+
+
+def test_phi_host_abi_exports(built):
+    from phi_amd import ilp_index as H
+    names = _declared("phi_host.h")
+    assert sorted(H.HOST_SYMBOLS) == names
+    L = H.host_lib()
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_host_gfa_reader_vs_reference_goldens(built, oracle):
+    from phi_amd import ilp_index as H
+    gold = json.load(open(os.path.join(GOLDEN, "gfa_flatten.json")))
+    g = H.Graph(os.path.join(DATA, "test.gfa"))
+    t = gold["test.gfa"]
+    assert g.seg_names == t["seg_names"] and g.hap_id2name == t["hap_names"]
+    assert [bytes(g.seq_concat[g.seq_off[v]:g.seq_off[v + 1]]).decode() for v in range(g.n_vtx)] == t["node_seq"]
+    assert [sorted(g.adj[g.adj_off[v]:g.adj_off[v + 1]].tolist()) for v in range(g.n_vtx)] == t["adj"]
+    assert [g.walk_vtx[g.walk_off[h]:g.walk_off[h + 1]].tolist() for h in range(g.num_walks)] == t["paths"]
+    g = H.Graph(os.path.join(DATA, "MHC_4.gfa.gz"))
+    m = gold["MHC_4.gfa.gz"]
+    assert g.n_vtx == m["n_vtx"] and len(g.adj) == m["n_edges"] and g.hap_id2name == m["hap_names"]
+    assert hashlib.sha256(g.seq_concat.tobytes()).hexdigest() == m["sha256_seq"]
+    assert hashlib.sha256(g.seq_off.tobytes()).hexdigest() == m["sha256_seq_off"]
+    assert hashlib.sha256(g.walk_vtx.tobytes()).hexdigest() == m["sha256_walk_vtx"]
+    adj_sorted = [sorted(g.adj[g.adj_off[v]:g.adj_off[v + 1]].tolist()) for v in range(g.n_vtx)]
+    assert hashlib.sha256(json.dumps(adj_sorted).encode()).hexdigest() == m["sha256_adj_sorted"]
+    # topological ranks: a permutation with every edge going forward; identical to the oracle's Kahn order
+    assert sorted(g.top_order_map.tolist()) == list(range(g.n_vtx))
+    og = oracle.parse_gfa(os.path.join(DATA, "MHC_4.gfa.gz"))
+    assert g.top_order_map.tolist() == og.top_rank
+
+
+def test_host_gfa_reader_errors(built, tmp_path):
+    from phi_amd import ilp_index as H
+    with pytest.raises(H.HostError) as e:
+        H.Graph(str(tmp_path / "missing.gfa"))
+    assert e.value.status == -1
+    # the third walk disagrees with the strand the first walk fixed for s2: reverse-strand vertex
+    p = tmp_path / "rev.gfa"
+    p.write_text("S\ts1\tACGT\nS\ts2\tGGA\nS\ts3\tTT\nL\ts1\t+\ts2\t+\t0M\nL\ts2\t+\ts3\t+\t0M\n"
+                 "W\ta\t0\tc\t0\t1\t>s1>s2>s3\nW\tb\t0\tc\t0\t1\t>s1<s2>s3\n")
+    with pytest.raises(H.HostError) as e:
+        H.Graph(str(p))
+    assert e.value.status == -2
+    p = tmp_path / "cyc.gfa"
+    p.write_text("S\ts1\tACGT\nS\ts2\tGGA\nL\ts1\t+\ts2\t+\t0M\nL\ts2\t+\ts1\t+\t0M\nW\ta\t0\tc\t0\t1\t>s1>s2\n")
+    with pytest.raises(H.HostError) as e:
+        H.Graph(str(p))
+    assert e.value.status == -3
+    # a fully reversed walk is flipped to the forward strand (gfa_walk_flip), CRLF and no final newline
+    p = tmp_path / "flip.gfa"
+    p.write_bytes(b"S\ts1\tACGT\r\nS\ts2\tGGA\r\nL\ts1\t+\ts2\t+\t0M\r\nW\ta\t0\tc\t0\t1\t>s1>s2\r\nW\tb\t1\tc\t0\t1\t<s2<s1")
+    g = H.Graph(str(p))
+    assert g.walk_vtx.tolist() == [0, 1, 0, 1] and g.hap_id2name == ["a.0", "b.1"]
+
+
+def test_host_reads_reader(built, oracle, tmp_path):
+    from phi_amd import ilp_index as H
+    bases, off, names = H.read_reads(os.path.join(DATA, "CHM13_reads.fq.gz"))
+    exp = oracle.read_reads(os.path.join(DATA, "CHM13_reads.fq.gz"))
+    assert len(names) == len(exp) == 16401
+    raw = bases.tobytes()
+    assert [raw[off[i]:off[i + 1]] for i in range(len(names))] == [s for _, s in exp]
+    assert [n.encode() for n in names] == [n for n, _ in exp]
+    p = tmp_path / "r.fa"
+    p.write_text(">a desc\nACGT\nAC GT\n>b\n\n>c\nTT\n@q1 x\nGGCC\n+\nIIII\n@q2\nAA\nCC\n+q2\nII\nII\n")
+    bases, off, names = H.read_reads(str(p))
+    raw = bases.tobytes()
+    assert names == ["a", "b", "c", "q1", "q2"]
+    assert [raw[off[i]:off[i + 1]] for i in range(5)] == [b"ACGTACGT", b"", b"TT", b"GGCC", b"AACC"]
+    assert [(n.decode(), s) for n, s in oracle.read_reads(str(p))] == list(zip(names, [raw[off[i]:off[i + 1]] for i in range(5)]))
+
+
+def test_host_hap_name_and_fasta(built, tmp_path):
+    from phi_amd import ilp_index as H
+    for c in json.load(open(os.path.join(GOLDEN, "hap_names.json"))):
+        assert H.get_hap_name(c["gfa"], c["reads"]) == c["name"]
+    L = H.host_lib()
+    seq = b"ACGT" * 50 + b"A"
+    out = tmp_path / "o.fa"
+    assert L.phi_write_fasta(str(out).encode(), b"name_x", seq, len(seq)) == 0
+    lines = out.read_text().split("\n")
+    assert lines[0] == ">name_x LN:201" and [len(x) for x in lines[1:]] == [80, 80, 41, 0]
+    assert "".join(lines[1:]).encode() == seq
+    assert L.phi_write_fasta(str(out).encode(), b"empty", b"", 0) == 0
+    assert out.read_text() == ">empty LN:0\n"           # the reference's output when the solve fails (:1583-1598)
+
+
+def test_device_primitives_on_host(oracle, tmp_path):
+    """phi_dev.h is host/device code: compile it with g++ and check the 2-bit k-mer hash, the
+    reverse complement and the base codes against the reference's murmur known answers."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "phi_dev.h"\nextern "C" {\n'
+                   'uint64_t t_hash(uint64_t v, int k) { return phi_kmer_hash(v, k); }\n'
+                   'uint64_t t_rc(uint64_t v, int k) { return phi_revcomp(v, k); }\n'
+                   'uint32_t t_code(uint32_t c) { return phi_code(c); }\n'
+                   'int t_ok(uint32_t c) { return phi_is_acgt(c); }\n'
+                   'uint64_t t_ext(const uint64_t* w, long i) { return phi_extract64(w, i); }\n}\n')
+    lib = tmp_path / "libt.so"
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "phi_amd", "csrc"), "-o", str(lib), str(src)])
+    L = C.CDLL(str(lib))
+    L.t_hash.restype = C.c_uint64
+    L.t_hash.argtypes = [C.c_uint64, C.c_int]
+    L.t_rc.restype = C.c_uint64
+    L.t_rc.argtypes = [C.c_uint64, C.c_int]
+    L.t_ext.restype = C.c_uint64
+    L.t_ext.argtypes = [C.c_void_p, C.c_long]
+
+    def val(s):
+        v = 0
+        for ch in s:
+            v = (v << 2) | b"ACGT".index(ch)
+        return v
+    n_checked = 0
+    for v in json.load(open(os.path.join(GOLDEN, "murmur_vectors.json"))):
+        b = bytes.fromhex(v["hex"])
+        if 1 <= len(b) <= 32 and set(b) <= set(b"ACGT"):
+            assert L.t_hash(val(b), len(b)) == int(v["hash"])
+            n_checked += 1
+    assert n_checked >= 30
+    rng = np.random.default_rng(9)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for k in range(1, 33):
+        s = bytes(rng.choice(list(b"ACGT"), size=k).tolist())
+        assert L.t_hash(val(s), k) == oracle.hash128_to_64(s)
+        assert L.t_rc(val(s), k) == val(s.translate(comp)[::-1])
+    for ch in b"ACGTacgt":
+        assert L.t_code(ch) == b"ACGT".index(bytes([ch]).upper()) and L.t_ok(ch)
+    for ch in b"NnRYxX*-0":
+        assert not L.t_ok(ch)
+    seq = bytes(rng.choice(list(b"ACGT"), size=200).tolist())
+    words = np.zeros(9, np.uint64)
+    for i, ch in enumerate(seq):
+        words[i // 32] |= np.uint64(b"ACGT".index(ch)) << np.uint64(62 - 2 * (i % 32))
+    for i in (0, 1, 31, 32, 33, 100, 167):
+        assert L.t_ext(words.ctypes.data, i) == val(seq[i:i + 32])

@@ -1,0 +1,88 @@
+"""GPU tests of the drop-in surface: the `PHI` command line (same flags / log lines / FASTA as the
+reference's src/main.cpp) and the Python mirror of class ILP_index, on the reference's fixtures."""
+import io
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import DATA, GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+PHI = os.path.join(ROOT, "phi_amd", "PHI")
+
+
+def _run_cli(args, tmp_path):
+    if not os.path.exists(PHI):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "phi_amd", "csrc", "host")])
+    return subprocess.run([PHI] + args, capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+
+
+def test_cli_config1_logs_and_fasta(tmp_path):
+    gold = json.load(open(os.path.join(GOLDEN, "counters.json")))["mhc4_chm13_k31_w25"]
+    out = tmp_path / "CHM13.fa"
+    r = _run_cli(["-t32", "-g", os.path.join(DATA, "MHC_4.gfa.gz"), "-r", os.path.join(DATA, "CHM13_reads.fq.gz"), "-o", str(out)], tmp_path)
+    assert r.returncode == 0, r.stderr
+    log = r.stderr
+    # the lines data/postprocessing_2_MIQP.py:55-79 scrapes, and the per-walk tables
+    assert re.search(r"\[M::main::[\d.]+\*[\d.]+\] Loaded graph from: ", log)
+    assert "Graph has 111805 vertices, 5 walks and read has 16401 reads" in log
+    for name, n in zip(gold["hap_names"], gold["n_minimizers"]):
+        assert f"{name} : {n}\n" in log
+    assert f"Indexed reads with spectrum size: {gold['spectrum_size']}\n" in log
+    for name, n in zip(gold["hap_names"], gold["n_anchors"]):
+        assert f"{name} : {n}\n" in log
+    assert f"Filtered/Retained Minimizers: {gold['filtered_retained_pct']}%\n" in log
+    assert f"{gold['pct_in_model']}% Minimizers are in ILP\n" in log
+    assert "QP model started" in log and "Using Mixed Integer Programming" in log
+    assert "Recombination count: 0\n" in log
+    m = re.search(r"Recombined haplotypes: >\(CHM13\.0,\[0,(\d+)\]\)\n", log)
+    assert m
+    assert re.search(r"Real time: [\d.]+ sec; CPU: [\d.]+ sec; Peak RSS: [\d.]+ GB", log)
+    txt = out.read_text().split("\n")
+    mm = re.match(r">MHC_4\.gfa_CHM13_reads\.fq LN:(\d+)$", txt[0])
+    assert mm and int(mm.group(1)) == int(m.group(1)) + 1
+    seq = "".join(txt[1:])
+    assert len(seq) == int(mm.group(1)) and all(len(x) == 80 for x in txt[1:-2])
+    assert f"Haplotype of size: {len(seq)} written to: {out}" in log
+
+
+def test_cli_toy_and_python_mirror_agree(tmp_path):
+    from phi_amd import ilp_index as H
+    gfa, rd = os.path.join(DATA, "test.gfa"), os.path.join(DATA, "read.fa")
+    out = tmp_path / "toy.fa"
+    r = _run_cli(["-g", gfa, "-r", rd, "-o", str(out), "-k3", "-w2", "-q0", "-m0", "-R", "10"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "ILP model started" in r.stderr and "Using Integer Programming" in r.stderr
+    assert "test_hap_4.4 : 5\n" in r.stderr and "50.00% Minimizers are in ILP" in r.stderr
+    assert "Filtered/Retained Minimizers: 37.50/62.50%" in r.stderr
+    cli_fa = out.read_text()
+    assert cli_fa.startswith(">test_read LN:")
+    # the Python mirror of main.cpp:114-140
+    log = io.StringIO()
+    idx = H.ILP_index(gfa, log=log)
+    idx.read_gfa()
+    idx.k_mer, idx.window, idx.recombination, idx.is_qclp, idx.is_mixed = 3, 2, 10, 0, False
+    idx.hap_file = str(tmp_path / "toy_py.fa")
+    idx.hap_name = H.get_hap_name(gfa, rd)
+    reads = []
+    idx.read_ip_reads(reads, rd)
+    assert reads == [("test_read_1", b"ATCGATCATACTTACCATG")]
+    res = idx.ILP_function(reads)
+    assert res["objective"] == 4
+    assert open(idx.hap_file).read() == cli_fa
+    py_log = log.getvalue()
+    for line in ("Number of Minimizers", "test_hap_1.0 : 10", "Indexed reads with spectrum size: 8", "Recombination count: 0"):
+        assert line in py_log and line in r.stderr
+
+
+def test_cli_errors(tmp_path):
+    r = _run_cli([], tmp_path)
+    assert r.returncode == 1 and r.stderr.startswith("Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta>")
+    r = _run_cli(["-g", "nope.gfa", "-r", os.path.join(DATA, "read.fa"), "-o", "x.fa"], tmp_path)
+    assert r.returncode == 1 and "failed to load the GFA file" in r.stderr
+    r = _run_cli(["--version"], tmp_path)
+    assert r.returncode == 0 and "PHI version" in r.stderr
