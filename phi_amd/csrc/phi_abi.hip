@@ -54,6 +54,22 @@ template <class T> static int upload(phi_ctx *c, DevBuf &b, const T *src, size_t
 }
 
 static uint64_t *scalar(phi_ctx *c, int i) { return c->d_scalars.as<uint64_t>() + i; }
+static unsigned long long *sp_stripes(phi_ctx *c) { return c->d_stripes.as<unsigned long long>(); }
+static unsigned long long *emit_stripes(phi_ctx *c) { return c->d_stripes.as<unsigned long long>() + PHI_STRIPES * 8; }
+#define STRIPE_BYTES ((size_t)PHI_STRIPES * 8 * 8)
+
+int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted)
+{
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return phi_fail(c, PHI_ERR_DEVICE, "stream synchronize failed");
+    std::vector<uint64_t> h(2 * PHI_STRIPES * 8);
+    int rc = phi_hip_check(c, hipMemcpy(h.data(), c->d_stripes.p, 2 * STRIPE_BYTES, hipMemcpyDeviceToHost), "D2H counters");
+    if (rc) return rc;
+    uint64_t a = 0, b = 0;
+    for (int i = 0; i < PHI_STRIPES; i++) { a += h[(size_t)i * 8]; b += h[(size_t)(PHI_STRIPES + i) * 8]; }
+    if (n_distinct) *n_distinct = a;
+    if (n_emitted) *n_emitted = b;
+    return PHI_OK;
+}
 
 // wait for the stream and translate the device error word
 int phi_sync_check(phi_ctx *c)
@@ -102,7 +118,8 @@ int phi_ctx_create(int device_id, phi_ctx **out)
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PHI_ERR_DEVICE; }
     c->stream = c->own_stream;
-    if (phi_dev_ensure(c, c->d_scalars, S_N * 8) || hipMemset(c->d_scalars.p, 0, S_N * 8) != hipSuccess) {
+    if (phi_dev_ensure(c, c->d_scalars, S_N * 8) || hipMemset(c->d_scalars.p, 0, S_N * 8) != hipSuccess ||
+        phi_dev_ensure(c, c->d_stripes, 2 * STRIPE_BYTES) || hipMemset(c->d_stripes.p, 0, 2 * STRIPE_BYTES) != hipSuccess) {
         (void)hipStreamDestroy(c->own_stream); delete c; return PHI_ERR_DEVICE;
     }
     *out = c;
@@ -117,7 +134,7 @@ void phi_ctx_destroy(phi_ctx *c)
     DevBuf *all[] = {&c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
-                     &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_blk_cnt,
+                     &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_qbest, &c->d_lent, &c->d_top,
@@ -339,6 +356,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
 
     // ---- stage 1a on the GPU: pack the walks, sketch them, build the minimiser table
     HIPCHK(hipMemsetAsync(c->d_scalars.p, 0, S_N * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_stripes.p, 0, 2 * STRIPE_BYTES, c->stream));
     const int64_t n_words = (run + 31) / 32;
     PHICHK(phi_dev_ensure(c, c->d_wwords, (size_t)(n_words + 2) * 8));
     HIPCHK(hipMemsetAsync(c->d_wwords.as<uint64_t>() + n_words, 0, 16, c->stream));
@@ -405,12 +423,11 @@ static int sp_ensure(phi_ctx *c, int64_t add_bases)
         PHICHK(phi_dev_ensure(c, c->d_sp_keys, need * 8));
         c->sp_cap = need;
         phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)need, PHI_EMPTY_KEY);
-        HIPCHK(hipMemsetAsync(scalar(c, S_SPCOUNT), 0, 8, c->stream));
+        HIPCHK(hipMemsetAsync(sp_stripes(c), 0, STRIPE_BYTES, c->stream));
     } else if (need > c->sp_cap) {
         // the bound is pessimistic: look at the real size before growing
-        HIPCHK(hipStreamSynchronize(c->stream));
         uint64_t cnt = 0;
-        HIPCHK(hipMemcpy(&cnt, scalar(c, S_SPCOUNT), 8, hipMemcpyDeviceToHost));
+        PHICHK(phi_read_counts(c, &cnt, nullptr));
         c->sp_bound = (int64_t)cnt;
         need = pow2_at_least(std::max<uint64_t>(1u << 16, 2 * (uint64_t)(c->sp_bound + est)));
         if (need > c->sp_cap) {
@@ -423,9 +440,9 @@ static int sp_ensure(phi_ctx *c, int64_t add_bases)
             PHICHK(phi_dev_ensure(c, c->d_sp_keys, need * 8));
             c->sp_cap = need;
             phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)need, PHI_EMPTY_KEY);
-            HIPCHK(hipMemsetAsync(scalar(c, S_SPCOUNT), 0, 8, c->stream));
+            HIPCHK(hipMemsetAsync(sp_stripes(c), 0, STRIPE_BYTES, c->stream));
             phi_launch_spectrum_insert(c->stream, c->d_export.as<uint64_t>(), (int64_t)cnt, c->d_sp_keys.as<uint64_t>(),
-                                       c->sp_cap - 1, (unsigned long long *)scalar(c, S_SPCOUNT),
+                                       c->sp_cap - 1, sp_stripes(c),
                                        (uint32_t *)scalar(c, S_ERR));
         }
     }
@@ -456,8 +473,8 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     A.starts = c->d_rstarts.as<unsigned long long>();
     A.n_bases = n_bases; A.k = c->k; A.w = c->w;
     A.sp_keys = c->d_sp_keys.as<uint64_t>(); A.sp_mask = c->sp_cap - 1;
-    A.sp_count = (unsigned long long *)scalar(c, S_SPCOUNT);
-    A.n_emitted = (unsigned long long *)scalar(c, S_NEMIT);
+    A.sp_count = sp_stripes(c);
+    A.n_emitted = emit_stripes(c);
     A.u_keys = c->d_u_keys.as<uint64_t>(); A.u_uid = c->d_u_uid.as<uint32_t>(); A.u_mask = c->u_cap - 1;
     A.hit = c->d_hit.as<uint8_t>();
     A.err = (uint32_t *)scalar(c, S_ERR);
@@ -512,7 +529,7 @@ int phi_reset_reads(phi_ctx *c)
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reset_reads before phi_set_graph");
     HIPCHK(hipSetDevice(c->device));
     if (c->sp_cap) phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, PHI_EMPTY_KEY);
-    HIPCHK(hipMemsetAsync(scalar(c, S_SPCOUNT), 0, 16, c->stream));       // sp_count and n_emitted
+    HIPCHK(hipMemsetAsync(c->d_stripes.p, 0, 2 * STRIPE_BYTES, c->stream));   // distinct-hash and emitted counters
     HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)std::max<int64_t>(c->n_unique, 1), c->stream));
     c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
     c->solved = false;
@@ -525,12 +542,12 @@ int phi_reads_stats(phi_ctx *c, int64_t *n_reads, int64_t *n_bases, int64_t *n_e
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reads_stats before phi_set_graph");
     HIPCHK(hipSetDevice(c->device));
     PHICHK(phi_sync_check(c));
-    uint64_t s[S_N];
-    HIPCHK(hipMemcpy(s, c->d_scalars.p, sizeof s, hipMemcpyDeviceToHost));
+    uint64_t nd = 0, ne = 0;
+    PHICHK(phi_read_counts(c, &nd, &ne));
     if (n_reads) *n_reads = c->reads_count;
     if (n_bases) *n_bases = c->reads_bases;
-    if (n_emitted) *n_emitted = (int64_t)s[S_NEMIT];
-    if (n_distinct) *n_distinct = c->sp_cap ? (int64_t)s[S_SPCOUNT] : 0;
+    if (n_emitted) *n_emitted = (int64_t)ne;
+    if (n_distinct) *n_distinct = c->sp_cap ? (int64_t)nd : 0;
     return PHI_OK;
 }
 
@@ -552,7 +569,7 @@ int phi_spectrum_export(phi_ctx *c, void **d_hashes, int64_t *n)
     if (c->sp_cap == 0) return PHI_OK;
     PHICHK(phi_sync_check(c));
     uint64_t cnt = 0;
-    HIPCHK(hipMemcpy(&cnt, scalar(c, S_SPCOUNT), 8, hipMemcpyDeviceToHost));
+    PHICHK(phi_read_counts(c, &cnt, nullptr));
     PHICHK(phi_dev_ensure(c, c->d_export, (size_t)std::max<uint64_t>(cnt, 1) * 8));
     HIPCHK(hipMemsetAsync(scalar(c, S_EXPORT), 0, 8, c->stream));
     phi_launch_spectrum_export(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_export.as<uint64_t>(),
@@ -572,7 +589,7 @@ int phi_spectrum_import(phi_ctx *c, const void *d_hashes, int64_t n)
     if (d_hashes == c->d_export.p) return phi_fail(c, PHI_ERR_INVALID, "phi_spectrum_import: pass a copy, not the export buffer");
     PHICHK(sp_ensure(c, n * 4));
     phi_launch_spectrum_insert(c->stream, (const uint64_t *)d_hashes, n, c->d_sp_keys.as<uint64_t>(), c->sp_cap - 1,
-                               (unsigned long long *)scalar(c, S_SPCOUNT), (uint32_t *)scalar(c, S_ERR));
+                               sp_stripes(c), (uint32_t *)scalar(c, S_ERR));
     HIPCHK(hipGetLastError());
     c->solved = false;
     return PHI_OK;

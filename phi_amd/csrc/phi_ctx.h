@@ -59,6 +59,7 @@ struct phi_ctx {
     DevBuf d_rbases, d_roff, d_rwords, d_rstarts, d_export;
     // device scalars: [0] err(u32 in low half) [1] n_bad [2] sp_count [3] n_emitted [4..] scratch
     DevBuf d_scalars;
+    DevBuf d_stripes;                                 // [2][PHI_STRIPES][8] u64: distinct read hashes, emitted records
 
     // ---- scratch for sketch passes and compaction
     DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2;
@@ -90,5 +91,7 @@ int phi_fail(phi_ctx *c, int code, const char *fmt, ...);
 int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes);
 int phi_hip_check(phi_ctx *c, hipError_t e, const char *what);
 int phi_sync_check(phi_ctx *c);
+// sums of the striped counters (waits for the stream)
+int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted);
 // flags[n] (0/1) -> ascending list of flagged indices (int32) in out
 int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_t *n_out);

@@ -4,10 +4,12 @@
 #include <hip/hip_runtime.h>
 
 #define PHI_TPB 256            // lanes per workgroup of the sketch kernel (4 waves)
-#define PHI_CH 2048            // window positions per workgroup
+#define PHI_WCH 512            // window positions per wave (each wave sketches its own chunk)
 #define PHI_MAX_W 256
 #define PHI_MAX_K 32
 #define PHI_MAX_PROBE 4096     // linear-probe bound of the open-addressed tables
+#define PHI_STRIPES 256          // counters are striped over 256 cache lines: one hot address
+                                 // serialises at ~12 ns per atomic (MI355X_MICROARCH.md "fanin")
 #define PHI_RCAP 32            // DP run-length states 0..31 (an anchor spans <= k-1 <= 31 edges)
 
 enum { PHI_MODE_COUNT = 0, PHI_MODE_WRITE = 1, PHI_MODE_PROBE = 2 };
@@ -29,8 +31,8 @@ struct PhiSketchArgs {
     int64_t *out_pos;
     // PHI_MODE_PROBE
     uint64_t *sp_keys; uint64_t sp_mask;   // read spectrum set
-    unsigned long long *sp_count;
-    unsigned long long *n_emitted;
+    unsigned long long *sp_count;          // [PHI_STRIPES][8] striped counter of new spectrum entries
+    unsigned long long *n_emitted;         // [PHI_STRIPES][8] striped counter of emitted records
     const uint64_t *u_keys; const uint32_t *u_uid; uint64_t u_mask;   // walk-minimiser table: slot -> dense id
     uint8_t *hit;                          // per distinct walk minimiser (dense id)
     uint32_t *err;

@@ -24,8 +24,7 @@
 #include "phi_kernels.h"
 
 #define TPB PHI_TPB
-#define CH PHI_CH
-#define Q (CH / TPB)
+#define Q 8                     // windows per lane
 
 // ---------------------------------------------------------------------------------- packing
 
@@ -120,46 +119,37 @@ __global__ void __launch_bounds__(256) phi_pack_walks_kernel(const uint8_t *__re
 
 // ---------------------------------------------------------------------------------- helpers
 
-// exclusive prefix sum of one int per lane over the workgroup; *total = sum.  s_w: [TPB/64+1].
-__device__ __forceinline__ int block_excl_scan(int x, int *total, int *s_w)
+// Lanes of one wave exchange data through LDS without a workgroup barrier: LDS instructions of a
+// wave execute in issue order, so only the compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_sync()
 {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    int v = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    if (lane == 63) s_w[wid] = v;
-    __syncthreads();
-    int woff = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < TPB / 64; i++) {
-        const int s = s_w[i];
-        if (i < wid) woff += s;
-        tot += s;
-    }
-    __syncthreads();
-    *total = tot;
-    return woff + v - x;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
-// position of the first start bit in [from, limit), or INT64_MAX
-__device__ __forceinline__ int64_t next_start(const unsigned long long *__restrict__ starts, int64_t from,
-                                              int64_t limit)
+// first set bit at local index >= from and < limit in an LDS bitmap, or INT_MAX
+__device__ __forceinline__ int next_start_lds(const unsigned long long *s_bits, int from, int limit)
 {
-    if (from >= limit) return INT64_MAX;
-    int64_t wi = from >> 6;
-    const int64_t wl = (limit - 1) >> 6;
-    unsigned long long word = starts[wi] & (~0ull << (from & 63));
+    if (from >= limit) return INT_MAX;
+    int wi = from >> 6;
+    const int wl = (limit - 1) >> 6;
+    unsigned long long word = s_bits[wi] & (~0ull << (from & 63));
     for (;;) {
         if (word) {
-            const int64_t p = (wi << 6) + (__ffsll((long long)word) - 1);
-            return p < limit ? p : INT64_MAX;
+            const int p = (wi << 6) + (__ffsll((long long)word) - 1);
+            return p < limit ? p : INT_MAX;
         }
-        if (++wi > wl) return INT64_MAX;
-        word = starts[wi];
+        if (++wi > wl) return INT_MAX;
+        word = s_bits[wi];
     }
+}
+
+// 32 bases starting at local base lb of the staged words, left-aligned
+__device__ __forceinline__ uint64_t lds_extract64(const uint64_t *s_words, int lb)
+{
+    const int wi = lb >> 5, s = (lb & 31) * 2;
+    const uint64_t hi = s_words[wi];
+    return s ? (hi << s) | (s_words[wi + 1] >> (64 - s)) : hi;
 }
 
 struct MinEnt { uint64_t v; int i; };
@@ -167,72 +157,106 @@ struct MinEnt { uint64_t v; int i; };
 __device__ __forceinline__ MinEnt take_right(MinEnt a, MinEnt b) { return (b.v <= a.v) ? b : a; }
 
 // ---------------------------------------------------------------------------------- sketch
+//
+// Every WAVE owns one chunk of WCH consecutive window positions and never waits for another wave:
+// no workgroup barrier anywhere, so the CU overlaps the phases of different waves freely.
 
-template <int MODE>
+#define WCH PHI_WCH
+#define SWW 32          // staged packed words per wave:  (WCH + w + k + 62) / 32 + 1 <= 29
+#define SBW 16          // staged start-bitmap words:     (WCH + 64 + w + k) / 64 + 2 <= 16
+#define SM(l) s_mp[(l) + ((l) >> 3)]   // one pad word per 8 entries: lane t reads entries 8t+i
+                                        // = u64 index 9t+i: conflict-free for ds_read_b64
+
+__host__ __device__ static inline int phi_wave_region_u64(int w)
+{
+    return ((WCH + w + 8) * 9) / 8 + 8 + SWW + SBW + WCH / 2 + 4;
+}
+
+// WIDE: w > Q (windows of one lane overlap in a common core); otherwise brute force per window.
+// KT/WT: compile-time k and w of the specialised instance (0 = take them from the arguments).
+template <int MODE, bool WIDE, int KT, int WT>
 __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 {
-    __shared__ uint64_t s_m[CH + PHI_MAX_W + 8];   // canonical k-mers, later candidate values
-    __shared__ uint64_t s_hash[CH];
-    __shared__ uint32_t s_meta[CH];
-    __shared__ uint64_t s_prev;
-    __shared__ uint64_t s_hprev;
-    __shared__ int s_w[TPB / 64 + 1];
+    constexpr bool NEED_POS = MODE == PHI_MODE_WRITE;   // only the ordered write stores positions (ILP_index.cpp:423)
+    extern __shared__ uint64_t s_dyn[];
 
-    const int tid = threadIdx.x;
-    const int k = A.k, w = A.w;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int k = KT ? KT : A.k, w = WT ? WT : A.w;
     const int64_t N = A.n_bases;
-    const int64_t c0 = (int64_t)blockIdx.x * CH;          // first window start of this chunk
+    const int64_t chunk = (int64_t)blockIdx.x * (TPB / 64) + wid;
+    const int64_t c0 = chunk * WCH;                       // first window start of this chunk
+    if (c0 >= N) return;                                  // wave-uniform
     const uint64_t kmask = phi_kmask(k);
-    const int M = CH + w;                                 // canonical values m[l], l -> k-mer c0-1+l
+    const int M = WCH + w;                                // canonical values m[l], l -> k-mer c0-1+l
+    const int span = w + k - 1;                           // bases under one window
 
-    // ---- phase 1: canonical k-mers
+    const int mp_words = ((M + 8) * 9) / 8 + 8;
+    uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w);   // k-mers; later candidate values, then hashes
+    uint64_t *s_words = s_mp + mp_words;
+    unsigned long long *s_bits = (unsigned long long *)(s_words + SWW);
+    uint32_t *s_meta = (uint32_t *)(s_bits + SBW);
+
+    // ---- phase 0: stage the chunk's packed words and start bits (the only global reads up to
+    //      the output phase).  Local base lb <-> base c0-32+lb; local bit lp <-> base c0-64+lp.
     {
-        const int P = (M + TPB - 1) / TPB;
-        const int l0 = tid * P;
-        const int64_t j0 = c0 - 1 + l0;
-        if (l0 < M) {
-            const int l1 = min(l0 + P, M);
-            uint64_t F = 0, R = 0, nxt = 0;
-            bool live = false;
-            for (int l = l0; l < l1; l++) {
-                const int64_t j = j0 + (l - l0);
-                uint64_t m = ~0ull;
-                if (j >= 0 && j + k <= N) {
-                    if (!live) {
-                        F = phi_extract64(A.words, j) >> (64 - 2 * k);
-                        R = phi_revcomp(F, k);
-                        nxt = phi_extract64(A.words, j + k);   // bases j+k .. j+k+31
-                        live = true;
-                    } else {
-                        const uint64_t b = nxt >> 62;
-                        nxt <<= 2;
-                        F = ((F << 2) | b) & kmask;
-                        R = (R >> 2) | ((3 - b) << (2 * k - 2));
-                    }
-                    m = F < R ? F : R;
-                }
-                s_m[l] = m;
-            }
+        const int64_t n_words = (N + 31) / 32 + 2;        // the buffer carries two zero padding words
+        const int64_t n_sw = N / 64 + 2;
+        if (lane < SWW) {
+            const int64_t wi = (c0 >> 5) - 1 + lane;
+            s_words[lane] = (wi >= 0 && wi < n_words) ? A.words[wi] : 0;
+        } else if (lane - SWW < SBW) {
+            const int64_t wi = (c0 >> 6) - 1 + (lane - SWW);
+            s_bits[lane - SWW] = (wi >= 0 && wi < n_sw) ? A.starts[wi] : 0;
         }
     }
-    __syncthreads();
+    wave_sync();
 
-    // ---- phase 2: minima of windows la = tid*Q .. tid*Q+Q  (window la = m[la .. la+w))
+    // ---- phase 1: canonical k-mers, P consecutive per lane
+    {
+        const int P = (M + 63) / 64;
+        const int l0 = lane * P;
+        const int l1 = min(l0 + P, M);
+        const int64_t j0 = c0 - 1 + l0;
+        uint64_t F = 0, R = 0, nxt = 0;
+        bool live = false;
+        for (int l = l0; l < l1; l++) {
+            const int64_t j = j0 + (l - l0);
+            uint64_t m = ~0ull;
+            if (j >= 0 && j + k <= N) {
+                if (!live) {
+                    F = lds_extract64(s_words, l + 31) >> (64 - 2 * k);
+                    R = phi_revcomp(F, k);
+                    nxt = lds_extract64(s_words, l + 31 + k);   // bases j+k .. j+k+31
+                    live = true;
+                } else {
+                    const uint64_t b = nxt >> 62;
+                    nxt <<= 2;
+                    F = ((F << 2) | b) & kmask;
+                    R = (R >> 2) | ((3 - b) << (2 * k - 2));
+                }
+                m = F < R ? F : R;
+            }
+            SM(l) = m;
+        }
+    }
+    wave_sync();
+
+    // ---- phase 2: minima of windows la = lane*Q .. lane*Q+Q  (window la = m[la .. la+w))
     uint64_t wv[Q + 1];
     int wp[Q + 1];
     {
-        const int base = tid * Q;
-        if (w > Q) {
+        const int base = lane * Q;
+        if (WIDE) {
             MinEnt L[Q + 1];                      // L[i] = min of m[base+i .. base+Q), ties right
             L[Q].v = 0; L[Q].i = -1;
 #pragma unroll
             for (int i = Q - 1; i >= 0; i--) {
-                MinEnt e; e.v = s_m[base + i]; e.i = base + i;
+                MinEnt e; e.v = SM(base + i); e.i = NEED_POS ? base + i : 0;
                 L[i] = (i == Q - 1) ? e : take_right(e, L[i + 1]);
             }
-            MinEnt core; core.v = s_m[base + Q]; core.i = base + Q;
+            MinEnt core; core.v = SM(base + Q); core.i = NEED_POS ? base + Q : 0;
             for (int x = base + Q + 1; x < base + w; x++) {
-                MinEnt e; e.v = s_m[x]; e.i = x;
+                MinEnt e; e.v = SM(x); e.i = NEED_POS ? x : 0;
                 core = take_right(core, e);
             }
             MinEnt Rr; Rr.v = 0; Rr.i = -1;       // min of m[base+w .. base+w+i)
@@ -240,7 +264,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             for (int i = 0; i <= Q; i++) {
                 MinEnt t = (i < Q) ? take_right(L[i], core) : core;
                 if (i > 0) {
-                    MinEnt e; e.v = s_m[base + w + i - 1]; e.i = base + w + i - 1;
+                    MinEnt e; e.v = SM(base + w + i - 1); e.i = NEED_POS ? base + w + i - 1 : 0;
                     Rr = (i == 1) ? e : take_right(Rr, e);
                     t = take_right(t, Rr);
                 }
@@ -249,9 +273,9 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
         } else {
 #pragma unroll
             for (int i = 0; i <= Q; i++) {
-                MinEnt t; t.v = s_m[base + i]; t.i = base + i;
+                MinEnt t; t.v = SM(base + i); t.i = NEED_POS ? base + i : 0;
                 for (int x = 1; x < w; x++) {
-                    MinEnt e; e.v = s_m[base + i + x]; e.i = base + i + x;
+                    MinEnt e; e.v = SM(base + i + x); e.i = NEED_POS ? base + i + x : 0;
                     t = take_right(t, e);
                 }
                 wv[i] = t.v; wp[i] = t.i;
@@ -259,86 +283,121 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
         }
     }
 
-    // ---- phase 3: candidate windows of this lane: outputs i = 1..Q, window start a = c0-1+tid*Q+i
+    // ---- phase 3: candidate windows of this lane: outputs i = 1..Q, window start a = c0-1+lane*Q+i
+    //      (local bit of base a = la + 63 with la = lane*Q + i)
     uint32_t cflag = 0, fflag = 0;
     {
-        const int64_t a0 = c0 - 1 + (int64_t)tid * Q;
-        const int span = w + k - 1;                       // bases under one window
-        int64_t ns = next_start(A.starts, a0 + 2, min(N, a0 + Q + span + 1));
+        const int64_t a0 = c0 - 1 + (int64_t)lane * Q;
+        const int lp0 = lane * Q + 63;                    // local bit of base a0
+        // windows a0+i with i <= imax end inside the batch
+        const int64_t room = N - span - a0;
+        const int imax = room > Q ? Q : (int)room;
+        if (span <= 64 - Q) {
+            // sb bit j <-> base a0+1+j: one funnel shift serves all Q windows of this lane
+            const int lb = lp0 + 1;
+            const int wi = lb >> 6, sh = lb & 63;
+            const unsigned long long lo = s_bits[wi];
+            const unsigned long long sb = sh ? (lo >> sh) | (s_bits[wi + 1] << (64 - sh)) : lo;
+            const unsigned long long inside = (span > 1) ? ((1ull << (span - 1)) - 1) : 0ull;
 #pragma unroll
-        for (int i = 1; i <= Q; i++) {
-            const int64_t a = a0 + i;
-            if (ns <= a) ns = next_start(A.starts, a + 1, min(N, a0 + Q + span + 1));
-            const bool valid = (a + span <= N) && (ns > a + span - 1);
-            if (valid) {
-                const bool first = (A.starts[a >> 6] >> (a & 63)) & 1ull;
-                if (first || wv[i] != wv[i - 1]) {
+            for (int i = 1; i <= Q; i++) {
+                // no sequence may start at bases a+1 .. a+span-1 = sb bits i .. i+span-2
+                const bool valid = (i <= imax) && (((sb >> i) & inside) == 0);
+                const bool first = (sb >> (i - 1)) & 1ull;
+                if (valid && (first || wv[i] != wv[i - 1])) {
                     cflag |= 1u << i;
                     if (first) fflag |= 1u << i;
                 }
             }
+        } else {
+            const int lim = lp0 + Q + span + 1;
+            int ns = next_start_lds(s_bits, lp0 + 2, lim);
+#pragma unroll
+            for (int i = 1; i <= Q; i++) {
+                const int lp = lp0 + i;
+                if (ns <= lp) ns = next_start_lds(s_bits, lp + 1, lim);
+                const bool valid = (i <= imax) && (ns > lp + span - 1);
+                if (valid) {
+                    const bool first = (s_bits[lp >> 6] >> (lp & 63)) & 1ull;
+                    if (first || wv[i] != wv[i - 1]) {
+                        cflag |= 1u << i;
+                        if (first) fflag |= 1u << i;
+                    }
+                }
+            }
         }
     }
-    int ncand;
-    const int coff = block_excl_scan(__popc(cflag), &ncand, s_w);   // barriers: s_m reads are done
+    // wave prefix sum of the per-lane candidate counts
+    int ncand, coff;
+    {
+        const int cnt = __popc(cflag);
+        int v = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(v, d, 64);
+            if (lane >= d) v += t;
+        }
+        ncand = __shfl(v, 63, 64);
+        coff = v - cnt;
+    }
+    wave_sync();                                          // every lane has read its k-mers
     {
         int c = coff;
 #pragma unroll
         for (int i = 1; i <= Q; i++) {
             if (cflag & (1u << i)) {
-                s_m[c] = wv[i];
-                s_meta[c] = (uint32_t)(tid * Q + i) | ((uint32_t)wp[i] << 12) | ((fflag >> i) & 1u) << 31;
-                if (c == 0) s_prev = wv[i - 1];
+                SM(c) = wv[i];
+                s_meta[c] = (uint32_t)(lane * Q + i) | ((uint32_t)wp[i] << 10) | ((fflag >> i) & 1u) << 31;
+                if (c == 0) SM(ncand) = wv[i - 1];        // the window before the first candidate
                 c++;
             }
         }
     }
-    __syncthreads();
+    wave_sync();
 
-    // ---- phase 4: hash candidates on dense lanes
-    for (int c = tid; c < ncand; c += TPB) s_hash[c] = phi_kmer_hash(s_m[c], k);
-    if (tid == TPB - 1 && ncand > 0) s_hprev = phi_kmer_hash(s_prev, k);
-    __syncthreads();
+    // ---- phase 4: hash candidates (and the predecessor value in slot ncand) on dense lanes, in
+    //      place: lane c reads and writes slot c only
+    if (ncand > 0)
+        for (int c = lane; c <= ncand; c += 64) SM(c) = phi_kmer_hash(SM(c), k);
+    wave_sync();
 
     // ---- phase 5: hash-change test, ordered compaction, output
     int64_t out_base = 0;
-    if (MODE == PHI_MODE_WRITE) out_base = A.block_off[blockIdx.x];
+    if (MODE == PHI_MODE_WRITE) out_base = A.block_off[chunk];
     int n_emit = 0, n_new = 0;
-    for (int r0 = 0; r0 < ncand; r0 += TPB) {
-        const int c = r0 + tid;
+    for (int r0 = 0; r0 < ncand; r0 += 64) {
+        const int c = r0 + lane;
         bool emit = false;
         uint64_t h = 0;
         uint32_t meta = 0;
         if (c < ncand) {
-            h = s_hash[c];
+            h = SM(c);
             meta = s_meta[c];
-            const uint64_t hp = (meta >> 31) ? PHI_EMPTY_KEY : (c == 0 ? s_hprev : s_hash[c - 1]);
+            const uint64_t hp = (meta >> 31) ? PHI_EMPTY_KEY : SM(c == 0 ? ncand : c - 1);
             emit = h != hp;
         }
         const unsigned long long bal = __ballot(emit);
-        const int lane = tid & 63, wid = tid >> 6;
-        if (lane == 0) s_w[wid] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, tot = 0;
-#pragma unroll
-        for (int i = 0; i < TPB / 64; i++) {
-            const int s = s_w[i];
-            if (i < wid) woff += s;
-            tot += s;
-        }
-        __syncthreads();
         if (emit) {
-            const int rank = n_emit + woff + __popcll(bal & ((1ull << lane) - 1));
+            const int rank = n_emit + __popcll(bal & ((1ull << lane) - 1));
             if (MODE == PHI_MODE_WRITE) {
                 A.out_hash[out_base + rank] = h;
-                A.out_pos[out_base + rank] = c0 - 1 + (int64_t)((meta >> 12) & 0x7FFFFu);
+                A.out_pos[out_base + rank] = c0 - 1 + (int64_t)((meta >> 10) & 0x3FFu);
             } else if (MODE == PHI_MODE_PROBE) {
                 if (h == PHI_EMPTY_KEY) {
                     atomicOr(A.err, PHI_KERR_SENTINEL);
                 } else {
+                    // walk-minimiser table: lookup, mark the minimiser as hit
+                    uint64_t slot = h & A.u_mask;
+                    int probes;
+                    for (probes = 0; probes <= PHI_MAX_PROBE; probes++) {
+                        const uint64_t key = A.u_keys[slot];
+                        if (key == h) { A.hit[A.u_uid[slot]] = 1; break; }
+                        if (key == PHI_EMPTY_KEY) break;
+                        slot = (slot + 1) & A.u_mask;
+                    }
                     // read spectrum: open-addressed insert (ILP_index.cpp:622-635 keeps a set)
-                    uint64_t slot = h & A.sp_mask;
-                    int probes = 0;
+                    slot = h & A.sp_mask;
+                    probes = 0;
                     for (;;) {
                         const unsigned long long prev =
                             atomicCAS((unsigned long long *)&A.sp_keys[slot], PHI_EMPTY_KEY, h);
@@ -347,28 +406,21 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
                         slot = (slot + 1) & A.sp_mask;
                         if (++probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
                     }
-                    // walk-minimiser table: lookup, mark the minimiser as hit
-                    slot = h & A.u_mask;
-                    for (probes = 0; probes <= PHI_MAX_PROBE; probes++) {
-                        const uint64_t key = A.u_keys[slot];
-                        if (key == h) { A.hit[A.u_uid[slot]] = 1; break; }
-                        if (key == PHI_EMPTY_KEY) break;
-                        slot = (slot + 1) & A.u_mask;
-                    }
                 }
             }
         }
-        n_emit += tot;
+        n_emit += __popcll(bal);
     }
     if (MODE == PHI_MODE_COUNT) {
-        if (tid == 0) A.block_cnt[blockIdx.x] = n_emit;
+        if (lane == 0) A.block_cnt[chunk] = n_emit;
     } else if (MODE == PHI_MODE_PROBE) {
-        // one atomic per workgroup for the number of new spectrum entries and emitted records
-        int tot_new;
-        block_excl_scan(n_new, &tot_new, s_w);
-        if (tid == 0) {
-            if (tot_new) atomicAdd(A.sp_count, (unsigned long long)tot_new);
-            if (n_emit) atomicAdd(A.n_emitted, (unsigned long long)n_emit);
+        // one atomic per wave for the number of new spectrum entries and emitted records
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n_new += __shfl_xor(n_new, d, 64);
+        if (lane == 0) {
+            const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
+            if (n_new) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new);
+            if (n_emit) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
         }
     }
 }
@@ -422,18 +474,29 @@ void phi_launch_pack_walks(hipStream_t st, const uint8_t *seq_concat, const int6
                        ebase, n_entries, words, n_words, n_bad);
 }
 
-int64_t phi_sketch_num_blocks(int64_t n_bases) { return n_bases <= 0 ? 0 : (n_bases + CH - 1) / CH; }
+// number of per-wave chunks (= entries of block_cnt / block_off)
+int64_t phi_sketch_num_blocks(int64_t n_bases) { return n_bases <= 0 ? 0 : (n_bases + WCH - 1) / WCH; }
+
+template <int MODE>
+static void launch_sketch_mode(hipStream_t st, unsigned nb, size_t lds, const PhiSketchArgs &A)
+{
+    // the reference's defaults (options.cpp:7-8) get a fully unrolled instance, except for the
+    // ordered write whose position tracking would push it past 128 VGPRs
+    if (A.k == 31 && A.w == 25 && MODE != PHI_MODE_WRITE)
+        hipLaunchKernelGGL((phi_sketch_kernel<MODE, true, 31, 25>), dim3(nb), dim3(TPB), lds, st, A);
+    else if (A.w > Q) hipLaunchKernelGGL((phi_sketch_kernel<MODE, true, 0, 0>), dim3(nb), dim3(TPB), lds, st, A);
+    else hipLaunchKernelGGL((phi_sketch_kernel<MODE, false, 0, 0>), dim3(nb), dim3(TPB), lds, st, A);
+}
 
 void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A)
 {
-    const int64_t nb = phi_sketch_num_blocks(A.n_bases);
-    if (nb <= 0) return;
-    if (mode == PHI_MODE_COUNT)
-        hipLaunchKernelGGL(phi_sketch_kernel<PHI_MODE_COUNT>, dim3((unsigned)nb), dim3(TPB), 0, st, A);
-    else if (mode == PHI_MODE_WRITE)
-        hipLaunchKernelGGL(phi_sketch_kernel<PHI_MODE_WRITE>, dim3((unsigned)nb), dim3(TPB), 0, st, A);
-    else
-        hipLaunchKernelGGL(phi_sketch_kernel<PHI_MODE_PROBE>, dim3((unsigned)nb), dim3(TPB), 0, st, A);
+    const int64_t nchunks = phi_sketch_num_blocks(A.n_bases);
+    if (nchunks <= 0) return;
+    const unsigned nb = (unsigned)((nchunks + TPB / 64 - 1) / (TPB / 64));
+    const size_t lds = (size_t)phi_wave_region_u64(A.w) * 8 * (TPB / 64);
+    if (mode == PHI_MODE_COUNT) launch_sketch_mode<PHI_MODE_COUNT>(st, nb, lds, A);
+    else if (mode == PHI_MODE_WRITE) launch_sketch_mode<PHI_MODE_WRITE>(st, nb, lds, A);
+    else launch_sketch_mode<PHI_MODE_PROBE>(st, nb, lds, A);
 }
 
 void phi_launch_scan_counts(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off)

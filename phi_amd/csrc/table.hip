@@ -119,7 +119,10 @@ __global__ void __launch_bounds__(256) phi_spectrum_insert_kernel(const uint64_t
             if (++probes > PHI_MAX_PROBE) { atomicOr(err, PHI_KERR_TABLE_FULL); break; }
         }
     }
-    if (n_new) atomicAdd(sp_count, (unsigned long long)n_new);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n_new += __shfl_xor(n_new, d, 64);
+    if ((threadIdx.x & 63) == 0 && n_new)
+        atomicAdd(sp_count + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (PHI_STRIPES - 1)) * 8, (unsigned long long)n_new);
 }
 
 void phi_launch_spectrum_insert(hipStream_t st, const uint64_t *hashes, int64_t n, uint64_t *sp_keys,
