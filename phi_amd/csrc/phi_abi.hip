@@ -402,8 +402,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                            c->d_list2.as<int64_t>());
     c->h_walk_rec_off.resize(n_walks + 1);
     HIPCHK(hipMemcpyAsync(c->h_walk_rec_off.data(), c->d_list2.p, (size_t)(n_walks + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    PHICHK(phi_dev_ensure(c, c->d_hit, (size_t)std::max<int64_t>(c->n_unique, 1)));
-    HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)std::max<int64_t>(c->n_unique, 1), c->stream));
+    PHICHK(phi_dev_ensure(c, c->d_hit, (size_t)(c->n_unique / 8 + 1) * 8));
+    HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)(c->n_unique / 8 + 1) * 8, c->stream));
     HIPCHK(hipGetLastError());
     PHICHK(phi_sync_check(c));
     c->h_n_minimizers.resize(n_walks);
@@ -417,7 +417,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
 // make room in the read-spectrum set for the minimisers of add_bases more read bases
 static int sp_ensure(phi_ctx *c, int64_t add_bases)
 {
-    const int64_t est = add_bases / 4 + 16;
+    const int64_t est = add_bases / 8 + 16;       // emitted-minimiser density is ~2/(w+1); overflow is detected
     uint64_t need = pow2_at_least(std::max<uint64_t>(1u << 16, 2 * (uint64_t)(c->sp_bound + est)));
     if (c->sp_cap == 0) {
         PHICHK(phi_dev_ensure(c, c->d_sp_keys, need * 8));
@@ -461,11 +461,9 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     PHICHK(sp_ensure(c, n_bases));
     const int64_t n_words = (n_bases + 31) / 32;
     PHICHK(phi_dev_ensure(c, c->d_rwords, (size_t)(n_words + 2) * 8));
-    HIPCHK(hipMemsetAsync(c->d_rwords.as<uint64_t>() + n_words, 0, 16, c->stream));
     const size_t n_sw = (size_t)(n_bases / 64 + 2);
     PHICHK(phi_dev_ensure(c, c->d_rstarts, n_sw * 8));
-    HIPCHK(hipMemsetAsync(c->d_rstarts.p, 0, n_sw * 8, c->stream));
-    phi_launch_mark_starts(c->stream, (const int64_t *)d_read_off, n_reads, c->d_rstarts.as<unsigned long long>());
+    phi_launch_start_bitmap(c->stream, (const int64_t *)d_read_off, n_reads, c->d_rstarts.as<unsigned long long>(), (int64_t)n_sw);
     phi_launch_pack_ascii(c->stream, (const uint8_t *)d_bases, n_bases, c->d_rwords.as<uint64_t>(), n_words,
                           (unsigned long long *)scalar(c, S_NBAD));
     PhiSketchArgs A{};
@@ -528,9 +526,9 @@ int phi_reset_reads(phi_ctx *c)
     if (!c) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reset_reads before phi_set_graph");
     HIPCHK(hipSetDevice(c->device));
-    if (c->sp_cap) phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, PHI_EMPTY_KEY);
-    HIPCHK(hipMemsetAsync(c->d_stripes.p, 0, 2 * STRIPE_BYTES, c->stream));   // distinct-hash and emitted counters
-    HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)std::max<int64_t>(c->n_unique, 1), c->stream));
+    phi_launch_reset_reads(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_hit.as<uint64_t>(),
+                           c->n_unique / 8 + 1, c->d_stripes.as<uint64_t>(), 2 * PHI_STRIPES * 8);
+    HIPCHK(hipGetLastError());
     c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
     c->solved = false;
     return PHI_OK;
@@ -587,7 +585,7 @@ int phi_spectrum_import(phi_ctx *c, const void *d_hashes, int64_t n)
     if (n == 0) return PHI_OK;
     HIPCHK(hipSetDevice(c->device));
     if (d_hashes == c->d_export.p) return phi_fail(c, PHI_ERR_INVALID, "phi_spectrum_import: pass a copy, not the export buffer");
-    PHICHK(sp_ensure(c, n * 4));
+    PHICHK(sp_ensure(c, n * 8));          // room for n more distinct hashes
     phi_launch_spectrum_insert(c->stream, (const uint64_t *)d_hashes, n, c->d_sp_keys.as<uint64_t>(), c->sp_cap - 1,
                                sp_stripes(c), (uint32_t *)scalar(c, S_ERR));
     HIPCHK(hipGetLastError());

@@ -42,6 +42,10 @@ struct PhiSketchArgs {
 void phi_launch_pack_ascii(hipStream_t st, const uint8_t *bases, int64_t n, uint64_t *words, int64_t n_words,
                            unsigned long long *n_bad);
 void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts);
+void phi_launch_start_bitmap(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts,
+                             int64_t n_sw);
+void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, uint64_t *hit_words, int64_t n_hit_words,
+                            uint64_t *stripes, int64_t n_stripe_words);
 void phi_launch_pack_walks(hipStream_t st, const uint8_t *seq_concat, const int64_t *seq_off,
                            const int32_t *walk_vtx, const int64_t *ebase, int64_t n_entries, uint64_t *words,
                            int64_t n_words, unsigned long long *n_bad);

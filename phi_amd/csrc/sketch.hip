@@ -34,7 +34,8 @@ __global__ void __launch_bounds__(256) phi_pack_ascii_kernel(const uint8_t *__re
                                                              unsigned long long *__restrict__ n_bad)
 {
     const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wi >= n_words) return;
+    if (wi >= n_words + 2) return;
+    if (wi >= n_words) { words[wi] = 0; return; }           // the two zero padding words
     const int64_t b0 = wi * 32;
     uint64_t word = 0;
     int bad = 0;
@@ -71,6 +72,39 @@ __global__ void phi_mark_starts_kernel(const int64_t *__restrict__ seq_off, int6
     const int64_t p = seq_off[i];
     if (seq_off[i + 1] > p)                 // empty sequences own no base
         atomicOr(&starts[p >> 6], 1ull << (p & 63));
+}
+
+// Same bitmap, one whole word per lane: no memset, no atomics.  Word j covers bases [64j, 64j+64).
+__global__ void __launch_bounds__(256) phi_start_bitmap_kernel(const int64_t *__restrict__ seq_off, int64_t n_seq,
+                                                               unsigned long long *__restrict__ starts, int64_t n_sw)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_sw) return;
+    const int64_t lo_b = j * 64, hi_b = lo_b + 64;
+    int64_t lo = 0, hi = n_seq;                       // first sequence with seq_off >= lo_b
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (seq_off[mid] < lo_b) lo = mid + 1; else hi = mid;
+    }
+    unsigned long long word = 0;
+    for (int64_t r = lo; r < n_seq; r++) {
+        const int64_t p = seq_off[r];
+        if (p >= hi_b) break;
+        if (seq_off[r + 1] > p) word |= 1ull << (p & 63);   // empty sequences own no base
+    }
+    starts[j] = word;
+}
+
+// one launch that forgets all reads: empty spectrum set, zero hit vector, zero striped counters
+__global__ void __launch_bounds__(256) phi_reset_reads_kernel(uint64_t *__restrict__ sp_keys, int64_t sp_cap,
+                                                              uint64_t *__restrict__ hit_words, int64_t n_hit_words,
+                                                              uint64_t *__restrict__ stripes, int64_t n_stripe_words)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t; i < sp_cap; i += stride) sp_keys[i] = PHI_EMPTY_KEY;
+    for (int64_t i = t; i < n_hit_words; i += stride) hit_words[i] = 0;
+    for (int64_t i = t; i < n_stripe_words; i += stride) stripes[i] = 0;
 }
 
 // Walk sequences gathered straight into packed words: lane -> 32 bases of the flat walk space.
@@ -453,7 +487,7 @@ void phi_launch_pack_ascii(hipStream_t st, const uint8_t *bases, int64_t n, uint
                            unsigned long long *n_bad)
 {
     if (n_words <= 0) return;
-    const int64_t nb = (n_words + 255) / 256;
+    const int64_t nb = (n_words + 2 + 255) / 256;
     hipLaunchKernelGGL(phi_pack_ascii_kernel, dim3((unsigned)nb), dim3(256), 0, st, bases, n, words, n_words, n_bad);
 }
 
@@ -462,6 +496,26 @@ void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_se
     if (n_seq <= 0) return;
     const int64_t nb = (n_seq + 255) / 256;
     hipLaunchKernelGGL(phi_mark_starts_kernel, dim3((unsigned)nb), dim3(256), 0, st, seq_off, n_seq, starts);
+}
+
+void phi_launch_start_bitmap(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts,
+                             int64_t n_sw)
+{
+    if (n_sw <= 0) return;
+    hipLaunchKernelGGL(phi_start_bitmap_kernel, dim3((unsigned)((n_sw + 255) / 256)), dim3(256), 0, st, seq_off, n_seq,
+                       starts, n_sw);
+}
+
+void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, uint64_t *hit_words, int64_t n_hit_words,
+                            uint64_t *stripes, int64_t n_stripe_words)
+{
+    int64_t n = sp_cap > n_hit_words ? sp_cap : n_hit_words;
+    if (n_stripe_words > n) n = n_stripe_words;
+    int64_t nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(phi_reset_reads_kernel, dim3((unsigned)nb), dim3(256), 0, st, sp_keys, sp_cap, hit_words,
+                       n_hit_words, stripes, n_stripe_words);
 }
 
 void phi_launch_pack_walks(hipStream_t st, const uint8_t *seq_concat, const int64_t *seq_off,
