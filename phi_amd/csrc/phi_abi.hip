@@ -10,7 +10,7 @@
 #include "phi_dev.h"
 
 // scalar slots in d_scalars (8 bytes each)
-enum { S_ERR = 0, S_NBAD = 1, S_SPCOUNT = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_N = 8 };
+enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_N = 8 };
 
 int phi_fail(phi_ctx *c, int code, const char *fmt, ...)
 {
@@ -80,7 +80,6 @@ int phi_sync_check(phi_ctx *c)
     const uint32_t err = (uint32_t)s[S_ERR];
     if (err & PHI_KERR_TABLE_FULL) return phi_fail(c, PHI_ERR_OVERFLOW, "open-addressed table overflow (probe bound %d)", PHI_MAX_PROBE);
     if (err & PHI_KERR_SENTINEL) return phi_fail(c, PHI_ERR_UNSUPPORTED, "a minimiser hashes to UINT64_MAX (table sentinel)");
-    if (s[S_NBAD]) return phi_fail(c, PHI_ERR_UNSUPPORTED, "%llu bases outside ACGTacgt: the 2-bit path does not handle them yet", (unsigned long long)s[S_NBAD]);
     return PHI_OK;
 }
 
@@ -132,7 +131,8 @@ void phi_ctx_destroy(phi_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
-                     &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
+                     &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
+                     &c->d_wascii, &c->d_rbad, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
                      &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_m_rec, &c->d_m_group,
@@ -166,7 +166,8 @@ int phi_set_params(phi_ctx *c, int32_t k, int32_t w, float threshold, int32_t re
 
 // count pass -> scan -> ordered write of the minimiser records of one packed flat sequence
 static int sketch_records(phi_ctx *c, const uint64_t *words, const unsigned long long *starts, int64_t n_bases,
-                          int32_t k, int32_t w, DevBuf &out_hash, DevBuf &out_pos, int64_t *n_out)
+                          int32_t k, int32_t w, const uint8_t *ascii_if_bad, DevBuf &out_hash, DevBuf &out_pos,
+                          int64_t *n_out)
 {
     *n_out = 0;
     const int64_t nb = phi_sketch_num_blocks(n_bases);
@@ -175,9 +176,13 @@ static int sketch_records(phi_ctx *c, const uint64_t *words, const unsigned long
     PHICHK(phi_dev_ensure(c, c->d_blk_off, (size_t)(nb + 1) * 8));
     PhiSketchArgs A{};
     A.words = words; A.starts = starts; A.n_bases = n_bases; A.k = k; A.w = w;
+    // sequences with bases outside ACGT take the exact byte-wise path for every window, so that the
+    // ordered write stays in position order
+    A.ascii = ascii_if_bad; A.allslow = ascii_if_bad ? 1 : 0; A.badbits = nullptr;
     A.block_cnt = c->d_blk_cnt.as<int32_t>();
     A.err = (uint32_t *)scalar(c, S_ERR);
-    phi_launch_sketch(c->stream, PHI_MODE_COUNT, A);
+    if (A.allslow) phi_launch_sketch_bytes(c->stream, PHI_MODE_COUNT, A, nullptr);
+    else phi_launch_sketch(c->stream, PHI_MODE_COUNT, A);
     phi_launch_scan_counts(c->stream, c->d_blk_cnt.as<int32_t>(), nb, c->d_blk_off.as<int64_t>());
     int64_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, c->d_blk_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, c->stream));
@@ -187,7 +192,8 @@ static int sketch_records(phi_ctx *c, const uint64_t *words, const unsigned long
     A.block_off = c->d_blk_off.as<int64_t>();
     A.out_hash = out_hash.as<uint64_t>();
     A.out_pos = out_pos.as<int64_t>();
-    phi_launch_sketch(c->stream, PHI_MODE_WRITE, A);
+    if (A.allslow) phi_launch_sketch_bytes(c->stream, PHI_MODE_WRITE, A, nullptr);
+    else phi_launch_sketch(c->stream, PHI_MODE_WRITE, A);
     HIPCHK(hipGetLastError());
     *n_out = total;
     return PHI_OK;
@@ -359,10 +365,25 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     HIPCHK(hipMemsetAsync(c->d_stripes.p, 0, 2 * STRIPE_BYTES, c->stream));
     const int64_t n_words = (run + 31) / 32;
     PHICHK(phi_dev_ensure(c, c->d_wwords, (size_t)(n_words + 2) * 8));
-    HIPCHK(hipMemsetAsync(c->d_wwords.as<uint64_t>() + n_words, 0, 16, c->stream));
+    PHICHK(phi_dev_ensure(c, c->d_wbad, (size_t)(n_words + 6) * 4));
     phi_launch_pack_walks(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(),
                           c->d_ebase.as<int64_t>(), n_entries, c->d_wwords.as<uint64_t>(), n_words,
-                          (unsigned long long *)scalar(c, S_NBAD));
+                          c->d_wbad.as<uint32_t>(), nullptr, (unsigned long long *)scalar(c, S_NBAD));
+    // bases outside ACGTacgt in the graph: keep a flat ASCII copy of the walks for the byte-wise path
+    const uint8_t *walk_ascii = nullptr;
+    {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        uint64_t n_bad = 0;
+        HIPCHK(hipMemcpy(&n_bad, scalar(c, S_NBAD), 8, hipMemcpyDeviceToHost));
+        if (n_bad) {
+            PHICHK(phi_dev_ensure(c, c->d_wascii, (size_t)run + 64));
+            HIPCHK(hipMemsetAsync(scalar(c, S_NBAD), 0, 8, c->stream));
+            phi_launch_pack_walks(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(),
+                                  c->d_ebase.as<int64_t>(), n_entries, c->d_wwords.as<uint64_t>(), n_words,
+                                  c->d_wbad.as<uint32_t>(), c->d_wascii.as<uint8_t>(), (unsigned long long *)scalar(c, S_NBAD));
+            walk_ascii = c->d_wascii.as<uint8_t>();
+        }
+    }
     const size_t n_sw = (size_t)(run / 64 + 2);
     PHICHK(phi_dev_ensure(c, c->d_wstarts, n_sw * 8));
     HIPCHK(hipMemsetAsync(c->d_wstarts.p, 0, n_sw * 8, c->stream));
@@ -372,7 +393,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     phi_launch_mark_starts(c->stream, c->d_list.as<int64_t>(), n_walks, c->d_wstarts.as<unsigned long long>());
 
     PHICHK(sketch_records(c, c->d_wwords.as<uint64_t>(), c->d_wstarts.as<unsigned long long>(), run, c->k, c->w,
-                          c->d_rec_hash, c->d_rec_pos, &c->n_rec));
+                          walk_ascii, c->d_rec_hash, c->d_rec_pos, &c->n_rec));
     if (c->n_rec >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk minimisers");
     const int64_t nr = std::max<int64_t>(c->n_rec, 1);
     PHICHK(phi_dev_ensure(c, c->d_rec_slot, (size_t)nr * 4));
@@ -463,10 +484,15 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     PHICHK(phi_dev_ensure(c, c->d_rwords, (size_t)(n_words + 2) * 8));
     const size_t n_sw = (size_t)(n_bases / 64 + 2);
     PHICHK(phi_dev_ensure(c, c->d_rstarts, n_sw * 8));
-    phi_launch_start_bitmap(c->stream, (const int64_t *)d_read_off, n_reads, c->d_rstarts.as<unsigned long long>(), (int64_t)n_sw);
+    phi_launch_start_bitmap(c->stream, (const int64_t *)d_read_off, n_reads, c->d_rstarts.as<unsigned long long>(), (int64_t)n_sw,
+                            (unsigned long long *)scalar(c, S_BATCHBAD));
+    PHICHK(phi_dev_ensure(c, c->d_rbad, (size_t)(n_words + 6) * 4));
     phi_launch_pack_ascii(c->stream, (const uint8_t *)d_bases, n_bases, c->d_rwords.as<uint64_t>(), n_words,
-                          (unsigned long long *)scalar(c, S_NBAD));
+                          c->d_rbad.as<uint32_t>(), (unsigned long long *)scalar(c, S_BATCHBAD));
     PhiSketchArgs A{};
+    A.badbits = c->d_rbad.as<unsigned long long>();      // windows touching such bases take the byte-wise path
+    A.ascii = (const uint8_t *)d_bases;
+    A.allslow = 0;
     A.words = c->d_rwords.as<uint64_t>();
     A.starts = c->d_rstarts.as<unsigned long long>();
     A.n_bases = n_bases; A.k = c->k; A.w = c->w;
@@ -491,6 +517,8 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
         c->prof_used++;
         c->prof_bases += n_bases;
     }
+    // windows touching a base outside ACGT: exact byte-wise kernel (leaves at once on clean batches)
+    phi_launch_sketch_bytes(c->stream, PHI_MODE_PROBE, A, (const unsigned long long *)scalar(c, S_BATCHBAD));
     HIPCHK(hipGetLastError());
     c->reads_bases += n_bases;
     c->reads_count += n_reads;
@@ -643,7 +671,7 @@ int phi_sketch(phi_ctx *c, const char *bases, const int64_t *seq_off, int64_t n_
     std::vector<int64_t> off(seq_off, seq_off + n_seq + 1);
     for (auto &o : off) o -= seq_off[0];
     do {
-        if ((rc = phi_dev_ensure(c, dB, (size_t)n_bases))) break;
+        if ((rc = phi_dev_ensure(c, dB, (size_t)n_bases + 64))) break;
         if ((rc = phi_dev_ensure(c, dO, (size_t)(n_seq + 1) * 8))) break;
         const int64_t n_words = (n_bases + 31) / 32;
         if ((rc = phi_dev_ensure(c, dW, (size_t)(n_words + 2) * 8))) break;
@@ -655,10 +683,14 @@ int phi_sketch(phi_ctx *c, const char *bases, const int64_t *seq_off, int64_t n_
         if ((rc = phi_hip_check(c, hipMemsetAsync(dS.p, 0, n_sw * 8, c->stream), "memset"))) break;
         if ((rc = phi_hip_check(c, hipMemsetAsync(scalar(c, S_NBAD), 0, 8, c->stream), "memset"))) break;
         phi_launch_mark_starts(c->stream, dO.as<int64_t>(), n_seq, dS.as<unsigned long long>());
-        phi_launch_pack_ascii(c->stream, dB.as<uint8_t>(), n_bases, dW.as<uint64_t>(), n_words,
+        phi_launch_pack_ascii(c->stream, dB.as<uint8_t>(), n_bases, dW.as<uint64_t>(), n_words, nullptr,
                               (unsigned long long *)scalar(c, S_NBAD));
+        if ((rc = phi_hip_check(c, hipStreamSynchronize(c->stream), "sync"))) break;
+        uint64_t n_bad = 0;
+        if ((rc = phi_hip_check(c, hipMemcpy(&n_bad, scalar(c, S_NBAD), 8, hipMemcpyDeviceToHost), "D2H"))) break;
         int64_t total = 0;
-        if ((rc = sketch_records(c, dW.as<uint64_t>(), dS.as<unsigned long long>(), n_bases, k, w, dH, dP, &total))) break;
+        if ((rc = sketch_records(c, dW.as<uint64_t>(), dS.as<unsigned long long>(), n_bases, k, w,
+                                 n_bad ? dB.as<uint8_t>() : nullptr, dH, dP, &total))) break;
         if ((rc = phi_sync_check(c))) break;
         *n_out = total;
         if (cap >= total && total > 0) {

@@ -41,7 +41,7 @@ struct phi_ctx {
     DevBuf d_seq, d_seq_off, d_walk_vtx, d_walk_off, d_ebase, d_topo, d_in_off, d_in_src;
     DevBuf d_e_out, d_st_rec, d_st_mask, d_in_packed;  // DP step stream (dp.hip)
     int dp_nw = 1;                                    // waves of the DP workgroup
-    DevBuf d_wwords, d_wstarts;                       // packed walk sequences + start bitmap
+    DevBuf d_wwords, d_wstarts, d_wbad, d_wascii;     // packed walk sequences, start bitmap, non-ACGT mask, flat ASCII (only if needed)
     DevBuf d_rec_hash, d_rec_pos, d_rec_slot, d_rec_e0, d_rec_e1;   // walk minimiser records
     int64_t n_rec = 0;
     std::vector<int64_t> h_walk_rec_off;              // record range of each walk
@@ -56,7 +56,7 @@ struct phi_ctx {
     int64_t sp_bound = 0;                             // host-side upper bound of the set size
     int64_t reads_bases = 0, reads_count = 0;
     int64_t spectrum_override = -1;
-    DevBuf d_rbases, d_roff, d_rwords, d_rstarts, d_export;
+    DevBuf d_rbases, d_roff, d_rwords, d_rstarts, d_rbad, d_export;
     // device scalars: [0] err(u32 in low half) [1] n_bad [2] sp_count [3] n_emitted [4..] scratch
     DevBuf d_scalars;
     DevBuf d_stripes;                                 // [2][PHI_STRIPES][8] u64: distinct read hashes, emitted records

@@ -77,33 +77,23 @@ PHI_HD uint64_t phi_ascii8(uint32_t x16)
     return (uint64_t)phi_ascii4((x16 >> 8) & 0xFFu) | ((uint64_t)phi_ascii4(x16 & 0xFFu) << 32);
 }
 
-// hash128_to_64 (ILP_index.cpp:10-18) of the k ASCII bytes spelled by a right-aligned k-mer
-// value: MurmurHash3_x64_128 (MurmurHash3.cpp:255-332), seed 0, h1 ^ h2.  1 <= k <= 32.
-PHI_HD uint64_t phi_kmer_hash(uint64_t val, int k)
+// hash128_to_64 (ILP_index.cpp:10-18) of k <= 32 bytes given as four little-endian 8-byte lanes
+// (bytes beyond k are zero): MurmurHash3_x64_128 (MurmurHash3.cpp:255-332), seed 0, h1 ^ h2.
+PHI_HD uint64_t phi_murmur_lanes(uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3, int k)
 {
     const uint64_t c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
-    const uint64_t L = val << (64 - 2 * k);                        // base i at bits [62-2i]
-    uint64_t e[4];
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        uint64_t a = phi_ascii8((uint32_t)(L >> (48 - 16 * g)) & 0xFFFFu);
-        const int nb = k - 8 * g;                                   // bytes of this lane in use
-        if (nb <= 0) a = 0;
-        else if (nb < 8) a &= (1ull << (8 * nb)) - 1;
-        e[g] = a;
-    }
     uint64_t h1 = 0, h2 = 0;
     const int nblocks = k >> 4;
     uint64_t t1, t2;                                               // tail lanes
     if (nblocks >= 1) {
-        uint64_t k1 = e[0], k2 = e[1];
+        uint64_t k1 = e0, k2 = e1;
         k1 *= c1; k1 = phi_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
         h1 = phi_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
         k2 *= c2; k2 = phi_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
         h2 = phi_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-        t1 = e[2]; t2 = e[3];
+        t1 = e2; t2 = e3;
     } else {
-        t1 = e[0]; t2 = e[1];
+        t1 = e0; t2 = e1;
     }
     if (nblocks == 2) {                                            // k == 32: second full block
         uint64_t k1 = t1, k2 = t2;
@@ -121,4 +111,20 @@ PHI_HD uint64_t phi_kmer_hash(uint64_t val, int k)
     h1 = phi_fmix64(h1); h2 = phi_fmix64(h2);
     h1 += h2; h2 += h1;
     return h1 ^ h2;
+}
+
+// The same hash of the k ASCII bytes spelled by a right-aligned 2-bit k-mer value.  1 <= k <= 32.
+PHI_HD uint64_t phi_kmer_hash(uint64_t val, int k)
+{
+    const uint64_t L = val << (64 - 2 * k);                        // base i at bits [62-2i]
+    uint64_t e[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint64_t a = phi_ascii8((uint32_t)(L >> (48 - 16 * g)) & 0xFFFFu);
+        const int nb = k - 8 * g;                                   // bytes of this lane in use
+        if (nb <= 0) a = 0;
+        else if (nb < 8) a &= (1ull << (8 * nb)) - 1;
+        e[g] = a;
+    }
+    return phi_murmur_lanes(e[0], e[1], e[2], e[3], k);
 }

@@ -24,6 +24,11 @@ struct PhiSketchArgs {
     const unsigned long long *starts;      // sequence-start bitmap
     int64_t n_bases;
     int32_t k, w;
+    // bases outside ACGTacgt: one bit per base (null = none), the flat ASCII they live in, and
+    // allslow = take the exact byte-wise path for every window (ordered write of such sequences)
+    const unsigned long long *badbits;
+    const uint8_t *ascii;
+    int32_t allslow;
     // PHI_MODE_COUNT / PHI_MODE_WRITE
     int32_t *block_cnt;
     const int64_t *block_off;
@@ -40,15 +45,16 @@ struct PhiSketchArgs {
 
 // sketch.hip
 void phi_launch_pack_ascii(hipStream_t st, const uint8_t *bases, int64_t n, uint64_t *words, int64_t n_words,
-                           unsigned long long *n_bad);
+                           uint32_t *badbits, unsigned long long *n_bad);
 void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts);
 void phi_launch_start_bitmap(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts,
-                             int64_t n_sw);
+                             int64_t n_sw, unsigned long long *batch_bad);
+void phi_launch_sketch_bytes(hipStream_t st, int mode, const PhiSketchArgs &A, const unsigned long long *batch_bad);
 void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, uint64_t *hit_words, int64_t n_hit_words,
                             uint64_t *stripes, int64_t n_stripe_words);
 void phi_launch_pack_walks(hipStream_t st, const uint8_t *seq_concat, const int64_t *seq_off,
                            const int32_t *walk_vtx, const int64_t *ebase, int64_t n_entries, uint64_t *words,
-                           int64_t n_words, unsigned long long *n_bad);
+                           int64_t n_words, uint32_t *badbits, uint8_t *ascii, unsigned long long *n_bad);
 int64_t phi_sketch_num_blocks(int64_t n_bases);
 void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A);
 void phi_launch_scan_counts(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off);

@@ -9,8 +9,9 @@
 // UINT64_MAX per sequence), MurmurHash3_x64_128 seed 0 folded h1^h2.
 //
 // One flat base space holds all sequences of a batch back to back; a bitmap marks sequence
-// starts.  A window is live iff no sequence starts inside it.  Each workgroup owns PHI_CH
-// consecutive window positions:
+// starts.  A window is live iff no sequence starts inside it.  Every WAVE owns PHI_WCH consecutive
+// window positions and never waits for another wave (no workgroup barrier):
+//   phase 0  stage the chunk's packed words and bitmaps into LDS (the only global reads)
 //   phase 1  canonical k-mers of the chunk (rolling 2-bit arithmetic)      -> LDS
 //   phase 2  sliding-window minima, Q+1 consecutive windows per lane from a
 //            suffix-min / core / prefix-min split (w+Q LDS reads per lane)
@@ -19,6 +20,13 @@
 //   phase 4  murmur3 of each candidate, hash-change test against its predecessor
 //   phase 5  ballot/prefix-sum compaction of the emitted records and, by mode,
 //            count | ordered write | open-addressed spectrum insert + table probe
+//
+// Bases outside ACGTacgt (the reference keeps them as bytes: N sorts between G and T and is its
+// own complement, ILP_index.cpp:350-353) cannot live in 2 bits.  The pack kernels set one bit per
+// such base; the 2-bit path skips every window that, together with its predecessor, touches a
+// marked base, and an exact byte-wise routine (same wave, after its 2-bit phases) handles exactly
+// those windows.  With `allslow` the byte-wise routine handles every window (ordered write of
+// walks that contain such bases).
 #include <hip/hip_runtime.h>
 #include "phi_dev.h"
 #include "phi_kernels.h"
@@ -26,19 +34,26 @@
 #define TPB PHI_TPB
 #define Q 8                     // windows per lane
 
+int64_t phi_sketch_num_blocks(int64_t n_bases);
+
 // ---------------------------------------------------------------------------------- packing
 
-// 32 ASCII bases per lane -> one packed word.  n_bad counts bytes outside ACGTacgt.
+// 32 ASCII bases per lane -> one packed word (+ one 32-bit mask of the bases outside ACGTacgt).
 __global__ void __launch_bounds__(256) phi_pack_ascii_kernel(const uint8_t *__restrict__ bases, int64_t n,
                                                              uint64_t *__restrict__ words, int64_t n_words,
+                                                             uint32_t *__restrict__ badbits,
                                                              unsigned long long *__restrict__ n_bad)
 {
     const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wi >= n_words + 2) return;
-    if (wi >= n_words) { words[wi] = 0; return; }           // the two zero padding words
+    if (wi >= n_words + 4) return;
+    if (wi >= n_words) {                                    // zero padding: 2 words, 4 mask words
+        if (wi < n_words + 2) words[wi] = 0;
+        if (badbits) badbits[wi] = 0;
+        return;
+    }
     const int64_t b0 = wi * 32;
     uint64_t word = 0;
-    int bad = 0;
+    uint32_t bad = 0;
     if (b0 + 32 <= n && ((uintptr_t)(bases + b0) & 15) == 0) {
         const uint4 *p = reinterpret_cast<const uint4 *>(bases + b0);
         uint4 v[2] = {p[0], p[1]};
@@ -48,19 +63,20 @@ __global__ void __launch_bounds__(256) phi_pack_ascii_kernel(const uint8_t *__re
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t c = (u[q] >> (8 * j)) & 0xFFu;
-                bad += !phi_is_acgt(c);
+                bad |= (uint32_t)(!phi_is_acgt(c)) << (4 * q + j);
                 word = (word << 2) | phi_code(c);
             }
         }
     } else {
         for (int j = 0; j < 32; j++) {
             uint32_t c = 'A';
-            if (b0 + j < n) { c = bases[b0 + j]; bad += !phi_is_acgt(c); }
+            if (b0 + j < n) { c = bases[b0 + j]; bad |= (uint32_t)(!phi_is_acgt(c)) << j; }
             word = (word << 2) | phi_code(c);
         }
     }
     words[wi] = word;
-    if (bad) atomicAdd(n_bad, (unsigned long long)bad);
+    if (badbits) badbits[wi] = bad;
+    if (bad) atomicAdd(n_bad, (unsigned long long)__popc(bad));
 }
 
 // starts bitmap: bit (p & 63) of word p >> 6 set iff a sequence starts at base p.
@@ -76,9 +92,11 @@ __global__ void phi_mark_starts_kernel(const int64_t *__restrict__ seq_off, int6
 
 // Same bitmap, one whole word per lane: no memset, no atomics.  Word j covers bases [64j, 64j+64).
 __global__ void __launch_bounds__(256) phi_start_bitmap_kernel(const int64_t *__restrict__ seq_off, int64_t n_seq,
-                                                               unsigned long long *__restrict__ starts, int64_t n_sw)
+                                                               unsigned long long *__restrict__ starts, int64_t n_sw,
+                                                               unsigned long long *__restrict__ batch_bad)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && batch_bad) *batch_bad = 0;          // the pack kernel that follows counts into it
     if (j >= n_sw) return;
     const int64_t lo_b = j * 64, hi_b = lo_b + 64;
     int64_t lo = 0, hi = n_seq;                       // first sequence with seq_off >= lo_b
@@ -109,19 +127,26 @@ __global__ void __launch_bounds__(256) phi_reset_reads_kernel(uint64_t *__restri
 
 // Walk sequences gathered straight into packed words: lane -> 32 bases of the flat walk space.
 // ebase[e] = flat base offset of walk entry e (monotone, ebase[n_entries] = total bases).
+// ascii (optional): the same bases as a flat ASCII buffer, for the byte-wise routine.
 __global__ void __launch_bounds__(256) phi_pack_walks_kernel(const uint8_t *__restrict__ seq_concat,
                                                              const int64_t *__restrict__ seq_off,
                                                              const int32_t *__restrict__ walk_vtx,
                                                              const int64_t *__restrict__ ebase, int64_t n_entries,
                                                              uint64_t *__restrict__ words, int64_t n_words,
+                                                             uint32_t *__restrict__ badbits, uint8_t *__restrict__ ascii,
                                                              unsigned long long *__restrict__ n_bad)
 {
     const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wi >= n_words) return;
+    if (wi >= n_words + 4) return;
+    if (wi >= n_words) {
+        if (wi < n_words + 2) words[wi] = 0;
+        if (badbits) badbits[wi] = 0;
+        return;
+    }
     const int64_t total = ebase[n_entries];
     const int64_t b0 = wi * 32;
     uint64_t word = 0;
-    int bad = 0;
+    uint32_t bad = 0;
     if (b0 < total) {
         // last entry e with ebase[e] <= b0
         int64_t lo = 0, hi = n_entries;           // invariant: ebase[lo] <= b0 < ebase[hi]
@@ -142,13 +167,15 @@ __global__ void __launch_bounds__(256) phi_pack_walks_kernel(const uint8_t *__re
                     src = seq_concat + seq_off[walk_vtx[e]] - ebase[e];
                 }
                 c = src[b];
-                bad += !phi_is_acgt(c);
+                bad |= (uint32_t)(!phi_is_acgt(c)) << j;
+                if (ascii) ascii[b] = (uint8_t)c;
             }
             word = (word << 2) | phi_code(c);
         }
     }
     words[wi] = word;
-    if (bad) atomicAdd(n_bad, (unsigned long long)bad);
+    if (badbits) badbits[wi] = bad;
+    if (bad) atomicAdd(n_bad, (unsigned long long)__popc(bad));
 }
 
 // ---------------------------------------------------------------------------------- helpers
@@ -190,20 +217,136 @@ struct MinEnt { uint64_t v; int i; };
 // b lies to the right of a: ties go right (the reference's deque pops on >=, ILP_index.cpp:397)
 __device__ __forceinline__ MinEnt take_right(MinEnt a, MinEnt b) { return (b.v <= a.v) ? b : a; }
 
+// read spectrum insert + walk-minimiser table probe of one emitted read hash
+__device__ __forceinline__ void probe_tables(const PhiSketchArgs &A, uint64_t h, int &n_new)
+{
+    if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return; }
+    // walk-minimiser table: lookup, mark the minimiser as hit
+    uint64_t slot = h & A.u_mask;
+    int probes;
+    for (probes = 0; probes <= PHI_MAX_PROBE; probes++) {
+        const uint64_t key = A.u_keys[slot];
+        if (key == h) { A.hit[A.u_uid[slot]] = 1; break; }
+        if (key == PHI_EMPTY_KEY) break;
+        slot = (slot + 1) & A.u_mask;
+    }
+    // read spectrum: open-addressed insert (ILP_index.cpp:622-635 keeps a set)
+    slot = h & A.sp_mask;
+    probes = 0;
+    for (;;) {
+        const unsigned long long prev = atomicCAS((unsigned long long *)&A.sp_keys[slot], PHI_EMPTY_KEY, h);
+        if (prev == PHI_EMPTY_KEY) { n_new++; break; }
+        if (prev == h) break;
+        slot = (slot + 1) & A.sp_mask;
+        if (++probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
+    }
+}
+
+// ---------------------------------------------------------------------------------- byte-wise routine
+// Exact restatement on ASCII for windows the 2-bit path cannot take (ILP_index.cpp:330-357, 388-414).
+
+struct KRef { int64_t pos; int rc; };        // a k-mer: start base and strand
+
+__device__ __forceinline__ uint32_t up_byte(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
+__device__ __forceinline__ uint32_t comp_byte(uint32_t c)     // c is upper case; others map to themselves
+{
+    return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+}
+__device__ __forceinline__ uint32_t kbyte(const uint8_t *__restrict__ s, KRef r, int x, int k)
+{
+    return r.rc ? comp_byte(up_byte(s[r.pos + k - 1 - x])) : up_byte(s[r.pos + x]);
+}
+__device__ __forceinline__ int kcmp(const uint8_t *__restrict__ s, KRef a, KRef b, int k)
+{
+    for (int x = 0; x < k; x++) {
+        const uint32_t ca = kbyte(s, a, x, k), cb = kbyte(s, b, x, k);
+        if (ca != cb) return ca < cb ? -1 : 1;
+    }
+    return 0;
+}
+__device__ __forceinline__ KRef canon_bytes(const uint8_t *__restrict__ s, int64_t i, int k)
+{
+    const KRef f{i, 0}, r{i, 1};
+    return kcmp(s, r, f, k) < 0 ? r : f;                    // std::min(fwd, rev)
+}
+__device__ KRef window_best_bytes(const uint8_t *__restrict__ s, int64_t a, int k, int w)
+{
+    KRef best = canon_bytes(s, a, k);
+    for (int j = 1; j < w; j++) {
+        const KRef c = canon_bytes(s, a + j, k);
+        if (kcmp(s, c, best, k) <= 0) best = c;             // ties go right
+    }
+    return best;
+}
+__device__ uint64_t khash_bytes(const uint8_t *__restrict__ s, KRef r, int k)
+{
+    uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    for (int x = 0; x < k; x++) {
+        const uint64_t b = (uint64_t)kbyte(s, r, x, k) << (8 * (x & 7));
+        if (x < 8) e0 |= b; else if (x < 16) e1 |= b; else if (x < 24) e2 |= b; else e3 |= b;
+    }
+    return phi_murmur_lanes(e0, e1, e2, e3, k);
+}
+
+__device__ __forceinline__ bool range_has_bit(const unsigned long long *s_bits, int lo, int hi)   // [lo, hi]
+{
+    return next_start_lds(s_bits, lo, hi + 1) != INT_MAX;
+}
+
+// Windows la = 1..WCH of this wave's chunk that need the byte-wise path, in position order.
+template <int MODE>
+__device__ __forceinline__ void slow_windows(const PhiSketchArgs &A, int64_t c0, int64_t chunk, int lane, int k, int w,
+                                          const unsigned long long *s_bits, const unsigned long long *s_bad,
+                                          bool allslow, int64_t out_base, int &n_emit, int &n_new)
+{
+    const int64_t N = A.n_bases;
+    const int span = w + k - 1;
+    for (int r = 0; r < PHI_WCH / 64; r++) {
+        const int la = 1 + r * 64 + lane;
+        const int64_t a = c0 - 1 + la;
+        const int lp = la + 63;                                     // local bit of base a
+        bool todo = (a + span <= N) && !range_has_bit(s_bits, lp + 1, lp + span - 1);
+        if (todo && !allslow) todo = range_has_bit(s_bad, lp - 1, lp + span - 1);
+        bool emit = false;
+        uint64_t h = 0;
+        int64_t pos = 0;
+        if (todo) {
+            const bool first = (s_bits[lp >> 6] >> (lp & 63)) & 1ull;
+            const KRef best = window_best_bytes(A.ascii, a, k, w);
+            h = khash_bytes(A.ascii, best, k);
+            pos = best.pos;
+            if (first) emit = h != PHI_EMPTY_KEY;                   // prev_hash = UINT64_MAX (:383, :455)
+            else {
+                const KRef prev = window_best_bytes(A.ascii, a - 1, k, w);
+                emit = !(prev.pos == best.pos && prev.rc == best.rc) && khash_bytes(A.ascii, prev, k) != h;
+            }
+        }
+        const unsigned long long bal = __ballot(emit);
+        if (emit) {
+            const int rank = n_emit + __popcll(bal & ((1ull << lane) - 1));
+            if (MODE == PHI_MODE_WRITE) {
+                A.out_hash[out_base + rank] = h;
+                A.out_pos[out_base + rank] = pos;
+            } else if (MODE == PHI_MODE_PROBE) {
+                probe_tables(A, h, n_new);
+            }
+        }
+        n_emit += __popcll(bal);
+    }
+    (void)chunk;
+}
+
 // ---------------------------------------------------------------------------------- sketch
-//
-// Every WAVE owns one chunk of WCH consecutive window positions and never waits for another wave:
-// no workgroup barrier anywhere, so the CU overlaps the phases of different waves freely.
 
 #define WCH PHI_WCH
 #define SWW 32          // staged packed words per wave:  (WCH + w + k + 62) / 32 + 1 <= 29
-#define SBW 16          // staged start-bitmap words:     (WCH + 64 + w + k) / 64 + 2 <= 16
+#define SBW 16          // staged bitmap words per wave:  (WCH + 64 + w + k) / 64 + 2 <= 16
 #define SM(l) s_mp[(l) + ((l) >> 3)]   // one pad word per 8 entries: lane t reads entries 8t+i
                                         // = u64 index 9t+i: conflict-free for ds_read_b64
 
 __host__ __device__ static inline int phi_wave_region_u64(int w)
 {
-    return ((WCH + w + 8) * 9) / 8 + 8 + SWW + SBW + WCH / 2 + 4;
+    return ((WCH + w + 8) * 9) / 8 + 8 + SWW + 2 * SBW + WCH / 2 + 4;
 }
 
 // WIDE: w > Q (windows of one lane overlap in a common core); otherwise brute force per window.
@@ -223,15 +366,18 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     const uint64_t kmask = phi_kmask(k);
     const int M = WCH + w;                                // canonical values m[l], l -> k-mer c0-1+l
     const int span = w + k - 1;                           // bases under one window
+    const bool have_bad = A.badbits != nullptr;
 
     const int mp_words = ((M + 8) * 9) / 8 + 8;
     uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w);   // k-mers; later candidate values, then hashes
     uint64_t *s_words = s_mp + mp_words;
     unsigned long long *s_bits = (unsigned long long *)(s_words + SWW);
-    uint32_t *s_meta = (uint32_t *)(s_bits + SBW);
+    unsigned long long *s_bad = s_bits + SBW;
+    uint32_t *s_meta = (uint32_t *)(s_bad + SBW);
 
-    // ---- phase 0: stage the chunk's packed words and start bits (the only global reads up to
-    //      the output phase).  Local base lb <-> base c0-32+lb; local bit lp <-> base c0-64+lp.
+    // ---- phase 0: stage the chunk's packed words and bitmaps (the only global reads up to the
+    //      output phase).  Local base lb <-> base c0-32+lb; local bit lp <-> base c0-64+lp.
+    unsigned long long my_bad = 0;
     {
         const int64_t n_words = (N + 31) / 32 + 2;        // the buffer carries two zero padding words
         const int64_t n_sw = N / 64 + 2;
@@ -241,9 +387,18 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
         } else if (lane - SWW < SBW) {
             const int64_t wi = (c0 >> 6) - 1 + (lane - SWW);
             s_bits[lane - SWW] = (wi >= 0 && wi < n_sw) ? A.starts[wi] : 0;
+        } else {
+            const int64_t wi = (c0 >> 6) - 1 + (lane - SWW - SBW);
+            if (have_bad) my_bad = (wi >= 0 && wi < n_sw) ? A.badbits[wi] : 0;
+            s_bad[lane - SWW - SBW] = my_bad;
         }
     }
+    const bool chunk_bad = have_bad && __ballot(my_bad != 0) != 0ull;   // wave-uniform
     wave_sync();
+
+    int n_emit = 0, n_new = 0;
+    int64_t out_base = 0;
+    if (MODE == PHI_MODE_WRITE) out_base = A.block_off[chunk];
 
     // ---- phase 1: canonical k-mers, P consecutive per lane
     {
@@ -333,10 +488,18 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             const unsigned long long lo = s_bits[wi];
             const unsigned long long sb = sh ? (lo >> sh) | (s_bits[wi + 1] << (64 - sh)) : lo;
             const unsigned long long inside = (span > 1) ? ((1ull << (span - 1)) - 1) : 0ull;
+            // bb bit j <-> base a0+j is outside ACGT: window a and its predecessor cover a-1 .. a+span-1
+            unsigned long long bb = 0;
+            if (chunk_bad) {
+                const int wj = lp0 >> 6, sj = lp0 & 63;
+                const unsigned long long lo2 = s_bad[wj];
+                bb = sj ? (lo2 >> sj) | (s_bad[wj + 1] << (64 - sj)) : lo2;
+            }
+            const unsigned long long clean = (span + 1 >= 64) ? ~0ull : ((1ull << (span + 1)) - 1);
 #pragma unroll
             for (int i = 1; i <= Q; i++) {
                 // no sequence may start at bases a+1 .. a+span-1 = sb bits i .. i+span-2
-                const bool valid = (i <= imax) && (((sb >> i) & inside) == 0);
+                const bool valid = (i <= imax) && (((sb >> i) & inside) == 0) && (((bb >> (i - 1)) & clean) == 0);
                 const bool first = (sb >> (i - 1)) & 1ull;
                 if (valid && (first || wv[i] != wv[i - 1])) {
                     cflag |= 1u << i;
@@ -350,7 +513,8 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             for (int i = 1; i <= Q; i++) {
                 const int lp = lp0 + i;
                 if (ns <= lp) ns = next_start_lds(s_bits, lp + 1, lim);
-                const bool valid = (i <= imax) && (ns > lp + span - 1);
+                bool valid = (i <= imax) && (ns > lp + span - 1);
+                if (valid && chunk_bad) valid = !range_has_bit(s_bad, lp - 1, lp + span - 1);
                 if (valid) {
                     const bool first = (s_bits[lp >> 6] >> (lp & 63)) & 1ull;
                     if (first || wv[i] != wv[i - 1]) {
@@ -396,9 +560,6 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     wave_sync();
 
     // ---- phase 5: hash-change test, ordered compaction, output
-    int64_t out_base = 0;
-    if (MODE == PHI_MODE_WRITE) out_base = A.block_off[chunk];
-    int n_emit = 0, n_new = 0;
     for (int r0 = 0; r0 < ncand; r0 += 64) {
         const int c = r0 + lane;
         bool emit = false;
@@ -417,34 +578,12 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
                 A.out_hash[out_base + rank] = h;
                 A.out_pos[out_base + rank] = c0 - 1 + (int64_t)((meta >> 10) & 0x3FFu);
             } else if (MODE == PHI_MODE_PROBE) {
-                if (h == PHI_EMPTY_KEY) {
-                    atomicOr(A.err, PHI_KERR_SENTINEL);
-                } else {
-                    // walk-minimiser table: lookup, mark the minimiser as hit
-                    uint64_t slot = h & A.u_mask;
-                    int probes;
-                    for (probes = 0; probes <= PHI_MAX_PROBE; probes++) {
-                        const uint64_t key = A.u_keys[slot];
-                        if (key == h) { A.hit[A.u_uid[slot]] = 1; break; }
-                        if (key == PHI_EMPTY_KEY) break;
-                        slot = (slot + 1) & A.u_mask;
-                    }
-                    // read spectrum: open-addressed insert (ILP_index.cpp:622-635 keeps a set)
-                    slot = h & A.sp_mask;
-                    probes = 0;
-                    for (;;) {
-                        const unsigned long long prev =
-                            atomicCAS((unsigned long long *)&A.sp_keys[slot], PHI_EMPTY_KEY, h);
-                        if (prev == PHI_EMPTY_KEY) { n_new++; break; }
-                        if (prev == h) break;
-                        slot = (slot + 1) & A.sp_mask;
-                        if (++probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
-                    }
-                }
+                probe_tables(A, h, n_new);
             }
         }
         n_emit += __popcll(bal);
     }
+
     if (MODE == PHI_MODE_COUNT) {
         if (lane == 0) A.block_cnt[chunk] = n_emit;
     } else if (MODE == PHI_MODE_PROBE) {
@@ -455,6 +594,54 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
             if (n_new) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new);
             if (n_emit) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
+        }
+    }
+}
+
+// Exact byte-wise kernel: every wave walks chunks in a grid-stride loop.
+//   allslow = 0 (reads): launched after the 2-bit kernel with a small grid; leaves at once when the
+//                        batch holds no base outside ACGT (*batch_bad == 0), else handles the windows
+//                        the 2-bit kernel skipped;
+//   allslow = 1        : every window (count / ordered write of sequences with such bases).
+template <int MODE>
+__global__ void __launch_bounds__(TPB) phi_sketch_bytes_kernel(PhiSketchArgs A, const unsigned long long *batch_bad)
+{
+    __shared__ unsigned long long s_all[TPB / 64][2 * SBW];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (!A.allslow && *batch_bad == 0) return;
+    const int64_t N = A.n_bases;
+    const int64_t n_chunks = (N + WCH - 1) / WCH;
+    const int64_t n_sw = N / 64 + 2;
+    unsigned long long *s_bits = s_all[wid], *s_bad = s_all[wid] + SBW;
+    for (int64_t chunk = (int64_t)blockIdx.x * (TPB / 64) + wid; chunk < n_chunks; chunk += (int64_t)gridDim.x * (TPB / 64)) {
+        const int64_t c0 = chunk * WCH;
+        unsigned long long my_bad = 0;
+        wave_sync();
+        if (lane < SBW) {
+            const int64_t wi = (c0 >> 6) - 1 + lane;
+            s_bits[lane] = (wi >= 0 && wi < n_sw) ? A.starts[wi] : 0;
+        } else if (lane < 2 * SBW) {
+            const int64_t wi = (c0 >> 6) - 1 + (lane - SBW);
+            if (A.badbits) my_bad = (wi >= 0 && wi < n_sw) ? A.badbits[wi] : 0;
+            s_bad[lane - SBW] = my_bad;
+        }
+        const bool chunk_bad = __ballot(my_bad != 0) != 0ull;
+        wave_sync();
+        int n_emit = 0, n_new = 0;
+        if (A.allslow || chunk_bad) {
+            const int64_t out_base = (MODE == PHI_MODE_WRITE) ? A.block_off[chunk] : 0;
+            slow_windows<MODE>(A, c0, chunk, lane, A.k, A.w, s_bits, s_bad, A.allslow != 0, out_base, n_emit, n_new);
+        }
+        if (MODE == PHI_MODE_COUNT) {
+            if (lane == 0) A.block_cnt[chunk] = n_emit;
+        } else if (MODE == PHI_MODE_PROBE) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) n_new += __shfl_xor(n_new, d, 64);
+            if (lane == 0) {
+                const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
+                if (n_new) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new);
+                if (n_emit) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
+            }
         }
     }
 }
@@ -484,11 +671,12 @@ __global__ void __launch_bounds__(1024) phi_scan_counts_kernel(const int32_t *__
 // ---------------------------------------------------------------------------------- launchers
 
 void phi_launch_pack_ascii(hipStream_t st, const uint8_t *bases, int64_t n, uint64_t *words, int64_t n_words,
-                           unsigned long long *n_bad)
+                           uint32_t *badbits, unsigned long long *n_bad)
 {
     if (n_words <= 0) return;
-    const int64_t nb = (n_words + 2 + 255) / 256;
-    hipLaunchKernelGGL(phi_pack_ascii_kernel, dim3((unsigned)nb), dim3(256), 0, st, bases, n, words, n_words, n_bad);
+    const int64_t nb = (n_words + 4 + 255) / 256;
+    hipLaunchKernelGGL(phi_pack_ascii_kernel, dim3((unsigned)nb), dim3(256), 0, st, bases, n, words, n_words, badbits,
+                       n_bad);
 }
 
 void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts)
@@ -499,11 +687,25 @@ void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_se
 }
 
 void phi_launch_start_bitmap(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts,
-                             int64_t n_sw)
+                             int64_t n_sw, unsigned long long *batch_bad)
 {
     if (n_sw <= 0) return;
     hipLaunchKernelGGL(phi_start_bitmap_kernel, dim3((unsigned)((n_sw + 255) / 256)), dim3(256), 0, st, seq_off, n_seq,
-                       starts, n_sw);
+                       starts, n_sw, batch_bad);
+}
+
+void phi_launch_sketch_bytes(hipStream_t st, int mode, const PhiSketchArgs &A, const unsigned long long *batch_bad)
+{
+    const int64_t nchunks = phi_sketch_num_blocks(A.n_bases);
+    if (nchunks <= 0) return;
+    int64_t nb = (nchunks + TPB / 64 - 1) / (TPB / 64);
+    if (!A.allslow && nb > 1024) nb = 1024;           // usually leaves at once: keep the launch small
+    if (mode == PHI_MODE_COUNT)
+        hipLaunchKernelGGL(phi_sketch_bytes_kernel<PHI_MODE_COUNT>, dim3((unsigned)nb), dim3(TPB), 0, st, A, batch_bad);
+    else if (mode == PHI_MODE_WRITE)
+        hipLaunchKernelGGL(phi_sketch_bytes_kernel<PHI_MODE_WRITE>, dim3((unsigned)nb), dim3(TPB), 0, st, A, batch_bad);
+    else
+        hipLaunchKernelGGL(phi_sketch_bytes_kernel<PHI_MODE_PROBE>, dim3((unsigned)nb), dim3(TPB), 0, st, A, batch_bad);
 }
 
 void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, uint64_t *hit_words, int64_t n_hit_words,
@@ -520,12 +722,12 @@ void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, u
 
 void phi_launch_pack_walks(hipStream_t st, const uint8_t *seq_concat, const int64_t *seq_off,
                            const int32_t *walk_vtx, const int64_t *ebase, int64_t n_entries, uint64_t *words,
-                           int64_t n_words, unsigned long long *n_bad)
+                           int64_t n_words, uint32_t *badbits, uint8_t *ascii, unsigned long long *n_bad)
 {
     if (n_words <= 0) return;
-    const int64_t nb = (n_words + 255) / 256;
+    const int64_t nb = (n_words + 4 + 255) / 256;
     hipLaunchKernelGGL(phi_pack_walks_kernel, dim3((unsigned)nb), dim3(256), 0, st, seq_concat, seq_off, walk_vtx,
-                       ebase, n_entries, words, n_words, n_bad);
+                       ebase, n_entries, words, n_words, badbits, ascii, n_bad);
 }
 
 // number of per-wave chunks (= entries of block_cnt / block_off)
