@@ -166,16 +166,26 @@ def main():
     kern_avg_ms = kern_ms / max(1, n_launch)
     achieved = (kern_bases / max(1, n_launch)) * b_alg / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0
 
+    # HBM bytes per launch from PMC counters: measured in a separate rocprofv3 run (bench.py cannot
+    # profile itself) and kept, with the commands, under profiles/
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj.get("config") == args.config:
+            traffic = tj["bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     out = {
         "metric": "read Gbases/s scored (49-hap MHC graph stand-in synMHC-49)",
         "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{args.config}: synMHC-49 graph (seed {gk['seed']}, {g.n_walks} walks, {g.n_vtx} vertices <=30 bp, "
-                               f"{walk_bases / 1e6:.1f} Mbases of walks) + {n_reads} x 150 bp reads per GPU (seed {rk['seed']}, {n_bases / 1e6:.2f} Mbases)",
+                               f"{walk_bases / 1e6:.1f} Mbases of walks) + {n_reads} reads of mean {n_bases / max(1, n_reads):.0f} bp per GPU (seed {rk['seed']}, {n_bases / 1e6:.2f} Mbases)",
                    "k": K, "w": W, "R": 100, "reads_per_gpu_bases": n_bases, "parallelism": f"read-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "phi_sketch_kernel<PHI_MODE_PROBE>", "kernel_avg_ms": kern_avg_ms,
                      "kernel_launches": n_launch, "bytes_per_base_algorithmic": b_alg, "minimiser_density": density,
                      "kernel_gbases_per_s": (kern_bases / max(1, n_launch)) / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0},

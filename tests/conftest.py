@@ -7,6 +7,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# torch (plumbing for device buffers in a few tests) bundles its own HIP runtime: when both it and
+# libphi_amd.so live in one process, torch must initialise first (bench.py imports it first too).
+try:
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+except ImportError:
+    pass
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 DATA = os.path.join(GOLDEN, "data")
 

@@ -300,3 +300,48 @@ def test_synthetic_vs_highs_golden(oracle, ctx_factory):
         st, res, m = _check_against_oracle(oracle, ctx, G, reads, case["k"], case["w"], case["T"], case["R"])
         assert res["spectrum_size"] == case["spectrum_size"] and res["n_in_model"] == case["n_in_model"]
         assert res["objective"] == case["objective"], (case, res["objective"], res["n_dp_runs"])
+
+
+# --------------------------------------------------------------------------- torch / multi-GPU plumbing
+
+def test_torch_views_of_device_buffers(oracle, ctx_factory):
+    """bench.py and phi_amd/dist.py wrap the hit vector and the exported spectrum as torch tensors
+    (zero copy) for the RCCL all-reduce / all-gather: check the views see the kernels' data."""
+    import torch
+    from phi_amd import dist as pdist
+    rng = np.random.default_rng(11)
+    g = random_graph(rng, n_sites=8, n_walks=4, seg_len=(10, 30))
+    reads = mosaic_reads(rng, g, n_reads=50, read_len=36, n_seg=2)
+    k, w = 9, 4
+    ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=10)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    _set_graph(ctx, g)
+    off = np.zeros(len(reads) + 1, np.int64)
+    np.cumsum([len(r) for r in reads], out=off[1:])
+    d_b = torch.from_numpy(np.frombuffer(b"".join(reads), np.uint8).copy()).cuda()
+    d_o = torch.from_numpy(off).cuda()
+    ctx.add_reads_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), int(off[-1]))
+    torch.cuda.synchronize()
+    # hit vector: one byte per distinct walk minimiser, in first-occurrence order
+    p, n = ctx.hits_buffer()
+    hit = torch.as_tensor(pdist.DevArray(p, n), device="cuda")
+    walk_h = np.concatenate([oracle.sketch(b"".join(g.node_seq[v] for v in path), k, w)[0] for path in g.paths])
+    _, first = np.unique(walk_h, return_index=True)
+    uniq = walk_h[np.sort(first)]
+    read_h = np.unique(np.concatenate([oracle.sketch(r, k, w)[0] for r in reads]))
+    assert n == len(uniq)
+    assert np.array_equal(hit.cpu().numpy(), np.isin(uniq, read_h).astype(np.uint8))
+    pdist.allreduce_hits(hit)                       # world size 1: a no-op that must not fail
+    # exported spectrum = the distinct read hashes
+    p, m = ctx.spectrum_export()
+    sp = torch.as_tensor(pdist.DevArray(p, m, "<i8"), device="cuda").clone()
+    assert np.array_equal(np.sort(sp.cpu().numpy().view(np.uint64)), read_h)
+    # importing a copy of it (what another rank would send) leaves the set unchanged
+    ctx.spectrum_import(sp.data_ptr(), m)
+    torch.cuda.synchronize()
+    assert ctx.reads_stats()["n_distinct"] == len(read_h)
+    extra = torch.tensor([12345, 67890], dtype=torch.int64, device="cuda")
+    ctx.spectrum_import(extra.data_ptr(), 2)
+    torch.cuda.synchronize()
+    res = ctx.solve()
+    assert res["spectrum_size"] == len(read_h) + 2
