@@ -217,28 +217,36 @@ struct MinEnt { uint64_t v; int i; };
 // b lies to the right of a: ties go right (the reference's deque pops on >=, ILP_index.cpp:397)
 __device__ __forceinline__ MinEnt take_right(MinEnt a, MinEnt b) { return (b.v <= a.v) ? b : a; }
 
-// read spectrum insert + walk-minimiser table probe of one emitted read hash
+// read spectrum insert + walk-minimiser table probe of one emitted read hash.  The first probe
+// of both tables (and the speculative id load) are issued back to back so that their round trips
+// overlap; at load factors <= 0.5 almost every hash settles on that first probe.
 __device__ __forceinline__ void probe_tables(const PhiSketchArgs &A, uint64_t h, int &n_new)
 {
     if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return; }
+    uint64_t su = h & A.u_mask, ss = h & A.sp_mask;
+    const uint64_t key0 = A.u_keys[su];
+    const uint32_t uid0 = A.u_uid[su];
+    const unsigned long long prev0 = atomicCAS((unsigned long long *)&A.sp_keys[ss], PHI_EMPTY_KEY, h);
     // walk-minimiser table: lookup, mark the minimiser as hit
-    uint64_t slot = h & A.u_mask;
-    int probes;
-    for (probes = 0; probes <= PHI_MAX_PROBE; probes++) {
-        const uint64_t key = A.u_keys[slot];
-        if (key == h) { A.hit[A.u_uid[slot]] = 1; break; }
-        if (key == PHI_EMPTY_KEY) break;
-        slot = (slot + 1) & A.u_mask;
+    if (key0 == h) A.hit[uid0] = 1;
+    else if (key0 != PHI_EMPTY_KEY) {
+        for (int probes = 1; probes <= PHI_MAX_PROBE; probes++) {
+            su = (su + 1) & A.u_mask;
+            const uint64_t key = A.u_keys[su];
+            if (key == h) { A.hit[A.u_uid[su]] = 1; break; }
+            if (key == PHI_EMPTY_KEY) break;
+        }
     }
     // read spectrum: open-addressed insert (ILP_index.cpp:622-635 keeps a set)
-    slot = h & A.sp_mask;
-    probes = 0;
-    for (;;) {
-        const unsigned long long prev = atomicCAS((unsigned long long *)&A.sp_keys[slot], PHI_EMPTY_KEY, h);
-        if (prev == PHI_EMPTY_KEY) { n_new++; break; }
-        if (prev == h) break;
-        slot = (slot + 1) & A.sp_mask;
-        if (++probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
+    if (prev0 == PHI_EMPTY_KEY) n_new++;
+    else if (prev0 != h) {
+        for (int probes = 1;; probes++) {
+            ss = (ss + 1) & A.sp_mask;
+            const unsigned long long prev = atomicCAS((unsigned long long *)&A.sp_keys[ss], PHI_EMPTY_KEY, h);
+            if (prev == PHI_EMPTY_KEY) { n_new++; break; }
+            if (prev == h) break;
+            if (probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
+        }
     }
 }
 
