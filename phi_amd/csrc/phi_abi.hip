@@ -10,7 +10,7 @@
 #include "phi_dev.h"
 
 // scalar slots in d_scalars (8 bytes each)
-enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_N = 8 };
+enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_BATCHBAD2 = 7, S_N = 8 };
 
 int phi_fail(phi_ctx *c, int code, const char *fmt, ...)
 {
@@ -58,8 +58,22 @@ static unsigned long long *sp_stripes(phi_ctx *c) { return c->d_stripes.as<unsig
 static unsigned long long *emit_stripes(phi_ctx *c) { return c->d_stripes.as<unsigned long long>() + PHI_STRIPES * 8; }
 #define STRIPE_BYTES ((size_t)PHI_STRIPES * 8 * 8)
 
+// phi_reset_reads only notes the reset; the next read batch folds it into its preparation launch.
+// Everything else that looks at the spectrum, the hit vector or the counters calls this first.
+int phi_flush_reset(phi_ctx *c)
+{
+    if (!c->reset_pending) return PHI_OK;
+    c->reset_pending = false;
+    if (c->sp_cap == 0 && c->n_unique == 0) return PHI_OK;
+    phi_launch_reset_reads(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_hit.as<uint64_t>(),
+                           c->n_unique / 8 + 1, c->d_stripes.as<uint64_t>(), 2 * PHI_STRIPES * 8);
+    return phi_hip_check(c, hipGetLastError(), "reset launch");
+}
+
 int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted)
 {
+    int frc = phi_flush_reset(c);
+    if (frc) return frc;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return phi_fail(c, PHI_ERR_DEVICE, "stream synchronize failed");
     std::vector<uint64_t> h(2 * PHI_STRIPES * 8);
     int rc = phi_hip_check(c, hipMemcpy(h.data(), c->d_stripes.p, 2 * STRIPE_BYTES, hipMemcpyDeviceToHost), "D2H counters");
@@ -74,6 +88,7 @@ int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted)
 // wait for the stream and translate the device error word
 int phi_sync_check(phi_ctx *c)
 {
+    PHICHK(phi_flush_reset(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     uint64_t s[S_N];
     HIPCHK(hipMemcpy(s, c->d_scalars.p, sizeof s, hipMemcpyDeviceToHost));
@@ -209,6 +224,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     if (adj_off[n_vtx] > 0 && !adj) return phi_fail(c, PHI_ERR_INVALID, "phi_set_graph: adj is null");
     HIPCHK(hipSetDevice(c->device));
     c->have_graph = false;
+    c->reset_pending = false; c->hits_exported = false;
     c->solved = false;
 
     // ---- validate and keep host copies
@@ -484,11 +500,24 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     PHICHK(phi_dev_ensure(c, c->d_rwords, (size_t)(n_words + 2) * 8));
     const size_t n_sw = (size_t)(n_bases / 64 + 2);
     PHICHK(phi_dev_ensure(c, c->d_rstarts, n_sw * 8));
-    phi_launch_start_bitmap(c->stream, (const int64_t *)d_read_off, n_reads, c->d_rstarts.as<unsigned long long>(), (int64_t)n_sw,
-                            (unsigned long long *)scalar(c, S_BATCHBAD));
     PHICHK(phi_dev_ensure(c, c->d_rbad, (size_t)(n_words + 6) * 4));
-    phi_launch_pack_ascii(c->stream, (const uint8_t *)d_bases, n_bases, c->d_rwords.as<uint64_t>(), n_words,
-                          c->d_rbad.as<uint32_t>(), (unsigned long long *)scalar(c, S_BATCHBAD));
+    // one preparation launch: [pending reset] + read-start bitmap + 2-bit pack
+    unsigned long long *batch_bad = (unsigned long long *)scalar(c, c->bad_parity ? S_BATCHBAD2 : S_BATCHBAD);
+    {
+        PhiPrepArgs P{};
+        P.sp_keys = c->d_sp_keys.as<uint64_t>(); P.sp_cap = (int64_t)c->sp_cap;
+        P.hit_words = c->d_hit.as<uint64_t>(); P.n_hit_words = c->n_unique / 8 + 1;
+        P.stripes = c->d_stripes.as<uint64_t>(); P.n_stripe_words = 2 * PHI_STRIPES * 8;
+        P.seq_off = (const int64_t *)d_read_off; P.n_seq = n_reads;
+        P.starts = c->d_rstarts.as<unsigned long long>(); P.n_sw = (int64_t)n_sw;
+        P.bases = (const uint8_t *)d_bases; P.n = n_bases; P.words = c->d_rwords.as<uint64_t>(); P.n_words = n_words;
+        P.badbits = c->d_rbad.as<uint32_t>();
+        P.batch_bad = batch_bad;
+        P.batch_bad_next = (unsigned long long *)scalar(c, c->bad_parity ? S_BATCHBAD : S_BATCHBAD2);
+        phi_launch_prep_reads(c->stream, P, c->reset_pending);
+        c->reset_pending = false;
+        c->bad_parity ^= 1;
+    }
     PhiSketchArgs A{};
     A.badbits = c->d_rbad.as<unsigned long long>();      // windows touching such bases take the byte-wise path
     A.ascii = (const uint8_t *)d_bases;
@@ -518,7 +547,7 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
         c->prof_bases += n_bases;
     }
     // windows touching a base outside ACGT: exact byte-wise kernel (leaves at once on clean batches)
-    phi_launch_sketch_bytes(c->stream, PHI_MODE_PROBE, A, (const unsigned long long *)scalar(c, S_BATCHBAD));
+    phi_launch_sketch_bytes(c->stream, PHI_MODE_PROBE, A, batch_bad);
     HIPCHK(hipGetLastError());
     c->reads_bases += n_bases;
     c->reads_count += n_reads;
@@ -554,9 +583,9 @@ int phi_reset_reads(phi_ctx *c)
     if (!c) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reset_reads before phi_set_graph");
     HIPCHK(hipSetDevice(c->device));
-    phi_launch_reset_reads(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_hit.as<uint64_t>(),
-                           c->n_unique / 8 + 1, c->d_stripes.as<uint64_t>(), 2 * PHI_STRIPES * 8);
-    HIPCHK(hipGetLastError());
+    c->reset_pending = true;
+    // a caller that holds the hit-vector pointer (phi_hits_buffer) may read it at any time: reset now
+    if (c->hits_exported) PHICHK(phi_flush_reset(c));
     c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
     c->solved = false;
     return PHI_OK;
@@ -581,6 +610,9 @@ int phi_hits_buffer(phi_ctx *c, void **d_hits, int64_t *n)
 {
     if (!c || !d_hits || !n) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_hits_buffer before phi_set_graph");
+    HIPCHK(hipSetDevice(c->device));
+    PHICHK(phi_flush_reset(c));
+    c->hits_exported = true;
     *d_hits = c->d_hit.p;
     *n = c->n_unique;
     return PHI_OK;
@@ -613,6 +645,7 @@ int phi_spectrum_import(phi_ctx *c, const void *d_hashes, int64_t n)
     if (n == 0) return PHI_OK;
     HIPCHK(hipSetDevice(c->device));
     if (d_hashes == c->d_export.p) return phi_fail(c, PHI_ERR_INVALID, "phi_spectrum_import: pass a copy, not the export buffer");
+    PHICHK(phi_flush_reset(c));
     PHICHK(sp_ensure(c, n * 8));          // room for n more distinct hashes
     phi_launch_spectrum_insert(c->stream, (const uint64_t *)d_hashes, n, c->d_sp_keys.as<uint64_t>(), c->sp_cap - 1,
                                sp_stripes(c), (uint32_t *)scalar(c, S_ERR));

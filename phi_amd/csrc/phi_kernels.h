@@ -47,8 +47,17 @@ struct PhiSketchArgs {
 void phi_launch_pack_ascii(hipStream_t st, const uint8_t *bases, int64_t n, uint64_t *words, int64_t n_words,
                            uint32_t *badbits, unsigned long long *n_bad);
 void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts);
-void phi_launch_start_bitmap(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts,
-                             int64_t n_sw, unsigned long long *batch_bad);
+
+// one launch before the sketch of a read batch: [pending reset] + start bitmap + 2-bit pack
+struct PhiPrepArgs {
+    uint64_t *sp_keys; int64_t sp_cap; uint64_t *hit_words; int64_t n_hit_words;      // reset part
+    uint64_t *stripes; int64_t n_stripe_words;
+    const int64_t *seq_off; int64_t n_seq; unsigned long long *starts; int64_t n_sw;   // bitmap part
+    const uint8_t *bases; int64_t n; uint64_t *words; int64_t n_words; uint32_t *badbits;   // pack part
+    unsigned long long *batch_bad, *batch_bad_next;
+    unsigned reset_blocks, bitmap_blocks;                                                // set by the launcher
+};
+void phi_launch_prep_reads(hipStream_t st, PhiPrepArgs P, bool with_reset);
 void phi_launch_sketch_bytes(hipStream_t st, int mode, const PhiSketchArgs &A, const unsigned long long *batch_bad);
 void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, uint64_t *hit_words, int64_t n_hit_words,
                             uint64_t *stripes, int64_t n_stripe_words);

@@ -39,12 +39,11 @@ int64_t phi_sketch_num_blocks(int64_t n_bases);
 // ---------------------------------------------------------------------------------- packing
 
 // 32 ASCII bases per lane -> one packed word (+ one 32-bit mask of the bases outside ACGTacgt).
-__global__ void __launch_bounds__(256) phi_pack_ascii_kernel(const uint8_t *__restrict__ bases, int64_t n,
-                                                             uint64_t *__restrict__ words, int64_t n_words,
-                                                             uint32_t *__restrict__ badbits,
-                                                             unsigned long long *__restrict__ n_bad)
+static __device__ __forceinline__ void pack_ascii_word(int64_t wi, const uint8_t *__restrict__ bases, int64_t n,
+                                                       uint64_t *__restrict__ words, int64_t n_words,
+                                                       uint32_t *__restrict__ badbits,
+                                                       unsigned long long *__restrict__ n_bad)
 {
-    const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (wi >= n_words + 4) return;
     if (wi >= n_words) {                                    // zero padding: 2 words, 4 mask words
         if (wi < n_words + 2) words[wi] = 0;
@@ -79,6 +78,14 @@ __global__ void __launch_bounds__(256) phi_pack_ascii_kernel(const uint8_t *__re
     if (bad) atomicAdd(n_bad, (unsigned long long)__popc(bad));
 }
 
+__global__ void __launch_bounds__(256) phi_pack_ascii_kernel(const uint8_t *__restrict__ bases, int64_t n,
+                                                             uint64_t *__restrict__ words, int64_t n_words,
+                                                             uint32_t *__restrict__ badbits,
+                                                             unsigned long long *__restrict__ n_bad)
+{
+    pack_ascii_word((int64_t)blockIdx.x * blockDim.x + threadIdx.x, bases, n, words, n_words, badbits, n_bad);
+}
+
 // starts bitmap: bit (p & 63) of word p >> 6 set iff a sequence starts at base p.
 __global__ void phi_mark_starts_kernel(const int64_t *__restrict__ seq_off, int64_t n_seq,
                                        unsigned long long *__restrict__ starts)
@@ -91,12 +98,9 @@ __global__ void phi_mark_starts_kernel(const int64_t *__restrict__ seq_off, int6
 }
 
 // Same bitmap, one whole word per lane: no memset, no atomics.  Word j covers bases [64j, 64j+64).
-__global__ void __launch_bounds__(256) phi_start_bitmap_kernel(const int64_t *__restrict__ seq_off, int64_t n_seq,
-                                                               unsigned long long *__restrict__ starts, int64_t n_sw,
-                                                               unsigned long long *__restrict__ batch_bad)
+static __device__ __forceinline__ void start_bitmap_word(int64_t j, const int64_t *__restrict__ seq_off, int64_t n_seq,
+                                                         unsigned long long *__restrict__ starts, int64_t n_sw)
 {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0 && batch_bad) *batch_bad = 0;          // the pack kernel that follows counts into it
     if (j >= n_sw) return;
     const int64_t lo_b = j * 64, hi_b = lo_b + 64;
     int64_t lo = 0, hi = n_seq;                       // first sequence with seq_off >= lo_b
@@ -114,15 +118,45 @@ __global__ void __launch_bounds__(256) phi_start_bitmap_kernel(const int64_t *__
 }
 
 // one launch that forgets all reads: empty spectrum set, zero hit vector, zero striped counters
+static __device__ __forceinline__ void reset_reads_part(int64_t t, int64_t stride, uint64_t *__restrict__ sp_keys,
+                                                        int64_t sp_cap, uint64_t *__restrict__ hit_words,
+                                                        int64_t n_hit_words, uint64_t *__restrict__ stripes,
+                                                        int64_t n_stripe_words)
+{
+    for (int64_t i = t; i < sp_cap; i += stride) sp_keys[i] = PHI_EMPTY_KEY;
+    for (int64_t i = t; i < n_hit_words; i += stride) hit_words[i] = 0;
+    for (int64_t i = t; i < n_stripe_words; i += stride) stripes[i] = 0;
+}
+
 __global__ void __launch_bounds__(256) phi_reset_reads_kernel(uint64_t *__restrict__ sp_keys, int64_t sp_cap,
                                                               uint64_t *__restrict__ hit_words, int64_t n_hit_words,
                                                               uint64_t *__restrict__ stripes, int64_t n_stripe_words)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (int64_t i = t; i < sp_cap; i += stride) sp_keys[i] = PHI_EMPTY_KEY;
-    for (int64_t i = t; i < n_hit_words; i += stride) hit_words[i] = 0;
-    for (int64_t i = t; i < n_stripe_words; i += stride) stripes[i] = 0;
+    reset_reads_part((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, sp_keys, sp_cap,
+                     hit_words, n_hit_words, stripes, n_stripe_words);
+}
+
+// Everything a read batch needs before its sketch, in ONE launch (each tiny launch costs ~6 us on
+// the stream): blocks [0, reset_blocks) forget the previous reads when a reset is pending, the next
+// bitmap_blocks build the read-start bitmap, the rest pack the bases.  The three parts touch
+// disjoint buffers.  The per-batch count of bases outside ACGT ping-pongs between two scalars: this
+// launch counts into batch_bad (zeroed by the previous batch's launch) and zeroes batch_bad_next.
+__global__ void __launch_bounds__(256) phi_prep_reads_kernel(PhiPrepArgs P)
+{
+    unsigned b = blockIdx.x;
+    if (b == 0 && threadIdx.x == 0) *P.batch_bad_next = 0;
+    if (b < P.reset_blocks) {
+        reset_reads_part((int64_t)b * 256 + threadIdx.x, (int64_t)P.reset_blocks * 256, P.sp_keys, P.sp_cap, P.hit_words,
+                         P.n_hit_words, P.stripes, P.n_stripe_words);
+        return;
+    }
+    b -= P.reset_blocks;
+    if (b < P.bitmap_blocks) {
+        start_bitmap_word((int64_t)b * 256 + threadIdx.x, P.seq_off, P.n_seq, P.starts, P.n_sw);
+        return;
+    }
+    b -= P.bitmap_blocks;
+    pack_ascii_word((int64_t)b * 256 + threadIdx.x, P.bases, P.n, P.words, P.n_words, P.badbits, P.batch_bad);
 }
 
 // Walk sequences gathered straight into packed words: lane -> 32 bases of the flat walk space.
@@ -694,12 +728,20 @@ void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_se
     hipLaunchKernelGGL(phi_mark_starts_kernel, dim3((unsigned)nb), dim3(256), 0, st, seq_off, n_seq, starts);
 }
 
-void phi_launch_start_bitmap(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts,
-                             int64_t n_sw, unsigned long long *batch_bad)
+void phi_launch_prep_reads(hipStream_t st, PhiPrepArgs P, bool with_reset)
 {
-    if (n_sw <= 0) return;
-    hipLaunchKernelGGL(phi_start_bitmap_kernel, dim3((unsigned)((n_sw + 255) / 256)), dim3(256), 0, st, seq_off, n_seq,
-                       starts, n_sw, batch_bad);
+    int64_t rb = 0;
+    if (with_reset) {
+        int64_t n = P.sp_cap > P.n_hit_words ? P.sp_cap : P.n_hit_words;
+        if (n < P.n_stripe_words) n = P.n_stripe_words;
+        rb = (n + 255) / 256;
+        if (rb > 2048) rb = 2048;
+        if (rb < 1) rb = 1;
+    }
+    P.reset_blocks = (unsigned)rb;
+    P.bitmap_blocks = (unsigned)((P.n_sw + 255) / 256);
+    const int64_t pb = (P.n_words + 4 + 255) / 256;
+    hipLaunchKernelGGL(phi_prep_reads_kernel, dim3((unsigned)(rb + P.bitmap_blocks + pb)), dim3(256), 0, st, P);
 }
 
 void phi_launch_sketch_bytes(hipStream_t st, int mode, const PhiSketchArgs &A, const unsigned long long *batch_bad)
