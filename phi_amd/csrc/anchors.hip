@@ -27,6 +27,24 @@ static inline unsigned grid_for(int64_t n, int tpb)
 #define GRID_STRIDE(i, n) \
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
+// ------------------------------------------------------------------------- entry lengths
+// bases of every walk entry (their exclusive scan is ebase, the flat base offset of the entry)
+__global__ void __launch_bounds__(256) phi_entry_len_kernel(const int64_t *__restrict__ seq_off,
+                                                            const int32_t *__restrict__ walk_vtx, int64_t n_entries,
+                                                            int32_t *__restrict__ len)
+{
+    GRID_STRIDE(e, n_entries) {
+        const int32_t v = walk_vtx[e];
+        len[e] = (int32_t)(seq_off[v + 1] - seq_off[v]);
+    }
+}
+
+void phi_launch_entry_len(hipStream_t st, const int64_t *seq_off, const int32_t *walk_vtx, int64_t n_entries, int32_t *len)
+{
+    if (n_entries <= 0) return;
+    hipLaunchKernelGGL(phi_entry_len_kernel, dim3(grid_for(n_entries, 256)), dim3(256), 0, st, seq_off, walk_vtx, n_entries, len);
+}
+
 // ------------------------------------------------------------------------- locate
 // rec_e0/rec_e1: walk entries owning the first / last base of each minimiser's k-mer.
 __global__ void __launch_bounds__(256) phi_locate_kernel(const int64_t *__restrict__ rec_pos, int64_t n_rec,

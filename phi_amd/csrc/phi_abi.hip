@@ -150,7 +150,7 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_wascii, &c->d_rbad, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
                      &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
-                     &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_m_rec, &c->d_m_group,
+                     &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_qbest, &c->d_lent, &c->d_top,
                      &c->d_ent};
@@ -241,7 +241,6 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     c->h_adj_off.assign(adj_off, adj_off + n_vtx + 1);
     c->h_adj.assign(adj, adj + n_edges);
     c->h_walk_off.assign(walk_off, walk_off + n_walks + 1);
-    c->h_walk_vtx.assign(walk_vtx, walk_vtx + n_entries);
     c->h_topo_rank.assign(topo_rank, topo_rank + n_vtx);
 
     // topological order from the ranks; every edge must go forward (acyclic GFA, README.md:70-75)
@@ -259,50 +258,6 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             if (topo_rank[u] >= topo_rank[v]) return phi_fail(c, PHI_ERR_INVALID, "edge %d->%d goes backwards in topo_rank: graph must be acyclic", u, v);
             indeg[v]++;
         }
-    // walks follow edges of forward vertices (ILP_index.cpp:104-107 exits on reverse strand; an
-    // edge-less step would make the anchor's edge variables unconstrained, :799-815)
-    bool start_interior = false, end_interior = false;
-    for (int32_t h = 0; h < n_walks; h++) {
-        for (int64_t e = walk_off[h]; e < walk_off[h + 1]; e++) {
-            const int32_t v = walk_vtx[e];
-            if (v < 0 || v >= n_vtx) return phi_fail(c, PHI_ERR_WALK, "walk %d holds vertex %d out of range", h, v);
-            if (seq_off[v + 1] == seq_off[v]) return phi_fail(c, PHI_ERR_UNSUPPORTED, "walk %d passes through empty segment %d", h, v);
-            if (e > walk_off[h]) {
-                const int32_t u = walk_vtx[e - 1];
-                bool ok = false;
-                for (int64_t x = adj_off[u]; x < adj_off[u + 1] && !ok; x++) ok = adj[x] == v;
-                if (!ok) return phi_fail(c, PHI_ERR_WALK, "walk %d steps %d->%d without a graph edge", h, u, v);
-            }
-        }
-        if (indeg[walk_vtx[walk_off[h]]] > 0) start_interior = true;
-        const int32_t last = walk_vtx[walk_off[h + 1] - 1];
-        if (adj_off[last + 1] > adj_off[last]) end_interior = true;
-    }
-    if (start_interior && end_interior)
-        return phi_fail(c, PHI_ERR_UNSUPPORTED, "walks both start and end at interior vertices: the reference model "
-                        "admits flow leak/spawn artefacts there (ILP_index.cpp:1330) that are not emulated");
-
-    // flat base offset of every walk entry; walk of every entry
-    c->h_ebase.resize(n_entries + 1);
-    c->h_entry_walk.resize(n_entries);
-    int64_t run = 0;
-    for (int32_t h = 0; h < n_walks; h++)
-        for (int64_t e = walk_off[h]; e < walk_off[h + 1]; e++) {
-            c->h_ebase[e] = run;
-            c->h_entry_walk[e] = h;
-            run += seq_off[walk_vtx[e] + 1] - seq_off[walk_vtx[e]];
-        }
-    c->h_ebase[n_entries] = run;
-    c->walk_bases = run;
-    // entries on each vertex, ascending walk id (host side: backtracking)
-    c->h_vh_off.assign(n_vtx + 1, 0);
-    for (int64_t e = 0; e < n_entries; e++) c->h_vh_off[walk_vtx[e] + 1]++;
-    for (int32_t v = 0; v < n_vtx; v++) c->h_vh_off[v + 1] += c->h_vh_off[v];
-    c->h_vh_entry.resize(n_entries);
-    {
-        std::vector<int64_t> cur(c->h_vh_off.begin(), c->h_vh_off.end() - 1);
-        for (int64_t e = 0; e < n_entries; e++) c->h_vh_entry[cur[walk_vtx[e]]++] = (int32_t)e;
-    }
     // reverse adjacency
     c->h_in_off.assign(n_vtx + 1, 0);
     for (int32_t v = 0; v < n_vtx; v++) c->h_in_off[v + 1] = c->h_in_off[v] + indeg[v];
@@ -313,52 +268,104 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) c->h_in_src[cur[adj[x]]++] = u;
     }
 
-    // ---- DP step stream (dp.hip): per step the live in-edges as (steps back, out-edge index),
-    //      per step and wave the mask of walks on the vertex, per entry the out-edge index
+    // ---- one parallel pass over the walk entries (host threads over fixed chunks of entries):
+    //   * walks follow edges of forward vertices (ILP_index.cpp:104-107 exits on reverse strand; an
+    //     edge-less step would make the anchor's edge variables unconstrained, :799-815)
+    //   * out-edge index of every entry, walks per edge (DP step stream, dp.hip)
+    //   * mask of walks on every topological step, bases of every walk, host copy of the entries
     if (n_walks > PHI_DP_MAX_WALKS) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than %d walks", PHI_DP_MAX_WALKS);
     c->dp_nw = phi_dp_num_waves(n_walks);
+    const int nw64 = c->dp_nw;
+    c->h_walk_vtx.resize(n_entries);
     std::vector<uint8_t> e_out(n_entries, 255);
     std::vector<int32_t> cnt_edge(std::max<int64_t>(n_edges, 1), 0), cont_total(n_vtx, 0);
-    for (int32_t h = 0; h < n_walks; h++)
-        for (int64_t e = walk_off[h]; e + 1 < walk_off[h + 1]; e++) {
-            const int32_t u = walk_vtx[e], v = walk_vtx[e + 1];
-            int64_t x = adj_off[u];
-            while (adj[x] != v) x++;
-            if (x - adj_off[u] >= 255) return phi_fail(c, PHI_ERR_UNSUPPORTED, "vertex %d has more than 254 out-edges", u);
-            e_out[e] = (uint8_t)(x - adj_off[u]);
-            cnt_edge[x]++;
-            cont_total[u]++;
-        }
+    std::vector<unsigned long long> st_mask((size_t)n_vtx * nw64, 0ull);
+    std::vector<int64_t> walk_len(n_walks, 0);
+    {
+        PhiHostError herr;
+        int32_t *h_wv = c->h_walk_vtx.data();
+        phi_parallel_chunks(n_entries, (int64_t)1 << 16, [&](int64_t lo, int64_t hi) {
+            if (herr.failed()) return;
+            int32_t h = (int32_t)(std::upper_bound(walk_off, walk_off + n_walks + 1, lo) - walk_off) - 1;
+            int64_t bases = 0;
+            for (int64_t e = lo; e < hi; e++) {
+                while (e >= walk_off[h + 1]) {
+                    __atomic_fetch_add(&walk_len[h], bases, __ATOMIC_RELAXED);
+                    bases = 0; h++;
+                }
+                const int32_t u = walk_vtx[e];
+                if (u < 0 || u >= n_vtx) { herr.set(PHI_ERR_WALK, "walk %d holds vertex %d out of range", h, u); return; }
+                const int64_t len = seq_off[u + 1] - seq_off[u];
+                if (len == 0) { herr.set(PHI_ERR_UNSUPPORTED, "walk %d passes through empty segment %d", h, u); return; }
+                bases += len;
+                h_wv[e] = u;
+                __atomic_fetch_or(&st_mask[(size_t)topo_rank[u] * nw64 + (h >> 6)], 1ull << (h & 63), __ATOMIC_RELAXED);
+                if (e + 1 < walk_off[h + 1]) {
+                    const int32_t v = walk_vtx[e + 1];
+                    if (v < 0 || v >= n_vtx) { herr.set(PHI_ERR_WALK, "walk %d holds vertex %d out of range", h, v); return; }
+                    int64_t x = adj_off[u];
+                    const int64_t xe = adj_off[u + 1];
+                    while (x < xe && adj[x] != v) x++;
+                    if (x == xe) { herr.set(PHI_ERR_WALK, "walk %d steps %d->%d without a graph edge", h, u, v); return; }
+                    if (x - adj_off[u] >= 255) { herr.set(PHI_ERR_UNSUPPORTED, "vertex %d has more than 254 out-edges", u); return; }
+                    e_out[e] = (uint8_t)(x - adj_off[u]);
+                    __atomic_fetch_add(&cnt_edge[x], 1, __ATOMIC_RELAXED);
+                }
+            }
+            __atomic_fetch_add(&walk_len[h], bases, __ATOMIC_RELAXED);
+        });
+        if (herr.failed()) return phi_fail(c, herr.code, "%s", herr.msg.c_str());
+    }
+    bool start_interior = false, end_interior = false;
+    c->h_walk_base.assign(n_walks + 1, 0);
+    for (int32_t h = 0; h < n_walks; h++) {
+        if (indeg[walk_vtx[walk_off[h]]] > 0) start_interior = true;
+        const int32_t last = walk_vtx[walk_off[h + 1] - 1];
+        if (adj_off[last + 1] > adj_off[last]) end_interior = true;
+        c->h_walk_base[h + 1] = c->h_walk_base[h] + walk_len[h];
+    }
+    if (start_interior && end_interior)
+        return phi_fail(c, PHI_ERR_UNSUPPORTED, "walks both start and end at interior vertices: the reference model "
+                        "admits flow leak/spawn artefacts there (ILP_index.cpp:1330) that are not emulated");
+    const int64_t run = c->h_walk_base[n_walks];
+    c->walk_bases = run;
+    for (int32_t u = 0; u < n_vtx; u++)
+        for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) cont_total[u] += cnt_edge[x];
+
+    // ---- DP step stream (dp.hip): per step the live in-edges as (steps back, out-edge index)
     std::vector<int32_t> st_rec((size_t)n_vtx * 8, 0), in_packed;
-    std::vector<unsigned long long> st_mask((size_t)n_vtx * c->dp_nw, 0ull);
     {
         // live in-edges of v: (u, x) with some walk on u continuing along another edge than x
-        std::vector<std::vector<int32_t>> live(n_vtx);
+        std::vector<int32_t> live_cnt(n_vtx + 1, 0);
         std::vector<uint8_t> tops(n_vtx, 0);
         for (int32_t u = 0; u < n_vtx; u++)
             for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++)
                 if (cont_total[u] - cnt_edge[x] > 0) {
                     const int64_t back = (int64_t)topo_rank[adj[x]] - topo_rank[u];
                     if (back >= (1 << 23)) return phi_fail(c, PHI_ERR_UNSUPPORTED, "edge spans more than 2^23 topological steps");
-                    live[adj[x]].push_back((int32_t)(back << 8) | (int32_t)(x - adj_off[u]));
+                    live_cnt[adj[x] + 1]++;
                     tops[u] = 1;
+                }
+        for (int32_t v = 0; v < n_vtx; v++) live_cnt[v + 1] += live_cnt[v];
+        std::vector<int32_t> live(std::max<int32_t>(live_cnt[n_vtx], 1)), cur(live_cnt.begin(), live_cnt.end() - 1);
+        for (int32_t u = 0; u < n_vtx; u++)
+            for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++)
+                if (cont_total[u] - cnt_edge[x] > 0) {
+                    const int64_t back = (int64_t)topo_rank[adj[x]] - topo_rank[u];
+                    live[cur[adj[x]]++] = (int32_t)(back << 8) | (int32_t)(x - adj_off[u]);
                 }
         for (int32_t s = 0; s < n_vtx; s++) {
             const int32_t v = c->h_topo[s];
             int32_t *r = &st_rec[(size_t)s * 8];
-            const int n_in = (int)live[v].size();
+            const int n_in = live_cnt[v + 1] - live_cnt[v];
             if (n_in > 255) return phi_fail(c, PHI_ERR_UNSUPPORTED, "vertex %d has more than 255 in-edges", v);
             r[0] = (n_in ? PHI_DP_NEED_ENTRY : 0) | (tops[v] ? PHI_DP_NEED_TOPS : 0) | (n_in << 8);
             r[1] = (int32_t)in_packed.size();
             for (int j = 0; j < n_in; j++) {
-                if (j < 3) r[2 + j] = live[v][j];
-                else in_packed.push_back(live[v][j]);
+                if (j < 3) r[2 + j] = live[live_cnt[v] + j];
+                else in_packed.push_back(live[live_cnt[v] + j]);
             }
             r[5] = v;
-            for (int64_t x = c->h_vh_off[v]; x < c->h_vh_off[v + 1]; x++) {
-                const int32_t h = c->h_entry_walk[c->h_vh_entry[x]];
-                st_mask[(size_t)s * c->dp_nw + (h >> 6)] |= 1ull << (h & 63);
-            }
         }
     }
 
@@ -371,7 +378,11 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     PHICHK(upload(c, c->d_seq_off, c->h_seq_off.data(), c->h_seq_off.size()));
     PHICHK(upload(c, c->d_walk_vtx, c->h_walk_vtx.data(), c->h_walk_vtx.size()));
     PHICHK(upload(c, c->d_walk_off, c->h_walk_off.data(), c->h_walk_off.size()));
-    PHICHK(upload(c, c->d_ebase, c->h_ebase.data(), c->h_ebase.size()));
+    // flat base offset of every walk entry: exclusive scan of the segment lengths, on the GPU
+    PHICHK(phi_dev_ensure(c, c->d_ebase, (size_t)(n_entries + 1) * 8));
+    PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)n_entries * 4));
+    phi_launch_entry_len(c->stream, c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(), n_entries, c->d_list3.as<int32_t>());
+    phi_launch_scan_counts(c->stream, c->d_list3.as<int32_t>(), n_entries, c->d_ebase.as<int64_t>());
     PHICHK(upload(c, c->d_topo, c->h_topo.data(), c->h_topo.size()));
     PHICHK(upload(c, c->d_in_off, c->h_in_off.data(), c->h_in_off.size()));
     PHICHK(upload(c, c->d_in_src, c->h_in_src.data(), c->h_in_src.size()));
@@ -404,7 +415,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     PHICHK(phi_dev_ensure(c, c->d_wstarts, n_sw * 8));
     HIPCHK(hipMemsetAsync(c->d_wstarts.p, 0, n_sw * 8, c->stream));
     std::vector<int64_t> wstart(n_walks + 1);
-    for (int32_t h = 0; h <= n_walks; h++) wstart[h] = c->h_ebase[walk_off[h]];
+    for (int32_t h = 0; h <= n_walks; h++) wstart[h] = c->h_walk_base[h];
     PHICHK(upload(c, c->d_list, wstart.data(), wstart.size()));
     phi_launch_mark_starts(c->stream, c->d_list.as<int64_t>(), n_walks, c->d_wstarts.as<unsigned long long>());
 
@@ -757,7 +768,7 @@ int phi_walk_minimizers(phi_ctx *c, int32_t walk, uint64_t *out_hash, int64_t *o
     if (out_hash) HIPCHK(hipMemcpy(out_hash, c->d_rec_hash.as<uint64_t>() + lo, (size_t)n * 8, hipMemcpyDeviceToHost));
     if (out_pos) {
         HIPCHK(hipMemcpy(out_pos, c->d_rec_pos.as<int64_t>() + lo, (size_t)n * 8, hipMemcpyDeviceToHost));
-        const int64_t base = c->h_ebase[c->h_walk_off[walk]];
+        const int64_t base = c->h_walk_base[walk];
         for (int64_t i = 0; i < n; i++) out_pos[i] -= base;
     }
     return PHI_OK;
@@ -773,7 +784,7 @@ int phi_kept_anchors(phi_ctx *c, uint64_t *out_hash, int32_t *out_walk, int32_t 
     if (cap < n) return PHI_OK;
     for (int64_t i = 0; i < n; i++) {
         const PhiAnchorHost &a = c->h_kept[i];
-        const int32_t h = c->h_entry_walk[a.e0];
+        const int32_t h = phi_entry_walk(c, a.e0);
         if (out_hash) out_hash[i] = c->h_kept_hash[i];
         if (out_walk) out_walk[i] = h;
         if (out_t0) out_t0[i] = a.e0 - (int32_t)c->h_walk_off[h];

@@ -1,7 +1,14 @@
 // phi_ctx.h -- the context behind the opaque phi_ctx handle of include/phi_amd.h.
 #pragma once
 #include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include "../../include/phi_amd.h"
@@ -33,8 +40,8 @@ struct phi_ctx {
     bool have_graph = false;
     int32_t n_vtx = 0, n_walks = 0;
     std::vector<char> h_seq;
-    std::vector<int64_t> h_seq_off, h_adj_off, h_walk_off, h_ebase, h_vh_off, h_in_off;
-    std::vector<int32_t> h_adj, h_walk_vtx, h_topo_rank, h_topo, h_vh_entry, h_in_src, h_entry_walk;
+    std::vector<int64_t> h_seq_off, h_adj_off, h_walk_off, h_walk_base, h_in_off;   // h_walk_base: flat base offset of each walk
+    std::vector<int32_t> h_adj, h_walk_vtx, h_topo_rank, h_topo, h_in_src;
     int64_t n_entries = 0, walk_bases = 0;
 
     // ---- graph, device side
@@ -62,7 +69,7 @@ struct phi_ctx {
     DevBuf d_stripes;                                 // [2][PHI_STRIPES][8] u64: distinct read hashes, emitted records
 
     // ---- scratch for sketch passes and compaction
-    DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2;
+    DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2, d_list3;
 
     // ---- solve state
     DevBuf d_m_rec, d_m_group, d_g_keys, d_g_rep, d_g_cnt, d_slot_maxcnt, d_slot_multi;
@@ -85,6 +92,66 @@ struct phi_ctx {
     int64_t prof_bases = 0;
     double prof_ms_done = 0.0;
     int64_t prof_n_done = 0;
+};
+
+// walk of a walk entry
+static inline int32_t phi_entry_walk(const phi_ctx *c, int64_t e)
+{
+    return (int32_t)(std::upper_bound(c->h_walk_off.begin(), c->h_walk_off.end(), e) - c->h_walk_off.begin()) - 1;
+}
+
+// ---- host threads for the O(walk entries) preparation of phi_set_graph
+static inline int phi_host_threads()
+{
+    const char *e = getenv("PHI_HOST_THREADS");
+    int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    return n > 32 ? 32 : n;
+}
+
+// fn(lo, hi) over [0, n) in chunks handed out dynamically
+template <class F> static void phi_parallel_chunks(int64_t n, int64_t chunk, F fn)
+{
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    int nt = phi_host_threads();
+    if (nt > n_chunks) nt = (int)n_chunks;
+    if (nt <= 1) {
+        for (int64_t i = 0; i < n_chunks; i++) fn(i * chunk, std::min(n, (i + 1) * chunk));
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_chunks) break;
+            fn(i * chunk, std::min(n, (i + 1) * chunk));
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
+// first error raised by any worker
+struct PhiHostError {
+    std::atomic<int> flag{0};
+    std::mutex m;
+    int code = 0;
+    std::string msg;
+    bool failed() const { return flag.load(std::memory_order_relaxed) != 0; }
+    void set(int code_, const char *fmt, ...)
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (flag.load()) return;
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        code = code_; msg = buf;
+        flag.store(1);
+    }
 };
 
 // phi_solve.cpp: host orchestration of the exact solve on top of the DP kernel

@@ -109,9 +109,16 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
         const int32_t src = H.ent_u[c->h_topo_rank[v]], h2 = H.ent_h[c->h_topo_rank[v]];   // by step
         const int32_t u = src >= 0 ? c->h_topo[src] : -1;
         if (u < 0 || h2 < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack hit a vertex without an entry (internal error)");
+        // entry of walk h2 on vertex u: topological ranks increase along a walk
         int64_t e2 = -1;
-        for (int64_t x = c->h_vh_off[u]; x < c->h_vh_off[u + 1]; x++)
-            if (c->h_entry_walk[c->h_vh_entry[x]] == h2) { e2 = c->h_vh_entry[x]; break; }
+        {
+            int64_t lo = c->h_walk_off[h2], hi = c->h_walk_off[h2 + 1];
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (c->h_topo_rank[c->h_walk_vtx[mid]] < src) lo = mid + 1; else hi = mid;
+            }
+            if (lo < c->h_walk_off[h2 + 1] && c->h_walk_vtx[lo] == u) e2 = lo;
+        }
         if (e2 < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack: walk %d is not on vertex %d (internal error)", h2, u);
         h = h2; e = e2;
     }
@@ -228,7 +235,7 @@ int phi_solve_impl(phi_ctx *c)
     c->h_n_anchors.assign(nw, 0);
     for (int64_t i = 0; i < n_kept; i++) {
         c->h_kept[i] = PhiAnchorHost{(uint32_t)k_slot[i], k_e0[i], k_e1[i]};
-        c->h_n_anchors[c->h_entry_walk[k_e0[i]]]++;
+        c->h_n_anchors[phi_entry_walk(c, k_e0[i])]++;
         if (k_e1[i] > k_e0[i]) c->h_dp.push_back(c->h_kept[i]);     // single-vertex anchors are ignored (:795/:846)
     }
     const int64_t n_dp = (int64_t)c->h_dp.size();
@@ -279,7 +286,7 @@ int phi_solve_impl(phi_ctx *c)
         std::vector<Iv> iv;
         for (int32_t a : idx) {
             const PhiAnchorHost &A = c->h_dp[a];
-            iv.push_back(Iv{c->h_topo_rank[c->h_walk_vtx[A.e0]], c->h_topo_rank[c->h_walk_vtx[A.e1]], c->h_entry_walk[A.e0], a});
+            iv.push_back(Iv{c->h_topo_rank[c->h_walk_vtx[A.e0]], c->h_topo_rank[c->h_walk_vtx[A.e1]], phi_entry_walk(c, A.e0), a});
         }
         std::sort(iv.begin(), iv.end(), [](const Iv &x, const Iv &y) { return x.lo != y.lo ? x.lo < y.lo : x.a < y.a; });
         std::vector<std::vector<int32_t>> out;

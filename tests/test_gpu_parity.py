@@ -216,6 +216,61 @@ def test_streaming_batches_equal_one_batch(oracle, ctx_factory):
     assert rc["objective"] == ra["objective"] and rc["spectrum_size"] == ra["spectrum_size"]
 
 
+def test_reset_is_deferred_but_never_visible(oracle, ctx_factory):
+    """phi_reset_reads is folded into the next batch's preparation launch; every observer in between
+    (stats, hit vector, spectrum export, solve) must still see the reads forgotten."""
+    import torch
+    from phi_amd import dist as pdist
+    rng = np.random.default_rng(15)
+    g = random_graph(rng, n_sites=8, n_walks=4, seg_len=(8, 30))
+    reads = mosaic_reads(rng, g, n_reads=40, read_len=30, n_seg=2)
+    other = mosaic_reads(np.random.default_rng(16), g, n_reads=9, read_len=30, n_seg=1)
+    fresh = ctx_factory(k=7, w=4, threshold=1.0, recombination=5)
+    _set_graph(fresh, g)
+    fresh.add_reads(other)
+    want = fresh.solve()
+    want_stats = fresh.reads_stats()
+
+    c = ctx_factory(k=7, w=4, threshold=1.0, recombination=5)
+    _set_graph(c, g)
+    c.add_reads(reads)
+    c.reset_reads()
+    s0 = c.reads_stats()
+    assert s0["n_reads"] == 0 and s0["n_bases"] == 0 and s0["n_emitted"] == 0 and s0["n_distinct"] == 0
+    c.add_reads(reads)
+    c.reset_reads()
+    p, n = c.spectrum_export()
+    assert n == 0
+    c.add_reads(reads)
+    c.reset_reads()
+    assert c.solve()["spectrum_size"] == 0
+    c.add_reads(reads)
+    c.reset_reads()
+    p, n = c.hits_buffer()                          # from here on resets are eager (the caller holds the pointer)
+    hit = torch.as_tensor(pdist.DevArray(p, n), device="cuda")
+    torch.cuda.synchronize()
+    assert int(hit.sum().item()) == 0
+    c.add_reads(reads)
+    c.reset_reads()
+    torch.cuda.synchronize()
+    assert int(hit.sum().item()) == 0
+    # reset + other reads == a fresh context with the other reads (twice, to exercise both parities)
+    for _ in range(2):
+        c.reset_reads()
+        c.add_reads(other)
+        got = c.solve()
+        assert c.reads_stats() == want_stats
+        for key in ("objective", "spectrum_size", "filtered", "n_in_model", "n_covered"):
+            assert got[key] == want[key]
+    # deferred reset in front of a batch with bases outside ACGT
+    c2 = ctx_factory(k=7, w=4, threshold=1.0, recombination=5)
+    _set_graph(c2, g)
+    c2.add_reads([b"ACGTNNACGTAGCTAGCTAGGATCGATCGTAGCTAGC"] * 3)
+    c2.reset_reads()
+    c2.add_reads(other)
+    assert c2.reads_stats() == want_stats and c2.solve()["objective"] == want["objective"]
+
+
 def test_bad_inputs(oracle, ctx_factory):
     import phi_amd
     g = oracle.parse_gfa(os.path.join(DATA, "test.gfa"))
