@@ -150,7 +150,7 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_wascii, &c->d_rbad, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
                      &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
-                     &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_m_rec, &c->d_m_group,
+                     &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_qbest, &c->d_lent, &c->d_top,
                      &c->d_ent};
@@ -227,6 +227,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     c->reset_pending = false; c->hits_exported = false;
     c->solved = false;
 
+    PhiStageTimer tm("set_graph");
     // ---- validate and keep host copies
     if (seq_off[0] != 0 || adj_off[0] != 0 || walk_off[0] != 0) return phi_fail(c, PHI_ERR_INVALID, "offset arrays must start at 0");
     for (int32_t v = 0; v < n_vtx; v++)
@@ -268,6 +269,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) c->h_in_src[cur[adj[x]]++] = u;
     }
 
+    tm.lap("validate graph, copies");
     // ---- one parallel pass over the walk entries (host threads over fixed chunks of entries):
     //   * walks follow edges of forward vertices (ILP_index.cpp:104-107 exits on reverse strand; an
     //     edge-less step would make the anchor's edge variables unconstrained, :799-815)
@@ -316,6 +318,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         });
         if (herr.failed()) return phi_fail(c, herr.code, "%s", herr.msg.c_str());
     }
+    tm.lap("walk entries (threads)");
     bool start_interior = false, end_interior = false;
     c->h_walk_base.assign(n_walks + 1, 0);
     for (int32_t h = 0; h < n_walks; h++) {
@@ -369,6 +372,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         }
     }
 
+    tm.lap("DP step stream");
     // ---- device copies
     PHICHK(upload(c, c->d_e_out, e_out.data(), e_out.size()));
     PHICHK(upload(c, c->d_st_rec, st_rec.data(), st_rec.size()));
@@ -387,6 +391,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     PHICHK(upload(c, c->d_in_off, c->h_in_off.data(), c->h_in_off.size()));
     PHICHK(upload(c, c->d_in_src, c->h_in_src.data(), c->h_in_src.size()));
 
+    if (tm.on) (void)hipStreamSynchronize(c->stream);
+    tm.lap("uploads + ebase scan");
     // ---- stage 1a on the GPU: pack the walks, sketch them, build the minimiser table
     HIPCHK(hipMemsetAsync(c->d_scalars.p, 0, S_N * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_stripes.p, 0, 2 * STRIPE_BYTES, c->stream));
@@ -454,6 +460,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)(c->n_unique / 8 + 1) * 8, c->stream));
     HIPCHK(hipGetLastError());
     PHICHK(phi_sync_check(c));
+    tm.lap("walk sketch + table (GPU)");
     c->h_n_minimizers.resize(n_walks);
     for (int32_t h = 0; h < n_walks; h++) c->h_n_minimizers[h] = c->h_walk_rec_off[h + 1] - c->h_walk_rec_off[h];
 

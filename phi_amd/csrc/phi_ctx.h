@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -22,7 +23,7 @@ struct DevBuf {
 };
 
 struct PhiAnchorHost {       // one dp anchor on the host (certificate / branch-and-bound)
-    uint32_t slot;           // minimiser identity: slot of the walk-minimiser table
+    uint32_t slot;           // minimiser identity: dense id (rank of first occurrence among the walk minimisers)
     int32_t e0, e1;          // first / last walk entry
 };
 
@@ -69,7 +70,7 @@ struct phi_ctx {
     DevBuf d_stripes;                                 // [2][PHI_STRIPES][8] u64: distinct read hashes, emitted records
 
     // ---- scratch for sketch passes and compaction
-    DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2, d_list3;
+    DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2, d_list3, d_walk_last;
 
     // ---- solve state
     DevBuf d_m_rec, d_m_group, d_g_keys, d_g_rep, d_g_cnt, d_slot_maxcnt, d_slot_multi;
@@ -92,6 +93,21 @@ struct phi_ctx {
     int64_t prof_bases = 0;
     double prof_ms_done = 0.0;
     int64_t prof_n_done = 0;
+};
+
+// PHI_TIMING=1: stage timings of phi_set_graph / phi_solve on stderr
+struct PhiStageTimer {
+    bool on;
+    const char *what;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhiStageTimer(const char *w) : on(getenv("PHI_TIMING") != nullptr), what(w), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char *stage)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[phi timing] %s: %-28s %8.3f ms\n", what, stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
 };
 
 // walk of a walk entry

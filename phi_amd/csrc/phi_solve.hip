@@ -53,7 +53,7 @@ int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_
 
 // ------------------------------------------------------------------------------------------ DP
 struct DpHost {
-    std::vector<int32_t> dmax, lent, ent_u, ent_h;
+    std::vector<int32_t> ends, lent, ent_u, ent_h;
     std::vector<uint8_t> qbest;
 };
 
@@ -79,19 +79,30 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
     A.ent_src = c->d_ent.as<int32_t>(); A.ent_h = c->d_ent.as<int32_t>() + nv;
     phi_launch_dp(c->stream, A);
     HIPCHK(hipGetLastError());
-    H.dmax.resize(ne); H.lent.resize(ne); H.qbest.resize(ne); H.ent_u.resize(nv); H.ent_h.resize(nv);
-    HIPCHK(hipMemcpyAsync(H.dmax.data(), A.dmax, (size_t)ne * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(H.lent.data(), A.lent, (size_t)ne * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(H.qbest.data(), A.qbest, (size_t)ne, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(H.ent_u.data(), A.ent_src, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(H.ent_h.data(), A.ent_h, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
+    // Backtracking touches a handful of entries (two per haplotype switch): read them one by one
+    // instead of downloading 9 bytes per walk entry; a path with very many switches (tiny R)
+    // falls back to one bulk download.
+    H.ends.resize(c->n_walks);
+    phi_launch_gather_i32(c->stream, A.dmax, c->d_walk_last.as<int32_t>(), c->n_walks, c->d_list3.as<int32_t>());
+    HIPCHK(hipMemcpyAsync(H.ends.data(), c->d_list3.p, (size_t)c->n_walks * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    bool bulk = false;
+    auto fetch_bulk = [&]() -> int {
+        H.lent.resize(ne); H.qbest.resize(ne); H.ent_u.resize(nv); H.ent_h.resize(nv);
+        HIPCHK(hipMemcpyAsync(H.lent.data(), A.lent, (size_t)ne * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(H.qbest.data(), A.qbest, (size_t)ne, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(H.ent_u.data(), A.ent_src, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(H.ent_h.data(), A.ent_h, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        bulk = true;
+        return PHI_OK;
+    };
 
     // end at (last(h), h) for the best h; ties go to the lowest walk id
     int32_t bh = -1;
     int64_t best = INT64_MIN;
     for (int32_t h = 0; h < c->n_walks; h++) {
-        const int32_t d = H.dmax[c->h_walk_off[h + 1] - 1];
+        const int32_t d = H.ends[h];
         if (d > -(1 << 28) && d > best) { best = d; bh = h; }
     }
     if (bh < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP found no s->e path (internal error)");
@@ -100,13 +111,27 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
     int32_t h = bh;
     int64_t e = c->h_walk_off[h + 1] - 1;
     for (int64_t guard = 0; guard <= (int64_t)nv; guard++) {
-        const int32_t q = H.qbest[e];
-        const int64_t es = (q < PHI_RCAP - 1) ? e - q : c->h_walk_off[h] + H.lent[e];
+        if (!bulk && guard == 64) PHICHK(fetch_bulk());
+        int32_t q, lent_e = 0;
+        if (bulk) { q = H.qbest[e]; lent_e = H.lent[e]; }
+        else {
+            uint8_t q8 = 0;
+            HIPCHK(hipMemcpy(&q8, A.qbest + e, 1, hipMemcpyDeviceToHost));
+            q = q8;
+            if (q >= PHI_RCAP - 1) HIPCHK(hipMemcpy(&lent_e, A.lent + e, 4, hipMemcpyDeviceToHost));
+        }
+        const int64_t es = (q < PHI_RCAP - 1) ? e - q : c->h_walk_off[h] + lent_e;
         if (es < c->h_walk_off[h] || es > e) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack left the walk (internal error)");
         segs->push_back(Seg{h, (int32_t)es, (int32_t)e});
         if (es == c->h_walk_off[h]) break;                     // reached s_{first(h),h}
         const int32_t v = c->h_walk_vtx[es];
-        const int32_t src = H.ent_u[c->h_topo_rank[v]], h2 = H.ent_h[c->h_topo_rank[v]];   // by step
+        const int32_t step = c->h_topo_rank[v];
+        int32_t src, h2;
+        if (bulk) { src = H.ent_u[step]; h2 = H.ent_h[step]; }
+        else {
+            HIPCHK(hipMemcpy(&src, A.ent_src + step, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&h2, A.ent_h + step, 4, hipMemcpyDeviceToHost));
+        }
         const int32_t u = src >= 0 ? c->h_topo[src] : -1;
         if (u < 0 || h2 < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack hit a vertex without an entry (internal error)");
         // entry of walk h2 on vertex u: topological ranks increase along a walk
@@ -146,6 +171,7 @@ int phi_solve_impl(phi_ctx *c)
 {
     c->solved = false;
     PHICHK(phi_sync_check(c));
+    PhiStageTimer tm("solve");
     uint64_t sc[S_N];
     HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
     uint64_t n_distinct = 0;
@@ -161,6 +187,7 @@ int phi_solve_impl(phi_ctx *c)
                            c->d_hit.as<uint8_t>(), c->d_flags.as<uint8_t>());
     PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_rec, c->d_m_rec, &n_matched));
 
+    tm.lap("match + compact");
     // ---- 2. shared-anchor filter (:670-743)
     PhiFilterArgs F{};
     F.rec_slot = c->d_rec_slot.as<uint32_t>(); F.rec_e0 = c->d_rec_e0.as<int32_t>(); F.rec_e1 = c->d_rec_e1.as<int32_t>();
@@ -205,6 +232,7 @@ int phi_solve_impl(phi_ctx *c)
     phi_launch_kept_flags(c->stream, F, n_matched, c->d_flags.as<uint8_t>(), c->d_flags2.as<uint8_t>());
     int64_t n_kept = 0;
     PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_matched, c->d_list, &n_kept));
+    tm.lap("filter kernels");
     // kept anchors to the host: record index -> (slot, e0, e1, hash)
     std::vector<int32_t> k_slot(n_kept), k_e0(n_kept), k_e1(n_kept);
     c->h_kept_hash.resize(n_kept);
@@ -214,7 +242,10 @@ int phi_solve_impl(phi_ctx *c)
         phi_launch_gather_i32(c->stream, c->d_m_rec.as<int32_t>(), c->d_list.as<int32_t>(), n_kept, k_rec);
         PHICHK(phi_dev_ensure(c, c->d_a_e1, (size_t)n_kept * 8));
         int32_t *tmp = c->d_a_e1.as<int32_t>();
-        phi_launch_gather_i32(c->stream, (const int32_t *)c->d_rec_slot.p, k_rec, n_kept, tmp);
+        // minimiser identity on the host: the dense id (rank of first occurrence) behind the table slot
+        PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)n_kept * 4));
+        phi_launch_gather_i32(c->stream, (const int32_t *)c->d_rec_slot.p, k_rec, n_kept, c->d_list3.as<int32_t>());
+        phi_launch_gather_i32(c->stream, (const int32_t *)c->d_u_uid.p, c->d_list3.as<int32_t>(), n_kept, tmp);
         HIPCHK(hipMemcpyAsync(k_slot.data(), tmp, (size_t)n_kept * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         phi_launch_gather_i32(c->stream, c->d_rec_e0.as<int32_t>(), k_rec, n_kept, tmp);
@@ -230,16 +261,24 @@ int phi_solve_impl(phi_ctx *c)
     HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
     const int64_t filtered = (int64_t)sc[S_FILTERED], in_model = (int64_t)sc[S_INMODEL];
 
+    tm.lap("anchors D2H");
     c->h_kept.resize(n_kept);
     c->h_dp.clear();
+    c->h_dp.reserve(n_kept);
     c->h_n_anchors.assign(nw, 0);
-    for (int64_t i = 0; i < n_kept; i++) {
-        c->h_kept[i] = PhiAnchorHost{(uint32_t)k_slot[i], k_e0[i], k_e1[i]};
-        c->h_n_anchors[phi_entry_walk(c, k_e0[i])]++;
-        if (k_e1[i] > k_e0[i]) c->h_dp.push_back(c->h_kept[i]);     // single-vertex anchors are ignored (:795/:846)
+    {
+        int32_t hw = 0;                                            // kept anchors come in walk order
+        for (int64_t i = 0; i < n_kept; i++) {
+            c->h_kept[i] = PhiAnchorHost{(uint32_t)k_slot[i], k_e0[i], k_e1[i]};
+            if (k_e0[i] < c->h_walk_off[hw] || k_e0[i] >= c->h_walk_off[hw + 1]) hw = phi_entry_walk(c, k_e0[i]);
+            c->h_n_anchors[hw]++;
+            if (k_e1[i] > k_e0[i]) c->h_dp.push_back(c->h_kept[i]);     // single-vertex anchors are ignored (:795/:846)
+        }
     }
     const int64_t n_dp = (int64_t)c->h_dp.size();
 
+    if (tm.on) fprintf(stderr, "[phi timing] solve: n_rec %lld matched %lld kept %lld dp %lld\n", (long long)n_rec, (long long)n_matched, (long long)n_kept, (long long)n_dp);
+    tm.lap("filter (GPU) + anchors D2H");
     // ---- 3. DP inputs
     {
         std::vector<int32_t> a_e1(n_dp);
@@ -260,6 +299,13 @@ int phi_solve_impl(phi_ctx *c)
         }
         phi_launch_entry_csr(c->stream, c->d_a_e1.as<int32_t>(), n_dp, c->n_entries, c->d_g_off.as<int64_t>());
         HIPCHK(hipStreamSynchronize(c->stream));
+        {
+            std::vector<int32_t> last(nw);
+            for (int32_t h = 0; h < nw; h++) last[h] = (int32_t)(c->h_walk_off[h + 1] - 1);
+            PHICHK(phi_dev_ensure(c, c->d_walk_last, (size_t)nw * 4));
+            PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)nw * 4));
+            HIPCHK(hipMemcpy(c->d_walk_last.p, last.data(), (size_t)nw * 4, hipMemcpyHostToDevice));
+        }
         PHICHK(phi_dev_ensure(c, c->d_dmax, (size_t)c->n_entries * 4));
         PHICHK(phi_dev_ensure(c, c->d_lent, (size_t)c->n_entries * 4));
         PHICHK(phi_dev_ensure(c, c->d_qbest, (size_t)c->n_entries));
@@ -268,20 +314,33 @@ int phi_solve_impl(phi_ctx *c)
         PHICHK(phi_dev_ensure(c, c->d_word, (size_t)c->n_entries * 8));
     }
 
+    tm.lap("DP inputs");
     // ---- 4. exact solve
     const int64_t cost = 2 * (int64_t)(c->recombination / 2);
-    std::unordered_map<uint32_t, std::vector<int32_t>> slot_anchors;     // minimisers with >= 2 dp anchors
+    // dp anchors of every minimiser (CSR over the dense minimiser ids), ascending anchor index
+    const int64_t n_ids = c->n_unique;
+    std::vector<int32_t> sa_off(n_ids + 1, 0), sa_idx(std::max<int64_t>(n_dp, 1));
     {
-        std::unordered_map<uint32_t, int32_t> cnt;
-        for (const PhiAnchorHost &a : c->h_dp) cnt[a.slot]++;
-        for (int64_t i = 0; i < n_dp; i++)
-            if (cnt[c->h_dp[i].slot] >= 2) slot_anchors[c->h_dp[i].slot].push_back((int32_t)i);
+        for (const PhiAnchorHost &a : c->h_dp) {
+            if ((int64_t)a.slot >= n_ids) return phi_fail(c, PHI_ERR_DEVICE, "minimiser id out of range (internal error)");
+            sa_off[a.slot + 1]++;
+        }
+        for (int64_t i = 0; i < n_ids; i++) sa_off[i + 1] += sa_off[i];
+        std::vector<int32_t> cur(sa_off.begin(), sa_off.end() - 1);
+        for (int64_t i = 0; i < n_dp; i++) sa_idx[cur[c->h_dp[i].slot]++] = (int32_t)i;
     }
+    struct Span {
+        const int32_t *p; int32_t n;
+        const int32_t *begin() const { return p; }
+        const int32_t *end() const { return p + n; }
+        int32_t operator[](int32_t i) const { return p[i]; }
+    };
+    auto anchors_of = [&](uint32_t s) { return Span{sa_idx.data() + sa_off[s], sa_off[s + 1] - sa_off[s]}; };
     // clusters of pairwise mutually exclusive anchors of one minimiser: anchors on different walks
     // whose topological-rank intervals overlap cannot both be traversed (a path holds one
     // haplotype label per vertex).  Anything else becomes a singleton cluster.
     auto clusters_of = [&](uint32_t slot) {
-        const std::vector<int32_t> &idx = slot_anchors[slot];
+        const Span idx = anchors_of(slot);
         struct Iv { int32_t lo, hi, h, a; };
         std::vector<Iv> iv;
         for (int32_t a : idx) {
@@ -311,6 +370,7 @@ int phi_solve_impl(phi_ctx *c)
         return out;
     };
 
+    tm.lap("minimiser -> anchors map");
     DpHost H;
     std::vector<uint8_t> wgt(n_dp, 1);
     std::vector<Seg> best_segs;
@@ -321,7 +381,8 @@ int phi_solve_impl(phi_ctx *c)
     std::vector<Node> stack;
     stack.push_back(Node{});
     std::vector<int64_t> open_ub;                              // bounds of nodes given up on
-    std::vector<int32_t> cov_cnt;                              // scratch: per dp anchor slot counts
+    std::vector<int32_t> cov_all(n_ids, 0), cov_w(n_ids, 0);   // per minimiser: dp anchors traversed (all / weighted)
+    std::vector<uint32_t> touched;                             // minimisers with cov_all > 0
     while (!stack.empty()) {
         Node node = stack.back();
         stack.pop_back();
@@ -338,7 +399,7 @@ int phi_solve_impl(phi_ctx *c)
             if (n_runs >= max_runs) { exhausted = true; break; }
             // weights of this relaxation
             std::fill(wgt.begin(), wgt.end(), 1);
-            for (uint32_t s : S) for (int32_t a : slot_anchors[s]) wgt[a] = 0;
+            for (uint32_t s : S) for (int32_t a : anchors_of(s)) wgt[a] = 0;
             for (auto &kv : assign) {
                 if (S.count(kv.first)) continue;
                 const auto &cl = assign_clusters[kv.first];
@@ -349,17 +410,20 @@ int phi_solve_impl(phi_ctx *c)
             std::vector<Seg> segs;
             PHICHK(run_dp(c, wgt, H, &val, &segs));
             n_runs++;
+            tm.lap("  DP run + backtrack");
             // exact value of this path and its additive value under wgt
-            std::unordered_map<uint32_t, int32_t> cov_all, cov_w;
+            for (uint32_t s : touched) { cov_all[s] = 0; cov_w[s] = 0; }
+            touched.clear();
             int64_t add_w = 0;
             for_covered(c, segs, [&](int64_t a) {
-                cov_all[c->h_dp[a].slot]++;
-                if (wgt[a]) { cov_w[c->h_dp[a].slot]++; add_w++; }
+                const uint32_t s = c->h_dp[a].slot;
+                if (!cov_all[s]++) touched.push_back(s);
+                if (wgt[a]) { cov_w[s]++; add_w++; }
             });
             const int64_t n_sw = (int64_t)segs.size() - 1;
             add_w -= cost * n_sw;
             if (add_w != val) return phi_fail(c, PHI_ERR_DEVICE, "DP value %lld != value %lld of its own path (internal error)", (long long)val, (long long)add_w);
-            const int64_t true_val = (int64_t)cov_all.size() - cost * n_sw;
+            const int64_t true_val = (int64_t)touched.size() - cost * n_sw;
             if (true_val > incumbent) { incumbent = true_val; best_segs = segs; }
             const int64_t ub = val + (int64_t)S.size();
             node_ub = std::min(node_ub, ub);
@@ -367,11 +431,11 @@ int phi_solve_impl(phi_ctx *c)
             if (node_ub <= incumbent) { closed = true; break; }
             // tighten: bound doubly-counted minimisers by the constant 1, release unused constants
             std::set<uint32_t> D, Z;
-            for (auto &kv : cov_w) if (kv.second >= 2) D.insert(kv.first);
+            for (uint32_t s : touched) if (cov_w[s] >= 2) D.insert(s);
             for (uint32_t s : S) {
                 // is any anchor this node still allows for s traversed?
                 bool covered = false;
-                if (cov_all.count(s)) {
+                if (cov_all[s]) {
                     auto it = assign.find(s);
                     if (it == assign.end()) covered = true;
                     else {
@@ -383,12 +447,13 @@ int phi_solve_impl(phi_ctx *c)
                 }
                 if (!covered) Z.insert(s);
             }
+            tm.lap("  path value, tighten sets");
             if (D.empty() && Z.empty()) { closed = true; break; }   // bound attained by this path
             // remember a branching candidate in canonical (first anchor) order
             {
                 int32_t best_a = INT32_MAX;
-                for (uint32_t s : D) if (slot_anchors[s][0] < best_a) { best_a = slot_anchors[s][0]; branch_slot = s; }
-                if (D.empty()) for (uint32_t s : Z) if (!assign.count(s) && slot_anchors[s][0] < best_a) { best_a = slot_anchors[s][0]; branch_slot = s; }
+                for (uint32_t s : D) if (anchors_of(s)[0] < best_a) { best_a = anchors_of(s)[0]; branch_slot = s; }
+                if (D.empty()) for (uint32_t s : Z) if (!assign.count(s) && anchors_of(s)[0] < best_a) { best_a = anchors_of(s)[0]; branch_slot = s; }
                 have_branch = best_a != INT32_MAX;
             }
             std::set<uint32_t> S2 = S;
@@ -411,6 +476,7 @@ int phi_solve_impl(phi_ctx *c)
     int64_t ub = incumbent;
     for (int64_t u : open_ub) ub = std::max(ub, u);
 
+    tm.lap("DP runs + certificate");
     // ---- 5. decode (:1431-1525)
     c->h_path_vtx.clear();
     c->h_path_hap.clear();
@@ -424,15 +490,16 @@ int phi_solve_impl(phi_ctx *c)
         }
     int32_t recomb = 0;
     for (size_t i = 1; i < c->h_path_hap.size(); i++) recomb += c->h_path_hap[i] != c->h_path_hap[i - 1];   // :1517-1519
-    std::unordered_map<uint32_t, int32_t> cov;
-    for_covered(c, best_segs, [&](int64_t a) { cov[c->h_dp[a].slot]++; });
+    for (uint32_t s : touched) cov_all[s] = 0;
+    int64_t n_cov = 0;
+    for_covered(c, best_segs, [&](int64_t a) { if (!cov_all[c->h_dp[a].slot]++) n_cov++; });
 
     phi_result &R = c->result;
     R.objective = incumbent;
     R.upper_bound = ub;
     R.optimal = ub == incumbent;
     R.n_dp_runs = n_runs;
-    R.n_covered = (int64_t)cov.size();
+    R.n_covered = n_cov;
     R.n_path = (int64_t)c->h_path_vtx.size();
     R.path_vtx = c->h_path_vtx.data();
     R.path_hap = c->h_path_hap.data();
@@ -446,6 +513,7 @@ int phi_solve_impl(phi_ctx *c)
     R.filtered = filtered;
     R.retained = spectrum - filtered;
     R.n_in_model = in_model;
+    tm.lap("decode");
     c->solved = true;
     return PHI_OK;
 }

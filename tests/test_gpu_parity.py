@@ -216,6 +216,38 @@ def test_streaming_batches_equal_one_batch(oracle, ctx_factory):
     assert rc["objective"] == ra["objective"] and rc["spectrum_size"] == ra["spectrum_size"]
 
 
+def test_many_switches_backtrack(oracle, ctx_factory):
+    """R = 0 on a long bubble chain: the best path switches walks hundreds of times, so the
+    backtrack leaves its read-a-few-entries mode for the bulk download."""
+    rng = np.random.default_rng(321)
+    g = random_graph(rng, n_sites=400, n_walks=4, seg_len=(6, 14), alt_len=(3, 6), p_del=0.0)
+    # truth alternates ref / alt allele site by site; the walks chose theirs at random
+    succ = {v: sorted(a) for v, a in enumerate(g.adj)}
+    v, truth, site = g.paths[0][0], [], 0
+    while True:
+        truth.append(v)
+        nx = succ[v]
+        if not nx:
+            break
+        if len(nx) == 2:
+            v = nx[site % 2]
+            site += 1
+        else:
+            v = nx[0]
+    hap = b"".join(g.node_seq[x] for x in truth)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for _ in range(700):
+        a = int(rng.integers(0, len(hap) - 60))
+        r = hap[a:a + 60]
+        reads.append(r.translate(comp)[::-1] if rng.random() < 0.5 else r)
+    ctx = ctx_factory(k=9, w=3, threshold=1.0, recombination=0)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads)
+    st, res, m = _check_against_oracle(oracle, ctx, g, reads, 9, 3, 1.0, 0)
+    assert res["n_switches"] > 64, res["n_switches"]
+
+
 def test_reset_is_deferred_but_never_visible(oracle, ctx_factory):
     """phi_reset_reads is folded into the next batch's preparation launch; every observer in between
     (stats, hit vector, spectrum export, solve) must still see the reads forgotten."""
