@@ -26,7 +26,10 @@
 //   * the best leaving states of recent vertices live in an LDS ring indexed by step, so a
 //     recombination entry is two LDS look-ups; older ones fall back to the HBM copy;
 //   * per-entry data (out-edge index + spans of the weight-1 anchors ending there, packed in one
-//     64-bit word by phi_dp_words_kernel) is prefetched four entries ahead in registers.
+//     64-bit word by phi_dp_words_kernel) sits in a per-lane LDS ring refilled in bulk every WD/2
+//     steps: the step loop itself issues no global load, so no step waits on HBM latency (a
+//     register prefetch "four entries ahead" made every step wait for the load it had just
+//     issued -- vmcnt counts in order -- and cost 0.67 us per step).
 #include <hip/hip_runtime.h>
 #include "phi_kernels.h"
 
@@ -94,6 +97,8 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
     __shared__ int32_t r_t1v[RING], r_t1h[RING], r_t1n[RING], r_t2v[RING], r_t2h[RING];
     __shared__ unsigned long long s_red[NW > 1 ? NW : 1];
     __shared__ int32_t s_oidx[NT];
+    constexpr int WD = NW == 1 ? 64 : NW == 2 ? 32 : NW == 4 ? 16 : 4;   // per-lane ring of entry words
+    __shared__ uint64_t s_w[WD][NT];
 
     const int h = threadIdx.x;
     const int lane = h & 63, wid = h >> 6;
@@ -101,10 +106,29 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
     const int64_t eb = has_walk ? A.walk_off[h] : 0;
     const int64_t ee = has_walk ? A.walk_off[h + 1] : 0;
     int64_t e = eb;                                  // next entry of this lane
-    // per-entry words, four entries ahead
-    uint64_t w0 = (e < ee) ? A.word[e] : 0, w1 = (e + 1 < ee) ? A.word[e + 1] : 0;
-    uint64_t w2 = (e + 2 < ee) ? A.word[e + 2] : 0, w3 = (e + 3 < ee) ? A.word[e + 3] : 0;
+    int64_t wl = eb;                                 // first entry not yet in the word ring
     int32_t T = NEG, L = NEG, entL = 0;
+
+    // bring entries [wl, min(ee, e + WD)) into the ring: at most WD/2 per call (a lane consumes at
+    // most one entry per step and this runs every WD/2 steps); all loads are issued before the
+    // first ring write, so one call costs one memory latency
+    auto refill = [&]() {
+        const int64_t hi = min(ee, e + WD);
+        uint64_t tmp[WD / 2];
+#pragma unroll
+        for (int j = 0; j < WD / 2; j++) {
+            const int64_t x = wl + j;
+            tmp[j] = A.word[has_walk ? min(x, ee - 1) : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < WD / 2; j++) {
+            const int64_t x = wl + j;
+            if (x < hi) s_w[x & (WD - 1)][h] = tmp[j];
+        }
+        wl = max(wl, min(hi, wl + WD / 2));
+    };
+    refill();
+    refill();
 
     const int32_t n_steps = A.n_vtx;
     const int n_chunks = (n_steps + CHK - 1) / CHK;
@@ -130,6 +154,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
         const int32_t s0 = c * CHK;
         const int32_t ns = min(CHK, n_steps - s0);
         for (int i = 0; i < ns; i++) {
+            if ((i & (WD / 2 - 1)) == 0 && (c | i)) refill();
             const int32_t step = s0 + i;
             const int32_t flags = s_rec[b][i][0];
             const bool active = has_walk && ((s_mask[b][i][wid] >> lane) & 1ull);
@@ -163,9 +188,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
             int32_t oidx = 255;
             if (active) {
                 const int32_t t = (int32_t)(e - eb);
-                const uint64_t word = w0;
-                w0 = w1; w1 = w2; w2 = w3;
-                w3 = (e + 4 < ee) ? A.word[e + 4] : 0;
+                const uint64_t word = s_w[e & (WD - 1)][h];
                 oidx = (int32_t)(word & 0xFF);
                 if (t == 0) {
                     // walk start s_{first(h),h}: run length 0 scores 0, nothing older exists

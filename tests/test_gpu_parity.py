@@ -216,6 +216,24 @@ def test_streaming_batches_equal_one_batch(oracle, ctx_factory):
     assert rc["objective"] == ra["objective"] and rc["spectrum_size"] == ra["spectrum_size"]
 
 
+@pytest.mark.parametrize("n_walks", [70, 130, 300])
+def test_more_than_64_walks_vs_highs(oracle, ctx_factory, n_walks):
+    """lane <-> walk: more than 64 walks take the multi-wave instances of the DP kernel.  Brute
+    force is out of reach with this many labels; the objective is checked against HiGHS on the
+    reference's restated -q0 program (oracle/solve_oracle.py build_milp)."""
+    rng = np.random.default_rng(1000 + n_walks)
+    g = random_graph(rng, n_sites=8, n_walks=n_walks, seg_len=(6, 12), alt_len=(2, 5), p_del=0.3)
+    reads = mosaic_reads(rng, g, n_reads=60, read_len=28, n_seg=4)
+    R = 4
+    ctx = ctx_factory(k=5, w=2, threshold=0.6, recombination=R)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads)
+    st, res, m = _check_against_oracle(oracle, ctx, g, reads, 5, 2, 0.6, R)
+    assert res["objective"] < res["n_in_model"]          # switching costs bite
+    best, _, _ = m.milp_solve(time_limit=120.0)
+    assert res["objective"] == best, (n_walks, res["objective"], best)
+
+
 def test_many_switches_backtrack(oracle, ctx_factory):
     """R = 0 on a long bubble chain: the best path switches walks hundreds of times, so the
     backtrack leaves its read-a-few-entries mode for the bulk download."""
