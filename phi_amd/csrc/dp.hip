@@ -77,27 +77,38 @@ __device__ __forceinline__ unsigned long long pack_vh(int32_t val, int32_t h)
     return ((unsigned long long)(uint32_t)(val - NEG) << 32) | (uint32_t)(0x7FFFFFFF - h);
 }
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+// max over the 64 lanes on the VALU: DPP rotations inside each row of 16 lanes, then the four row
+// results through v_readlane.  (__shfl_xor is ds_bpermute: six LDS round trips per reduction.)
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_xor(k, d, 64);
-        k = o > k ? o : k;
-    }
-    return k;
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xF, 0xF, false));     // row_ror:1
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xF, 0xF, false));     // row_ror:2
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false));     // row_ror:4
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));     // row_ror:8
+    const int32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// tops of a step packed in 16 bytes: x = top1 value, y = top2 value,
+// z = (top1 walk + 1) | (top1 out-edge + 1) << 10 | (top2 walk + 1) << 20
+__device__ __forceinline__ int4 pack_tops(int32_t t1v, int32_t t1h, int32_t t1n, int32_t t2v, int32_t t2h)
+{
+    return make_int4(t1v, t2v, (t1h + 1) | ((t1n + 1) << 10) | ((t2h + 1) << 20), 0);
 }
 
 template <int NW>   // waves in the workgroup
 __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
 {
     constexpr int NT = NW * 64;
-    __shared__ int32_t s_rec[2][CHK][8];
+    constexpr int WD = NW == 1 ? 64 : NW == 2 ? 32 : NW == 4 ? 16 : 4;   // per-lane ring of entry words
+    constexpr int WP = WD / 2;                                           // refill period in steps
+    __shared__ int4 s_rec[2][CHK][2];
     __shared__ unsigned long long s_mask[2][CHK][NW];
     __shared__ int32_t s_d[32][NT];                 // difference ring, slot-major: bank = lane
-    __shared__ int32_t r_t1v[RING], r_t1h[RING], r_t1n[RING], r_t2v[RING], r_t2h[RING];
+    __shared__ int4 s_top[RING];                    // packed tops of recent steps
     __shared__ unsigned long long s_red[NW > 1 ? NW : 1];
     __shared__ int32_t s_oidx[NT];
-    constexpr int WD = NW == 1 ? 64 : NW == 2 ? 32 : NW == 4 ? 16 : 4;   // per-lane ring of entry words
     __shared__ uint64_t s_w[WD][NT];
 
     const int h = threadIdx.x;
@@ -109,26 +120,30 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
     int64_t wl = eb;                                 // first entry not yet in the word ring
     int32_t T = NEG, L = NEG, entL = 0;
 
-    // bring entries [wl, min(ee, e + WD)) into the ring: at most WD/2 per call (a lane consumes at
-    // most one entry per step and this runs every WD/2 steps); all loads are issued before the
-    // first ring write, so one call costs one memory latency
-    auto refill = [&]() {
-        const int64_t hi = min(ee, e + WD);
-        uint64_t tmp[WD / 2];
+    // Word ring refill, split in two so that no step waits on HBM: `issue` starts the loads of
+    // entries [wl, wl + WP) into registers, `land` (WP/2 steps later) writes those below
+    // min(ee, e_at_issue + WD) into the ring.  A lane consumes at most one entry per step, so the
+    // ring always holds the entries of the next WP/2 steps at least.
+    uint64_t wtmp[WP];
+    int64_t whi = eb;
+    auto issue = [&]() {
+        whi = min(ee, e + WD);
 #pragma unroll
-        for (int j = 0; j < WD / 2; j++) {
-            const int64_t x = wl + j;
-            tmp[j] = A.word[has_walk ? min(x, ee - 1) : 0];
-        }
-#pragma unroll
-        for (int j = 0; j < WD / 2; j++) {
-            const int64_t x = wl + j;
-            if (x < hi) s_w[x & (WD - 1)][h] = tmp[j];
-        }
-        wl = max(wl, min(hi, wl + WD / 2));
+        for (int j = 0; j < WP; j++) wtmp[j] = A.word[has_walk ? min(wl + j, ee - 1) : 0];
     };
-    refill();
-    refill();
+    auto land = [&]() {
+#pragma unroll
+        for (int j = 0; j < WP; j++) {
+            const int64_t x = wl + j;
+            if (x < whi) s_w[x & (WD - 1)][h] = wtmp[j];
+        }
+        wl = max(wl, min(whi, wl + WP));
+    };
+    issue(); land();
+    issue(); land();
+    // per-lane values of the NEXT entry, read right after the previous one was processed
+    uint64_t nword = has_walk ? s_w[e & (WD - 1)][h] : 0;
+    int32_t nold = 0;
 
     const int32_t n_steps = A.n_vtx;
     const int n_chunks = (n_steps + CHK - 1) / CHK;
@@ -139,7 +154,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
         const int32_t s0 = c * CHK;
         const int32_t ns = min(CHK, n_steps - s0);
         const int4 *src = reinterpret_cast<const int4 *>(A.st_rec + (int64_t)s0 * 8);
-        int4 *dst = reinterpret_cast<int4 *>(&s_rec[b][0][0]);
+        int4 *dst = &s_rec[b][0][0];
         for (int i = h; i < ns * 2; i += NT) dst[i] = src[i];
         const unsigned long long *ms = A.st_mask + (int64_t)s0 * NW;
         unsigned long long *md = &s_mask[b][0][0];
@@ -153,32 +168,48 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
         if (c + 1 < n_chunks) stage(c + 1);          // lands while this chunk is processed
         const int32_t s0 = c * CHK;
         const int32_t ns = min(CHK, n_steps - s0);
+        // the step record travels one step ahead in registers
+        int4 ra = s_rec[b][0][0], rb = s_rec[b][0][1];
+        unsigned long long mk = s_mask[b][0][wid];
         for (int i = 0; i < ns; i++) {
-            if ((i & (WD / 2 - 1)) == 0 && (c | i)) refill();
+            const int inx = min(i + 1, CHK - 1);
+            const int4 na = s_rec[b][inx][0], nb = s_rec[b][inx][1];
+            const unsigned long long nm = s_mask[b][inx][wid];
+            if ((c | i) && (i & (WP - 1)) == 0) issue();
+            if ((c | i) && (i & (WP - 1)) == WP / 2) land();
             const int32_t step = s0 + i;
-            const int32_t flags = s_rec[b][i][0];
-            const bool active = has_walk && ((s_mask[b][i][wid] >> lane) & 1ull);
+            const int32_t flags = ra.x;
+            const bool active = has_walk && ((mk >> lane) & 1ull);
 
             // ---- recombination entry into this vertex (uniform over the workgroup)
             int32_t E = NEG, Eh = -1, Esrc = -1;
             if (flags & PHI_DP_NEED_ENTRY) {
                 const int n_in = (flags >> 8) & 0xFF;
-                for (int j = 0; j < n_in; j++) {
-                    const int32_t p = (j < 3) ? s_rec[b][i][2 + j] : A.in_packed[s_rec[b][i][1] + j - 3];
-                    const int32_t back = (int32_t)((uint32_t)p >> 8), oj = p & 0xFF;
-                    const int32_t src = step - back;
-                    int32_t t1v, t1h, t1n, t2v, t2h;
-                    if (back < RING) {
-                        const int sl = src & (RING - 1);
-                        t1v = r_t1v[sl]; t1h = r_t1h[sl]; t1n = r_t1n[sl]; t2v = r_t2v[sl]; t2h = r_t2h[sl];
-                    } else {
-                        const int32_t *g = A.tops + (int64_t)src * 5;
-                        t1v = g[0]; t1h = g[1]; t1n = g[2]; t2v = g[3]; t2h = g[4];
-                    }
+                auto consider = [&](const int4 q, int32_t oj, int32_t src) {
+                    const int32_t t1h = (q.z & 0x3FF) - 1, t1n = ((q.z >> 10) & 0x3FF) - 1, t2h = ((q.z >> 20) & 0x3FF) - 1;
                     const bool cont = t1n == oj;             // top1 continues along this edge: use top2
-                    const int32_t val = cont ? t2v : t1v, hh = cont ? t2h : t1h;
-                    if (hh < 0) continue;
+                    const int32_t val = cont ? q.y : q.x, hh = cont ? t2h : t1h;
+                    if (hh < 0) return;
                     if (val > E || (val == E && (hh < Eh || (hh == Eh && src < Esrc)))) { E = val; Eh = hh; Esrc = src; }
+                };
+                const uint32_t b0 = (uint32_t)ra.z >> 8, b1 = (uint32_t)ra.w >> 8, b2 = (uint32_t)rb.x >> 8;
+                if (n_in <= 3 && (b0 | b1 | b2) < RING) {
+                    // usual case: all sources in the LDS ring, the three look-ups in flight together
+                    const int4 q0 = s_top[(step - b0) & (RING - 1)];
+                    const int4 q1 = s_top[(step - b1) & (RING - 1)];
+                    const int4 q2 = s_top[(step - b2) & (RING - 1)];
+                    consider(q0, ra.z & 0xFF, step - (int32_t)b0);
+                    if (n_in > 1) consider(q1, ra.w & 0xFF, step - (int32_t)b1);
+                    if (n_in > 2) consider(q2, rb.x & 0xFF, step - (int32_t)b2);
+                } else {
+                    for (int j = 0; j < n_in; j++) {
+                        const int32_t p = j == 0 ? ra.z : j == 1 ? ra.w : j == 2 ? rb.x : A.in_packed[ra.y + j - 3];
+                        const int32_t back = (int32_t)((uint32_t)p >> 8);
+                        const int32_t src = step - back;
+                        const int4 q = back < RING ? s_top[src & (RING - 1)]
+                                                   : reinterpret_cast<const int4 *>(A.tops)[src];
+                        consider(q, p & 0xFF, src);
+                    }
                 }
                 if (Eh >= 0) E -= A.cost;
                 if (h == 0) { A.ent_src[step] = Esrc; A.ent_h[step] = Eh; }
@@ -188,7 +219,8 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
             int32_t oidx = 255;
             if (active) {
                 const int32_t t = (int32_t)(e - eb);
-                const uint64_t word = s_w[e & (WD - 1)][h];
+                const uint64_t word = nword;
+                const int s2 = (t + 2) & 31;
                 oidx = (int32_t)(word & 0xFF);
                 if (t == 0) {
                     // walk start s_{first(h),h}: run length 0 scores 0, nothing older exists
@@ -199,10 +231,9 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
                     T = 0; L = NEG; entL = 0;
                 } else {
                     // the run that reaches length 31 leaves the ring and joins class L
-                    const int so = (t + 1) & 31;
-                    const int32_t v_old = s_d[so][h];
+                    const int32_t v_old = nold;               // = s_d[(t + 1) & 31][h]
                     if (v_old > L) { L = v_old; entL = t - 31; }
-                    atomicAdd(&s_d[(t + 2) & 31][h], v_old);  // next oldest becomes absolute
+                    atomicAdd(&s_d[s2][h], v_old);            // next oldest becomes absolute
                     const int32_t Enew = (Eh >= 0) ? E : NEG;
                     s_d[t & 31][h] = Enew - T;
                     T = Enew;
@@ -214,7 +245,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
                         if (!A.a_weight[g]) continue;
                         const int sp = A.g_span[g];
                         L += 1;
-                        if (sp <= 30) { atomicAdd(&s_d[(t + 2) & 31][h], 1); atomicAdd(&s_d[(t - sp + 1) & 31][h], -1); }
+                        if (sp <= 30) { atomicAdd(&s_d[s2][h], 1); atomicAdd(&s_d[(t - sp + 1) & 31][h], -1); }
                     }
                 } else {
                     while (gw & 0x7FFFFFFFFFFFFFull) {
@@ -222,7 +253,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
                         gw >>= 5;
                         if (sp == 0) continue;
                         L += 1;
-                        if (sp <= 30) { atomicAdd(&s_d[(t + 2) & 31][h], 1); atomicAdd(&s_d[(t - sp + 1) & 31][h], -1); }
+                        if (sp <= 30) { atomicAdd(&s_d[s2][h], 1); atomicAdd(&s_d[(t - sp + 1) & 31][h], -1); }
                     }
                 }
                 if ((flags & PHI_DP_NEED_TOPS) || e == ee - 1) {
@@ -241,49 +272,64 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
                     }
                 }
                 e++;
+                // the next entry's word and expiring slot: in flight until this lane is active again
+                nword = s_w[e & (WD - 1)][h];
+                nold = s_d[s2][h];
             }
 
             // ---- best states leaving this vertex, by out-edge: top1 overall, top2 the best on
             //      another out-edge.  Walks that end here do not leave.
             if (flags & PHI_DP_NEED_TOPS) {
                 const bool leaving = active && oidx != 255 && dmax > NEG / 2;
-                s_oidx[h] = oidx;
-                const unsigned long long key = leaving ? pack_vh(dmax, h) : 0ull;
-                unsigned long long k1 = wave_max_u64(key);
-                if (NW > 1) {
+                int32_t t1v = NEG, t1h = -1, t1n = -1, t2v = NEG, t2h = -1;
+                if (NW == 1) {
+                    const int32_t m1 = wave_max_i32(leaving ? dmax : NEG);
+                    if (m1 > NEG / 2) {
+                        const int l1 = __ffsll((long long)__ballot(leaving && dmax == m1)) - 1;   // lowest walk id
+                        t1v = m1; t1h = l1;
+                        t1n = __builtin_amdgcn_readlane(oidx, l1);
+                        const bool other = leaving && oidx != t1n;
+                        const int32_t m2 = wave_max_i32(other ? dmax : NEG);
+                        if (m2 > NEG / 2) { t2v = m2; t2h = __ffsll((long long)__ballot(other && dmax == m2)) - 1; }
+                    }
+                } else {
+                    s_oidx[h] = oidx;
+                    const int32_t m1 = wave_max_i32(leaving ? dmax : NEG);
+                    unsigned long long k1 = 0;
+                    if (m1 > NEG / 2) k1 = pack_vh(m1, wid * 64 + __ffsll((long long)__ballot(leaving && dmax == m1)) - 1);
                     if (lane == 0) s_red[wid] = k1;
                     __syncthreads();
                     k1 = s_red[0];
 #pragma unroll
                     for (int x = 1; x < NW; x++) k1 = s_red[x] > k1 ? s_red[x] : k1;
+                    if (k1) {
+                        t1v = (int32_t)(uint32_t)(k1 >> 32) + NEG;
+                        t1h = 0x7FFFFFFF - (int32_t)(uint32_t)k1;
+                        t1n = s_oidx[t1h];
+                    }
                     __syncthreads();
-                }
-                int32_t t1v = NEG, t1h = -1, t1n = -1, t2v = NEG, t2h = -1;
-                if (k1) {
-                    t1v = (int32_t)(uint32_t)(k1 >> 32) + NEG;
-                    t1h = 0x7FFFFFFF - (int32_t)(uint32_t)k1;
-                    t1n = s_oidx[t1h];
-                }
-                unsigned long long k2 = wave_max_u64((leaving && oidx != t1n) ? key : 0ull);
-                if (NW > 1) {
+                    const bool other = leaving && oidx != t1n;
+                    const int32_t m2 = wave_max_i32(other ? dmax : NEG);
+                    unsigned long long k2 = 0;
+                    if (m2 > NEG / 2) k2 = pack_vh(m2, wid * 64 + __ffsll((long long)__ballot(other && dmax == m2)) - 1);
                     if (lane == 0) s_red[wid] = k2;
                     __syncthreads();
                     k2 = s_red[0];
 #pragma unroll
                     for (int x = 1; x < NW; x++) k2 = s_red[x] > k2 ? s_red[x] : k2;
-                }
-                if (k2) {
-                    t2v = (int32_t)(uint32_t)(k2 >> 32) + NEG;
-                    t2h = 0x7FFFFFFF - (int32_t)(uint32_t)k2;
+                    if (k2) {
+                        t2v = (int32_t)(uint32_t)(k2 >> 32) + NEG;
+                        t2h = 0x7FFFFFFF - (int32_t)(uint32_t)k2;
+                    }
                 }
                 if (h == 0) {
-                    const int sl = step & (RING - 1);
-                    r_t1v[sl] = t1v; r_t1h[sl] = t1h; r_t1n[sl] = t1n; r_t2v[sl] = t2v; r_t2h[sl] = t2h;
-                    int32_t *g = A.tops + (int64_t)step * 5;
-                    g[0] = t1v; g[1] = t1h; g[2] = t1n; g[3] = t2v; g[4] = t2h;
+                    const int4 q = pack_tops(t1v, t1h, t1n, t2v, t2h);
+                    s_top[step & (RING - 1)] = q;
+                    reinterpret_cast<int4 *>(A.tops)[step] = q;
                 }
                 if (NW > 1) __syncthreads();             // ring entry visible to the other waves
             }
+            ra = na; rb = nb; mk = nm;
         }
         __threadfence_block();
         __syncthreads();                                 // chunk c+1 staged; HBM tops visible
