@@ -266,9 +266,9 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
                     }
                     if (best > NEG / 2) {
                         dmax = best;
-                        A.dmax[e] = best; A.qbest[e] = (uint8_t)qb; A.lent[e] = entL;
+                        A.dmax[e] = best; A.bstart[e] = qb < 31 ? t - qb : entL;
                     } else {
-                        A.dmax[e] = NEG; A.qbest[e] = 0; A.lent[e] = 0;
+                        A.dmax[e] = NEG; A.bstart[e] = 0;
                     }
                 }
                 e++;

@@ -1,0 +1,477 @@
+// dp_events.hip -- the max-plus DP of dp.hip, event driven: only the vertices where something can
+// happen are walked serially, everything else is prefix sums made by wide kernels.
+//
+// dp.hip spends one serial step on EVERY vertex because each lane shifts a 31-slot run-length
+// window per walk entry.  Here a run of walk h that began at entry s (entered by a recombination
+// of value E_s, or the walk start with E = 0) is kept as that pair only.  With
+//     End(x) = number of weight-1 anchors of the walk with last entry  <= x
+//     SB(s)  = number of weight-1 anchors of the walk with first entry <  s
+// its score at entry x is  E_s + #{anchors inside [s, x]}, which is
+//     E_s - SB(s) + End(x)                      once x - s >= 31  (no anchor spans more than 31 edges)
+//     E_s + G_x[x - s]                          before that, G_x[a] = #{anchors inside [x - a, x]}
+// End, SB and the 31 small counts G_x are functions of the anchor weights only: three wide kernels
+// make them per DP run (phi_dp_event_fill_kernel packs them into a 48-byte record per EVENT).  An
+// event is a walk entry on a vertex where the serial part has work: a recombination can enter
+// (ENTRY), leave (TOPS), or the walk starts / ends.  On the synthetic MHC graph that is one vertex
+// in four; chain vertices cost nothing.
+//
+// Per lane (= walk) the live runs form a deque in LDS: a new run (s, E) is dropped when an older
+// run already has E' >= E (the older run contains every anchor the younger one does, and ties go
+// to the older run as in dp.hip), and it evicts younger-or-equal... older runs from the back whose
+// key E' - SB(s') is smaller than its own (they can never catch up).  Runs older than 30 entries
+// are folded into one scalar (best key).  A query (TOPS / walk end) is then
+// max(best key + End, max over the few young runs of E_s + G[age]).
+//
+// Same transitions, same tie-breaks and the same outputs as dp.hip (which stays as the kernel for
+// more than 128 walks): tests/test_gpu_parity.py runs both on the same inputs.
+#include <hip/hip_runtime.h>
+#include "phi_kernels.h"
+
+#define NEG (-(1 << 28))
+#define NEGK (-(1 << 30))
+#define CHK PHI_DP_CHUNK
+#define RING PHI_DP_RING
+
+// ------------------------------------------------------------------ static: which entries are events
+__global__ void __launch_bounds__(256) phi_event_flags_kernel(const int32_t *__restrict__ walk_vtx, int64_t n_entries,
+                                                              const int32_t *__restrict__ cvtx, uint8_t *__restrict__ flags)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += (int64_t)gridDim.x * blockDim.x)
+        flags[e] = cvtx[walk_vtx[e]] >= 0;
+}
+
+// ev_off[h] = first event of walk h (ev_e ascending, walk_off[n_walks] = n_entries)
+__global__ void phi_event_off_kernel(const int32_t *__restrict__ ev_e, int64_t n_ev, const int64_t *__restrict__ walk_off,
+                                     int32_t n_walks, int64_t *__restrict__ ev_off)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > n_walks) return;
+    const int64_t key = walk_off[h];
+    int64_t lo = 0, hi = n_ev;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ev_e[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    ev_off[h] = lo;
+}
+
+void phi_launch_event_flags(hipStream_t st, const int32_t *walk_vtx, int64_t n_entries, const int32_t *cvtx, uint8_t *flags)
+{
+    if (n_entries <= 0) return;
+    int64_t nb = (n_entries + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(phi_event_flags_kernel, dim3((unsigned)nb), dim3(256), 0, st, walk_vtx, n_entries, cvtx, flags);
+}
+
+void phi_launch_event_off(hipStream_t st, const int32_t *ev_e, int64_t n_ev, const int64_t *walk_off, int32_t n_walks,
+                          int64_t *ev_off)
+{
+    hipLaunchKernelGGL(phi_event_off_kernel, dim3((unsigned)((n_walks + 1 + 63) / 64)), dim3(64), 0, st, ev_e, n_ev,
+                       walk_off, n_walks, ev_off);
+}
+
+// ------------------------------------------------------------------ per run: counts, prefix sums, event records
+// cnt_end[e] / cnt_start[e] += 1 for every weight-1 anchor ending / starting at entry e (arrays zeroed by the caller)
+__global__ void __launch_bounds__(256) phi_dp_counts_kernel(const int32_t *__restrict__ a_e1, const uint8_t *__restrict__ a_span,
+                                                            const uint8_t *__restrict__ a_weight, int64_t n_a,
+                                                            int32_t *__restrict__ cnt_end, int32_t *__restrict__ cnt_start)
+{
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_a; g += (int64_t)gridDim.x * blockDim.x) {
+        if (!a_weight[g]) continue;
+        const int32_t e1 = a_e1[g];
+        atomicAdd(&cnt_end[e1], 1);
+        atomicAdd(&cnt_start[e1 - a_span[g]], 1);
+    }
+}
+
+// exclusive prefix sums of int32 counts, three phases (1024 items per workgroup)
+__global__ void __launch_bounds__(256) phi_scan_blocksum_kernel(const int32_t *__restrict__ cnt, int64_t n,
+                                                                int32_t *__restrict__ blk)
+{
+    __shared__ int s_w[4];
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (base + j < n) c += cnt[base + j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ void __launch_bounds__(256) phi_scan_apply_kernel(const int32_t *__restrict__ cnt, int64_t n,
+                                                             const int64_t *__restrict__ blk_off, int32_t *__restrict__ off)
+{
+    __shared__ int s_w[4];
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    int v[4], c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { v[j] = (base + j < n) ? cnt[base + j] : 0; c += v[j]; }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_w[wid] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < wid; i++) woff += s_w[i];
+    int run = (int)blk_off[blockIdx.x] + woff + inc - c;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (base + j < n) off[base + j] = run;
+        run += v[j];
+    }
+    if (base <= n && n < base + 4) off[n] = run - 0;   // total (the items past n are zero)
+}
+
+int64_t phi_scan_i32_num_blocks(int64_t n) { return (n + 1 + 1023) / 1024; }
+
+// off[0..n] = exclusive prefix sums of cnt[0..n); blk / blk_off: scratch of phi_scan_i32_num_blocks(n) (+1) items
+void phi_launch_scan_i32(hipStream_t st, const int32_t *cnt, int64_t n, int32_t *off, int32_t *blk, int64_t *blk_off)
+{
+    const int64_t nb = phi_scan_i32_num_blocks(n);
+    hipLaunchKernelGGL(phi_scan_blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, st, cnt, n, blk);
+    phi_launch_scan_counts(st, blk, nb, blk_off);
+    hipLaunchKernelGGL(phi_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, cnt, n, blk_off, off);
+}
+
+// One 48-byte record per event:
+//   int4  A = { compact step, entry | overflow << 31, End (inclusive), SB }
+//   32 B  G : byte a (1..30) = #{weight-1 anchors of the walk inside [entry - a, entry]}, byte 0 = 0,
+//             byte 31 = out-edge index of the entry (255: the walk ends here)
+// overflow: more than 255 anchors end inside the window (the DP then counts from the CSR).
+__global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const int32_t *__restrict__ ev_e, int64_t n_ev,
+                                                                const int32_t *__restrict__ walk_vtx,
+                                                                const int32_t *__restrict__ cvtx,
+                                                                const int64_t *__restrict__ walk_off, int32_t n_walks,
+                                                                const uint8_t *__restrict__ e_out,
+                                                                const int64_t *__restrict__ g_off,
+                                                                const uint8_t *__restrict__ g_span,
+                                                                const uint8_t *__restrict__ a_weight,
+                                                                const int32_t *__restrict__ off_end,
+                                                                const int32_t *__restrict__ off_start,
+                                                                uint4 *__restrict__ ev)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ev; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t e = ev_e[i];
+        // walk of e: last h with walk_off[h] <= e
+        int lo = 0, hi = n_walks;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (walk_off[mid] <= e) lo = mid; else hi = mid;
+        }
+        const int64_t eb = walk_off[lo];
+        unsigned long long w[4] = {0, 0, 0, 0};
+        int total = 0;
+        const int64_t x0 = (int64_t)e - 29 > eb ? (int64_t)e - 29 : eb;
+        for (int64_t x = x0; x <= e; x++) {
+            for (int64_t g = g_off[x]; g < g_off[x + 1]; g++) {
+                if (!a_weight[g]) continue;
+                const int a = (int)(e - (x - g_span[g]));       // age a run needs to contain this anchor
+                if (a > 30) continue;
+                total++;
+                const unsigned long long one = 1ull << (8 * (a & 7));
+                if ((a >> 3) == 0) w[0] += one; else if ((a >> 3) == 1) w[1] += one; else if ((a >> 3) == 2) w[2] += one; else w[3] += one;
+            }
+        }
+        const bool ovf = total > 255;
+        // byte-wise inclusive prefix sums across the four words
+        unsigned long long carry = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            w[q] = w[q] * 0x0101010101010101ull + carry * 0x0101010101010101ull;
+            carry = w[q] >> 56;
+        }
+        w[3] = (w[3] & 0x00FFFFFFFFFFFFFFull) | ((unsigned long long)e_out[e] << 56);
+        uint4 A;
+        A.x = (uint32_t)cvtx[walk_vtx[e]];
+        A.y = (uint32_t)e | (ovf ? 0x80000000u : 0u);
+        A.z = (uint32_t)off_end[e + 1];
+        A.w = (uint32_t)off_start[e];
+        ev[i * 3 + 0] = A;
+        ev[i * 3 + 1] = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
+        ev[i * 3 + 2] = make_uint4((uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32));
+    }
+}
+
+void phi_launch_dp_counts(hipStream_t st, const int32_t *a_e1, const uint8_t *a_span, const uint8_t *a_weight, int64_t n_a,
+                          int32_t *cnt_end, int32_t *cnt_start)
+{
+    if (n_a <= 0) return;
+    int64_t nb = (n_a + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(phi_dp_counts_kernel, dim3((unsigned)nb), dim3(256), 0, st, a_e1, a_span, a_weight, n_a, cnt_end,
+                       cnt_start);
+}
+
+void phi_launch_dp_event_fill(hipStream_t st, const PhiDpEventArgs &A, const uint8_t *e_out, const int32_t *walk_vtx,
+                              const int32_t *cvtx, const int32_t *off_end, const int32_t *off_start)
+{
+    if (A.n_ev <= 0) return;
+    int64_t nb = (A.n_ev + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(phi_dp_event_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, A.ev_e, A.n_ev, walk_vtx, cvtx,
+                       A.walk_off, A.n_walks, e_out, A.g_off, A.g_span, A.a_weight, off_end, off_start,
+                       reinterpret_cast<uint4 *>(A.ev));
+}
+
+// ------------------------------------------------------------------ the DP
+__device__ __forceinline__ unsigned long long ev_pack_vh(int32_t val, int32_t h)
+{
+    return ((unsigned long long)(uint32_t)(val - NEG) << 32) | (uint32_t)(0x7FFFFFFF - h);
+}
+
+__device__ __forceinline__ int32_t ev_wave_max_i32(int32_t v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xF, 0xF, false));     // row_ror:1
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xF, 0xF, false));     // row_ror:2
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false));     // row_ror:4
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));     // row_ror:8
+    const int32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+__device__ __forceinline__ int4 ev_pack_tops(int32_t t1v, int32_t t1h, int32_t t1n, int32_t t2v, int32_t t2h)
+{
+    return make_int4(t1v, t2v, (t1h + 1) | ((t1n + 1) << 10) | ((t2h + 1) << 20), 0);
+}
+
+// exact count for an event whose window overflowed the byte counters: weight-1 anchors inside [es, e]
+__device__ int32_t ev_count_inside(const PhiDpEventArgs &A, int64_t es, int64_t e)
+{
+    int32_t n = 0;
+    for (int64_t x = es; x <= e; x++)
+        for (int64_t g = A.g_off[x]; g < A.g_off[x + 1]; g++)
+            if (A.a_weight[g] && x - A.g_span[g] >= es) n++;
+    return n;
+}
+
+template <int NW>   // waves in the workgroup (1 or 2)
+__global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A)
+{
+    constexpr int NT = NW * 64;
+    constexpr int D = NW == 1 ? 16 : 8;              // per-lane ring of event records
+    constexpr int P = D / 2;                         // refill period in steps
+    __shared__ int4 s_rec[2][CHK][2];
+    __shared__ int4 s_top[RING];                    // packed tops of recent steps
+    __shared__ uint4 s_ev[D][3][NT];
+    __shared__ int32_t s_qs[32][NT], s_qE[32][NT], s_qK[32][NT];   // live young runs: start, value, key
+    __shared__ unsigned long long s_red[NW > 1 ? NW : 1];
+    __shared__ int32_t s_oidx[NT];
+
+    const int h = threadIdx.x;
+    const int lane = h & 63, wid = h >> 6;
+    const bool has_walk = h < A.n_walks;
+    const int64_t eb = has_walk ? A.walk_off[h] : 0;
+    const int64_t ee = has_walk ? A.walk_off[h + 1] : 0;
+    const int64_t vb = has_walk ? A.ev_off[h] : 0;   // events of this lane: [vb, ve)
+    const int64_t ve = has_walk ? A.ev_off[h + 1] : 0;
+    int64_t vi = vb;                                 // next event
+    int64_t wl = vb;                                 // first event not yet in the ring
+    const uint4 *evg = reinterpret_cast<const uint4 *>(A.ev);
+
+    // ring refill in two halves (see dp.hip): loads issued at step 0 mod P land P/2 steps later
+    uint4 wtmp[P][3];
+    int64_t whi = vb;
+    auto issue = [&]() {
+        whi = min(ve, vi + D);
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const int64_t x = (ve > vb) ? min(wl + j, ve - 1) : 0;
+            wtmp[j][0] = evg[x * 3 + 0]; wtmp[j][1] = evg[x * 3 + 1]; wtmp[j][2] = evg[x * 3 + 2];
+        }
+    };
+    auto land = [&]() {
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const int64_t x = wl + j;
+            if (x < whi) {
+                const int sl = (int)(x & (D - 1));
+                s_ev[sl][0][h] = wtmp[j][0]; s_ev[sl][1][h] = wtmp[j][1]; s_ev[sl][2][h] = wtmp[j][2];
+            }
+        }
+        wl = max(wl, min(whi, wl + P));
+    };
+    if (A.n_ev > 0) { issue(); land(); issue(); land(); }
+    // the next event of this lane, in registers
+    uint4 cA = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+    if (vi < ve) cA = s_ev[vi & (D - 1)][0][h];
+
+    int32_t qh = 0, qt = 0;                          // deque [qh, qt) of young runs
+    int32_t M = NEGK, sL = 0, Emax = NEG;            // best key of the old runs, its start; best value ever entered
+
+    const int32_t n_steps = A.n_k;
+    const int n_chunks = (n_steps + CHK - 1) / CHK;
+    auto stage = [&](int c) {
+        const int b = c & 1;
+        const int32_t s0 = c * CHK;
+        const int32_t ns = min(CHK, n_steps - s0);
+        const int4 *src = reinterpret_cast<const int4 *>(A.k_rec + (int64_t)s0 * 8);
+        int4 *dst = &s_rec[b][0][0];
+        for (int i = h; i < ns * 2; i += NT) dst[i] = src[i];
+    };
+    stage(0);
+    __syncthreads();
+
+    for (int c = 0; c < n_chunks; c++) {
+        const int b = c & 1;
+        if (c + 1 < n_chunks) stage(c + 1);
+        const int32_t s0 = c * CHK;
+        const int32_t ns = min(CHK, n_steps - s0);
+        int4 ra = s_rec[b][0][0], rb = s_rec[b][0][1];
+        for (int i = 0; i < ns; i++) {
+            const int inx = min(i + 1, CHK - 1);
+            const int4 na = s_rec[b][inx][0], nb = s_rec[b][inx][1];
+            if ((c | i) && (i & (P - 1)) == 0) issue();
+            if ((c | i) && (i & (P - 1)) == P / 2) land();
+            const int32_t k = s0 + i;
+            const int32_t flags = ra.x;
+            const bool active = (int32_t)cA.x == k;
+
+            // ---- recombination entry into this vertex (uniform over the workgroup)
+            int32_t E = NEG, Eh = -1, Esrc = -1;
+            if (flags & PHI_DP_NEED_ENTRY) {
+                const int n_in = (flags >> 8) & 0xFF;
+                auto consider = [&](const int4 q, int32_t oj, int32_t src) {
+                    const int32_t t1h = (q.z & 0x3FF) - 1, t1n = ((q.z >> 10) & 0x3FF) - 1, t2h = ((q.z >> 20) & 0x3FF) - 1;
+                    const bool cont = t1n == oj;
+                    const int32_t val = cont ? q.y : q.x, hh = cont ? t2h : t1h;
+                    if (hh < 0) return;
+                    if (val > E || (val == E && (hh < Eh || (hh == Eh && src < Esrc)))) { E = val; Eh = hh; Esrc = src; }
+                };
+                const uint32_t b0 = (uint32_t)ra.z >> 8, b1 = (uint32_t)ra.w >> 8, b2 = (uint32_t)rb.x >> 8;
+                if (n_in <= 3 && (b0 | b1 | b2) < RING) {
+                    const int4 q0 = s_top[(k - b0) & (RING - 1)];
+                    const int4 q1 = s_top[(k - b1) & (RING - 1)];
+                    const int4 q2 = s_top[(k - b2) & (RING - 1)];
+                    consider(q0, ra.z & 0xFF, k - (int32_t)b0);
+                    if (n_in > 1) consider(q1, ra.w & 0xFF, k - (int32_t)b1);
+                    if (n_in > 2) consider(q2, rb.x & 0xFF, k - (int32_t)b2);
+                } else {
+                    for (int j = 0; j < n_in; j++) {
+                        const int32_t p = j == 0 ? ra.z : j == 1 ? ra.w : j == 2 ? rb.x : A.k_in_packed[ra.y + j - 3];
+                        const int32_t back = (int32_t)((uint32_t)p >> 8);
+                        const int32_t src = k - back;
+                        const int4 q = back < RING ? s_top[src & (RING - 1)] : reinterpret_cast<const int4 *>(A.tops)[src];
+                        consider(q, p & 0xFF, src);
+                    }
+                }
+                if (Eh >= 0) E -= A.cost;
+                if (h == 0) { A.ent_src[k] = Esrc; A.ent_h[k] = Eh; }
+            }
+
+            int32_t dmax = NEG;
+            int32_t oidx = 255;
+            if (active) {
+                const int64_t e = (int64_t)(cA.y & 0x7FFFFFFFu);
+                const bool ovf = (cA.y >> 31) != 0;
+                const int32_t t = (int32_t)(e - eb);
+                const int32_t End = (int32_t)cA.z, SB = (int32_t)cA.w;
+                const int sl = (int)(vi & (D - 1));
+                const uint8_t *gb = reinterpret_cast<const uint8_t *>(&s_ev[sl][1][h]);
+                oidx = reinterpret_cast<const uint8_t *>(&s_ev[sl][2][h])[15];
+                // runs older than 30 entries: one scalar
+                while (qh != qt && t - s_qs[qh & 31][h] >= 31) {
+                    const int32_t key = s_qK[qh & 31][h];
+                    if (key > M) { M = key; sL = s_qs[qh & 31][h]; }
+                    qh++;
+                }
+                // a run begins here: the walk start, or a recombination entry worth keeping
+                int32_t newE = NEG;
+                if (t == 0) { newE = 0; qh = qt = 0; M = NEGK; Emax = NEG; }
+                else if ((flags & PHI_DP_NEED_ENTRY) && Eh >= 0) newE = E;
+                if (newE > Emax) {
+                    Emax = newE;
+                    const int32_t key = newE - SB;
+                    while (qh != qt && s_qK[(qt - 1) & 31][h] < key) qt--;
+                    s_qs[qt & 31][h] = t; s_qE[qt & 31][h] = newE; s_qK[qt & 31][h] = key;
+                    qt++;
+                }
+                if ((flags & PHI_DP_NEED_TOPS) || e == ee - 1) {
+                    // oldest first, strict improvement: ties keep the older run
+                    int32_t best = M > NEGK / 2 ? M + End : NEG, bs = sL;
+                    for (int32_t j = qh; j != qt; j++) {
+                        const int32_t s = s_qs[j & 31][h];
+                        const int a = t - s;
+                        int32_t inside;
+                        if (!ovf) inside = a < 16 ? gb[a] : reinterpret_cast<const uint8_t *>(&s_ev[sl][2][h])[a - 16];
+                        else inside = ev_count_inside(A, eb + s, e);
+                        const int32_t val = s_qE[j & 31][h] + inside;
+                        if (val > best) { best = val; bs = s; }
+                    }
+                    if (best > NEG / 2) { dmax = best; A.dmax[e] = best; A.bstart[e] = bs; }
+                    else { A.dmax[e] = NEG; A.bstart[e] = 0; }
+                }
+                vi++;
+                cA = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+                if (vi < ve) cA = s_ev[vi & (D - 1)][0][h];
+            }
+
+            // ---- best states leaving this vertex (as in dp.hip)
+            if (flags & PHI_DP_NEED_TOPS) {
+                const bool leaving = active && oidx != 255 && dmax > NEG / 2;
+                int32_t t1v = NEG, t1h = -1, t1n = -1, t2v = NEG, t2h = -1;
+                if (NW == 1) {
+                    const int32_t m1 = ev_wave_max_i32(leaving ? dmax : NEG);
+                    if (m1 > NEG / 2) {
+                        const int l1 = __ffsll((long long)__ballot(leaving && dmax == m1)) - 1;
+                        t1v = m1; t1h = l1;
+                        t1n = __builtin_amdgcn_readlane(oidx, l1);
+                        const bool other = leaving && oidx != t1n;
+                        const int32_t m2 = ev_wave_max_i32(other ? dmax : NEG);
+                        if (m2 > NEG / 2) { t2v = m2; t2h = __ffsll((long long)__ballot(other && dmax == m2)) - 1; }
+                    }
+                } else {
+                    s_oidx[h] = oidx;
+                    const int32_t m1 = ev_wave_max_i32(leaving ? dmax : NEG);
+                    unsigned long long k1 = 0;
+                    if (m1 > NEG / 2) k1 = ev_pack_vh(m1, wid * 64 + __ffsll((long long)__ballot(leaving && dmax == m1)) - 1);
+                    if (lane == 0) s_red[wid] = k1;
+                    __syncthreads();
+                    k1 = s_red[0];
+#pragma unroll
+                    for (int x = 1; x < NW; x++) k1 = s_red[x] > k1 ? s_red[x] : k1;
+                    if (k1) {
+                        t1v = (int32_t)(uint32_t)(k1 >> 32) + NEG;
+                        t1h = 0x7FFFFFFF - (int32_t)(uint32_t)k1;
+                        t1n = s_oidx[t1h];
+                    }
+                    __syncthreads();
+                    const bool other = leaving && oidx != t1n;
+                    const int32_t m2 = ev_wave_max_i32(other ? dmax : NEG);
+                    unsigned long long k2 = 0;
+                    if (m2 > NEG / 2) k2 = ev_pack_vh(m2, wid * 64 + __ffsll((long long)__ballot(other && dmax == m2)) - 1);
+                    if (lane == 0) s_red[wid] = k2;
+                    __syncthreads();
+                    k2 = s_red[0];
+#pragma unroll
+                    for (int x = 1; x < NW; x++) k2 = s_red[x] > k2 ? s_red[x] : k2;
+                    if (k2) {
+                        t2v = (int32_t)(uint32_t)(k2 >> 32) + NEG;
+                        t2h = 0x7FFFFFFF - (int32_t)(uint32_t)k2;
+                    }
+                }
+                if (h == 0) {
+                    const int4 q = ev_pack_tops(t1v, t1h, t1n, t2v, t2h);
+                    s_top[k & (RING - 1)] = q;
+                    reinterpret_cast<int4 *>(A.tops)[k] = q;
+                }
+                if (NW > 1) __syncthreads();
+            }
+            ra = na; rb = nb;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A)
+{
+    if (A.n_walks <= 64) hipLaunchKernelGGL(phi_dp_events_kernel<1>, dim3(1), dim3(64), 0, st, A);
+    else hipLaunchKernelGGL(phi_dp_events_kernel<2>, dim3(1), dim3(128), 0, st, A);    // n_walks <= PHI_DP_EVENT_MAX_WALKS
+}

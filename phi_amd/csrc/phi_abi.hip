@@ -152,7 +152,8 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
-                     &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_qbest, &c->d_lent, &c->d_top,
+                     &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_bstart, &c->d_k_rec, &c->d_k_in, &c->d_cvtx, &c->d_ev_e, &c->d_ev_off, &c->d_ev,
+                     &c->d_cnt_end, &c->d_cnt_start, &c->d_off_end, &c->d_off_start, &c->d_scan_blk, &c->d_scan_blkoff, &c->d_top,
                      &c->d_ent};
     for (DevBuf *b : all) dev_free(*b);
     for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -372,6 +373,47 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         }
     }
 
+    // ---- compact step stream of the event-driven DP (dp_events.hip): only the vertices where a
+    //      recombination can enter or leave, or a walk starts or ends; in-edges count compact steps back
+    c->dp_events = n_walks <= PHI_DP_EVENT_MAX_WALKS && !getenv("PHI_DP_DENSE");
+    c->n_k = 0; c->n_ev = 0;
+    if (c->dp_events) {
+        std::vector<uint8_t> lane_only(n_vtx, 0);
+        for (int32_t h = 0; h < n_walks; h++) {
+            lane_only[walk_vtx[walk_off[h]]] = 1;
+            lane_only[walk_vtx[walk_off[h + 1] - 1]] = 1;
+        }
+        c->h_cstep.assign(n_vtx, -1);
+        c->h_kstep.clear();
+        for (int32_t s = 0; s < n_vtx; s++)
+            if ((st_rec[(size_t)s * 8] & 3) || lane_only[c->h_topo[s]]) {
+                c->h_cstep[s] = (int32_t)c->h_kstep.size();
+                c->h_kstep.push_back(s);
+            }
+        c->n_k = (int32_t)c->h_kstep.size();
+        std::vector<int32_t> k_rec((size_t)c->n_k * 8, 0), k_in, cvtx(n_vtx);
+        for (int32_t k = 0; k < c->n_k; k++) {
+            const int32_t s = c->h_kstep[k];
+            const int32_t *ro = &st_rec[(size_t)s * 8];
+            int32_t *r = &k_rec[(size_t)k * 8];
+            const int n_in = (ro[0] >> 8) & 0xFF;
+            r[0] = ro[0] | (lane_only[c->h_topo[s]] ? PHI_DP_LANE_ONLY : 0);
+            r[1] = (int32_t)k_in.size();
+            for (int j = 0; j < n_in; j++) {
+                const int32_t p = j < 3 ? ro[2 + j] : in_packed[ro[1] + j - 3];
+                const int32_t kc = c->h_cstep[s - (int32_t)((uint32_t)p >> 8)];
+                if (kc < 0) return phi_fail(c, PHI_ERR_DEVICE, "live in-edge from a vertex without leaving states (internal error)");
+                const int32_t pc = ((k - kc) << 8) | (p & 0xFF);
+                if (j < 3) r[2 + j] = pc; else k_in.push_back(pc);
+            }
+            r[5] = ro[5];
+        }
+        for (int32_t v = 0; v < n_vtx; v++) cvtx[v] = c->h_cstep[topo_rank[v]];
+        PHICHK(upload(c, c->d_k_rec, k_rec.data(), k_rec.size()));
+        PHICHK(upload(c, c->d_k_in, k_in.data(), k_in.size()));
+        PHICHK(upload(c, c->d_cvtx, cvtx.data(), cvtx.size()));
+        HIPCHK(hipStreamSynchronize(c->stream));              // the vectors above go out of scope
+    }
     tm.lap("DP step stream");
     // ---- device copies
     PHICHK(upload(c, c->d_e_out, e_out.data(), e_out.size()));
@@ -391,6 +433,15 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     PHICHK(upload(c, c->d_in_off, c->h_in_off.data(), c->h_in_off.size()));
     PHICHK(upload(c, c->d_in_src, c->h_in_src.data(), c->h_in_src.size()));
 
+    // events of every walk: its entries on the compact steps
+    if (c->dp_events) {
+        PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)n_entries));
+        phi_launch_event_flags(c->stream, c->d_walk_vtx.as<int32_t>(), n_entries, c->d_cvtx.as<int32_t>(), c->d_flags.as<uint8_t>());
+        PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_entries, c->d_ev_e, &c->n_ev));
+        PHICHK(phi_dev_ensure(c, c->d_ev_off, (size_t)(n_walks + 1) * 8));
+        phi_launch_event_off(c->stream, c->d_ev_e.as<int32_t>(), c->n_ev, c->d_walk_off.as<int64_t>(), n_walks,
+                             c->d_ev_off.as<int64_t>());
+    }
     if (tm.on) (void)hipStreamSynchronize(c->stream);
     tm.lap("uploads + ebase scan");
     // ---- stage 1a on the GPU: pack the walks, sketch them, build the minimiser table

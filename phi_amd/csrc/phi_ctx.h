@@ -75,7 +75,13 @@ struct phi_ctx {
     // ---- solve state
     DevBuf d_m_rec, d_m_group, d_g_keys, d_g_rep, d_g_cnt, d_slot_maxcnt, d_slot_multi;
     DevBuf d_a_e1, d_g_off, d_g_span, d_a_weight;
-    DevBuf d_dmax, d_qbest, d_lent, d_top, d_ent, d_word;
+    DevBuf d_dmax, d_bstart, d_top, d_ent, d_word;
+    // event-driven DP (dp_events.hip)
+    bool dp_events = false;
+    int32_t n_k = 0;                                  // compact steps
+    int64_t n_ev = 0;                                 // events
+    std::vector<int32_t> h_cstep, h_kstep;            // topological step -> compact step (-1) and back
+    DevBuf d_k_rec, d_k_in, d_cvtx, d_ev_e, d_ev_off, d_ev, d_cnt_end, d_cnt_start, d_off_end, d_off_start, d_scan_blk, d_scan_blkoff;
     std::vector<PhiAnchorHost> h_kept, h_dp;          // kept anchors; dp anchors (span >= 1 edge)
     std::vector<uint64_t> h_kept_hash;
     std::vector<int32_t> h_path_vtx, h_path_hap;

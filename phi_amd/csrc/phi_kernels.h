@@ -140,12 +140,43 @@ struct PhiDpArgs {
     int32_t cost;                        // 2 * (R / 2)
     // outputs
     int32_t *dmax;                       // per entry (only where a path can end or leave): best score
-    uint8_t *qbest;                      // per entry: run length attaining it (31 = 31 or more; ties: longest)
-    int32_t *lent;                       // per entry: walk index where the >=31 run began
+    int32_t *bstart;                     // per entry: walk index where the run attaining it began (ties: the longest run)
     int32_t *tops;                       // [n_vtx][5] by step: top1 value/walk/out-edge, top2 value/walk
     int32_t *ent_src, *ent_h;            // per step: source step and walk of the best recombination entry
 };
 void phi_launch_dp(hipStream_t st, const PhiDpArgs &A);
+
+// event-driven DP (dp_events.hip): up to PHI_DP_EVENT_MAX_WALKS walks
+#define PHI_DP_EVENT_MAX_WALKS 128
+#define PHI_DP_LANE_ONLY 4      // compact-step flag: a walk starts or ends on the vertex (no ENTRY / TOPS work)
+struct PhiDpEventArgs {
+    int32_t n_k, n_walks;                // compact steps (vertices with ENTRY / TOPS / a walk start or end)
+    int64_t n_ev;                        // events = walk entries on those vertices
+    // static per graph
+    const int32_t *k_rec;                // [n_k][8]: flags | n_in<<8, overflow start, 3 inline in-edges (compact steps back<<8 | out-edge), vertex
+    const int32_t *k_in_packed;
+    const int64_t *walk_off;
+    const int32_t *ev_e;                 // [n_ev] walk entry of each event, ascending
+    const int64_t *ev_off;               // [n_walks + 1] first event of each walk
+    // per run
+    void *ev;                            // [n_ev] 48-byte event records (phi_dp_event_fill_kernel)
+    const int64_t *g_off; const uint8_t *g_span; const uint8_t *a_weight;   // CSR of the dp anchors by last entry
+    int32_t cost;
+    // outputs
+    int32_t *dmax, *bstart;              // per entry, written at query events
+    int32_t *tops;                       // [n_k] packed 16-byte tops
+    int32_t *ent_src, *ent_h;            // per compact step
+};
+void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A);
+void phi_launch_event_flags(hipStream_t st, const int32_t *walk_vtx, int64_t n_entries, const int32_t *cvtx, uint8_t *flags);
+void phi_launch_event_off(hipStream_t st, const int32_t *ev_e, int64_t n_ev, const int64_t *walk_off, int32_t n_walks,
+                          int64_t *ev_off);
+void phi_launch_dp_counts(hipStream_t st, const int32_t *a_e1, const uint8_t *a_span, const uint8_t *a_weight, int64_t n_a,
+                          int32_t *cnt_end, int32_t *cnt_start);
+int64_t phi_scan_i32_num_blocks(int64_t n);
+void phi_launch_scan_i32(hipStream_t st, const int32_t *cnt, int64_t n, int32_t *off, int32_t *blk, int64_t *blk_off);
+void phi_launch_dp_event_fill(hipStream_t st, const PhiDpEventArgs &A, const uint8_t *e_out, const int32_t *walk_vtx,
+                              const int32_t *cvtx, const int32_t *off_end, const int32_t *off_start);
 int phi_dp_num_waves(int n_walks);
 void phi_launch_dp_words(hipStream_t st, const uint8_t *e_out, const int64_t *g_off, const uint8_t *g_span,
                          const uint8_t *a_weight, int64_t n_entries, uint64_t *word);

@@ -53,8 +53,7 @@ int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_
 
 // ------------------------------------------------------------------------------------------ DP
 struct DpHost {
-    std::vector<int32_t> ends, lent, ent_u, ent_h;
-    std::vector<uint8_t> qbest;
+    std::vector<int32_t> ends, bstart, ent_u, ent_h;
 };
 
 // one DP launch with the given anchor weights; returns its value and the argmax path
@@ -63,36 +62,65 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
     const int64_t n_dp = (int64_t)c->h_dp.size();
     const int64_t ne = c->n_entries;
     const int32_t nv = c->n_vtx;
+    const bool events = c->dp_events;
+    const int32_t n_ent = events ? c->n_k : nv;                // length of the per-step outputs
     if (n_dp) HIPCHK(hipMemcpyAsync(c->d_a_weight.p, wgt.data(), (size_t)n_dp, hipMemcpyHostToDevice, c->stream));
-    phi_launch_dp_words(c->stream, c->d_e_out.as<uint8_t>(), c->d_g_off.as<int64_t>(), c->d_g_span.as<uint8_t>(),
-                        c->d_a_weight.as<uint8_t>(), ne, c->d_word.as<uint64_t>());
-    PhiDpArgs A{};
-    A.n_vtx = nv; A.n_walks = c->n_walks;
-    A.st_rec = c->d_st_rec.as<int32_t>(); A.st_mask = c->d_st_mask.as<unsigned long long>();
-    A.in_packed = c->d_in_packed.as<int32_t>();
-    A.walk_off = c->d_walk_off.as<int64_t>();
-    A.word = c->d_word.as<uint64_t>();
-    A.g_off = c->d_g_off.as<int64_t>(); A.g_span = c->d_g_span.as<uint8_t>(); A.a_weight = c->d_a_weight.as<uint8_t>();
-    A.cost = 2 * (c->recombination / 2);                       // (c_1/2) twice, ILP_index.cpp:1276,1299
-    A.dmax = c->d_dmax.as<int32_t>(); A.qbest = c->d_qbest.as<uint8_t>(); A.lent = c->d_lent.as<int32_t>();
-    A.tops = c->d_top.as<int32_t>();
-    A.ent_src = c->d_ent.as<int32_t>(); A.ent_h = c->d_ent.as<int32_t>() + nv;
-    phi_launch_dp(c->stream, A);
+    int32_t *d_dmax = c->d_dmax.as<int32_t>(), *d_bstart = c->d_bstart.as<int32_t>();
+    int32_t *d_ent_src = c->d_ent.as<int32_t>(), *d_ent_h = c->d_ent.as<int32_t>() + n_ent;
+    if (events) {
+        // per run: anchors ending / starting per entry -> prefix sums -> one record per event
+        HIPCHK(hipMemsetAsync(c->d_cnt_end.p, 0, (size_t)ne * 4, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_cnt_start.p, 0, (size_t)ne * 4, c->stream));
+        phi_launch_dp_counts(c->stream, c->d_a_e1.as<int32_t>(), c->d_g_span.as<uint8_t>(), c->d_a_weight.as<uint8_t>(), n_dp,
+                             c->d_cnt_end.as<int32_t>(), c->d_cnt_start.as<int32_t>());
+        phi_launch_scan_i32(c->stream, c->d_cnt_end.as<int32_t>(), ne, c->d_off_end.as<int32_t>(), c->d_scan_blk.as<int32_t>(),
+                            c->d_scan_blkoff.as<int64_t>());
+        phi_launch_scan_i32(c->stream, c->d_cnt_start.as<int32_t>(), ne, c->d_off_start.as<int32_t>(), c->d_scan_blk.as<int32_t>(),
+                            c->d_scan_blkoff.as<int64_t>());
+        PhiDpEventArgs A{};
+        A.n_k = c->n_k; A.n_walks = c->n_walks; A.n_ev = c->n_ev;
+        A.k_rec = c->d_k_rec.as<int32_t>(); A.k_in_packed = c->d_k_in.as<int32_t>();
+        A.walk_off = c->d_walk_off.as<int64_t>();
+        A.ev_e = c->d_ev_e.as<int32_t>(); A.ev_off = c->d_ev_off.as<int64_t>();
+        A.ev = c->d_ev.p;
+        A.g_off = c->d_g_off.as<int64_t>(); A.g_span = c->d_g_span.as<uint8_t>(); A.a_weight = c->d_a_weight.as<uint8_t>();
+        A.cost = 2 * (c->recombination / 2);                   // (c_1/2) twice, ILP_index.cpp:1276,1299
+        A.dmax = d_dmax; A.bstart = d_bstart;
+        A.tops = c->d_top.as<int32_t>();
+        A.ent_src = d_ent_src; A.ent_h = d_ent_h;
+        phi_launch_dp_event_fill(c->stream, A, c->d_e_out.as<uint8_t>(), c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(),
+                                 c->d_off_end.as<int32_t>(), c->d_off_start.as<int32_t>());
+        phi_launch_dp_events(c->stream, A);
+    } else {
+        phi_launch_dp_words(c->stream, c->d_e_out.as<uint8_t>(), c->d_g_off.as<int64_t>(), c->d_g_span.as<uint8_t>(),
+                            c->d_a_weight.as<uint8_t>(), ne, c->d_word.as<uint64_t>());
+        PhiDpArgs A{};
+        A.n_vtx = nv; A.n_walks = c->n_walks;
+        A.st_rec = c->d_st_rec.as<int32_t>(); A.st_mask = c->d_st_mask.as<unsigned long long>();
+        A.in_packed = c->d_in_packed.as<int32_t>();
+        A.walk_off = c->d_walk_off.as<int64_t>();
+        A.word = c->d_word.as<uint64_t>();
+        A.g_off = c->d_g_off.as<int64_t>(); A.g_span = c->d_g_span.as<uint8_t>(); A.a_weight = c->d_a_weight.as<uint8_t>();
+        A.cost = 2 * (c->recombination / 2);
+        A.dmax = d_dmax; A.bstart = d_bstart;
+        A.tops = c->d_top.as<int32_t>();
+        A.ent_src = d_ent_src; A.ent_h = d_ent_h;
+        phi_launch_dp(c->stream, A);
+    }
     HIPCHK(hipGetLastError());
     // Backtracking touches a handful of entries (two per haplotype switch): read them one by one
-    // instead of downloading 9 bytes per walk entry; a path with very many switches (tiny R)
-    // falls back to one bulk download.
+    // instead of downloading them per walk entry; a path with very many switches (tiny R) falls
+    // back to one bulk download.
     H.ends.resize(c->n_walks);
-    phi_launch_gather_i32(c->stream, A.dmax, c->d_walk_last.as<int32_t>(), c->n_walks, c->d_list3.as<int32_t>());
+    phi_launch_gather_i32(c->stream, d_dmax, c->d_walk_last.as<int32_t>(), c->n_walks, c->d_list3.as<int32_t>());
     HIPCHK(hipMemcpyAsync(H.ends.data(), c->d_list3.p, (size_t)c->n_walks * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     bool bulk = false;
     auto fetch_bulk = [&]() -> int {
-        H.lent.resize(ne); H.qbest.resize(ne); H.ent_u.resize(nv); H.ent_h.resize(nv);
-        HIPCHK(hipMemcpyAsync(H.lent.data(), A.lent, (size_t)ne * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(H.qbest.data(), A.qbest, (size_t)ne, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(H.ent_u.data(), A.ent_src, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(H.ent_h.data(), A.ent_h, (size_t)nv * 4, hipMemcpyDeviceToHost, c->stream));
+        H.bstart.resize(ne); H.ent_u.resize(n_ent); H.ent_h.resize(n_ent);
+        HIPCHK(hipMemcpyAsync(H.bstart.data(), d_bstart, (size_t)ne * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(H.ent_u.data(), d_ent_src, (size_t)n_ent * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(H.ent_h.data(), d_ent_h, (size_t)n_ent * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         bulk = true;
         return PHI_OK;
@@ -112,26 +140,23 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
     int64_t e = c->h_walk_off[h + 1] - 1;
     for (int64_t guard = 0; guard <= (int64_t)nv; guard++) {
         if (!bulk && guard == 64) PHICHK(fetch_bulk());
-        int32_t q, lent_e = 0;
-        if (bulk) { q = H.qbest[e]; lent_e = H.lent[e]; }
-        else {
-            uint8_t q8 = 0;
-            HIPCHK(hipMemcpy(&q8, A.qbest + e, 1, hipMemcpyDeviceToHost));
-            q = q8;
-            if (q >= PHI_RCAP - 1) HIPCHK(hipMemcpy(&lent_e, A.lent + e, 4, hipMemcpyDeviceToHost));
-        }
-        const int64_t es = (q < PHI_RCAP - 1) ? e - q : c->h_walk_off[h] + lent_e;
+        int32_t bs = 0;
+        if (bulk) bs = H.bstart[e];
+        else HIPCHK(hipMemcpy(&bs, d_bstart + e, 4, hipMemcpyDeviceToHost));
+        const int64_t es = c->h_walk_off[h] + bs;
         if (es < c->h_walk_off[h] || es > e) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack left the walk (internal error)");
         segs->push_back(Seg{h, (int32_t)es, (int32_t)e});
         if (es == c->h_walk_off[h]) break;                     // reached s_{first(h),h}
         const int32_t v = c->h_walk_vtx[es];
-        const int32_t step = c->h_topo_rank[v];
+        const int32_t step = events ? c->h_cstep[c->h_topo_rank[v]] : c->h_topo_rank[v];
+        if (step < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack: run begins on a vertex without events (internal error)");
         int32_t src, h2;
         if (bulk) { src = H.ent_u[step]; h2 = H.ent_h[step]; }
         else {
-            HIPCHK(hipMemcpy(&src, A.ent_src + step, 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(&h2, A.ent_h + step, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&src, d_ent_src + step, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&h2, d_ent_h + step, 4, hipMemcpyDeviceToHost));
         }
+        if (events && src >= 0) src = c->h_kstep[src];          // compact step -> topological step
         const int32_t u = src >= 0 ? c->h_topo[src] : -1;
         if (u < 0 || h2 < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack hit a vertex without an entry (internal error)");
         // entry of walk h2 on vertex u: topological ranks increase along a walk
@@ -307,8 +332,18 @@ int phi_solve_impl(phi_ctx *c)
             HIPCHK(hipMemcpy(c->d_walk_last.p, last.data(), (size_t)nw * 4, hipMemcpyHostToDevice));
         }
         PHICHK(phi_dev_ensure(c, c->d_dmax, (size_t)c->n_entries * 4));
-        PHICHK(phi_dev_ensure(c, c->d_lent, (size_t)c->n_entries * 4));
-        PHICHK(phi_dev_ensure(c, c->d_qbest, (size_t)c->n_entries));
+        PHICHK(phi_dev_ensure(c, c->d_bstart, (size_t)c->n_entries * 4));
+        if (c->dp_events) {
+            const int64_t ne1 = c->n_entries + 1;
+            PHICHK(phi_dev_ensure(c, c->d_cnt_end, (size_t)ne1 * 4));
+            PHICHK(phi_dev_ensure(c, c->d_cnt_start, (size_t)ne1 * 4));
+            PHICHK(phi_dev_ensure(c, c->d_off_end, (size_t)ne1 * 4));
+            PHICHK(phi_dev_ensure(c, c->d_off_start, (size_t)ne1 * 4));
+            const int64_t nb = phi_scan_i32_num_blocks(c->n_entries);
+            PHICHK(phi_dev_ensure(c, c->d_scan_blk, (size_t)nb * 4));
+            PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
+            PHICHK(phi_dev_ensure(c, c->d_ev, (size_t)std::max<int64_t>(c->n_ev, 1) * 48));
+        }
         PHICHK(phi_dev_ensure(c, c->d_top, (size_t)c->n_vtx * 5 * 4));
         PHICHK(phi_dev_ensure(c, c->d_ent, (size_t)c->n_vtx * 2 * 4));
         PHICHK(phi_dev_ensure(c, c->d_word, (size_t)c->n_entries * 8));
