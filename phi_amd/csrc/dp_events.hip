@@ -128,7 +128,85 @@ __global__ void __launch_bounds__(256) phi_scan_apply_kernel(const int32_t *__re
     if (base <= n && n < base + 4) off[n] = run - 0;   // total (the items past n are zero)
 }
 
+// 64-bit variant (flat base offsets of the walk entries)
+__global__ void __launch_bounds__(256) phi_scan_blocksum64_kernel(const int32_t *__restrict__ cnt, int64_t n,
+                                                                  int64_t *__restrict__ blk)
+{
+    __shared__ long long s_w[4];
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    long long c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (base + j < n) c += cnt[base + j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// single-workgroup exclusive scan of 64-bit block sums (a few thousand items)
+__global__ void __launch_bounds__(1024) phi_scan_sums64_kernel(const int64_t *__restrict__ v, int64_t n, int64_t *__restrict__ off)
+{
+    __shared__ long long s_part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = min(n, tid * per), hi = min(n, lo + per);
+    long long s = 0;
+    for (int64_t i = lo; i < hi; i++) s += v[i];
+    s_part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; i++) { const long long t = s_part[i]; s_part[i] = run; run += t; }
+        off[n] = run;
+    }
+    __syncthreads();
+    long long run = s_part[tid];
+    for (int64_t i = lo; i < hi; i++) { off[i] = run; run += v[i]; }
+}
+
+__global__ void __launch_bounds__(256) phi_scan_apply64_kernel(const int32_t *__restrict__ cnt, int64_t n,
+                                                               const int64_t *__restrict__ blk_off, int64_t *__restrict__ off)
+{
+    __shared__ long long s_w[4];
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    long long v[4], c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { v[j] = (base + j < n) ? cnt[base + j] : 0; c += v[j]; }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    long long inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_w[wid] = inc;
+    __syncthreads();
+    long long woff = 0;
+    for (int i = 0; i < wid; i++) woff += s_w[i];
+    long long run = blk_off[blockIdx.x] + woff + inc - c;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (base + j < n) off[base + j] = run;
+        run += v[j];
+    }
+    if (base <= n && n < base + 4) off[n] = run;
+}
+
 int64_t phi_scan_i32_num_blocks(int64_t n) { return (n + 1 + 1023) / 1024; }
+
+void phi_launch_scan_sums_i64(hipStream_t st, const int64_t *v, int64_t n, int64_t *off)
+{
+    hipLaunchKernelGGL(phi_scan_sums64_kernel, dim3(1), dim3(1024), 0, st, v, n, off);
+}
+
+void phi_launch_scan_i64(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off, int64_t *blk, int64_t *blk_off)
+{
+    const int64_t nb = phi_scan_i32_num_blocks(n);
+    hipLaunchKernelGGL(phi_scan_blocksum64_kernel, dim3((unsigned)nb), dim3(256), 0, st, cnt, n, blk);
+    phi_launch_scan_sums_i64(st, blk, nb, blk_off);
+    hipLaunchKernelGGL(phi_scan_apply64_kernel, dim3((unsigned)nb), dim3(256), 0, st, cnt, n, blk_off, off);
+}
 
 // off[0..n] = exclusive prefix sums of cnt[0..n); blk / blk_off: scratch of phi_scan_i32_num_blocks(n) (+1) items
 void phi_launch_scan_i32(hipStream_t st, const int32_t *cnt, int64_t n, int32_t *off, int32_t *blk, int64_t *blk_off)
@@ -470,8 +548,239 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
     }
 }
 
+// ------------------------------------------------------------------ up to 64 walks: consumer + producers
+// The serial wave (the consumer) touches LDS only.  NPW producer waves of the same workgroup keep it
+// fed and carry its results out, one barrier every P steps:
+//   * refill the per-lane event ring from HBM and stage the step records, a period ahead;
+//   * write the (best score, run start) pairs of the events consumed in the previous period, the
+//     packed tops and the entry choices of its steps back to HBM.
+template <int NPW>
+__global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpEventArgs A)
+{
+    constexpr int D = 16, P = 8;
+    constexpr int PER_CHUNK = CHK / P;
+    static_assert(P % NPW == 0 && D == 2 * P && CHK % P == 0, "ring geometry");
+    __shared__ int4 s_rec[2][CHK][2];
+    __shared__ int4 s_top[RING];                    // packed tops of recent steps
+    __shared__ int2 s_ent[2 * P];                   // (source step, walk) of the entries of the last two periods
+    __shared__ uint4 s_ev[D][3][64];
+    __shared__ int4 s_res[D][64];                   // (best score, run start, entry) of consumed events
+    __shared__ int32_t s_qs[32][64], s_qE[32][64], s_qK[32][64];
+    __shared__ int32_t s_vi[64];
+
+    const int wave = threadIdx.x >> 6, h = threadIdx.x & 63;
+    const bool has_walk = h < A.n_walks;
+    const int32_t eb = has_walk ? (int32_t)A.walk_off[h] : 0;
+    const int32_t ee = has_walk ? (int32_t)A.walk_off[h + 1] : 0;
+    const int32_t vb = has_walk ? (int32_t)A.ev_off[h] : 0;     // events of this lane: [vb, ve)
+    const int32_t ve = has_walk ? (int32_t)A.ev_off[h + 1] : 0;
+    const int32_t n_k = A.n_k;
+    const int n_per = (n_k + P - 1) / P;
+
+    if (wave > 0) {
+        // ================================================================ producers
+        const int pw = wave - 1;
+        const uint4 *evg = reinterpret_cast<const uint4 *>(A.ev);
+        auto stage = [&](int c) {
+            const int32_t s0 = c * CHK;
+            const int32_t ns = min(CHK, n_k - s0);
+            const int4 *src = reinterpret_cast<const int4 *>(A.k_rec + (int64_t)s0 * 8);
+            int4 *dst = &s_rec[c & 1][0][0];
+            for (int i = pw * 64 + h; i < ns * 2; i += 64 * NPW) dst[i] = src[i];
+        };
+        stage(0);
+#pragma unroll
+        for (int n = 0; n < D / NPW; n++) {
+            const int32_t x = vb + pw + n * NPW;
+            if (x < ve) {
+                const uint4 a = evg[(int64_t)x * 3 + 0], g0 = evg[(int64_t)x * 3 + 1], g1 = evg[(int64_t)x * 3 + 2];
+                s_ev[x & (D - 1)][0][h] = a; s_ev[x & (D - 1)][1][h] = g0; s_ev[x & (D - 1)][2][h] = g1;
+            }
+        }
+        int32_t wl = min(ve, vb + D);                // first event not in the ring (the same in every producer wave)
+        int32_t vprev = vb;                          // consumer position one barrier ago
+        __syncthreads();                             // B_0
+        for (int p = 0;; p++) {
+            const int32_t vi = has_walk ? s_vi[h] : 0;
+            // 1. results of the events consumed during the previous period
+#pragma unroll
+            for (int n = 0; n < P / NPW; n++) {
+                const int32_t x = vprev + pw + n * NPW;
+                if (x < vi) {
+                    const int4 r = s_res[x & (D - 1)][h];
+                    A.dmax[r.z] = r.x; A.bstart[r.z] = r.y;
+                }
+            }
+            // 2. tops and entry choices of the previous period's steps (values of steps without
+            //    TOPS / ENTRY are never read back)
+            if (pw == 0 && p > 0 && h < P) {
+                const int32_t k = (p - 1) * P + h;
+                if (k < n_k) {
+                    reinterpret_cast<int4 *>(A.tops)[k] = s_top[k & (RING - 1)];
+                    const int2 en = s_ent[k & (2 * P - 1)];
+                    A.ent_src[k] = en.x; A.ent_h[k] = en.y;
+                }
+            }
+            if (p == n_per) break;                   // after the last barrier: only the write-backs
+            // 3. refill: events [wl, min(ve, vi + D)), at most P of them; all loads first
+            const int32_t hi = min(ve, vi + D);
+            uint4 t0[P / NPW], t1[P / NPW], t2[P / NPW];
+#pragma unroll
+            for (int n = 0; n < P / NPW; n++) {
+                const int64_t xc = (ve > vb) ? min(wl + pw + n * NPW, ve - 1) : 0;
+                t0[n] = evg[xc * 3 + 0]; t1[n] = evg[xc * 3 + 1]; t2[n] = evg[xc * 3 + 2];
+            }
+#pragma unroll
+            for (int n = 0; n < P / NPW; n++) {
+                const int32_t x = wl + pw + n * NPW;
+                if (x < hi) { s_ev[x & (D - 1)][0][h] = t0[n]; s_ev[x & (D - 1)][1][h] = t1[n]; s_ev[x & (D - 1)][2][h] = t2[n]; }
+            }
+            wl = max(wl, min(hi, wl + P));
+            // 4. the step records of the next chunk
+            if (p % PER_CHUNK == 0 && (p / PER_CHUNK + 1) * CHK < n_k) stage(p / PER_CHUNK + 1);
+            vprev = vi;
+            __syncthreads();                         // B_{p+1}
+        }
+        return;
+    }
+
+    // ==================================================================== the consumer
+    int32_t vi = vb;                                 // next event
+    s_vi[h] = vi;
+    __syncthreads();                                 // B_0
+    uint4 cA = make_uint4(0xFFFFFFFFu, 0, 0, 0);     // the next event of this lane, in registers
+    if (vi < ve) cA = s_ev[vi & (D - 1)][0][h];
+    // live young runs: deque in LDS; the head (start, value) and the tail key also in registers
+    int32_t qh = 0, qn = 0, hs = 0, hE = 0, tk = 0;
+    int32_t M = NEGK, sL = 0, Emax = NEG;            // best key of the old runs and its start; best value ever entered
+    int4 ra = s_rec[0][0][0], rb = s_rec[0][0][1];
+
+    for (int p = 0; p < n_per; p++) {
+        const int32_t k_end = min(n_k, (p + 1) * P);
+        for (int32_t k = p * P; k < k_end; k++) {
+            const int32_t kn = min(k + 1, n_k - 1);
+            const int4 na = s_rec[(kn / CHK) & 1][kn % CHK][0], nb = s_rec[(kn / CHK) & 1][kn % CHK][1];
+            const int32_t flags = ra.x;
+            const bool active = (int32_t)cA.x == k;
+
+            // ---- recombination entry into this vertex (uniform)
+            int32_t E = NEG, Eh = -1, Esrc = -1;
+            if (flags & PHI_DP_NEED_ENTRY) {
+                const int n_in = (flags >> 8) & 0xFF;
+                auto consider = [&](const int4 q, int32_t oj, int32_t src) {
+                    const int32_t t1h = (q.z & 0x3FF) - 1, t1n = ((q.z >> 10) & 0x3FF) - 1, t2h = ((q.z >> 20) & 0x3FF) - 1;
+                    const bool cont = t1n == oj;
+                    const int32_t val = cont ? q.y : q.x, hh = cont ? t2h : t1h;
+                    if (hh < 0) return;
+                    if (val > E || (val == E && (hh < Eh || (hh == Eh && src < Esrc)))) { E = val; Eh = hh; Esrc = src; }
+                };
+                const uint32_t b0 = (uint32_t)ra.z >> 8, b1 = (uint32_t)ra.w >> 8, b2 = (uint32_t)rb.x >> 8;
+                if (n_in == 1 && b0 < RING) {
+                    const int4 q = s_top[(k - b0) & (RING - 1)];
+                    const int32_t t1h = (q.z & 0x3FF) - 1, t1n = ((q.z >> 10) & 0x3FF) - 1, t2h = ((q.z >> 20) & 0x3FF) - 1;
+                    const bool cont = t1n == (ra.z & 0xFF);
+                    const int32_t hh = cont ? t2h : t1h;
+                    if (hh >= 0) { E = cont ? q.y : q.x; Eh = hh; Esrc = k - (int32_t)b0; }
+                } else if (n_in <= 3 && (b0 | b1 | b2) < RING) {
+                    const int4 q0 = s_top[(k - b0) & (RING - 1)];
+                    const int4 q1 = s_top[(k - b1) & (RING - 1)];
+                    const int4 q2 = s_top[(k - b2) & (RING - 1)];
+                    consider(q0, ra.z & 0xFF, k - (int32_t)b0);
+                    if (n_in > 1) consider(q1, ra.w & 0xFF, k - (int32_t)b1);
+                    if (n_in > 2) consider(q2, rb.x & 0xFF, k - (int32_t)b2);
+                } else {
+                    for (int j = 0; j < n_in; j++) {
+                        const int32_t pk = j == 0 ? ra.z : j == 1 ? ra.w : j == 2 ? rb.x : A.k_in_packed[ra.y + j - 3];
+                        const int32_t back = (int32_t)((uint32_t)pk >> 8);
+                        const int32_t src = k - back;
+                        // tops older than the ring come from HBM: the producers wrote them at least RING - 2P steps ago
+                        const int4 q = back < RING ? s_top[src & (RING - 1)] : reinterpret_cast<const int4 *>(A.tops)[src];
+                        consider(q, pk & 0xFF, src);
+                    }
+                }
+                if (Eh >= 0) E -= A.cost;
+                if (h == 0) s_ent[k & (2 * P - 1)] = make_int2(Esrc, Eh);
+            }
+
+            int32_t dmax = NEG;
+            int32_t oidx = 255;
+            if (active) {
+                const int sl = (int)(vi & (D - 1));
+                const int32_t e = (int32_t)(cA.y & 0x7FFFFFFFu);
+                const bool ovf = (cA.y >> 31) != 0;
+                const int32_t t = e - eb;
+                const int32_t End = (int32_t)cA.z, SB = (int32_t)cA.w;
+                const uint8_t *gb = reinterpret_cast<const uint8_t *>(&s_ev[sl][1][h]);   // byte a of G at gb[(a & 15) + (a >> 4) * 1024]
+                oidx = gb[15 + 1024];
+                // runs older than 30 entries: one scalar
+                while (qn > 0 && t - hs >= 31) {
+                    const int32_t key = qn == 1 ? tk : s_qK[qh & 31][h];
+                    if (key > M) { M = key; sL = hs; }
+                    qh++; qn--;
+                    if (qn > 0) { hs = s_qs[qh & 31][h]; hE = s_qE[qh & 31][h]; }
+                }
+                // a run begins here: the walk start, or a recombination entry worth keeping
+                int32_t newE = NEG;
+                if (t == 0) { newE = 0; qn = 0; M = NEGK; Emax = NEG; }
+                else if ((flags & PHI_DP_NEED_ENTRY) && Eh >= 0) newE = E;
+                if (newE > Emax) {
+                    Emax = newE;
+                    const int32_t key = newE - SB;
+                    while (qn > 0 && tk < key) {
+                        qn--;
+                        if (qn > 0) tk = s_qK[(qh + qn - 1) & 31][h];
+                    }
+                    const int slq = (qh + qn) & 31;
+                    s_qs[slq][h] = t; s_qE[slq][h] = newE; s_qK[slq][h] = key;
+                    if (qn == 0) { hs = t; hE = newE; }
+                    tk = key;
+                    qn++;
+                }
+                int32_t bs = 0;
+                if ((flags & PHI_DP_NEED_TOPS) || e == ee - 1) {
+                    // oldest first, strict improvement: ties keep the older run
+                    int32_t best = M > NEGK / 2 ? M + End : NEG;
+                    bs = sL;
+                    for (int32_t j = 0; j < qn; j++) {
+                        const int32_t s = j == 0 ? hs : s_qs[(qh + j) & 31][h];
+                        const int32_t Es = j == 0 ? hE : s_qE[(qh + j) & 31][h];
+                        const int a = t - s;
+                        const int32_t inside = !ovf ? (int32_t)gb[(a & 15) + (a >> 4) * 1024] : ev_count_inside(A, (int64_t)eb + s, e);
+                        const int32_t val = Es + inside;
+                        if (val > best) { best = val; bs = s; }
+                    }
+                    if (best > NEG / 2) dmax = best; else bs = 0;
+                }
+                s_res[sl][h] = make_int4(dmax, bs, e, 0);
+                vi++;
+                cA = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+                if (vi < ve) cA = s_ev[vi & (D - 1)][0][h];
+            }
+
+            // ---- best states leaving this vertex (as in dp.hip)
+            if (flags & PHI_DP_NEED_TOPS) {
+                const bool leaving = active && oidx != 255 && dmax > NEG / 2;
+                int32_t t1v = NEG, t1h = -1, t1n = -1, t2v = NEG, t2h = -1;
+                const int32_t m1 = ev_wave_max_i32(leaving ? dmax : NEG);
+                if (m1 > NEG / 2) {
+                    const int l1 = __ffsll((long long)__ballot(leaving && dmax == m1)) - 1;
+                    t1v = m1; t1h = l1;
+                    t1n = __builtin_amdgcn_readlane(oidx, l1);
+                    const bool other = leaving && oidx != t1n;
+                    const int32_t m2 = ev_wave_max_i32(other ? dmax : NEG);
+                    if (m2 > NEG / 2) { t2v = m2; t2h = __ffsll((long long)__ballot(other && dmax == m2)) - 1; }
+                }
+                if (h == 0) s_top[k & (RING - 1)] = ev_pack_tops(t1v, t1h, t1n, t2v, t2h);
+            }
+            ra = na; rb = nb;
+        }
+        s_vi[h] = vi;
+        __syncthreads();                             // B_{p+1}
+    }
+}
+
 void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A)
 {
-    if (A.n_walks <= 64) hipLaunchKernelGGL(phi_dp_events_kernel<1>, dim3(1), dim3(64), 0, st, A);
+    if (A.n_walks <= 64) hipLaunchKernelGGL(phi_dp_events_pc_kernel<2>, dim3(1), dim3(64 * 3), 0, st, A);
     else hipLaunchKernelGGL(phi_dp_events_kernel<2>, dim3(1), dim3(128), 0, st, A);    // n_walks <= PHI_DP_EVENT_MAX_WALKS
 }

@@ -153,7 +153,7 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_bstart, &c->d_k_rec, &c->d_k_in, &c->d_cvtx, &c->d_ev_e, &c->d_ev_off, &c->d_ev,
-                     &c->d_cnt_end, &c->d_cnt_start, &c->d_off_end, &c->d_off_start, &c->d_scan_blk, &c->d_scan_blkoff, &c->d_top,
+                     &c->d_cnt_end, &c->d_cnt_start, &c->d_off_end, &c->d_off_start, &c->d_scan_blk, &c->d_scan_blk64, &c->d_scan_blkoff, &c->d_top,
                      &c->d_ent};
     for (DevBuf *b : all) dev_free(*b);
     for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -428,7 +428,13 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     PHICHK(phi_dev_ensure(c, c->d_ebase, (size_t)(n_entries + 1) * 8));
     PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)n_entries * 4));
     phi_launch_entry_len(c->stream, c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(), n_entries, c->d_list3.as<int32_t>());
-    phi_launch_scan_counts(c->stream, c->d_list3.as<int32_t>(), n_entries, c->d_ebase.as<int64_t>());
+    {
+        const int64_t nb = phi_scan_i32_num_blocks(n_entries);
+        PHICHK(phi_dev_ensure(c, c->d_scan_blk64, (size_t)nb * 8));
+        PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
+        phi_launch_scan_i64(c->stream, c->d_list3.as<int32_t>(), n_entries, c->d_ebase.as<int64_t>(), c->d_scan_blk64.as<int64_t>(),
+                            c->d_scan_blkoff.as<int64_t>());
+    }
     PHICHK(upload(c, c->d_topo, c->h_topo.data(), c->h_topo.size()));
     PHICHK(upload(c, c->d_in_off, c->h_in_off.data(), c->h_in_off.size()));
     PHICHK(upload(c, c->d_in_src, c->h_in_src.data(), c->h_in_src.size()));
@@ -443,6 +449,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                              c->d_ev_off.as<int64_t>());
     }
     if (tm.on) (void)hipStreamSynchronize(c->stream);
+    if (tm.on) fprintf(stderr, "[phi timing] set_graph: %d vertices, %d compact steps, %lld entries, %lld events\n", n_vtx, c->n_k, (long long)n_entries, (long long)c->n_ev);
     tm.lap("uploads + ebase scan");
     // ---- stage 1a on the GPU: pack the walks, sketch them, build the minimiser table
     HIPCHK(hipMemsetAsync(c->d_scalars.p, 0, S_N * 8, c->stream));

@@ -81,7 +81,7 @@ struct phi_ctx {
     int32_t n_k = 0;                                  // compact steps
     int64_t n_ev = 0;                                 // events
     std::vector<int32_t> h_cstep, h_kstep;            // topological step -> compact step (-1) and back
-    DevBuf d_k_rec, d_k_in, d_cvtx, d_ev_e, d_ev_off, d_ev, d_cnt_end, d_cnt_start, d_off_end, d_off_start, d_scan_blk, d_scan_blkoff;
+    DevBuf d_k_rec, d_k_in, d_cvtx, d_ev_e, d_ev_off, d_ev, d_cnt_end, d_cnt_start, d_off_end, d_off_start, d_scan_blk, d_scan_blk64, d_scan_blkoff;
     std::vector<PhiAnchorHost> h_kept, h_dp;          // kept anchors; dp anchors (span >= 1 edge)
     std::vector<uint64_t> h_kept_hash;
     std::vector<int32_t> h_path_vtx, h_path_hap;

@@ -175,6 +175,9 @@ void phi_launch_dp_counts(hipStream_t st, const int32_t *a_e1, const uint8_t *a_
                           int32_t *cnt_end, int32_t *cnt_start);
 int64_t phi_scan_i32_num_blocks(int64_t n);
 void phi_launch_scan_i32(hipStream_t st, const int32_t *cnt, int64_t n, int32_t *off, int32_t *blk, int64_t *blk_off);
+// same with 64-bit sums: off[0..n] int64, blk int64 scratch
+void phi_launch_scan_i64(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off, int64_t *blk, int64_t *blk_off);
+void phi_launch_scan_sums_i64(hipStream_t st, const int64_t *v, int64_t n, int64_t *off);
 void phi_launch_dp_event_fill(hipStream_t st, const PhiDpEventArgs &A, const uint8_t *e_out, const int32_t *walk_vtx,
                               const int32_t *cvtx, const int32_t *off_end, const int32_t *off_start);
 int phi_dp_num_waves(int n_walks);
