@@ -15,12 +15,12 @@
 // (ENTRY), leave (TOPS), or the walk starts / ends.  On the synthetic MHC graph that is one vertex
 // in four; chain vertices cost nothing.
 //
-// Per lane (= walk) the live runs form a deque in LDS: a new run (s, E) is dropped when an older
-// run already has E' >= E (the older run contains every anchor the younger one does, and ties go
-// to the older run as in dp.hip), and it evicts younger-or-equal... older runs from the back whose
-// key E' - SB(s') is smaller than its own (they can never catch up).  Runs older than 30 entries
-// are folded into one scalar (best key).  A query (TOPS / walk end) is then
-// max(best key + End, max over the few young runs of E_s + G[age]).
+// Per lane (= walk) the live runs form a deque in LDS.  A new run (s, E) is dropped when an older
+// run already has E' >= E: the older run contains every anchor the younger one does, and ties go
+// to the older run as in dp.hip.  When it is kept it evicts, from the back, the runs whose key
+// E' - SB(s') is smaller than its own: they lead by fewer anchors than they trail in value and
+// can never catch up.  Runs older than 30 entries are folded into one scalar (the best key).  A
+// query (TOPS / walk end) is then max(best key + End, max over the few young runs of E_s + G[age]).
 //
 // Same transitions, same tie-breaks and the same outputs as dp.hip (which stays as the kernel for
 // more than 128 walks): tests/test_gpu_parity.py runs both on the same inputs.

@@ -234,6 +234,27 @@ def test_more_than_64_walks_vs_highs(oracle, ctx_factory, n_walks):
     assert res["objective"] == best, (n_walks, res["objective"], best)
 
 
+def test_dense_and_event_dp_agree(oracle, ctx_factory, monkeypatch):
+    """PHI_DP_DENSE=1 (read by phi_set_graph) forces the every-vertex kernel of dp.hip that otherwise
+    only serves more than 128 walks; both kernels must give the same objective and a feasible path."""
+    rng = np.random.default_rng(4242)
+    g = random_graph(rng, n_sites=60, n_walks=9, seg_len=(4, 12), alt_len=(2, 6), p_del=0.25)
+    reads = mosaic_reads(rng, g, n_reads=200, read_len=40, n_seg=4, err=0.01)
+    out = {}
+    for mode in ("events", "dense"):
+        if mode == "dense":
+            monkeypatch.setenv("PHI_DP_DENSE", "1")
+        for R in (0, 3, 100):
+            ctx = ctx_factory(k=7, w=3, threshold=0.8, recombination=R)
+            _set_graph(ctx, g)
+            ctx.add_reads(reads)
+            st, res, m = _check_against_oracle(oracle, ctx, g, reads, 7, 3, 0.8, R)
+            out[(mode, R)] = res["objective"]
+    monkeypatch.delenv("PHI_DP_DENSE")
+    for R in (0, 3, 100):
+        assert out[("events", R)] == out[("dense", R)], (R, out)
+
+
 def test_many_switches_backtrack(oracle, ctx_factory):
     """R = 0 on a long bubble chain: the best path switches walks hundreds of times, so the
     backtrack leaves its read-a-few-entries mode for the bulk download."""
