@@ -24,9 +24,10 @@
 // Bases outside ACGTacgt (the reference keeps them as bytes: N sorts between G and T and is its
 // own complement, ILP_index.cpp:350-353) cannot live in 2 bits.  The pack kernels set one bit per
 // such base; the 2-bit path skips every window that, together with its predecessor, touches a
-// marked base, and an exact byte-wise routine (same wave, after its 2-bit phases) handles exactly
-// those windows.  With `allslow` the byte-wise routine handles every window (ordered write of
-// walks that contain such bases).
+// marked base, and an exact byte-wise kernel (phi_sketch_bytes_kernel, launched after the 2-bit
+// kernel; it leaves at once when the batch holds no such base) handles exactly those windows.
+// With `allslow` the byte-wise kernel handles every window (ordered write of walks that contain
+// such bases).
 #include <hip/hip_runtime.h>
 #include "phi_dev.h"
 #include "phi_kernels.h"
