@@ -81,7 +81,10 @@ int phi_add_reads(phi_ctx *ctx, const char *bases, const int64_t *read_off, int6
 /* Same, with both arrays already resident in this GPU's HBM (n_bases = read_off[n_reads]). */
 int phi_add_reads_device(phi_ctx *ctx, const void *d_bases, const void *d_read_off, int64_t n_reads,
                          int64_t n_bases);
-/* Forget all reads seen so far (graph index is kept). */
+/* Forget all reads seen so far (graph index is kept).  The clearing itself may be folded into the
+ * next batch's first launch; every call that observes the spectrum, the counters or the hit
+ * vector sees the reads forgotten, and once phi_hits_buffer has handed the hit-vector pointer out
+ * the clearing is launched by this call. */
 int phi_reset_reads(phi_ctx *ctx);
 /* Totals since the last reset (waits for the stream): reads, bases, emitted read minimisers
  * (with multiplicity) and distinct read hashes so far. */
