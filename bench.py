@@ -11,7 +11,7 @@ The graph index (walk sketch + table) is built once before the timed region and 
 (filter + DP + certificate) runs once after it; both are timed and reported separately, and
 `end_to_end_s` = index build + one step + solve.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU; every rank holds the full graph index and its own shard of reads
@@ -59,8 +59,8 @@ def cpu_baseline(reads_concat, read_off, k, w, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C2", help="workload of phi_amd.synth.CONFIGS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true")
@@ -113,8 +113,10 @@ def main():
 
     d_bases = torch.from_numpy(bases).to(dev)
     d_off = torch.from_numpy(off).to(dev)
-    hit_ptr, n_unique = ctx.hits_buffer()
-    hit_t = torch.as_tensor(pdist.DevArray(hit_ptr, n_unique), device=dev) if world > 1 else None
+    hit_t = None
+    if world > 1:                                              # the only data-path collective works on this vector
+        hit_ptr, n_unique = ctx.hits_buffer()
+        hit_t = torch.as_tensor(pdist.DevArray(hit_ptr, n_unique), device=dev)
 
     def step():
         ctx.reset_reads()

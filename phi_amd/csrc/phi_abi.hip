@@ -607,6 +607,8 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     A.u_keys = c->d_u_keys.as<uint64_t>(); A.u_uid = c->d_u_uid.as<uint32_t>(); A.u_mask = c->u_cap - 1;
     A.hit = c->d_hit.as<uint8_t>();
     A.err = (uint32_t *)scalar(c, S_ERR);
+    A.batch_bad = batch_bad;                            // windows touching a base outside ACGT: byte-wise workgroups of the same launch
+    hipEvent_t t0 = nullptr, t1 = nullptr;
     if (c->prof) {
         if (c->prof_used == c->prof_events.size()) {
             hipEvent_t a, b;
@@ -614,16 +616,11 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
             HIPCHK(hipEventCreate(&b));
             c->prof_events.emplace_back(a, b);
         }
-        HIPCHK(hipEventRecord(c->prof_events[c->prof_used].first, c->stream));
-    }
-    phi_launch_sketch(c->stream, PHI_MODE_PROBE, A);
-    if (c->prof) {
-        HIPCHK(hipEventRecord(c->prof_events[c->prof_used].second, c->stream));
+        t0 = c->prof_events[c->prof_used].first; t1 = c->prof_events[c->prof_used].second;
         c->prof_used++;
         c->prof_bases += n_bases;
     }
-    // windows touching a base outside ACGT: exact byte-wise kernel (leaves at once on clean batches)
-    phi_launch_sketch_bytes(c->stream, PHI_MODE_PROBE, A, batch_bad);
+    phi_launch_sketch(c->stream, PHI_MODE_PROBE, A, t0, t1);
     HIPCHK(hipGetLastError());
     c->reads_bases += n_bases;
     c->reads_count += n_reads;
@@ -862,6 +859,16 @@ int phi_prof_enable(phi_ctx *c, int on)
 {
     if (!c) return PHI_ERR_INVALID;
     c->prof = on != 0;
+    if (c->prof) {
+        // create the event pairs of the next launches now, not inside the region being timed
+        HIPCHK(hipSetDevice(c->device));
+        while (c->prof_events.size() < c->prof_used + 256) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            c->prof_events.emplace_back(a, b);
+        }
+    }
     return PHI_OK;
 }
 

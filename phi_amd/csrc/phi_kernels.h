@@ -41,6 +41,10 @@ struct PhiSketchArgs {
     const uint64_t *u_keys; const uint32_t *u_uid; uint64_t u_mask;   // walk-minimiser table: slot -> dense id
     uint8_t *hit;                          // per distinct walk minimiser (dense id)
     uint32_t *err;
+    // read batches: count of bases outside ACGTacgt of this batch (device scalar); when set, the PROBE
+    // launch carries byte-wise workgroups behind its fast_blocks 2-bit ones (set by the launcher)
+    const unsigned long long *batch_bad;
+    unsigned fast_blocks;
 };
 
 // sketch.hip
@@ -65,7 +69,7 @@ void phi_launch_pack_walks(hipStream_t st, const uint8_t *seq_concat, const int6
                            const int32_t *walk_vtx, const int64_t *ebase, int64_t n_entries, uint64_t *words,
                            int64_t n_words, uint32_t *badbits, uint8_t *ascii, unsigned long long *n_bad);
 int64_t phi_sketch_num_blocks(int64_t n_bases);
-void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A);
+void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void phi_launch_scan_counts(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off);
 
 // table.hip

@@ -29,6 +29,7 @@
 // With `allslow` the byte-wise kernel handles every window (ordered write of walks that contain
 // such bases).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "phi_dev.h"
 #include "phi_kernels.h"
 
@@ -392,6 +393,50 @@ __host__ __device__ static inline int phi_wave_region_u64(int w)
     return ((WCH + w + 8) * 9) / 8 + 8 + SWW + 2 * SBW + WCH / 2 + 4;
 }
 
+// The byte-wise path of one workgroup: chunks blk, blk + n_blk, ... (see phi_sketch_bytes_kernel).
+template <int MODE>
+static __device__ __forceinline__ void bytes_role(const PhiSketchArgs &A, const unsigned long long *batch_bad,
+                                                  int64_t blk, int64_t n_blk, unsigned long long *s_all)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (!A.allslow && *batch_bad == 0) return;
+    const int64_t N = A.n_bases;
+    const int64_t n_chunks = (N + WCH - 1) / WCH;
+    const int64_t n_sw = N / 64 + 2;
+    unsigned long long *s_bits = s_all + (size_t)wid * 2 * SBW, *s_bad = s_bits + SBW;
+    for (int64_t chunk = blk * (TPB / 64) + wid; chunk < n_chunks; chunk += n_blk * (TPB / 64)) {
+        const int64_t c0 = chunk * WCH;
+        unsigned long long my_bad = 0;
+        wave_sync();
+        if (lane < SBW) {
+            const int64_t wi = (c0 >> 6) - 1 + lane;
+            s_bits[lane] = (wi >= 0 && wi < n_sw) ? A.starts[wi] : 0;
+        } else if (lane < 2 * SBW) {
+            const int64_t wi = (c0 >> 6) - 1 + (lane - SBW);
+            if (A.badbits) my_bad = (wi >= 0 && wi < n_sw) ? A.badbits[wi] : 0;
+            s_bad[lane - SBW] = my_bad;
+        }
+        const bool chunk_bad = __ballot(my_bad != 0) != 0ull;
+        wave_sync();
+        int n_emit = 0, n_new = 0;
+        if (A.allslow || chunk_bad) {
+            const int64_t out_base = (MODE == PHI_MODE_WRITE) ? A.block_off[chunk] : 0;
+            slow_windows<MODE>(A, c0, chunk, lane, A.k, A.w, s_bits, s_bad, A.allslow != 0, out_base, n_emit, n_new);
+        }
+        if (MODE == PHI_MODE_COUNT) {
+            if (lane == 0) A.block_cnt[chunk] = n_emit;
+        } else if (MODE == PHI_MODE_PROBE) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) n_new += __shfl_xor(n_new, d, 64);
+            if (lane == 0) {
+                const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
+                if (n_new) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new);
+                if (n_emit) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
+            }
+        }
+    }
+}
+
 // WIDE: w > Q (windows of one lane overlap in a common core); otherwise brute force per window.
 // KT/WT: compile-time k and w of the specialised instance (0 = take them from the arguments).
 template <int MODE, bool WIDE, int KT, int WT>
@@ -399,6 +444,14 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 {
     constexpr bool NEED_POS = MODE == PHI_MODE_WRITE;   // only the ordered write stores positions (ILP_index.cpp:423)
     extern __shared__ uint64_t s_dyn[];
+
+    // read batches: the workgroups past the 2-bit ones take the byte-wise path (they leave at once
+    // when the batch holds no base outside ACGTacgt) -- one launch less per batch
+    if (MODE == PHI_MODE_PROBE && A.fast_blocks && blockIdx.x >= A.fast_blocks) {
+        bytes_role<MODE>(A, A.batch_bad, (int64_t)blockIdx.x - A.fast_blocks, (int64_t)gridDim.x - A.fast_blocks,
+                         (unsigned long long *)s_dyn);
+        return;
+    }
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k = KT ? KT : A.k, w = WT ? WT : A.w;
@@ -649,44 +702,8 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 template <int MODE>
 __global__ void __launch_bounds__(TPB) phi_sketch_bytes_kernel(PhiSketchArgs A, const unsigned long long *batch_bad)
 {
-    __shared__ unsigned long long s_all[TPB / 64][2 * SBW];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (!A.allslow && *batch_bad == 0) return;
-    const int64_t N = A.n_bases;
-    const int64_t n_chunks = (N + WCH - 1) / WCH;
-    const int64_t n_sw = N / 64 + 2;
-    unsigned long long *s_bits = s_all[wid], *s_bad = s_all[wid] + SBW;
-    for (int64_t chunk = (int64_t)blockIdx.x * (TPB / 64) + wid; chunk < n_chunks; chunk += (int64_t)gridDim.x * (TPB / 64)) {
-        const int64_t c0 = chunk * WCH;
-        unsigned long long my_bad = 0;
-        wave_sync();
-        if (lane < SBW) {
-            const int64_t wi = (c0 >> 6) - 1 + lane;
-            s_bits[lane] = (wi >= 0 && wi < n_sw) ? A.starts[wi] : 0;
-        } else if (lane < 2 * SBW) {
-            const int64_t wi = (c0 >> 6) - 1 + (lane - SBW);
-            if (A.badbits) my_bad = (wi >= 0 && wi < n_sw) ? A.badbits[wi] : 0;
-            s_bad[lane - SBW] = my_bad;
-        }
-        const bool chunk_bad = __ballot(my_bad != 0) != 0ull;
-        wave_sync();
-        int n_emit = 0, n_new = 0;
-        if (A.allslow || chunk_bad) {
-            const int64_t out_base = (MODE == PHI_MODE_WRITE) ? A.block_off[chunk] : 0;
-            slow_windows<MODE>(A, c0, chunk, lane, A.k, A.w, s_bits, s_bad, A.allslow != 0, out_base, n_emit, n_new);
-        }
-        if (MODE == PHI_MODE_COUNT) {
-            if (lane == 0) A.block_cnt[chunk] = n_emit;
-        } else if (MODE == PHI_MODE_PROBE) {
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) n_new += __shfl_xor(n_new, d, 64);
-            if (lane == 0) {
-                const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
-                if (n_new) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new);
-                if (n_emit) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
-            }
-        }
-    }
+    __shared__ unsigned long long s_all[(TPB / 64) * 2 * SBW];
+    bytes_role<MODE>(A, batch_bad, blockIdx.x, gridDim.x, s_all);
 }
 
 // single-workgroup exclusive scan of the per-chunk counts (launch-bound, tiny)
@@ -784,26 +801,35 @@ void phi_launch_pack_walks(hipStream_t st, const uint8_t *seq_concat, const int6
 // number of per-wave chunks (= entries of block_cnt / block_off)
 int64_t phi_sketch_num_blocks(int64_t n_bases) { return n_bases <= 0 ? 0 : (n_bases + WCH - 1) / WCH; }
 
+// t0 / t1 (optional): events that take the kernel's own start / end timestamps (hipExtLaunchKernelGGL:
+// no extra marker packets on the stream, unlike hipEventRecord around the launch)
 template <int MODE>
-static void launch_sketch_mode(hipStream_t st, unsigned nb, size_t lds, const PhiSketchArgs &A)
+static void launch_sketch_mode(hipStream_t st, unsigned nb, size_t lds, const PhiSketchArgs &A, hipEvent_t t0, hipEvent_t t1)
 {
     // the reference's defaults (options.cpp:7-8) get a fully unrolled instance, except for the
     // ordered write whose position tracking would push it past 128 VGPRs
     if (A.k == 31 && A.w == 25 && MODE != PHI_MODE_WRITE)
-        hipLaunchKernelGGL((phi_sketch_kernel<MODE, true, 31, 25>), dim3(nb), dim3(TPB), lds, st, A);
-    else if (A.w > Q) hipLaunchKernelGGL((phi_sketch_kernel<MODE, true, 0, 0>), dim3(nb), dim3(TPB), lds, st, A);
-    else hipLaunchKernelGGL((phi_sketch_kernel<MODE, false, 0, 0>), dim3(nb), dim3(TPB), lds, st, A);
+        hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, true, 31, 25>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
+    else if (A.w > Q) hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, true, 0, 0>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
+    else hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, false, 0, 0>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
 }
 
-void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A)
+void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A0, hipEvent_t t0, hipEvent_t t1)
 {
-    const int64_t nchunks = phi_sketch_num_blocks(A.n_bases);
+    const int64_t nchunks = phi_sketch_num_blocks(A0.n_bases);
     if (nchunks <= 0) return;
-    const unsigned nb = (unsigned)((nchunks + TPB / 64 - 1) / (TPB / 64));
+    PhiSketchArgs A = A0;
+    unsigned nb = (unsigned)((nchunks + TPB / 64 - 1) / (TPB / 64));
+    A.fast_blocks = 0;
+    if (mode == PHI_MODE_PROBE && A.batch_bad && !A.allslow) {
+        // byte-wise workgroups ride along (grid-stride over the chunks; usually they leave at once)
+        A.fast_blocks = nb;
+        nb += nb < 1024 ? nb : 1024;
+    }
     const size_t lds = (size_t)phi_wave_region_u64(A.w) * 8 * (TPB / 64);
-    if (mode == PHI_MODE_COUNT) launch_sketch_mode<PHI_MODE_COUNT>(st, nb, lds, A);
-    else if (mode == PHI_MODE_WRITE) launch_sketch_mode<PHI_MODE_WRITE>(st, nb, lds, A);
-    else launch_sketch_mode<PHI_MODE_PROBE>(st, nb, lds, A);
+    if (mode == PHI_MODE_COUNT) launch_sketch_mode<PHI_MODE_COUNT>(st, nb, lds, A, t0, t1);
+    else if (mode == PHI_MODE_WRITE) launch_sketch_mode<PHI_MODE_WRITE>(st, nb, lds, A, t0, t1);
+    else launch_sketch_mode<PHI_MODE_PROBE>(st, nb, lds, A, t0, t1);
 }
 
 void phi_launch_scan_counts(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off)
