@@ -393,6 +393,19 @@ __host__ __device__ static inline int phi_wave_region_u64(int w)
     return ((WCH + w + 8) * 9) / 8 + 8 + SWW + 2 * SBW + WCH / 2 + 4;
 }
 
+// inclusive prefix sum over the 64 lanes on the VALU (DPP row shifts + row broadcasts; __shfl_up
+// would be six ds_bpermute round trips)
+__device__ __forceinline__ int wave_scan_inclusive(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 // The byte-wise path of one workgroup: chunks blk, blk + n_blk, ... (see phi_sketch_bytes_kernel).
 template <int MODE>
 static __device__ __forceinline__ void bytes_role(const PhiSketchArgs &A, const unsigned long long *batch_bad,
@@ -498,30 +511,48 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 
     // ---- phase 1: canonical k-mers, P consecutive per lane
     {
-        const int P = (M + 63) / 64;
+        const int P = KT ? (WCH + WT + 63) / 64 : (M + 63) / 64;
         const int l0 = lane * P;
-        const int l1 = min(l0 + P, M);
-        const int64_t j0 = c0 - 1 + l0;
-        uint64_t F = 0, R = 0, nxt = 0;
-        bool live = false;
-        for (int l = l0; l < l1; l++) {
-            const int64_t j = j0 + (l - l0);
-            uint64_t m = ~0ull;
-            if (j >= 0 && j + k <= N) {
-                if (!live) {
-                    F = lds_extract64(s_words, l + 31) >> (64 - 2 * k);
-                    R = phi_revcomp(F, k);
-                    nxt = lds_extract64(s_words, l + 31 + k);   // bases j+k .. j+k+31
-                    live = true;
-                } else {
+        if (c0 >= 1 && c0 - 1 + (int64_t)P * 64 + k <= N) {
+            // interior chunk (all but the first and last of a batch): every k-mer a lane touches
+            // exists, so the roll needs no per-position checks
+            uint64_t F = lds_extract64(s_words, l0 + 31) >> (64 - 2 * k);
+            uint64_t R = phi_revcomp(F, k);
+            uint64_t nxt = lds_extract64(s_words, l0 + 31 + k);     // bases j+k .. j+k+31
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                if (i) {
                     const uint64_t b = nxt >> 62;
                     nxt <<= 2;
                     F = ((F << 2) | b) & kmask;
                     R = (R >> 2) | ((3 - b) << (2 * k - 2));
                 }
-                m = F < R ? F : R;
+                if (l0 + i < M) SM(l0 + i) = F < R ? F : R;
             }
-            SM(l) = m;
+        } else {
+            const int l1 = min(l0 + P, M);
+            const int64_t j0 = c0 - 1 + l0;
+            uint64_t F = 0, R = 0, nxt = 0;
+            bool live = false;
+            for (int l = l0; l < l1; l++) {
+                const int64_t j = j0 + (l - l0);
+                uint64_t m = ~0ull;
+                if (j >= 0 && j + k <= N) {
+                    if (!live) {
+                        F = lds_extract64(s_words, l + 31) >> (64 - 2 * k);
+                        R = phi_revcomp(F, k);
+                        nxt = lds_extract64(s_words, l + 31 + k);   // bases j+k .. j+k+31
+                        live = true;
+                    } else {
+                        const uint64_t b = nxt >> 62;
+                        nxt <<= 2;
+                        F = ((F << 2) | b) & kmask;
+                        R = (R >> 2) | ((3 - b) << (2 * k - 2));
+                    }
+                    m = F < R ? F : R;
+                }
+                SM(l) = m;
+            }
         }
     }
     wave_sync();
@@ -625,26 +656,29 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     int ncand, coff;
     {
         const int cnt = __popc(cflag);
-        int v = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(v, d, 64);
-            if (lane >= d) v += t;
-        }
-        ncand = __shfl(v, 63, 64);
+        const int v = wave_scan_inclusive(cnt);
+        ncand = __builtin_amdgcn_readlane(v, 63);
         coff = v - cnt;
     }
     wave_sync();                                          // every lane has read its k-mers
     {
+        // every lane stores all Q windows, the non-candidates into trash slots past the last
+        // candidate slot SM(WCH) (they may reach into s_words, dead since phase 1) and past
+        // s_meta[WCH - 1]: no divergent branch per window
         int c = coff;
+        const int trash_v = WCH + 1 + ((WCH + 1) >> 3) + 1 + (lane & 31), trash_m = WCH + (lane & 7);
 #pragma unroll
         for (int i = 1; i <= Q; i++) {
-            if (cflag & (1u << i)) {
-                SM(c) = wv[i];
-                s_meta[c] = (uint32_t)(lane * Q + i) | ((uint32_t)wp[i] << 10) | ((fflag >> i) & 1u) << 31;
-                if (c == 0) SM(ncand) = wv[i - 1];        // the window before the first candidate
-                c++;
-            }
+            const bool on = (cflag >> i) & 1u;
+            s_mp[on ? c + (c >> 3) : trash_v] = wv[i];
+            s_meta[on ? c : trash_m] = (uint32_t)(lane * Q + i) | ((uint32_t)wp[i] << 10) | ((fflag >> i) & 1u) << 31;
+            c += on;
+        }
+        // the window before the first candidate of the chunk (one lane)
+        if (coff == 0 && cflag) {
+            const int i1 = __ffs((int)cflag) - 1;
+#pragma unroll
+            for (int i = 1; i <= Q; i++) if (i == i1) SM(ncand) = wv[i - 1];
         }
     }
     wave_sync();
