@@ -22,7 +22,7 @@ def _set_graph(ctx, g):
 
 # --------------------------------------------------------------------------- sketch kernel
 
-@pytest.mark.parametrize("k,w", [(31, 25), (3, 2), (15, 10), (32, 1), (1, 1), (21, 64), (31, 200), (5, 9)])
+@pytest.mark.parametrize("k,w", [(31, 25), (3, 2), (15, 10), (32, 1), (1, 1), (21, 64), (31, 200), (5, 9), (32, 256), (2, 256), (31, 8), (31, 9)])
 def test_sketch_random_sequences(oracle, ctx_factory, k, w):
     rng = np.random.default_rng(1000 * k + w)
     ctx = ctx_factory()
@@ -190,6 +190,68 @@ def test_random_small_graphs_vs_brute_force(oracle, ctx_factory, seed):
     st, res, m = _check_against_oracle(oracle, ctx, g, reads, k, w, T, R)
     best, arg = m.brute_force()
     assert res["objective"] == best, (seed, k, w, R, T)
+
+
+@pytest.mark.parametrize("k,w", [(15, 12), (11, 30), (31, 25)])
+def test_full_path_wide_windows(oracle, ctx_factory, k, w):
+    """w > 8 takes the suffix/core/prefix kernel instances (generic and the (31,25) one) in all
+    three modes; enough read bases for interior chunks (the check-free k-mer roll)."""
+    rng = np.random.default_rng(100 * k + w)
+    g = random_graph(rng, n_sites=40, n_walks=5, seg_len=(20, 60), alt_len=(1, 8), p_del=0.2)
+    reads = mosaic_reads(rng, g, n_reads=250, read_len=k + w + 60, n_seg=3, err=0.005)
+    reads[3] = reads[3][:k + w - 2]                       # too short for a window
+    reads[4] = b""
+    ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=6)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads[:100])
+    ctx.add_reads(reads[100:])
+    st, res, m = _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 6)
+    assert res["spectrum_size"] > 50
+
+
+def test_degenerate_inputs(oracle, ctx_factory):
+    """Single walk; reads too short for any window; thresholds that filter everything / nothing;
+    odd R (the reference halves it twice, ILP_index.cpp:1276,1299)."""
+    rng = np.random.default_rng(99)
+    g1 = random_graph(rng, n_sites=6, n_walks=1, seg_len=(8, 20))
+    reads = mosaic_reads(rng, g1, n_reads=30, read_len=30, n_seg=1)
+    ctx = ctx_factory(k=7, w=3, threshold=1.0, recombination=5)
+    _set_graph(ctx, g1)
+    ctx.add_reads(reads)
+    st, res, m = _check_against_oracle(oracle, ctx, g1, reads, 7, 3, 1.0, 5)
+    assert res["n_switches"] == 0
+    # reads without a single window: empty spectrum, objective 0, the path is still a walk
+    g = random_graph(rng, n_sites=6, n_walks=4, seg_len=(8, 20))
+    short = [b"ACGTACG", b"", b"AC", b"ACGTACGTA"]
+    ctx = ctx_factory(k=7, w=4, threshold=1.0, recombination=5)
+    _set_graph(ctx, g)
+    ctx.add_reads(short)
+    st, res, m = _check_against_oracle(oracle, ctx, g, short, 7, 4, 1.0, 5)
+    assert res["spectrum_size"] == 0 and res["objective"] == 0
+    reads = mosaic_reads(rng, g, n_reads=40, read_len=30, n_seg=2)
+    for T, R in [(0.0, 5), (0.26, 5), (100.0, 5), (1.0, 1), (1.0, 7)]:
+        ctx = ctx_factory(k=7, w=4, threshold=T, recombination=R)
+        _set_graph(ctx, g)
+        ctx.add_reads(reads)
+        st, res, m = _check_against_oracle(oracle, ctx, g, reads, 7, 4, T, R)
+        assert res["objective"] == m.brute_force()[0], (T, R)
+        if T == 0.0:
+            assert res["retained"] == 0 and res["objective"] == 0
+
+
+def test_walks_ending_inside_the_graph(oracle, ctx_factory):
+    """Walks that stop at a vertex with successors must stop there (sink row, ILP_index.cpp:1388-1401)."""
+    rng = np.random.default_rng(123)
+    g = random_graph(rng, n_sites=7, n_walks=4, seg_len=(8, 16))
+    g.paths[1] = g.paths[1][: len(g.paths[1]) // 2]       # ends on an interior vertex
+    g.paths[3] = g.paths[3][: len(g.paths[3]) - 2]
+    reads = mosaic_reads(rng, g, n_reads=40, read_len=28, n_seg=2)
+    for R in (0, 4):
+        ctx = ctx_factory(k=5, w=2, threshold=1.0, recombination=R)
+        _set_graph(ctx, g)
+        ctx.add_reads(reads)
+        st, res, m = _check_against_oracle(oracle, ctx, g, reads, 5, 2, 1.0, R)
+        assert res["objective"] == m.brute_force()[0]
 
 
 def test_streaming_batches_equal_one_batch(oracle, ctx_factory):
