@@ -15,9 +15,10 @@ The graph index (walk sketch + table) is built once before the timed region and 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU; every rank holds the full graph index and its own shard of reads
-(weak scaling: each rank scores one C2-sized read set drawn with its own seed); the only
-data-path collective is the all-reduce of the uint8 hit vector (one byte per distinct walk
-minimiser), as SURVEY.md 8(e) prescribes.
+(weak scaling: each rank scores one C2-sized read set per step, drawn with its own seed).  The path
+has ONE exchange per job: the hit vector (one byte per distinct walk minimiser) is
+a running OR over the batches a rank has scored, so it is all-reduced (MAX, RCCL over xGMI) once,
+after the rank's last batch -- inside the timed region, after the K steps.  No collective per step.
 """
 import argparse
 import json
@@ -64,6 +65,8 @@ def main():
     ap.add_argument("--config", default="C2", help="workload of phi_amd.synth.CONFIGS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N > 1 on ONE GPU for testing: every rank uses cuda:0 and the exchange goes through gloo on the host")
     args = ap.parse_args()
 
     import torch
@@ -84,8 +87,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.rehearse_gloo:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if args.rehearse_gloo else "nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -95,14 +100,20 @@ def main():
     t0 = time.perf_counter()
     g = synth.make_graph(**gk)
     rk = dict(rk)
-    rk["seed"] = rk["seed"] + 1000 * rank                    # each rank scores its own read shard
+    if rank:
+        rk["sample_seed"] = rk["seed"] + 1000 * rank           # each rank scores its own reads of the same sample
     bases, off, truth = synth.make_reads(g, **rk)
     t_gen = time.perf_counter() - t0
     n_reads, n_bases = len(off) - 1, int(off[-1])
 
+    # one explicit stream for everything: the kernels behind the C ABI, torch's copies and the RCCL
+    # collective are ordered on it (torch's default stream is the null stream, which the library
+    # would replace by a private non-blocking one -- unordered against torch)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx = phi_amd.Context(local_rank)
     ctx.set_params(k=K, w=W, threshold=1.0, recombination=100)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream(stream.cuda_stream)
     A = g.arrays()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -113,19 +124,19 @@ def main():
 
     d_bases = torch.from_numpy(bases).to(dev)
     d_off = torch.from_numpy(off).to(dev)
-    hit_t = None
-    if world > 1:                                              # the only data-path collective works on this vector
-        hit_ptr, n_unique = ctx.hits_buffer()
-        hit_t = torch.as_tensor(pdist.DevArray(hit_ptr, n_unique), device=dev)
-
     def step():
         ctx.reset_reads()
         ctx.add_reads_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases)
+
+    def exchange():
+        # the job's one data-path collective: all-reduce (MAX) of the hit vector, in place
         if world > 1:
-            pdist.allreduce_hits(hit_t)
+            hit_ptr, n_unique = ctx.hits_buffer()
+            pdist.allreduce_hits(torch.as_tensor(pdist.DevArray(hit_ptr, n_unique), device=dev))
 
     for _ in range(args.warmup):
         step()
+    exchange()                                                 # warms RCCL up as well
     ctx.prof_read()                                            # drop warmup timings
     ctx.prof_enable(True)
     if world > 1:
@@ -134,13 +145,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    exchange()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_launch, kern_ms, kern_bases = ctx.prof_read()
@@ -158,7 +170,7 @@ def main():
         torch.cuda.synchronize()
         t_solve = time.perf_counter() - t0
         if world > 1:
-            o = torch.tensor([res["objective"], -res["objective"]], dtype=torch.int64, device=dev)
+            o = torch.tensor([res["objective"], -res["objective"]], dtype=torch.int64, device="cpu" if args.rehearse_gloo else dev)
             dist.all_reduce(o, op=dist.ReduceOp.MAX)
             assert int(o[0].item()) == -int(o[1].item()), "ranks disagree on the objective"
 

@@ -47,7 +47,10 @@ int phi_ctx_create(int device_id, phi_ctx **out);
 void phi_ctx_destroy(phi_ctx *ctx);
 
 /* Run all work of this context on the caller's HIP stream (hipStream_t passed as void*);
- * NULL restores the context's private stream. */
+ * NULL restores the context's private stream, which is non-blocking: it is NOT ordered against
+ * the null stream.  A caller that shares buffers with this context (phi_hits_buffer,
+ * phi_add_reads_device, phi_spectrum_export) passes the stream its own work runs on, or
+ * synchronises the device. */
 int phi_set_stream(phi_ctx *ctx, void *hip_stream);
 
 /* Flags of phi_set_params. */
@@ -82,9 +85,9 @@ int phi_add_reads(phi_ctx *ctx, const char *bases, const int64_t *read_off, int6
 int phi_add_reads_device(phi_ctx *ctx, const void *d_bases, const void *d_read_off, int64_t n_reads,
                          int64_t n_bases);
 /* Forget all reads seen so far (graph index is kept).  The clearing itself may be folded into the
- * next batch's first launch; every call that observes the spectrum, the counters or the hit
- * vector sees the reads forgotten, and once phi_hits_buffer has handed the hit-vector pointer out
- * the clearing is launched by this call. */
+ * next batch's first launch; every call on this context that observes the spectrum, the counters
+ * or the hit vector sees the reads forgotten.  A hit-vector pointer obtained earlier from
+ * phi_hits_buffer must not be read between this call and the next phi_add_reads*: fetch it again. */
 int phi_reset_reads(phi_ctx *ctx);
 /* Totals since the last reset (waits for the stream): reads, bases, emitted read minimisers
  * (with multiplicity) and distinct read hashes so far. */
@@ -96,7 +99,8 @@ int phi_reads_stats(phi_ctx *ctx, int64_t *n_reads, int64_t *n_bases, int64_t *n
  * and tells every rank the size of the union spectrum.
  *   phi_hits_buffer     device pointer to uint8 hit[n], n = number of distinct walk minimisers;
  *                       index = dense minimiser id (rank of the hash's first occurrence in walk
- *                       position order), identical on every rank for the same graph
+ *                       position order), identical on every rank for the same graph; valid until
+ *                       the next phi_reset_reads / phi_set_graph on this context
  *   phi_spectrum_export this rank's distinct read hashes: device pointer to uint64[n]
  *                       (valid until the next call on this context)
  *   phi_spectrum_import insert another rank's exported hashes (a device buffer the caller owns)

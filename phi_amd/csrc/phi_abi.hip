@@ -225,7 +225,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     if (adj_off[n_vtx] > 0 && !adj) return phi_fail(c, PHI_ERR_INVALID, "phi_set_graph: adj is null");
     HIPCHK(hipSetDevice(c->device));
     c->have_graph = false;
-    c->reset_pending = false; c->hits_exported = false;
+    c->reset_pending = false;
     c->solved = false;
 
     PhiStageTimer tm("set_graph");
@@ -657,8 +657,6 @@ int phi_reset_reads(phi_ctx *c)
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reset_reads before phi_set_graph");
     HIPCHK(hipSetDevice(c->device));
     c->reset_pending = true;
-    // a caller that holds the hit-vector pointer (phi_hits_buffer) may read it at any time: reset now
-    if (c->hits_exported) PHICHK(phi_flush_reset(c));
     c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
     c->solved = false;
     return PHI_OK;
@@ -685,7 +683,6 @@ int phi_hits_buffer(phi_ctx *c, void **d_hits, int64_t *n)
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_hits_buffer before phi_set_graph");
     HIPCHK(hipSetDevice(c->device));
     PHICHK(phi_flush_reset(c));
-    c->hits_exported = true;
     *d_hits = c->d_hit.p;
     *n = c->n_unique;
     return PHI_OK;

@@ -89,7 +89,6 @@ struct phi_ctx {
     phi_result result{};
     bool solved = false;
     bool reset_pending = false;                       // phi_reset_reads noted, folded into the next batch's launch
-    bool hits_exported = false;                       // phi_hits_buffer handed the pointer out: resets are eager
     int bad_parity = 0;                               // which of the two per-batch bad-base scalars is live
 
     // ---- profiling of the sketch kernel

@@ -190,6 +190,7 @@ template <class F> static void for_covered(const phi_ctx *c, const std::vector<S
 // ------------------------------------------------------------------------------------------ solve
 struct Node {
     std::vector<std::pair<uint32_t, int32_t>> assign;          // minimiser slot -> chosen cluster
+    int64_t ub = INT64_MAX;                                    // bound proven for the parent (holds for the child)
 };
 
 int phi_solve_impl(phi_ctx *c)
@@ -427,7 +428,7 @@ int phi_solve_impl(phi_ctx *c)
         std::set<uint32_t> S;
         std::set<std::set<uint32_t>> seenS;
         bool closed = false;
-        int64_t node_ub = INT64_MAX;
+        int64_t node_ub = node.ub;
         uint32_t branch_slot = 0;
         bool have_branch = false;
         for (int iter = 0; iter < 8 && !closed; iter++) {
@@ -499,15 +500,16 @@ int phi_solve_impl(phi_ctx *c)
             S = S2;
         }
         if (closed) continue;
-        if (exhausted || !have_branch) { open_ub.push_back(node_ub); if (exhausted) break; continue; }
+        if (exhausted || !have_branch) { open_ub.push_back(std::min(node_ub, global_ub)); if (exhausted) break; continue; }
         const auto cl = clusters_of(branch_slot);
         for (int32_t ci = (int32_t)cl.size() - 1; ci >= 0; ci--) {
             Node ch = node;
+            ch.ub = node_ub;
             ch.assign.emplace_back(branch_slot, ci);
             stack.push_back(ch);
         }
     }
-    for (const Node &n : stack) { (void)n; open_ub.push_back(global_ub); }
+    for (const Node &n : stack) open_ub.push_back(std::min(n.ub, global_ub));
     int64_t ub = incumbent;
     for (int64_t u : open_ub) ub = std::max(ub, u);
 

@@ -27,10 +27,20 @@ def shard_bounds(read_off, world, rank):
     return int(cuts[rank]), int(cuts[rank + 1])
 
 
+def _staged():
+    """gloo (CPU tests, single-GPU rehearsals of the N > 1 path) moves device tensors through the host."""
+    return dist.get_backend() == "gloo"
+
+
 def allreduce_hits(hit):
     """In-place MAX all-reduce of the uint8 hit vector (one byte per distinct walk minimiser)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(hit, op=dist.ReduceOp.MAX)
+        if _staged() and hit.is_cuda:
+            h = hit.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            hit.copy_(h)
+        else:
+            dist.all_reduce(hit, op=dist.ReduceOp.MAX)
     return hit
 
 
@@ -40,6 +50,9 @@ def gather_spectra(mine):
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return [mine]
     world = dist.get_world_size()
+    if _staged() and mine.is_cuda:
+        dev = mine.device
+        return [t.to(dev) for t in gather_spectra(mine.cpu())]
     n = torch.tensor([mine.numel()], dtype=torch.int64, device=mine.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)

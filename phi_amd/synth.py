@@ -188,8 +188,10 @@ def make_graph(backbone_len=5_000_000, n_walks=49, seed=4901, site_spacing=250, 
 
 
 def make_reads(g, coverage=1.0, read_len=150, seed=4902, sub_err=0.005, n_mosaic=3, long_reads=False,
-               indel_err=0.0):
-    """Reads from a mosaic of n_mosaic walks.  Returns (uint8 concat, int64 offsets, truth dict)."""
+               indel_err=0.0, sample_seed=None):
+    """Reads from a mosaic of n_mosaic walks.  Returns (uint8 concat, int64 offsets, truth dict).
+    `seed` fixes the sample (which walks, where they are stitched); `sample_seed`, when given,
+    draws another set of reads from the same sample (read shards of the ranks of a multi-GPU job)."""
     rng = np.random.default_rng(seed)
     hs = rng.choice(g.n_walks, size=n_mosaic, replace=False)
     seqs = [g.walk_sequence(int(h)) for h in hs]
@@ -201,6 +203,8 @@ def make_reads(g, coverage=1.0, read_len=150, seed=4902, sub_err=0.005, n_mosaic
         parts.append(s[a:b])
     hap = np.concatenate(parts)
     L = len(hap)
+    if sample_seed is not None:
+        rng = np.random.default_rng(sample_seed)
     target = int(coverage * L)
     if long_reads:
         lens = np.minimum(np.maximum(rng.lognormal(np.log(8000), 0.6, size=max(1, target // 6000)).astype(np.int64), 500), L)

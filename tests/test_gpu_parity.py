@@ -349,6 +349,36 @@ def test_many_switches_backtrack(oracle, ctx_factory):
     assert res["n_switches"] > 64, res["n_switches"]
 
 
+def test_run_cap_reports_a_proven_bound(oracle, ctx_factory):
+    """A hard instance (R = 0, eight walks, short repeats) can exhaust the cap of 256 DP runs: the
+    result then says optimal = 0 and carries a finite bound that the feasible path respects."""
+    from oracle import solve_oracle as S
+    rng = np.random.default_rng(321)
+    g = random_graph(rng, n_sites=400, n_walks=8, seg_len=(8, 16), alt_len=(3, 6), p_del=0.0)
+    succ = {v: sorted(a) for v, a in enumerate(g.adj)}
+    v, truth, site = g.paths[0][0], [], 0
+    while True:
+        truth.append(v)
+        nx = succ[v]
+        if not nx:
+            break
+        v = nx[site % 2] if len(nx) == 2 else nx[0]
+        site += len(nx) == 2
+    hap = b"".join(g.node_seq[x] for x in truth)
+    reads = [hap[a:a + 60] for a in rng.integers(0, len(hap) - 60, size=700)]
+    ctx = ctx_factory(k=7, w=2, threshold=1.0, recombination=0)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads)
+    res = ctx.solve()
+    st = oracle.run_stage12(g, reads, 7, 2, 1.0)
+    m = S.Model(g, st, 0)
+    obj, cov, nsw = m.objective(S.states_from_path(res["path_vtx"], res["path_hap"]))
+    assert obj == res["objective"]
+    assert res["objective"] <= res["upper_bound"] <= res["n_in_model"]
+    assert res["optimal"] == (res["objective"] == res["upper_bound"])
+    assert res["n_dp_runs"] <= 256
+
+
 def test_reset_is_deferred_but_never_visible(oracle, ctx_factory):
     """phi_reset_reads is folded into the next batch's preparation launch; every observer in between
     (stats, hit vector, spectrum export, solve) must still see the reads forgotten."""
@@ -379,12 +409,16 @@ def test_reset_is_deferred_but_never_visible(oracle, ctx_factory):
     assert c.solve()["spectrum_size"] == 0
     c.add_reads(reads)
     c.reset_reads()
-    p, n = c.hits_buffer()                          # from here on resets are eager (the caller holds the pointer)
+    p, n = c.hits_buffer()                          # fetching the pointer applies the pending reset
     hit = torch.as_tensor(pdist.DevArray(p, n), device="cuda")
     torch.cuda.synchronize()
     assert int(hit.sum().item()) == 0
     c.add_reads(reads)
+    torch.cuda.synchronize()
+    assert int(hit.sum().item()) > 0
     c.reset_reads()
+    p2, n2 = c.hits_buffer()                        # by contract the pointer is fetched again after a reset
+    assert (p2, n2) == (p, n)
     torch.cuda.synchronize()
     assert int(hit.sum().item()) == 0
     # reset + other reads == a fresh context with the other reads (twice, to exercise both parities)
