@@ -314,6 +314,17 @@ __device__ __forceinline__ int32_t ev_wave_max_i32(int32_t v)
     return max(max(a, b), max(c, d));
 }
 
+// two independent maxima in one pass: the DPP chains interleave, a lone wave issues them back to back
+__device__ __forceinline__ void ev_wave_max2_i32(int32_t a, int32_t b, int32_t &ma, int32_t &mb)
+{
+    a = max(a, __builtin_amdgcn_update_dpp(a, a, 0x121, 0xF, 0xF, false)); b = max(b, __builtin_amdgcn_update_dpp(b, b, 0x121, 0xF, 0xF, false));
+    a = max(a, __builtin_amdgcn_update_dpp(a, a, 0x122, 0xF, 0xF, false)); b = max(b, __builtin_amdgcn_update_dpp(b, b, 0x122, 0xF, 0xF, false));
+    a = max(a, __builtin_amdgcn_update_dpp(a, a, 0x124, 0xF, 0xF, false)); b = max(b, __builtin_amdgcn_update_dpp(b, b, 0x124, 0xF, 0xF, false));
+    a = max(a, __builtin_amdgcn_update_dpp(a, a, 0x128, 0xF, 0xF, false)); b = max(b, __builtin_amdgcn_update_dpp(b, b, 0x128, 0xF, 0xF, false));
+    ma = max(max(__builtin_amdgcn_readlane(a, 0), __builtin_amdgcn_readlane(a, 16)), max(__builtin_amdgcn_readlane(a, 32), __builtin_amdgcn_readlane(a, 48)));
+    mb = max(max(__builtin_amdgcn_readlane(b, 0), __builtin_amdgcn_readlane(b, 16)), max(__builtin_amdgcn_readlane(b, 32), __builtin_amdgcn_readlane(b, 48)));
+}
+
 __device__ __forceinline__ int4 ev_pack_tops(int32_t t1v, int32_t t1h, int32_t t1n, int32_t t2v, int32_t t2h)
 {
     return make_int4(t1v, t2v, (t1h + 1) | ((t1n + 1) << 10) | ((t2h + 1) << 20), 0);
@@ -560,7 +571,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
     constexpr int D = 16, P = 8;
     constexpr int PER_CHUNK = CHK / P;
     static_assert(P % NPW == 0 && D == 2 * P && CHK % P == 0, "ring geometry");
-    __shared__ int4 s_rec[2][CHK][2];
+    __shared__ int4 s_rec[2 * CHK][2];              // step records: ring of two chunks, index = step mod 2*CHK
     __shared__ int4 s_top[RING];                    // packed tops of recent steps
     __shared__ int2 s_ent[2 * P];                   // (source step, walk) of the entries of the last two periods
     __shared__ uint4 s_ev[D][3][64];
@@ -585,7 +596,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             const int32_t s0 = c * CHK;
             const int32_t ns = min(CHK, n_k - s0);
             const int4 *src = reinterpret_cast<const int4 *>(A.k_rec + (int64_t)s0 * 8);
-            int4 *dst = &s_rec[c & 1][0][0];
+            int4 *dst = &s_rec[(c & 1) * CHK][0];
             for (int i = pw * 64 + h; i < ns * 2; i += 64 * NPW) dst[i] = src[i];
         };
         stage(0);
@@ -653,13 +664,15 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
     // live young runs: deque in LDS; the head (start, value) and the tail key also in registers
     int32_t qh = 0, qn = 0, hs = 0, hE = 0, tk = 0;
     int32_t M = NEGK, sL = 0, Emax = NEG;            // best key of the old runs and its start; best value ever entered
-    int4 ra = s_rec[0][0][0], rb = s_rec[0][0][1];
+    int4 ra = s_rec[0][0], rb = s_rec[0][1];
+    int4 lastq = make_int4(NEG, NEG, 0, 0);          // tops of the latest TOPS step, forwarded in registers
+    int32_t lastk = -1;
 
     for (int p = 0; p < n_per; p++) {
         const int32_t k_end = min(n_k, (p + 1) * P);
         for (int32_t k = p * P; k < k_end; k++) {
-            const int32_t kn = min(k + 1, n_k - 1);
-            const int4 na = s_rec[(kn / CHK) & 1][kn % CHK][0], nb = s_rec[(kn / CHK) & 1][kn % CHK][1];
+            // record of the next step (past the last step: a stale record, never used)
+            const int4 na = s_rec[(k + 1) & (2 * CHK - 1)][0], nb = s_rec[(k + 1) & (2 * CHK - 1)][1];
             const int32_t flags = ra.x;
             const bool active = (int32_t)cA.x == k;
 
@@ -676,7 +689,8 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                 };
                 const uint32_t b0 = (uint32_t)ra.z >> 8, b1 = (uint32_t)ra.w >> 8, b2 = (uint32_t)rb.x >> 8;
                 if (n_in == 1 && b0 < RING) {
-                    const int4 q = s_top[(k - b0) & (RING - 1)];
+                    const int32_t src = k - (int32_t)b0;
+                    const int4 q = src == lastk ? lastq : s_top[src & (RING - 1)];
                     const int32_t t1h = (q.z & 0x3FF) - 1, t1n = ((q.z >> 10) & 0x3FF) - 1, t2h = ((q.z >> 20) & 0x3FF) - 1;
                     const bool cont = t1n == (ra.z & 0xFF);
                     const int32_t hh = cont ? t2h : t1h;
@@ -761,16 +775,31 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             if (flags & PHI_DP_NEED_TOPS) {
                 const bool leaving = active && oidx != 255 && dmax > NEG / 2;
                 int32_t t1v = NEG, t1h = -1, t1n = -1, t2v = NEG, t2h = -1;
-                const int32_t m1 = ev_wave_max_i32(leaving ? dmax : NEG);
-                if (m1 > NEG / 2) {
-                    const int l1 = __ffsll((long long)__ballot(leaving && dmax == m1)) - 1;
-                    t1v = m1; t1h = l1;
-                    t1n = __builtin_amdgcn_readlane(oidx, l1);
-                    const bool other = leaving && oidx != t1n;
-                    const int32_t m2 = ev_wave_max_i32(other ? dmax : NEG);
-                    if (m2 > NEG / 2) { t2v = m2; t2h = __ffsll((long long)__ballot(other && dmax == m2)) - 1; }
+                if (__ballot(leaving && oidx > 1) == 0ull) {
+                    // at most two out-edges in use (a bubble): best walk per edge, two independent reductions
+                    const bool on0 = leaving && oidx == 0, on1 = leaving && oidx == 1;
+                    int32_t m0, m1;
+                    ev_wave_max2_i32(on0 ? dmax : NEG, on1 ? dmax : NEG, m0, m1);
+                    const int l0 = m0 > NEG / 2 ? __ffsll((long long)__ballot(on0 && dmax == m0)) - 1 : -1;
+                    const int l1 = m1 > NEG / 2 ? __ffsll((long long)__ballot(on1 && dmax == m1)) - 1 : -1;
+                    // top1: larger value, then the lower walk id; top2: the best on the other edge
+                    const bool first0 = l0 >= 0 && (l1 < 0 || m0 > m1 || (m0 == m1 && l0 < l1));
+                    if (first0) { t1v = m0; t1h = l0; t1n = 0; if (l1 >= 0) { t2v = m1; t2h = l1; } }
+                    else if (l1 >= 0) { t1v = m1; t1h = l1; t1n = 1; if (l0 >= 0) { t2v = m0; t2h = l0; } }
+                } else {
+                    const int32_t m1 = ev_wave_max_i32(leaving ? dmax : NEG);
+                    if (m1 > NEG / 2) {
+                        const int l1 = __ffsll((long long)__ballot(leaving && dmax == m1)) - 1;
+                        t1v = m1; t1h = l1;
+                        t1n = __builtin_amdgcn_readlane(oidx, l1);
+                        const bool other = leaving && oidx != t1n;
+                        const int32_t m2 = ev_wave_max_i32(other ? dmax : NEG);
+                        if (m2 > NEG / 2) { t2v = m2; t2h = __ffsll((long long)__ballot(other && dmax == m2)) - 1; }
+                    }
                 }
-                if (h == 0) s_top[k & (RING - 1)] = ev_pack_tops(t1v, t1h, t1n, t2v, t2h);
+                lastq = ev_pack_tops(t1v, t1h, t1n, t2v, t2h);
+                lastk = k;
+                if (h == 0) s_top[k & (RING - 1)] = lastq;
             }
             ra = na; rb = nb;
         }
