@@ -20,9 +20,11 @@
 #include <string.h>
 #include <zlib.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <queue>
 #include <string>
-#include <unordered_map>
+#include <thread>
 #include <vector>
 #include "../../../include/phi_host.h"
 
@@ -44,53 +46,136 @@ static int fail(char *err, int cap, int code, const char *fmt, ...)
     return code;
 }
 
-// whole lines from a (possibly gzip-compressed) file
-class LineReader {
-public:
-    explicit LineReader(const char *path) { fp_ = gzopen(path, "r"); if (fp_) gzbuffer(fp_, 1 << 20); }
-    ~LineReader() { if (fp_) gzclose(fp_); }
-    bool ok() const { return fp_ != nullptr; }
-    bool next(std::string &line)
-    {
-        line.clear();
-        bool got = false;
-        for (;;) {
-            if (pos_ == len_) {
-                len_ = gzread(fp_, buf_, sizeof buf_);
-                pos_ = 0;
-                if (len_ <= 0) { len_ = 0; break; }
-            }
-            got = true;
-            const char *nl = (const char *)memchr(buf_ + pos_, '\n', (size_t)(len_ - pos_));
-            if (nl) {
-                line.append(buf_ + pos_, (size_t)(nl - (buf_ + pos_)));
-                pos_ = (int)(nl - buf_) + 1;
-                if (!line.empty() && line.back() == '\r') line.pop_back();
+// the whole (possibly gzip-compressed) file in memory; lines and fields are slices of it
+static bool slurp(const char *path, std::vector<char> &buf)
+{
+    // plain files: one read of the whole file; gzip (magic 1f 8b): inflate through zlib
+    if (FILE *fp = fopen(path, "rb")) {
+        unsigned char magic[2] = {0, 0};
+        const size_t got = fread(magic, 1, 2, fp);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(fp, 0, SEEK_END) == 0) {
+            const long sz = ftell(fp);
+            if (sz >= 0) {
+                rewind(fp);
+                buf.resize((size_t)sz);
+                const size_t n = sz ? fread(buf.data(), 1, (size_t)sz, fp) : 0;
+                fclose(fp);
+                buf.resize(n);
                 return true;
             }
-            line.append(buf_ + pos_, (size_t)(len_ - pos_));
-            pos_ = len_;
         }
-        if (!got) return false;                       // end of file
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        return true;                                  // last line without a newline
+        fclose(fp);
+    } else {
+        return false;
     }
-private:
-    gzFile fp_ = nullptr;
-    char buf_[1 << 16];
-    int pos_ = 0, len_ = 0;
+    gzFile fp = gzopen(path, "r");
+    if (!fp) return false;
+    gzbuffer(fp, 1 << 20);
+    size_t len = 0;
+    buf.resize((size_t)1 << 22);
+    for (;;) {
+        if (buf.size() - len < ((size_t)1 << 20)) buf.resize(buf.size() * 2);
+        const int n = gzread(fp, buf.data() + len, (unsigned)std::min<size_t>(buf.size() - len, (size_t)1 << 30));
+        if (n <= 0) break;
+        len += (size_t)n;
+    }
+    gzclose(fp);
+    buf.resize(len);
+    return true;
+}
+
+struct Slice { const char *p; size_t n; };
+
+// PHI_TIMING=1: stage timings on stderr
+struct StageTimer {
+    bool on = getenv("PHI_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *stage)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[phi timing] gfa_read: %-28s %8.3f ms\n", stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
 };
 
-static void split_tabs(const std::string &s, std::vector<std::pair<const char *, size_t>> &f)
-{
-    f.clear();
-    size_t a = 0;
-    for (;;) {
-        size_t b = s.find('\t', a);
-        if (b == std::string::npos) { f.emplace_back(s.data() + a, s.size() - a); break; }
-        f.emplace_back(s.data() + a, b - a);
-        a = b + 1;
+// segment name -> id: open addressing over slices of the file buffer
+class NameTable {
+public:
+    NameTable() { grow(1 << 16); }
+    static uint64_t hash(const char *p, size_t n)
+    {
+        uint64_t h = 0xcbf29ce484222325ull ^ (n * 0x9E3779B97F4A7C15ull);
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = (h ^ w) * 0x100000001b3ull; h ^= h >> 29; }
+        uint64_t w = 0;
+        if (i < n) { memcpy(&w, p + i, n - i); h = (h ^ w) * 0x100000001b3ull; }
+        h ^= h >> 32; h *= 0xd6e8feb86659fd93ull; h ^= h >> 32;
+        return h;
     }
+    int32_t find(const char *p, size_t n) const
+    {
+        for (size_t i = hash(p, n) & mask_;; i = (i + 1) & mask_) {
+            const int32_t id = slot_[i];
+            if (id < 0) return -1;
+            const Slice &k = keys_[id];
+            if (k.n == n && memcmp(k.p, p, n) == 0) return id;
+        }
+    }
+    int32_t add(const char *p, size_t n)            // id of an existing or new name
+    {
+        const int32_t f = find(p, n);
+        if (f >= 0) return f;
+        if ((keys_.size() + 1) * 2 > slot_.size()) grow(slot_.size() * 2);
+        const int32_t id = (int32_t)keys_.size();
+        keys_.push_back(Slice{p, n});
+        insert(id);
+        return id;
+    }
+    const std::vector<Slice> &keys() const { return keys_; }
+private:
+    void insert(int32_t id)
+    {
+        size_t i = hash(keys_[id].p, keys_[id].n) & mask_;
+        while (slot_[i] >= 0) i = (i + 1) & mask_;
+        slot_[i] = id;
+    }
+    void grow(size_t cap)
+    {
+        slot_.assign(cap, -1);
+        mask_ = cap - 1;
+        for (int32_t id = 0; id < (int32_t)keys_.size(); id++) insert(id);
+    }
+    std::vector<int32_t> slot_;
+    std::vector<Slice> keys_;
+    size_t mask_ = 0;
+};
+
+// fields of a line: up to cap tab-separated slices
+static int split_tabs(const char *p, const char *e, Slice *f, int cap)
+{
+    int n = 0;
+    while (n < cap) {
+        const char *t = (const char *)memchr(p, '\t', (size_t)(e - p));
+        if (!t || n == cap - 1) { f[n++] = Slice{p, (size_t)(e - p)}; break; }
+        f[n++] = Slice{p, (size_t)(t - p)};
+        p = t + 1;
+    }
+    return n;
+}
+
+template <class F> static void parallel_for(int n, F fn)
+{
+    int nt = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("PHI_HOST_THREADS")) nt = atoi(e);
+    nt = std::max(1, std::min(std::min(nt, 32), n));
+    if (nt == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
 }
 
 extern "C" {
@@ -99,88 +184,108 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
 {
     if (!path || !out) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "null argument");
     *out = nullptr;
-    LineReader in(path);
-    if (!in.ok()) return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to load the GFA file %s", path);
+    StageTimer tm;
+    std::vector<char> buf;
+    if (!slurp(path, buf)) return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to load the GFA file %s", path);
+    tm.lap("read / inflate");
 
-    std::unordered_map<std::string, int32_t> name2id;
-    std::vector<std::string> names, seqs;
+    NameTable table;
+    std::vector<Slice> seqs;                                         // per segment; n = 0: no sequence
     std::vector<char> has_seq;
     std::vector<std::pair<uint32_t, uint32_t>> arcs;                 // oriented vertices v = seg<<1 | strand
-    struct Walk { std::string sample; int hap; std::vector<uint32_t> v; };
+    struct Walk { std::string sample; int hap; std::vector<uint32_t> v; Slice text; int32_t n_known; bool any_rev = false; };
     std::vector<Walk> walks;
-    auto add_seg = [&](const char *p, size_t n) {
-        std::string key(p, n);
-        auto it = name2id.find(key);
-        if (it != name2id.end()) return it->second;
-        const int32_t id = (int32_t)names.size();
-        name2id.emplace(key, id);
-        names.push_back(std::move(key));
-        seqs.emplace_back();
-        has_seq.push_back(0);
+    auto add_seg = [&](const Slice &f) {
+        const int32_t id = table.add(f.p, f.n);
+        if ((size_t)id == seqs.size()) { seqs.push_back(Slice{nullptr, 0}); has_seq.push_back(0); }
         return id;
     };
 
-    std::string line;
-    std::vector<std::pair<const char *, size_t>> f;
-    while (in.next(line)) {
-        if (line.size() < 3 || line[1] != '\t') continue;
-        const char t = line[0];
-        if (t != 'S' && t != 'L' && t != 'W') continue;
-        split_tabs(line, f);
-        if (t == 'S' && f.size() >= 3) {
-            const int32_t id = add_seg(f[1].first, f[1].second);
-            if (f[2].second > 0 && f[2].first[0] != '*') { seqs[id].assign(f[2].first, f[2].second); has_seq[id] = 1; }
-            else { seqs[id].clear(); has_seq[id] = 0; }
-        } else if (t == 'L' && f.size() >= 5) {
-            if (f[2].second != 1 || f[4].second != 1) continue;
-            const char ov = f[2].first[0], ow = f[4].first[0];
-            if ((ov != '+' && ov != '-') || (ow != '+' && ow != '-')) continue;
-            const uint32_t v = (uint32_t)add_seg(f[1].first, f[1].second) << 1 | (ov != '+');
-            const uint32_t w = (uint32_t)add_seg(f[3].first, f[3].second) << 1 | (ow != '+');
-            arcs.emplace_back(v, w);
-        } else if (t == 'W' && f.size() >= 7) {
-            Walk wk;
-            wk.sample.assign(f[1].first, f[1].second);
-            wk.hap = atoi(std::string(f[2].first, f[2].second).c_str());
-            const char *s = f[6].first;
-            const size_t n = f[6].second;
-            size_t i = 0;
-            while (i < n) {
-                if (s[i] == '>' || s[i] == '<') {
-                    size_t j = i + 1;
-                    while (j < n && s[j] != '>' && s[j] != '<') j++;
-                    auto it = name2id.find(std::string(s + i + 1, j - i - 1));
-                    if (it != name2id.end()) wk.v.push_back((uint32_t)it->second << 1 | (s[i] == '<'));
-                    i = j;
-                } else i++;
+    const char *p = buf.data(), *const end = buf.data() + buf.size();
+    Slice f[8];
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *next = nl ? nl + 1 : end;
+        if (le > p && le[-1] == '\r') le--;
+        if (le - p >= 3 && p[1] == '\t' && (p[0] == 'S' || p[0] == 'L' || p[0] == 'W')) {
+            const char t = p[0];
+            const int nf = split_tabs(p, le, f, t == 'W' ? 8 : 6);
+            if (t == 'S' && nf >= 3) {
+                const int32_t id = add_seg(f[1]);
+                if (f[2].n > 0 && f[2].p[0] != '*') { seqs[id] = f[2]; has_seq[id] = 1; }
+                else { seqs[id] = Slice{nullptr, 0}; has_seq[id] = 0; }
+            } else if (t == 'L' && nf >= 5) {
+                if (f[2].n == 1 && f[4].n == 1) {
+                    const char ov = f[2].p[0], ow = f[4].p[0];
+                    if ((ov == '+' || ov == '-') && (ow == '+' || ow == '-')) {
+                        const uint32_t v = (uint32_t)add_seg(f[1]) << 1 | (ov != '+');
+                        const uint32_t w = (uint32_t)add_seg(f[3]) << 1 | (ow != '+');
+                        arcs.emplace_back(v, w);
+                    }
+                }
+            } else if (t == 'W' && nf >= 7) {
+                Walk wk;
+                wk.sample.assign(f[1].p, f[1].n);
+                wk.hap = atoi(std::string(f[2].p, f[2].n).c_str());
+                wk.text = f[6];
+                wk.n_known = (int32_t)seqs.size();           // names are resolved against the segments seen so far
+                walks.push_back(std::move(wk));
             }
-            walks.push_back(std::move(wk));
         }
+        p = next;
     }
+    tm.lap("S / L lines");
+    // the walks' vertex lists: one host thread per W-line
+    parallel_for((int)walks.size(), [&](int wi) {
+        Walk &wk = walks[wi];
+        const char *s = wk.text.p;
+        const size_t n = wk.text.n;
+        wk.v.reserve(n / 4 + 4);
+        size_t i = 0;
+        while (i < n) {
+            if (s[i] == '>' || s[i] == '<') {
+                size_t j = i + 1;
+                while (j < n && s[j] != '>' && s[j] != '<' && s[j] != '\t') j++;
+                const int32_t id = table.find(s + i + 1, j - i - 1);
+                if (id >= 0 && id < wk.n_known) {
+                    wk.v.push_back((uint32_t)id << 1 | (s[i] == '<'));
+                    wk.any_rev |= s[i] == '<';
+                }
+                i = j;
+            } else if (s[i] == '\t') break;                // optional tags after the walk
+            else i++;
+        }
+    });
+    const std::vector<Slice> &names = table.keys();
+    tm.lap("W lines (threads)");
 
     const int32_t n_seg = (int32_t)names.size();
     // gfa_walk_flip: the first walk to touch a segment fixes its strand; a walk that disagrees
     // with the majority of its vertices is reverse-complemented
-    {
+    bool any_rev = false;
+    for (const Walk &w : walks) any_rev |= w.any_rev;
+    if (any_rev) {                                     // all-forward walks agree with every first touch: nothing to flip
         std::vector<int8_t> strand(n_seg, 0);
         for (const Walk &w : walks)
             for (uint32_t v : w.v)
                 if (strand[v >> 1] == 0) strand[v >> 1] = (v & 1) ? -1 : 1;
-        for (Walk &w : walks) {
+        parallel_for((int)walks.size(), [&](int wi) {
+            Walk &w = walks[wi];
             int64_t agree = 0;
             for (uint32_t v : w.v) agree += (((v & 1) ? -1 : 1) == strand[v >> 1]);
-            if (agree >= (int64_t)w.v.size() - agree) continue;
+            if (agree >= (int64_t)w.v.size() - agree) return;
             std::reverse(w.v.begin(), w.v.end());
             for (uint32_t &v : w.v) v ^= 1;
-        }
+        });
     }
     // arcs: drop those touching a sequence-less segment, add complements, merge duplicates
     {
         std::vector<std::pair<uint32_t, uint32_t>> all;
         all.reserve(arcs.size() * 2);
         for (auto &a : arcs) {
-            if (!has_seq[a.first >> 1] || seqs[a.first >> 1].empty()) continue;
-            if (!has_seq[a.second >> 1] || seqs[a.second >> 1].empty()) continue;
+            if (!has_seq[a.first >> 1] || seqs[a.first >> 1].n == 0) continue;
+            if (!has_seq[a.second >> 1] || seqs[a.second >> 1].n == 0) continue;
             all.push_back(a);
             all.emplace_back(a.second ^ 1, a.first ^ 1);
         }
@@ -189,12 +294,14 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
         arcs.swap(all);
     }
 
+    tm.lap("walk flips, arcs");
     phi_graph *g = new phi_graph();
-    g->seg_names = names;
+    g->seg_names.reserve(n_seg);
+    for (int32_t i = 0; i < n_seg; i++) g->seg_names.emplace_back(names[i].p, names[i].n);
     g->seq_off.assign(n_seg + 1, 0);
-    for (int32_t i = 0; i < n_seg; i++) g->seq_off[i + 1] = g->seq_off[i] + (int64_t)seqs[i].size();
-    g->seq_concat.reserve((size_t)g->seq_off[n_seg]);
-    for (int32_t i = 0; i < n_seg; i++) g->seq_concat += seqs[i];
+    for (int32_t i = 0; i < n_seg; i++) g->seq_off[i + 1] = g->seq_off[i] + (int64_t)seqs[i].n;
+    g->seq_concat.resize((size_t)g->seq_off[n_seg]);
+    for (int32_t i = 0; i < n_seg; i++) if (seqs[i].n) memcpy(&g->seq_concat[(size_t)g->seq_off[i]], seqs[i].p, seqs[i].n);
     g->adj_off.assign(n_seg + 1, 0);
     for (auto &a : arcs) if (!(a.first & 1)) g->adj_off[(a.first >> 1) + 1]++;
     for (int32_t i = 0; i < n_seg; i++) g->adj_off[i + 1] += g->adj_off[i];
@@ -217,17 +324,35 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
     }
     g->walk_off.assign(walks.size() + 1, 0);
     for (size_t w = 0; w < walks.size(); w++) {
-        for (uint32_t v : walks[w].v) {
-            if (v & 1) {
-                const int code = fail(err, err_cap, PHI_HOST_ERR_WALK, "Error: Walk %d has reverse strand vertices %u", (int)w, v);
-                delete g;
-                return code;
-            }
-            g->walk_vtx.push_back((int32_t)(v >> 1));
-        }
-        g->walk_off[w + 1] = (int64_t)g->walk_vtx.size();
+        g->walk_off[w + 1] = g->walk_off[w] + (int64_t)walks[w].v.size();
         g->hap_names.push_back(walks[w].sample + "." + std::to_string(walks[w].hap));
     }
+    g->walk_vtx.resize((size_t)g->walk_off[walks.size()]);
+    {
+        std::atomic<int64_t> bad{-1};                  // (walk << 32 | vertex) of the first reverse-strand vertex
+        parallel_for((int)walks.size(), [&](int wi) {
+            int32_t *dst = g->walk_vtx.data() + g->walk_off[wi];
+            const std::vector<uint32_t> &v = walks[wi].v;
+            for (size_t i = 0; i < v.size(); i++) {
+                if (v[i] & 1) {
+                    int64_t expect = -1;
+                    bad.compare_exchange_strong(expect, (int64_t)wi << 32 | v[i]);
+                    return;
+                }
+                dst[i] = (int32_t)(v[i] >> 1);
+            }
+        });
+        int64_t first = -1;                            // report the lowest walk, as the sequential loop did
+        if (bad.load() >= 0)
+            for (size_t w = 0; w < walks.size() && first < 0; w++)
+                for (uint32_t v : walks[w].v) if (v & 1) { first = (int64_t)w << 32 | v; break; }
+        if (first >= 0) {
+            const int code = fail(err, err_cap, PHI_HOST_ERR_WALK, "Error: Walk %d has reverse strand vertices %u", (int)(first >> 32), (uint32_t)first);
+            delete g;
+            return code;
+        }
+    }
+    tm.lap("arrays");
     // Kahn's algorithm, FIFO
     {
         std::vector<int32_t> indeg(n_seg, 0);
@@ -249,6 +374,7 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
             return code;
         }
     }
+    tm.lap("topological order");
     *out = g;
     return PHI_HOST_OK;
 }

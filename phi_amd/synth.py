@@ -243,6 +243,43 @@ def make_reads(g, coverage=1.0, read_len=150, seed=4902, sub_err=0.005, n_mosaic
     return bases, off, dict(walks=hs.tolist(), cuts=cuts.tolist(), hap_len=L)
 
 
+def write_gfa(g, path):
+    """GFA 1.1 with S, L (0M overlaps, forward strands) and W lines -- what the reference's reader and
+    phi_gfa_read accept.  Segment names are 1-based vertex ids."""
+    import gzip
+    op = gzip.open if str(path).endswith(".gz") else open
+    with op(path, "wb") as f:
+        f.write(b"H\tVN:Z:1.1\n")
+        so = g.seq_off
+        raw = g.seq_concat.tobytes()
+        for v in range(g.n_vtx):
+            f.write(b"S\t%d\t%s\n" % (v + 1, raw[so[v]:so[v + 1]]))
+        for u in range(g.n_vtx):
+            for x in range(g.adj_off[u], g.adj_off[u + 1]):
+                f.write(b"L\t%d\t+\t%d\t+\t0M\n" % (u + 1, g.adj[x] + 1))
+        for h in range(g.n_walks):
+            vs = g.walk_vtx[g.walk_off[h]:g.walk_off[h + 1]]
+            name = g.hap_names[h] if h < len(g.hap_names) else f"hap{h}.0"
+            sample, _, hap = name.rpartition(".")
+            f.write(b"W\t%s\t%s\tchr\t0\t%d\t" % (sample.encode(), hap.encode() or b"0", int((so[vs + 1] - so[vs]).sum())))
+            f.write(b"".join(b">%d" % (v + 1) for v in vs.tolist()))
+            f.write(b"\n")
+
+
+def write_reads(bases, off, path, fastq=False):
+    """Reads as FASTA (or FASTQ with constant qualities), optionally gzipped by extension."""
+    import gzip
+    op = gzip.open if str(path).endswith(".gz") else open
+    raw = bases.tobytes()
+    with op(path, "wb") as f:
+        for r in range(len(off) - 1):
+            s = raw[off[r]:off[r + 1]]
+            if fastq:
+                f.write(b"@r%d\n%s\n+\n%s\n" % (r, s, b"I" * len(s)))
+            else:
+                f.write(b">r%d\n%s\n" % (r, s))
+
+
 CONFIGS = {
     # name: (graph kwargs, reads kwargs) -- SURVEY.md 8(d) table
     "C2": (dict(backbone_len=5_000_000, n_walks=49, seed=4901), dict(coverage=1.0, seed=4902)),

@@ -79,6 +79,46 @@ def test_cli_toy_and_python_mirror_agree(tmp_path):
         assert line in py_log and line in r.stderr
 
 
+def test_cli_on_synthetic_files(tmp_path):
+    """The synthetic stand-in written as GFA 1.1 (S/L/W, gz) + FASTQ (gz): the command line, the
+    Python mirror on the same files and the array API on the generator's own arrays agree."""
+    import numpy as np
+    import phi_amd
+    from phi_amd import ilp_index as H
+    from phi_amd import synth
+    gk, rk = synth.CONFIGS["tiny"]
+    g = synth.make_graph(**gk)
+    bases, off, truth = synth.make_reads(g, **rk)
+    gfa, rd = str(tmp_path / "tiny.gfa.gz"), str(tmp_path / "tiny_reads.fq.gz")
+    synth.write_gfa(g, gfa)
+    synth.write_reads(bases, off, rd, fastq=True)
+    out = tmp_path / "tiny.fa"
+    r = _run_cli(["-t8", "-g", gfa, "-r", rd, "-o", str(out), "-R", "10"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert f"Graph has {g.n_vtx} vertices, {g.n_walks} walks and read has {len(off) - 1} reads" in r.stderr
+    cli_fa = out.read_text()
+    idx = H.ILP_index(gfa, log=io.StringIO())
+    idx.read_gfa()
+    idx.recombination = 10
+    idx.hap_file = str(tmp_path / "tiny_py.fa")
+    idx.hap_name = H.get_hap_name(gfa, rd)
+    reads = []
+    idx.read_ip_reads(reads, rd)
+    assert len(reads) == len(off) - 1
+    res = idx.ILP_function(reads)
+    assert open(idx.hap_file).read() == cli_fa
+    # the array API on the generator's arrays (other vertex numbering, same optimum)
+    ctx = phi_amd.Context(0)
+    ctx.set_params(k=31, w=25, threshold=1.0, recombination=10)
+    A = g.arrays()
+    ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
+    ctx.add_reads((bases, off))
+    res2 = ctx.solve()
+    ctx.close()
+    assert res2["objective"] == res["objective"] and res2["spectrum_size"] == res["spectrum_size"]
+    assert res2["optimal"] == 1
+
+
 def test_cli_errors(tmp_path):
     r = _run_cli([], tmp_path)
     assert r.returncode == 1 and r.stderr.startswith("Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta>")
