@@ -168,7 +168,7 @@ template <class F> static void parallel_for(int n, F fn)
 {
     int nt = (int)std::thread::hardware_concurrency();
     if (const char *e = getenv("PHI_HOST_THREADS")) nt = atoi(e);
-    nt = std::max(1, std::min(std::min(nt, 32), n));
+    nt = std::max(1, std::min(std::min(nt, 16), n));
     if (nt == 1) { for (int i = 0; i < n; i++) fn(i); return; }
     std::atomic<int> next{0};
     auto work = [&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };

@@ -9,14 +9,16 @@
 #include <stdio.h>
 #include <string.h>
 #include <zlib.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "../../../include/phi_host.h"
 
 struct phi_reads {
-    std::string bases;
+    std::vector<char> bases;
     std::vector<int64_t> off{0};
-    std::vector<std::string> names;
+    std::vector<char> names;                          // NUL-terminated names back to back
+    std::vector<int64_t> name_off;
 };
 
 static int fail(char *err, int cap, int code, const char *fmt, ...)
@@ -31,41 +33,52 @@ static int fail(char *err, int cap, int code, const char *fmt, ...)
 }
 
 namespace {
-class Lines {
-public:
-    explicit Lines(const char *path) { fp_ = gzopen(path, "r"); if (fp_) gzbuffer(fp_, 1 << 20); }
-    ~Lines() { if (fp_) gzclose(fp_); }
-    bool ok() const { return fp_ != nullptr; }
-    bool next(std::string &line)
-    {
-        line.clear();
-        bool got = false;
-        for (;;) {
-            if (pos_ == len_) {
-                len_ = gzread(fp_, buf_, sizeof buf_);
-                pos_ = 0;
-                if (len_ <= 0) { len_ = 0; break; }
-            }
-            got = true;
-            const char *nl = (const char *)memchr(buf_ + pos_, '\n', (size_t)(len_ - pos_));
-            if (nl) {
-                line.append(buf_ + pos_, (size_t)(nl - (buf_ + pos_)));
-                pos_ = (int)(nl - buf_) + 1;
-                if (!line.empty() && line.back() == '\r') line.pop_back();
+// the whole (possibly gzip-compressed) file in memory
+bool slurp(const char *path, std::vector<char> &buf)
+{
+    if (FILE *fp = fopen(path, "rb")) {
+        unsigned char magic[2] = {0, 0};
+        const size_t got = fread(magic, 1, 2, fp);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(fp, 0, SEEK_END) == 0) {
+            const long sz = ftell(fp);
+            if (sz >= 0) {
+                rewind(fp);
+                buf.resize((size_t)sz);
+                const size_t n = sz ? fread(buf.data(), 1, (size_t)sz, fp) : 0;
+                fclose(fp);
+                buf.resize(n);
                 return true;
             }
-            line.append(buf_ + pos_, (size_t)(len_ - pos_));
-            pos_ = len_;
         }
-        if (!got) return false;
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        return true;
+        fclose(fp);
+    } else {
+        return false;
     }
-private:
-    gzFile fp_ = nullptr;
-    char buf_[1 << 16];
-    int pos_ = 0, len_ = 0;
-};
+    gzFile fp = gzopen(path, "r");
+    if (!fp) return false;
+    gzbuffer(fp, 1 << 20);
+    size_t len = 0;
+    buf.resize((size_t)1 << 22);
+    for (;;) {
+        if (buf.size() - len < ((size_t)1 << 20)) buf.resize(buf.size() * 2);
+        const int n = gzread(fp, buf.data() + len, (unsigned)std::min<size_t>(buf.size() - len, (size_t)1 << 30));
+        if (n <= 0) break;
+        len += (size_t)n;
+    }
+    gzclose(fp);
+    buf.resize(len);
+    return true;
+}
+
+// one line [p, e) of the buffer (without the newline / a trailing CR); returns the start of the next
+inline const char *next_line(const char *p, const char *end, const char *&e)
+{
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    e = nl ? nl : end;
+    const char *nx = nl ? nl + 1 : end;
+    if (e > p && e[-1] == '\r') e--;
+    return nx;
+}
 }  // namespace
 
 extern "C" {
@@ -74,41 +87,59 @@ int phi_reads_read(const char *path, phi_reads **out, char *err, int err_cap)
 {
     if (!path || !out) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "null argument");
     *out = nullptr;
-    Lines in(path);
-    if (!in.ok()) return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to open the reads file %s", path);
+    std::vector<char> buf;
+    if (!slurp(path, buf)) return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to open the reads file %s", path);
     phi_reads *r = new phi_reads();
-    std::string line;
-    bool have = in.next(line);
+    r->bases.resize(buf.size());                      // the bases are a subset of the file's bytes
+    char *bases = r->bases.data();
+    size_t nb = 0;
+    const char *p = buf.data(), *const end = buf.data() + buf.size();
+    const char *e = p;
+    bool have = p < end;
+    const char *line = p;
+    if (have) p = next_line(p, end, e);
+    auto advance = [&]() { have = p < end; line = p; if (have) p = next_line(p, end, e); };
     while (have) {
-        if (line.empty() || (line[0] != '>' && line[0] != '@')) { have = in.next(line); continue; }
-        size_t a = 1, b = 1;
-        while (b < line.size() && !isspace((unsigned char)line[b])) b++;
-        r->names.emplace_back(line, a, b - a);
-        const size_t start = r->bases.size();
-        have = in.next(line);
-        while (have && (line.empty() || (line[0] != '>' && line[0] != '@' && line[0] != '+'))) {
-            for (char ch : line) if (isgraph((unsigned char)ch)) r->bases.push_back(ch);
-            have = in.next(line);
+        if (e == line || (line[0] != '>' && line[0] != '@')) { advance(); continue; }
+        const char *b = line + 1;
+        while (b < e && !isspace((unsigned char)*b)) b++;
+        r->name_off.push_back((int64_t)r->names.size());
+        r->names.insert(r->names.end(), line + 1, b);
+        r->names.push_back('\0');
+        const size_t start = nb;
+        advance();
+        while (have && (e == line || (line[0] != '>' && line[0] != '@' && line[0] != '+'))) {
+            const size_t n = (size_t)(e - line);
+            memcpy(bases + nb, line, n);
+            unsigned bad = 0;
+            for (size_t i = 0; i < n; i++) bad |= (unsigned)((unsigned char)line[i] - 33) > 93u;   // not isgraph
+            if (bad) {
+                size_t k = nb;
+                for (size_t i = 0; i < n; i++) if (isgraph((unsigned char)line[i])) bases[k++] = line[i];
+                nb = k;
+            } else nb += n;
+            advance();
         }
-        const size_t len = r->bases.size() - start;
-        r->off.push_back((int64_t)r->bases.size());
+        const size_t len = nb - start;
+        r->off.push_back((int64_t)nb);
         if (have && line[0] == '+') {                 // FASTQ: skip the quality block
             size_t q = 0;
-            have = in.next(line);
-            while (have && q < len) { q += line.size(); have = in.next(line); }
+            advance();
+            while (have && q < len) { q += (size_t)(e - line); advance(); }
         }
     }
+    r->bases.resize(nb);
     *out = r;
     return PHI_HOST_OK;
 }
 
 void phi_reads_free(phi_reads *r) { delete r; }
-int64_t phi_reads_count(const phi_reads *r) { return (int64_t)r->names.size(); }
+int64_t phi_reads_count(const phi_reads *r) { return (int64_t)r->name_off.size(); }
 const char *phi_reads_bases(const phi_reads *r) { return r->bases.data(); }
 const int64_t *phi_reads_off(const phi_reads *r) { return r->off.data(); }
 const char *phi_reads_name(const phi_reads *r, int64_t i)
 {
-    return (i >= 0 && i < (int64_t)r->names.size()) ? r->names[(size_t)i].c_str() : "";
+    return (i >= 0 && i < (int64_t)r->name_off.size()) ? r->names.data() + r->name_off[(size_t)i] : "";
 }
 
 int phi_hap_name(const char *gfa_path, const char *reads_path, char *out, int cap)

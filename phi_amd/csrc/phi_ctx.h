@@ -127,7 +127,7 @@ static inline int phi_host_threads()
     const char *e = getenv("PHI_HOST_THREADS");
     int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
     if (n < 1) n = 1;
-    return n > 32 ? 32 : n;
+    return n > 16 ? 16 : n;
 }
 
 // fn(lo, hi) over [0, n) in chunks handed out dynamically
