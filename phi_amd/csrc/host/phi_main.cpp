@@ -16,6 +16,7 @@
 #include <sys/resource.h>
 #include <sys/time.h>
 #include <string>
+#include <future>
 #include <vector>
 #include "../../../include/phi_amd.h"
 #include "../../../include/phi_host.h"
@@ -100,42 +101,51 @@ int main(int argc, char *argv[])
     t0_real = realtime();
     char err[512] = "";
 
+    // The device context (HIP initialisation) and the reads file are prepared by two host threads
+    // while this one parses the graph: the three are independent.
+    phi_ctx *ctx = nullptr;
+    std::future<int> f_ctx = std::async(std::launch::async, [&]() { return phi_ctx_create(device, &ctx); });
+    phi_reads *rd = nullptr;
+    char rerr[512] = "";
+    std::future<int> f_reads = std::async(std::launch::async, [&]() { return phi_reads_read(reads_file.c_str(), &rd, rerr, sizeof rerr); });
+
     // ---- graph (main.cpp:101-115)
     phi_graph *g = nullptr;
     if (phi_gfa_read(gfa_file.c_str(), &g, err, sizeof err) != PHI_HOST_OK) {
         if (err[0] == 'E') fprintf(stderr, "%s\n", err);            // walk error text of ILP_index.cpp:105
         else fprintf(stderr, "[E::%s] failed to load the GFA file\n", __func__);
         if (err[0] && err[0] != 'E') fprintf(stderr, "[E::%s] %s\n", __func__, err);
+        f_ctx.wait(); f_reads.wait();
         return 1;
     }
     stamp(__func__);
     fprintf(stderr, "Loaded graph from: %s\n", gfa_file.c_str());
     char hap_name[4096];
-    if (phi_hap_name(gfa_file.c_str(), reads_file.c_str(), hap_name, sizeof hap_name) < 0) { fprintf(stderr, "[E::%s] output name too long\n", __func__); return 1; }
+    if (phi_hap_name(gfa_file.c_str(), reads_file.c_str(), hap_name, sizeof hap_name) < 0) { fprintf(stderr, "[E::%s] output name too long\n", __func__); f_ctx.wait(); f_reads.wait(); return 1; }
 
-    phi_ctx *ctx = nullptr;
-    int rc = phi_ctx_create(device, &ctx);
-    if (rc) { fprintf(stderr, "[E::%s] no usable MI355X (HIP) device %d: %s\n", __func__, device, phi_strerror(rc)); return 1; }
+    int rc = f_ctx.get();
+    if (rc) { fprintf(stderr, "[E::%s] no usable MI355X (HIP) device %d: %s\n", __func__, device, phi_strerror(rc)); f_reads.wait(); return 1; }
     auto die = [&](const char *what, int code) {
         fprintf(stderr, "[E::%s] %s: %s: %s\n", "main", what, phi_strerror(code), phi_last_error(ctx));
+        if (f_reads.valid()) f_reads.wait();
         return 1;
     };
     const uint32_t flags = (is_qclp ? PHI_FLAG_QCLP : 0) | (is_mixed ? PHI_FLAG_MIXED : 0);
     if ((rc = phi_set_params(ctx, k, w, threshold, recombination, flags))) return die("parameters", rc);
 
-    // ---- reads (main.cpp:136-137)
-    phi_reads *rd = nullptr;
-    if (phi_reads_read(reads_file.c_str(), &rd, err, sizeof err) != PHI_HOST_OK) { fprintf(stderr, "[E::%s] %s\n", __func__, err); return 1; }
+    // ---- stage 1a: walks (ILP_index.cpp:556-611), while the reads are still being parsed
     const int32_t n_walks = phi_graph_n_walks(g);
-    stamp("ILP_function");
-    fprintf(stderr, "Graph has %d vertices, %d walks and read has %d reads\n", phi_graph_n_vtx(g), n_walks, (int)phi_reads_count(rd));
-
-    // ---- stage 1a: walks (ILP_index.cpp:556-611)
     if ((rc = phi_set_graph(ctx, phi_graph_n_vtx(g), phi_graph_seq_concat(g), phi_graph_seq_off(g), phi_graph_adj_off(g),
                             phi_graph_adj(g), n_walks, phi_graph_walk_off(g), phi_graph_walk_vtx(g), phi_graph_topo_rank(g)))) {
         if (rc == PHI_ERR_WALK) fprintf(stderr, "Error: %s\n", phi_last_error(ctx));
         return die("graph", rc);
     }
+
+    // ---- reads (main.cpp:136-137)
+    if (f_reads.get() != PHI_HOST_OK) { fprintf(stderr, "[E::%s] %s\n", __func__, rerr); return 1; }
+    stamp("ILP_function");
+    fprintf(stderr, "Graph has %d vertices, %d walks and read has %d reads\n", phi_graph_n_vtx(g), n_walks, (int)phi_reads_count(rd));
+
     // ---- stage 1b/2a: reads (:615-655)
     if ((rc = phi_add_reads(ctx, phi_reads_bases(rd), phi_reads_off(rd), phi_reads_count(rd)))) return die("reads", rc);
     // ---- stages 2b-3 (:670-1525)
