@@ -527,10 +527,9 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     return PHI_OK;
 }
 
-// make room in the read-spectrum set for the minimisers of add_bases more read bases
-static int sp_ensure(phi_ctx *c, int64_t add_bases)
+// make room in the read-spectrum set for est more distinct hashes (load factor <= 0.5)
+static int sp_ensure(phi_ctx *c, int64_t est)
 {
-    const int64_t est = add_bases / 8 + 16;       // emitted-minimiser density is ~2/(w+1); overflow is detected
     uint64_t need = pow2_at_least(std::max<uint64_t>(1u << 16, 2 * (uint64_t)(c->sp_bound + est)));
     if (c->sp_cap == 0) {
         PHICHK(phi_dev_ensure(c, c->d_sp_keys, need * 8));
@@ -571,7 +570,10 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     if (n_reads == 0 || n_bases == 0) { c->reads_count += n_reads; return PHI_OK; }
     HIPCHK(hipSetDevice(c->device));
     c->solved = false;
-    PHICHK(sp_ensure(c, n_bases));
+    // distinct minimisers of this batch: the emitted density of random sequence is 2/(w+1) (0.077 at
+    // w = 25); room for 1.5x that.  Denser input (at most one per base) is caught by the probe bound
+    // and reported as PHI_ERR_OVERFLOW.
+    PHICHK(sp_ensure(c, (int64_t)((double)n_bases * std::min(1.0, 3.0 / (c->w + 1))) + 16));
     const int64_t n_words = (n_bases + 31) / 32;
     PHICHK(phi_dev_ensure(c, c->d_rwords, (size_t)(n_words + 2) * 8));
     const size_t n_sw = (size_t)(n_bases / 64 + 2);
@@ -716,7 +718,7 @@ int phi_spectrum_import(phi_ctx *c, const void *d_hashes, int64_t n)
     HIPCHK(hipSetDevice(c->device));
     if (d_hashes == c->d_export.p) return phi_fail(c, PHI_ERR_INVALID, "phi_spectrum_import: pass a copy, not the export buffer");
     PHICHK(phi_flush_reset(c));
-    PHICHK(sp_ensure(c, n * 8));          // room for n more distinct hashes
+    PHICHK(sp_ensure(c, n));
     phi_launch_spectrum_insert(c->stream, (const uint64_t *)d_hashes, n, c->d_sp_keys.as<uint64_t>(), c->sp_cap - 1,
                                sp_stripes(c), (uint32_t *)scalar(c, S_ERR));
     HIPCHK(hipGetLastError());

@@ -209,6 +209,23 @@ def test_full_path_wide_windows(oracle, ctx_factory, k, w):
     assert res["spectrum_size"] > 50
 
 
+def test_dense_spectrum_small_window(oracle, ctx_factory):
+    """w = 1 emits a minimiser per base: the read-spectrum set is sized for that (it used to be
+    sized for w = 25 and overflowed), in one batch and when it grows across batches."""
+    rng = np.random.default_rng(2024)
+    g = random_graph(rng, n_sites=12, n_walks=3, seg_len=(30, 60), alt_len=(2, 8))
+    reads = [bytes(rng.choice(list(b"ACGT"), size=1500).tolist()) for _ in range(200)]   # 300 kbases, ~all 15-mers distinct
+    reads += mosaic_reads(rng, g, n_reads=40, read_len=60, n_seg=2)
+    for batches in (1, 4):
+        ctx = ctx_factory(k=15, w=1, threshold=1.0, recombination=3)
+        _set_graph(ctx, g)
+        step = (len(reads) + batches - 1) // batches
+        for i in range(0, len(reads), step):
+            ctx.add_reads(reads[i:i + step])
+        st, res, m = _check_against_oracle(oracle, ctx, g, reads, 15, 1, 1.0, 3)
+        assert res["spectrum_size"] > 250_000
+
+
 def test_degenerate_inputs(oracle, ctx_factory):
     """Single walk; reads too short for any window; thresholds that filter everything / nothing;
     odd R (the reference halves it twice, ILP_index.cpp:1276,1299)."""
