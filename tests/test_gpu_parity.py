@@ -175,7 +175,7 @@ def test_reference_toy_graph(oracle, ctx_factory):
         assert res["objective"] == best
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_small_graphs_vs_brute_force(oracle, ctx_factory, seed):
     rng = np.random.default_rng(seed)
     k, w = int(rng.integers(3, 8)), int(rng.integers(1, 5))
@@ -224,6 +224,51 @@ def test_dense_spectrum_small_window(oracle, ctx_factory):
             ctx.add_reads(reads[i:i + step])
         st, res, m = _check_against_oracle(oracle, ctx, g, reads, 15, 1, 1.0, 3)
         assert res["spectrum_size"] > 250_000
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_mid_graphs_vs_highs(oracle, ctx_factory, seed):
+    """Graphs too large for path enumeration (25-40 sites, 4-9 walks, repeats, small R so that
+    recombinations pay): the objective against HiGHS on the restated program."""
+    rng = np.random.default_rng(5000 + seed)
+    k, w = int(rng.integers(5, 12)), int(rng.integers(1, 7))
+    rep = bytes(rng.choice(list(b"ACGT"), size=k + 4).tolist()) if seed % 2 else None
+    g = random_graph(rng, n_sites=int(rng.integers(25, 41)), n_walks=int(rng.integers(4, 10)), seg_len=(3, 14),
+                     alt_len=(1, 8), p_del=0.25, repeat=rep)
+    reads = mosaic_reads(rng, g, n_reads=150, read_len=k + w + 25, n_seg=int(rng.integers(2, 5)), err=0.01)
+    R = int(rng.choice([0, 1, 2, 4, 8]))
+    T = float(rng.choice([1.0, 0.6]))
+    ctx = ctx_factory(k=k, w=w, threshold=T, recombination=R)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads)
+    st, res, m = _check_against_oracle(oracle, ctx, g, reads, k, w, T, R)
+    best, _, _ = m.milp_solve(time_limit=200.0)
+    assert res["objective"] == best, (seed, k, w, R, T, res["objective"], best, res["n_dp_runs"])
+
+
+def test_more_than_255_anchors_in_a_window(oracle, ctx_factory):
+    """w = 1 on 10-12 bp vertices: ~11 anchors end per walk entry, so the 30-entry window of the
+    event DP holds more than 255 and its byte counters overflow -- the exact CSR count must take
+    over.  Checked against HiGHS on the restated program."""
+    rng = np.random.default_rng(77)
+    g = random_graph(rng, n_sites=24, n_walks=3, seg_len=(10, 12), alt_len=(10, 12), p_del=0.0)
+    # reads tile a mosaic of the three walks (a third of each): every k-mer of the mosaic is seen,
+    # and following it takes two recombinations right inside anchor-dense stretches
+    seqs = [b"".join(g.node_seq[v] for v in g.paths[hh]) for hh in range(g.n_walks)]
+    n3 = min(len(q) for q in seqs) // 3
+    hap = seqs[0][:n3] + seqs[1][n3:2 * n3] + seqs[2][2 * n3:]
+    reads = [hap[a:a + 90] for a in range(0, len(hap) - 20, 15)]
+    for R in (1, 6):
+        ctx = ctx_factory(k=21, w=1, threshold=100.0, recombination=R)
+        _set_graph(ctx, g)
+        ctx.add_reads(reads)
+        st, res, m = _check_against_oracle(oracle, ctx, g, reads, 21, 1, 100.0, R)
+        per_entry = res["n_anchors"].max() / (max(len(p) for p in g.paths) / 3)
+        assert per_entry * 30 > 255, per_entry                 # the overflow path is really taken
+        if R == 1:
+            assert res["n_switches"] >= 2
+        best, _, _ = m.milp_solve(time_limit=200.0)
+        assert res["objective"] == best, (R, res["objective"], best)
 
 
 def test_degenerate_inputs(oracle, ctx_factory):
