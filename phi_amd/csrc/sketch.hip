@@ -614,7 +614,6 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             const int wi = lb >> 6, sh = lb & 63;
             const unsigned long long lo = s_bits[wi];
             const unsigned long long sb = sh ? (lo >> sh) | (s_bits[wi + 1] << (64 - sh)) : lo;
-            const unsigned long long inside = (span > 1) ? ((1ull << (span - 1)) - 1) : 0ull;
             // bb bit j <-> base a0+j is outside ACGT: window a and its predecessor cover a-1 .. a+span-1
             unsigned long long bb = 0;
             if (chunk_bad) {
@@ -622,17 +621,48 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
                 const unsigned long long lo2 = s_bad[wj];
                 bb = sj ? (lo2 >> sj) | (s_bad[wj + 1] << (64 - sj)) : lo2;
             }
-            const unsigned long long clean = (span + 1 >= 64) ? ~0ull : ((1ull << (span + 1)) - 1);
-#pragma unroll
-            for (int i = 1; i <= Q; i++) {
-                // no sequence may start at bases a+1 .. a+span-1 = sb bits i .. i+span-2
-                const bool valid = (i <= imax) && (((sb >> i) & inside) == 0) && (((bb >> (i - 1)) & clean) == 0);
-                const bool first = (sb >> (i - 1)) & 1ull;
-                if (valid && (first || wv[i] != wv[i - 1])) {
-                    cflag |= 1u << i;
-                    if (first) fflag |= 1u << i;
+            // bit i of `blocked`: some sequence starts at bases a+1 .. a+span-1 of window i, i.e. sb has a
+            // bit in [i, i+span-2]: OR over a sliding range by doubling (1,2,4,...,32, then the rest)
+            unsigned long long t = sb;
+            t |= t >> 1; t |= t >> 2; t |= t >> 4; t |= t >> 8; t |= t >> 16;     // ranges of 32
+            const int len1 = span - 1;                                              // 1 .. 55
+            unsigned long long blocked;
+            if (len1 >= 32) blocked = t | (t >> (len1 - 32));
+            else {
+                // shorter ranges: rebuild from the powers of two below len1
+                unsigned long long u = sb, acc = 0;
+                int have = 0;
+                for (int b = 0; b < 5; b++) {
+                    if (len1 & (1 << b)) { acc |= u >> have; have += 1 << b; }
+                    u |= u >> (1 << b);
                 }
+                blocked = len1 > 0 ? acc : 0ull;
             }
+            // bit i of `dirty`: a base outside ACGT under window i or its predecessor: bb bit in [i-1, i+span-1]
+            unsigned long long dirty = 0;
+            if (chunk_bad) {
+                unsigned long long v = bb;
+                v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+                const int len2 = span + 1;                                          // 2 .. 57
+                if (len2 >= 32) v = v | (v >> (len2 - 32));
+                else {
+                    unsigned long long u = bb, acc = 0;
+                    int have = 0;
+                    for (int b = 0; b < 5; b++) {
+                        if (len2 & (1 << b)) { acc |= u >> have; have += 1 << b; }
+                        u |= u >> (1 << b);
+                    }
+                    v = acc;
+                }
+                dirty = v << 1;                                                     // bit i <-> range starting at i-1
+            }
+            uint32_t changed = 0;
+#pragma unroll
+            for (int i = 1; i <= Q; i++) changed |= (uint32_t)(wv[i] != wv[i - 1]) << i;
+            const uint32_t first = ((uint32_t)sb & ((1u << Q) - 1)) << 1;           // bit i <-> sb bit i-1
+            const uint32_t in_batch = imax >= 1 ? ((2u << imax) - 2u) : 0u;        // bits 1 .. imax
+            cflag = in_batch & ~(uint32_t)blocked & ~(uint32_t)dirty & (first | changed) & ((2u << Q) - 2u);
+            fflag = cflag & first;
         } else {
             const int lim = lp0 + Q + span + 1;
             int ns = next_start_lds(s_bits, lp0 + 2, lim);
