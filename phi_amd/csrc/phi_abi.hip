@@ -503,9 +503,28 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     phi_launch_rep_flags(c->stream, c->d_rec_slot.as<uint32_t>(), c->n_rec, c->d_u_rep.as<uint32_t>(),
                          c->d_flags.as<uint8_t>());
     PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), c->n_rec, c->d_m_rec, &c->n_unique));
-    PHICHK(phi_dev_ensure(c, c->d_u_uid, c->u_cap * 4));
-    phi_launch_slot_uid(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_slot.as<uint32_t>(),
-                        c->d_u_uid.as<uint32_t>());
+    // the final table is sized by the distinct minimisers, not by the records (table.hip): the
+    // records-sized one above only served to find the first record of every hash
+    {
+        const uint64_t cap2 = pow2_at_least(std::max<uint64_t>(1024, 32 * (uint64_t)c->n_unique));
+        if (cap2 < c->u_cap) {
+            DevBuf keys2, uid2;
+            PHICHK(phi_dev_ensure(c, keys2, cap2 * 8));
+            PHICHK(phi_dev_ensure(c, uid2, cap2 * 4));
+            phi_launch_fill_u64(c->stream, keys2.as<uint64_t>(), (int64_t)cap2, PHI_EMPTY_KEY);
+            phi_launch_table_compact(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_hash.as<uint64_t>(), c->n_rec,
+                                     keys2.as<uint64_t>(), uid2.as<uint32_t>(), cap2 - 1, c->d_rec_slot.as<uint32_t>(),
+                                     (uint32_t *)scalar(c, S_ERR));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            dev_free(c->d_u_keys); dev_free(c->d_u_uid); dev_free(c->d_u_rep);
+            c->d_u_keys = keys2; c->d_u_uid = uid2;
+            c->u_cap = cap2;
+        } else {
+            PHICHK(phi_dev_ensure(c, c->d_u_uid, c->u_cap * 4));
+            phi_launch_slot_uid(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_slot.as<uint32_t>(),
+                                c->d_u_uid.as<uint32_t>());
+        }
+    }
     phi_launch_locate(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_ebase.as<int64_t>(), n_entries, c->k,
                       c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>());
     // records of each walk ("Number of Minimizers", ILP_index.cpp:563)
@@ -527,7 +546,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     return PHI_OK;
 }
 
-// make room in the read-spectrum set for est more distinct hashes (load factor <= 0.5)
+// make room in the read-spectrum set for est more distinct hashes (load factor <= 0.5; measured at C2:
+// half the capacity slows the probes by 19 %, twice the capacity slows the per-reset clear by more than it gains)
 static int sp_ensure(phi_ctx *c, int64_t est)
 {
     uint64_t need = pow2_at_least(std::max<uint64_t>(1u << 16, 2 * (uint64_t)(c->sp_bound + est)));

@@ -79,6 +79,8 @@ void phi_launch_table_build(hipStream_t st, const uint64_t *rec_hash, int64_t n_
                             uint32_t *u_rep, uint64_t u_mask, uint32_t *rec_slot, uint32_t *err);
 void phi_launch_rep_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_rec, const uint32_t *u_rep,
                           uint8_t *flags);
+void phi_launch_table_compact(hipStream_t st, const int32_t *rep_list, int64_t n_unique, const uint64_t *rec_hash, int64_t n_rec,
+                              uint64_t *keys, uint32_t *uid, uint64_t mask, uint32_t *rec_slot, uint32_t *err);
 void phi_launch_slot_uid(hipStream_t st, const int32_t *rep_list, int64_t n_unique, const uint32_t *rec_slot,
                          uint32_t *u_uid);
 void phi_launch_fill_u64(hipStream_t st, uint64_t *p, int64_t n, uint64_t v);

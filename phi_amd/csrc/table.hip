@@ -100,6 +100,56 @@ void phi_launch_slot_uid(hipStream_t st, const int32_t *rep_list, int64_t n_uniq
                            rec_slot, u_uid);
 }
 
+// The table phi_table_build makes is sized by the RECORDS (every walk repeats most minimisers):
+// 2^26 slots for ~10^6 distinct keys at C2, 768 MB that every read probe walks into at random.
+// Once the distinct keys are known they are re-inserted into a table sized by THEM (load <= 0.25,
+// 32 MB at C2: cache resident) and every record looks its new slot up.
+__global__ void __launch_bounds__(256) phi_table_compact_insert_kernel(const int32_t *__restrict__ rep_list, int64_t n_unique,
+                                                                       const uint64_t *__restrict__ rec_hash,
+                                                                       uint64_t *__restrict__ keys, uint32_t *__restrict__ uid,
+                                                                       uint64_t mask, uint32_t *__restrict__ err)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_unique; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = rec_hash[rep_list[i]];
+        uint64_t slot = h & mask;
+        int probes = 0;
+        for (;;) {
+            const unsigned long long prev = atomicCAS((unsigned long long *)&keys[slot], PHI_EMPTY_KEY, h);
+            if (prev == PHI_EMPTY_KEY) break;                  // the keys are distinct
+            slot = (slot + 1) & mask;
+            if (++probes > PHI_MAX_PROBE) { atomicOr(err, PHI_KERR_TABLE_FULL); break; }
+        }
+        uid[slot] = (uint32_t)i;
+    }
+}
+
+__global__ void __launch_bounds__(256) phi_table_lookup_kernel(const uint64_t *__restrict__ rec_hash, int64_t n_rec,
+                                                               const uint64_t *__restrict__ keys, uint64_t mask,
+                                                               uint32_t *__restrict__ rec_slot, uint32_t *__restrict__ err)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = rec_hash[i];
+        uint64_t slot = h & mask;
+        int probes = 0;
+        while (keys[slot] != h) {
+            slot = (slot + 1) & mask;
+            if (++probes > PHI_MAX_PROBE) { atomicOr(err, PHI_KERR_TABLE_FULL); break; }
+        }
+        rec_slot[i] = (uint32_t)slot;
+    }
+}
+
+void phi_launch_table_compact(hipStream_t st, const int32_t *rep_list, int64_t n_unique, const uint64_t *rec_hash, int64_t n_rec,
+                              uint64_t *keys, uint32_t *uid, uint64_t mask, uint32_t *rec_slot, uint32_t *err)
+{
+    if (n_unique > 0)
+        hipLaunchKernelGGL(phi_table_compact_insert_kernel, dim3(grid_for(n_unique, 256)), dim3(256), 0, st, rep_list, n_unique,
+                           rec_hash, keys, uid, mask, err);
+    if (n_rec > 0)
+        hipLaunchKernelGGL(phi_table_lookup_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, st, rec_hash, n_rec, keys, mask,
+                           rec_slot, err);
+}
+
 __global__ void __launch_bounds__(256) phi_spectrum_insert_kernel(const uint64_t *__restrict__ hashes, int64_t n,
                                                                   uint64_t *__restrict__ sp_keys, uint64_t sp_mask,
                                                                   unsigned long long *__restrict__ sp_count,
