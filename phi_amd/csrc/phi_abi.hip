@@ -282,13 +282,21 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     c->h_walk_vtx.resize(n_entries);
     std::vector<uint8_t> e_out(n_entries, 255);
     std::vector<int32_t> cnt_edge(std::max<int64_t>(n_edges, 1), 0), cont_total(n_vtx, 0);
-    std::vector<unsigned long long> st_mask((size_t)n_vtx * nw64, 0ull);
+    // the step masks serve the every-vertex kernel only (dp.hip, more than 128 walks)
+    const bool want_masks = !(n_walks <= PHI_DP_EVENT_MAX_WALKS && !getenv("PHI_DP_DENSE"));
+    std::vector<unsigned long long> st_mask(want_masks ? (size_t)n_vtx * nw64 : 0, 0ull);
     std::vector<int64_t> walk_len(n_walks, 0);
     {
         PhiHostError herr;
         int32_t *h_wv = c->h_walk_vtx.data();
-        phi_parallel_chunks(n_entries, (int64_t)1 << 16, [&](int64_t lo, int64_t hi) {
+        // walks per edge: all walks cross the same edges at about the same time, so every host
+        // thread counts into its own array (shared counters bounce between the cores)
+        const int n_workers = phi_host_threads();
+        std::vector<std::vector<int32_t>> cnt_priv(n_workers);
+        phi_parallel_chunks(n_entries, (int64_t)1 << 16, [&](int64_t lo, int64_t hi, int worker) {
             if (herr.failed()) return;
+            std::vector<int32_t> &cnt = cnt_priv[worker];
+            if (cnt.empty()) cnt.assign(std::max<int64_t>(n_edges, 1), 0);
             int32_t h = (int32_t)(std::upper_bound(walk_off, walk_off + n_walks + 1, lo) - walk_off) - 1;
             int64_t bases = 0;
             for (int64_t e = lo; e < hi; e++) {
@@ -302,7 +310,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                 if (len == 0) { herr.set(PHI_ERR_UNSUPPORTED, "walk %d passes through empty segment %d", h, u); return; }
                 bases += len;
                 h_wv[e] = u;
-                __atomic_fetch_or(&st_mask[(size_t)topo_rank[u] * nw64 + (h >> 6)], 1ull << (h & 63), __ATOMIC_RELAXED);
+                if (want_masks) __atomic_fetch_or(&st_mask[(size_t)topo_rank[u] * nw64 + (h >> 6)], 1ull << (h & 63), __ATOMIC_RELAXED);
                 if (e + 1 < walk_off[h + 1]) {
                     const int32_t v = walk_vtx[e + 1];
                     if (v < 0 || v >= n_vtx) { herr.set(PHI_ERR_WALK, "walk %d holds vertex %d out of range", h, v); return; }
@@ -312,12 +320,16 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                     if (x == xe) { herr.set(PHI_ERR_WALK, "walk %d steps %d->%d without a graph edge", h, u, v); return; }
                     if (x - adj_off[u] >= 255) { herr.set(PHI_ERR_UNSUPPORTED, "vertex %d has more than 254 out-edges", u); return; }
                     e_out[e] = (uint8_t)(x - adj_off[u]);
-                    __atomic_fetch_add(&cnt_edge[x], 1, __ATOMIC_RELAXED);
+                    cnt[x]++;
                 }
             }
             __atomic_fetch_add(&walk_len[h], bases, __ATOMIC_RELAXED);
         });
         if (herr.failed()) return phi_fail(c, herr.code, "%s", herr.msg.c_str());
+        phi_parallel_chunks(n_edges, (int64_t)1 << 14, [&](int64_t lo, int64_t hi, int) {
+            for (const std::vector<int32_t> &cnt : cnt_priv)
+                if (!cnt.empty()) for (int64_t x = lo; x < hi; x++) cnt_edge[x] += cnt[x];
+        });
     }
     tm.lap("walk entries (threads)");
     bool start_interior = false, end_interior = false;
@@ -417,9 +429,11 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     tm.lap("DP step stream");
     // ---- device copies
     PHICHK(upload(c, c->d_e_out, e_out.data(), e_out.size()));
-    PHICHK(upload(c, c->d_st_rec, st_rec.data(), st_rec.size()));
-    PHICHK(upload(c, c->d_st_mask, st_mask.data(), st_mask.size()));
-    PHICHK(upload(c, c->d_in_packed, in_packed.data(), in_packed.size()));
+    if (!c->dp_events) {                                       // the every-vertex stream serves dp.hip only
+        PHICHK(upload(c, c->d_st_rec, st_rec.data(), st_rec.size()));
+        PHICHK(upload(c, c->d_st_mask, st_mask.data(), st_mask.size()));
+        PHICHK(upload(c, c->d_in_packed, in_packed.data(), in_packed.size()));
+    }
     PHICHK(upload(c, c->d_seq, c->h_seq.data(), c->h_seq.size()));
     PHICHK(upload(c, c->d_seq_off, c->h_seq_off.data(), c->h_seq_off.size()));
     PHICHK(upload(c, c->d_walk_vtx, c->h_walk_vtx.data(), c->h_walk_vtx.size()));

@@ -130,27 +130,27 @@ static inline int phi_host_threads()
     return n > 16 ? 16 : n;
 }
 
-// fn(lo, hi) over [0, n) in chunks handed out dynamically
+// fn(lo, hi, worker) over [0, n) in chunks handed out dynamically; worker < phi_host_threads()
 template <class F> static void phi_parallel_chunks(int64_t n, int64_t chunk, F fn)
 {
     const int64_t n_chunks = (n + chunk - 1) / chunk;
     int nt = phi_host_threads();
     if (nt > n_chunks) nt = (int)n_chunks;
     if (nt <= 1) {
-        for (int64_t i = 0; i < n_chunks; i++) fn(i * chunk, std::min(n, (i + 1) * chunk));
+        for (int64_t i = 0; i < n_chunks; i++) fn(i * chunk, std::min(n, (i + 1) * chunk), 0);
         return;
     }
     std::atomic<int64_t> next{0};
-    auto work = [&]() {
+    auto work = [&](int worker) {
         for (;;) {
             const int64_t i = next.fetch_add(1, std::memory_order_relaxed);
             if (i >= n_chunks) break;
-            fn(i * chunk, std::min(n, (i + 1) * chunk));
+            fn(i * chunk, std::min(n, (i + 1) * chunk), worker);
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
-    work();
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
     for (auto &t : th) t.join();
 }
 
