@@ -157,6 +157,13 @@ int phi_sketch(phi_ctx *ctx, const char *bases, const int64_t *seq_off, int64_t 
 /* Minimisers of walk h found by phi_set_graph, sorted by position. */
 int phi_walk_minimizers(phi_ctx *ctx, int32_t walk, uint64_t *out_hash, int64_t *out_pos,
                         int64_t cap, int64_t *n_out);
+/*
+ * The reference's -d1 report (ILP_index.cpp:565-604): hist[c], c = 1..n_walks, = number of distinct
+ * walk minimisers that occur in exactly c walks (hist[0] = 0); *n_distinct = their total.  hist has
+ * cap >= n_walks + 1 entries.  Valid after phi_set_graph.
+ */
+int phi_walk_sharing(phi_ctx *ctx, int64_t *hist, int32_t cap, int64_t *n_distinct);
+
 /* Kept anchors after the filter (valid after phi_solve): hash, walk, first/last walk index. */
 int phi_kept_anchors(phi_ctx *ctx, uint64_t *out_hash, int32_t *out_walk, int32_t *out_t0,
                      int32_t *out_t1, int64_t cap, int64_t *n_out);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "phi_strerror", "phi_last_error", "phi_ctx_create", "phi_ctx_destroy", "phi_set_stream", "phi_set_params",
     "phi_set_graph", "phi_add_reads", "phi_add_reads_device", "phi_reset_reads", "phi_reads_stats", "phi_hits_buffer",
     "phi_spectrum_export", "phi_spectrum_import", "phi_spectrum_set_size", "phi_solve", "phi_path_sequence",
-    "phi_sketch", "phi_walk_minimizers", "phi_kept_anchors", "phi_prof_enable", "phi_prof_read",
+    "phi_sketch", "phi_walk_minimizers", "phi_walk_sharing", "phi_kept_anchors", "phi_prof_enable", "phi_prof_read",
 ]
 
 
@@ -69,6 +69,7 @@ def load():
     L.phi_path_sequence.argtypes = [vp, vp, i64]
     L.phi_sketch.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64)]
     L.phi_walk_minimizers.argtypes = [vp, i32, vp, vp, i64, C.POINTER(i64)]
+    L.phi_walk_sharing.argtypes = [vp, vp, i32, C.POINTER(i64)]
     L.phi_kept_anchors.argtypes = [vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
     L.phi_prof_enable.argtypes = [vp, C.c_int]
     L.phi_prof_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64)]

@@ -147,6 +147,13 @@ class Context:
             self._chk(self._L.phi_walk_minimizers(self._h, walk, _ptr(h), _ptr(p), n.value, C.byref(n)))
         return h, p
 
+    def walk_sharing(self, n_walks):
+        """-d1 histogram: hist[c] = distinct walk minimisers occurring in exactly c walks."""
+        hist = np.zeros(n_walks + 1, np.int64)
+        n = C.c_int64()
+        self._chk(self._L.phi_walk_sharing(self._h, _ptr(hist), n_walks + 1, C.byref(n)))
+        return hist, n.value
+
     def kept_anchors(self):
         n = C.c_int64()
         self._chk(self._L.phi_kept_anchors(self._h, None, None, None, None, 0, C.byref(n)))

@@ -154,6 +154,14 @@ int main(int argc, char *argv[])
 
     fprintf(stderr, "Number of Minimizers\n");
     for (int32_t h = 0; h < n_walks; h++) fprintf(stderr, "%s : %d\n", phi_graph_hap_name(g, h), (int)res.n_minimizers[h]);
+    if (debug) {                                              // ILP_index.cpp:591-604
+        std::vector<int64_t> hist((size_t)n_walks + 1, 0);
+        int64_t n_distinct = 0;
+        if ((rc = phi_walk_sharing(ctx, hist.data(), n_walks + 1, &n_distinct))) return die("sharing histogram", rc);
+        fprintf(stderr, "Shared fraction of unique kmers by haplotypes\n");
+        for (int32_t i = 1; i <= n_walks; i++)
+            fprintf(stderr, "[Haplotypes: %d, fraction of unique shared kmers: %.5f]\n", i, (float)hist[i] / (float)n_distinct);
+    }
     stamp("ILP_function");
     fprintf(stderr, "Haplotypes sketched\n");
     stamp("ILP_function");

@@ -869,6 +869,37 @@ int phi_walk_minimizers(phi_ctx *c, int32_t walk, uint64_t *out_hash, int64_t *o
     return PHI_OK;
 }
 
+int phi_walk_sharing(phi_ctx *c, int64_t *hist, int32_t cap, int64_t *n_distinct)
+{
+    if (!c || !hist) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_walk_sharing before phi_set_graph");
+    if (cap < c->n_walks + 1) return phi_fail(c, PHI_ERR_INVALID, "phi_walk_sharing: hist needs n_walks + 1 entries");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf last, cnt, dh;
+    int rc = PHI_OK;
+    do {
+        if ((rc = phi_dev_ensure(c, last, c->u_cap * 4))) break;
+        if ((rc = phi_dev_ensure(c, cnt, c->u_cap * 4))) break;
+        if ((rc = phi_dev_ensure(c, dh, (size_t)(c->n_walks + 1) * 8))) break;
+        phi_launch_fill_u32(c->stream, last.as<uint32_t>(), (int64_t)c->u_cap, 0xFFFFFFFFu);
+        if ((rc = phi_hip_check(c, hipMemsetAsync(cnt.p, 0, c->u_cap * 4, c->stream), "memset"))) break;
+        if ((rc = phi_hip_check(c, hipMemsetAsync(dh.p, 0, (size_t)(c->n_walks + 1) * 8, c->stream), "memset"))) break;
+        for (int32_t h = 0; h < c->n_walks; h++)
+            phi_launch_share_count(c->stream, c->d_rec_slot.as<uint32_t>(), c->h_walk_rec_off[h], c->h_walk_rec_off[h + 1], h,
+                                   last.as<int32_t>(), cnt.as<int32_t>());
+        phi_launch_share_hist(c->stream, c->d_u_keys.as<uint64_t>(), (int64_t)c->u_cap, cnt.as<int32_t>(),
+                              dh.as<unsigned long long>());
+        if ((rc = phi_hip_check(c, hipGetLastError(), "launch"))) break;
+        if ((rc = phi_hip_check(c, hipStreamSynchronize(c->stream), "synchronize"))) break;
+        std::vector<unsigned long long> hh(c->n_walks + 1);
+        if ((rc = phi_hip_check(c, hipMemcpy(hh.data(), dh.p, hh.size() * 8, hipMemcpyDeviceToHost), "D2H"))) break;
+        for (int32_t i = 0; i <= c->n_walks; i++) hist[i] = (int64_t)hh[i];
+        if (n_distinct) *n_distinct = c->n_unique;
+    } while (0);
+    dev_free(last); dev_free(cnt); dev_free(dh);
+    return rc;
+}
+
 int phi_kept_anchors(phi_ctx *c, uint64_t *out_hash, int32_t *out_walk, int32_t *out_t0, int32_t *out_t1, int64_t cap,
                      int64_t *n_out)
 {

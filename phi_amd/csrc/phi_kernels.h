@@ -81,6 +81,9 @@ void phi_launch_rep_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_re
                           uint8_t *flags);
 void phi_launch_table_compact(hipStream_t st, const int32_t *rep_list, int64_t n_unique, const uint64_t *rec_hash, int64_t n_rec,
                               uint64_t *keys, uint32_t *uid, uint64_t mask, uint32_t *rec_slot, uint32_t *err);
+void phi_launch_share_count(hipStream_t st, const uint32_t *rec_slot, int64_t lo, int64_t hi, int32_t walk, int32_t *last_walk,
+                            int32_t *n_walks_of);
+void phi_launch_share_hist(hipStream_t st, const uint64_t *keys, int64_t cap, const int32_t *n_walks_of, unsigned long long *hist);
 void phi_launch_slot_uid(hipStream_t st, const int32_t *rep_list, int64_t n_unique, const uint32_t *rec_slot,
                          uint32_t *u_uid);
 void phi_launch_fill_u64(hipStream_t st, uint64_t *p, int64_t n, uint64_t v);

@@ -205,12 +205,18 @@ class ILP_index:
             ctx.add_reads(seqs)
             res = ctx.solve()
             hap = ctx.path_sequence(res["hap_len"])
+            sharing = ctx.walk_sharing(G.num_walks) if self.debug else None
         finally:
             ctx.close()
         self.result = res
         print("Number of Minimizers", file=self.log)
         for h in range(G.num_walks):
             print(f"{G.hap_id2name[h]} : {int(res['n_minimizers'][h])}", file=self.log)
+        if sharing is not None:                                # -d1 (ILP_index.cpp:591-604)
+            hist, n_distinct = sharing
+            print("Shared fraction of unique kmers by haplotypes", file=self.log)
+            for i in range(1, G.num_walks + 1):
+                print("[Haplotypes: %d, fraction of unique shared kmers: %.5f]" % (i, np.float32(hist[i]) / np.float32(n_distinct)), file=self.log)
         self._stamp("Haplotypes sketched")
         self._stamp(f"Indexed reads with spectrum size: {res['spectrum_size']}")
         print("Number of Anchors", file=self.log)

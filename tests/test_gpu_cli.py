@@ -77,6 +77,20 @@ def test_cli_toy_and_python_mirror_agree(tmp_path):
     py_log = log.getvalue()
     for line in ("Number of Minimizers", "test_hap_1.0 : 10", "Indexed reads with spectrum size: 8", "Recombination count: 0"):
         assert line in py_log and line in r.stderr
+    # -d1: the sharing histogram of ILP_index.cpp:591-604, same lines from both front ends
+    r2 = _run_cli(["-g", gfa, "-r", rd, "-o", str(tmp_path / "toy_d.fa"), "-k3", "-w2", "-q0", "-m0", "-R", "10", "-d1"], tmp_path)
+    assert r2.returncode == 0, r2.stderr
+    assert "Shared fraction of unique kmers by haplotypes" in r2.stderr and "Shared fraction" not in r.stderr
+    d_lines = [l for l in r2.stderr.splitlines() if l.startswith("[Haplotypes: ")]
+    assert len(d_lines) == 5 and abs(sum(float(l.split(": ")[-1].rstrip("]")) for l in d_lines) - 1.0) < 1e-4
+    log2 = io.StringIO()
+    idx2 = H.ILP_index(gfa, log=log2)
+    idx2.read_gfa()
+    idx2.k_mer, idx2.window, idx2.recombination, idx2.is_qclp, idx2.is_mixed, idx2.debug = 3, 2, 10, 0, False, True
+    idx2.hap_file = str(tmp_path / "toy_py_d.fa")
+    idx2.hap_name = H.get_hap_name(gfa, rd)
+    idx2.ILP_function([b"ATCGATCATACTTACCATG"])
+    assert [l for l in log2.getvalue().splitlines() if l.startswith("[Haplotypes: ")] == d_lines
 
 
 def test_cli_on_synthetic_files(tmp_path):

@@ -316,6 +316,22 @@ def test_walks_ending_inside_the_graph(oracle, ctx_factory):
         assert res["objective"] == m.brute_force()[0]
 
 
+def test_walk_sharing_histogram(oracle, ctx_factory):
+    """The reference's -d1 report (ILP_index.cpp:565-604): distinct walk minimisers by the number of
+    walks they occur in, against a recount from the oracle's per-walk sketches."""
+    rng = np.random.default_rng(8)
+    g = random_graph(rng, n_sites=30, n_walks=6, seg_len=(10, 40), alt_len=(1, 10))
+    k, w = 11, 5
+    ctx = ctx_factory(k=k, w=w)
+    _set_graph(ctx, g)
+    hist, n_distinct = ctx.walk_sharing(g.n_walks)
+    per_walk = [np.unique(oracle.sketch(b"".join(g.node_seq[v] for v in p), k, w)[0]) for p in g.paths]
+    allh, counts = np.unique(np.concatenate(per_walk), return_counts=True)
+    want = np.bincount(counts, minlength=g.n_walks + 1)
+    assert n_distinct == len(allh)
+    assert hist.tolist() == want.tolist() and hist[0] == 0 and hist.sum() == n_distinct
+
+
 def test_streaming_batches_equal_one_batch(oracle, ctx_factory):
     rng = np.random.default_rng(5)
     g = random_graph(rng, n_sites=8, n_walks=4, seg_len=(8, 30))
