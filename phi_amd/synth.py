@@ -243,6 +243,19 @@ def make_reads(g, coverage=1.0, read_len=150, seed=4902, sub_err=0.005, n_mosaic
     return bases, off, dict(walks=hs.tolist(), cuts=cuts.tolist(), hap_len=L)
 
 
+def graph_from_gfa(path):
+    """A GFA file (through the host reader of libphi_host.so) as a SynGraph, so that make_reads can
+    draw synthetic reads from a real graph's walks (C1 with the generator's reads)."""
+    from .ilp_index import Graph
+    G = Graph(path)
+    g = SynGraph()
+    g.seq_concat = G.seq_concat
+    g.seq_off, g.adj_off, g.adj = G.seq_off, G.adj_off, G.adj
+    g.walk_off, g.walk_vtx, g.top_rank = G.walk_off, G.walk_vtx, G.top_order_map
+    g.n_vtx, g.n_walks, g.hap_names = G.n_vtx, G.num_walks, list(G.hap_id2name)
+    return g
+
+
 def write_gfa(g, path):
     """GFA 1.1 with S, L (0M overlaps, forward strands) and W lines -- what the reference's reader and
     phi_gfa_read accept.  Segment names are 1-based vertex ids."""
