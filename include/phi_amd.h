@@ -14,6 +14,11 @@
  *     phi_ctx_destroy;
  *   - one context per process per GPU, calls serialised by the caller (the reference is not
  *     re-entrant either: src/main.cpp:136-140).
+ *
+ * Limits (PHI_ERR_UNSUPPORTED / PHI_ERR_INVALID beyond them): k <= 32, w <= 256, at most 512 walks,
+ * fewer than 2^31 walk entries and walk minimisers, fewer than 2^27 anchors in the model, at most
+ * 254 out-edges and 255 recombination in-edges per vertex, no walk through a segment without
+ * sequence, no graph whose walks both start and end at interior vertices.
  */
 #ifndef PHI_AMD_H
 #define PHI_AMD_H

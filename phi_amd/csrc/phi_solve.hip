@@ -302,6 +302,8 @@ int phi_solve_impl(phi_ctx *c)
         }
     }
     const int64_t n_dp = (int64_t)c->h_dp.size();
+    // DP scores are int32 with -2^28 as "no state": a path scores at most one per anchor
+    if (n_dp >= ((int64_t)1 << 27)) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^27 anchors in the model");
 
     if (tm.on) fprintf(stderr, "[phi timing] solve: n_rec %lld matched %lld kept %lld dp %lld\n", (long long)n_rec, (long long)n_matched, (long long)n_kept, (long long)n_dp);
     tm.lap("filter (GPU) + anchors D2H");
