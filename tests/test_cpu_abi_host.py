@@ -200,3 +200,35 @@ def test_device_primitives_on_host(oracle, tmp_path):
         words[i // 32] |= np.uint64(b"ACGT".index(ch)) << np.uint64(62 - 2 * (i % 32))
     for i in (0, 1, 31, 32, 33, 100, 167):
         assert L.t_ext(words.ctypes.data, i) == val(seq[i:i + 32])
+
+
+def test_synthetic_gfa_round_trip(tmp_path):
+    """phi_amd.synth.write_gfa / write_reads -> phi_gfa_read / phi_reads_read give back the generator's
+    arrays (segment ids are first-seen order, so even the numbering agrees); plain and gzip."""
+    import numpy as np
+    from phi_amd import ilp_index as H
+    from phi_amd import synth
+    gk, rk = synth.CONFIGS["tiny"]
+    g = synth.make_graph(**gk)
+    bases, off, _ = synth.make_reads(g, **rk)
+    for ext in ("", ".gz"):
+        gfa, fq = str(tmp_path / ("t.gfa" + ext)), str(tmp_path / ("t.fq" + ext))
+        synth.write_gfa(g, gfa)
+        synth.write_reads(bases, off, fq, fastq=True)
+        G = H.Graph(gfa)
+        assert (G.n_vtx, G.num_walks) == (g.n_vtx, g.n_walks)
+        assert np.array_equal(G.seq_off, g.seq_off) and np.array_equal(G.seq_concat, g.seq_concat)
+        assert np.array_equal(G.adj_off, g.adj_off)
+        for v in range(g.n_vtx):                       # the reader sorts each adjacency list
+            assert sorted(g.adj[g.adj_off[v]:g.adj_off[v + 1]].tolist()) == G.adj[G.adj_off[v]:G.adj_off[v + 1]].tolist()
+        assert np.array_equal(G.walk_off, g.walk_off) and np.array_equal(G.walk_vtx, g.walk_vtx)
+        assert G.hap_id2name == g.hap_names
+        # a topological order: every edge goes forward
+        src = np.repeat(np.arange(g.n_vtx), np.diff(G.adj_off))
+        assert (G.top_order_map[src] < G.top_order_map[G.adj]).all()
+        reads = []
+        idx = H.ILP_index.__new__(H.ILP_index)
+        H.ILP_index.read_ip_reads(idx, reads, fq)
+        assert len(reads) == len(off) - 1
+        assert b"".join(r[1] for r in reads) == bases.tobytes()
+        assert [len(r[1]) for r in reads] == np.diff(off).tolist()
