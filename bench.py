@@ -70,6 +70,9 @@ def main():
     args = ap.parse_args()
 
     import torch
+    import __graft_entry__
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        __graft_entry__.ensure_built()                         # a checkout without built libraries (no fallback exists)
     import phi_amd
     from phi_amd import dist as pdist
     from phi_amd import synth

@@ -35,7 +35,10 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def ctx_factory():
-    """Contexts on cuda:0 through the C ABI; fails loudly when the HIP library is missing."""
+    """Contexts on cuda:0 through the C ABI; fails loudly when the HIP library is missing (a checkout
+    without built libraries is built first: no fallback exists)."""
+    import __graft_entry__
+    __graft_entry__.ensure_built()
     import phi_amd
     made = []
 
