@@ -73,6 +73,10 @@ def main():
     import __graft_entry__
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         __graft_entry__.ensure_built()                         # a checkout without built libraries (no fallback exists)
+    else:
+        t_wait = time.time()
+        while not os.path.exists(os.path.join(ROOT, "phi_amd", "libphi_amd.so")) and time.time() - t_wait < 600:
+            time.sleep(1.0)                                    # rank 0 is building
     import phi_amd
     from phi_amd import dist as pdist
     from phi_amd import synth
