@@ -45,6 +45,30 @@ void phi_launch_entry_len(hipStream_t st, const int64_t *seq_off, const int32_t 
     hipLaunchKernelGGL(phi_entry_len_kernel, dim3(grid_for(n_entries, 256)), dim3(256), 0, st, seq_off, walk_vtx, n_entries, len);
 }
 
+// ------------------------------------------------------------------------- anchors for the host
+// out[3i..3i+2] = (dense minimiser id, first entry, last entry) of kept record rec[i]
+__global__ void __launch_bounds__(256) phi_anchor_triples_kernel(const int32_t *__restrict__ rec, int64_t n,
+                                                                 const uint32_t *__restrict__ rec_slot,
+                                                                 const uint32_t *__restrict__ u_uid,
+                                                                 const int32_t *__restrict__ rec_e0,
+                                                                 const int32_t *__restrict__ rec_e1, int32_t *__restrict__ out)
+{
+    GRID_STRIDE(i, n) {
+        const int32_t r = rec[i];
+        out[3 * i + 0] = (int32_t)u_uid[rec_slot[r]];
+        out[3 * i + 1] = rec_e0[r];
+        out[3 * i + 2] = rec_e1[r];
+    }
+}
+
+void phi_launch_anchor_triples(hipStream_t st, const int32_t *rec, int64_t n, const uint32_t *rec_slot, const uint32_t *u_uid,
+                               const int32_t *rec_e0, const int32_t *rec_e1, int32_t *out)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(phi_anchor_triples_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, rec, n, rec_slot, u_uid, rec_e0,
+                           rec_e1, out);
+}
+
 // ------------------------------------------------------------------------- locate
 // rec_e0/rec_e1: walk entries owning the first / last base of each minimiser's k-mer.
 __global__ void __launch_bounds__(256) phi_locate_kernel(const int64_t *__restrict__ rec_pos, int64_t n_rec,

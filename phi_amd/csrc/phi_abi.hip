@@ -150,7 +150,7 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_wascii, &c->d_rbad, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
                      &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
-                     &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_m_rec, &c->d_m_group,
+                     &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_kept_rec, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_bstart, &c->d_k_rec, &c->d_k_in, &c->d_cvtx, &c->d_ev_e, &c->d_ev_off, &c->d_ev,
                      &c->d_cnt_end, &c->d_cnt_start, &c->d_off_end, &c->d_off_start, &c->d_scan_blk, &c->d_scan_blk64, &c->d_scan_blkoff, &c->d_top,
@@ -908,6 +908,15 @@ int phi_kept_anchors(phi_ctx *c, uint64_t *out_hash, int32_t *out_walk, int32_t 
     const int64_t n = (int64_t)c->h_kept.size();
     *n_out = n;
     if (cap < n) return PHI_OK;
+    if (out_hash && n && (int64_t)c->h_kept_hash.size() != n) {
+        // the hashes stayed on the device (phi_solve does not need them): fetch them now
+        HIPCHK(hipSetDevice(c->device));
+        c->h_kept_hash.resize(n);
+        PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)n * 8));
+        phi_launch_gather_u64(c->stream, c->d_rec_hash.as<uint64_t>(), c->d_kept_rec.as<int32_t>(), n, c->d_list2.as<uint64_t>());
+        HIPCHK(hipMemcpyAsync(c->h_kept_hash.data(), c->d_list2.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     for (int64_t i = 0; i < n; i++) {
         const PhiAnchorHost &a = c->h_kept[i];
         const int32_t h = phi_entry_walk(c, a.e0);

@@ -98,6 +98,8 @@ void phi_launch_spectrum_export(hipStream_t st, const uint64_t *sp_keys, int64_t
 // anchors.hip
 #define PHI_KERR_FP_COLLISION 8u   // two different vertex lists share a fingerprint: reseed
 void phi_launch_entry_len(hipStream_t st, const int64_t *seq_off, const int32_t *walk_vtx, int64_t n_entries, int32_t *len);
+void phi_launch_anchor_triples(hipStream_t st, const int32_t *rec, int64_t n, const uint32_t *rec_slot, const uint32_t *u_uid,
+                               const int32_t *rec_e0, const int32_t *rec_e1, int32_t *out);
 void phi_launch_locate(hipStream_t st, const int64_t *rec_pos, int64_t n_rec, const int64_t *ebase,
                        int64_t n_entries, int32_t k, int32_t *rec_e0, int32_t *rec_e1);
 void phi_launch_lower_bound(hipStream_t st, const int64_t *a, int64_t n, const int64_t *keys, int64_t m,

@@ -259,47 +259,70 @@ int phi_solve_impl(phi_ctx *c)
     int64_t n_kept = 0;
     PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_matched, c->d_list, &n_kept));
     tm.lap("filter kernels");
-    // kept anchors to the host: record index -> (slot, e0, e1, hash)
-    std::vector<int32_t> k_slot(n_kept), k_e0(n_kept), k_e1(n_kept);
-    c->h_kept_hash.resize(n_kept);
+    // kept anchors to the host as (minimiser id, first entry, last entry) triples, gathered into
+    // that layout on the GPU; their hashes stay behind (phi_kept_anchors fetches them on demand)
+    c->h_kept.resize(n_kept);
+    c->h_kept_hash.clear();
+    PHICHK(phi_dev_ensure(c, c->d_kept_rec, (size_t)std::max<int64_t>(n_kept, 1) * 4));
     if (n_kept) {
-        PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)n_kept * 8));
-        int32_t *k_rec = c->d_list2.as<int32_t>();
-        phi_launch_gather_i32(c->stream, c->d_m_rec.as<int32_t>(), c->d_list.as<int32_t>(), n_kept, k_rec);
-        PHICHK(phi_dev_ensure(c, c->d_a_e1, (size_t)n_kept * 8));
-        int32_t *tmp = c->d_a_e1.as<int32_t>();
-        // minimiser identity on the host: the dense id (rank of first occurrence) behind the table slot
-        PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)n_kept * 4));
-        phi_launch_gather_i32(c->stream, (const int32_t *)c->d_rec_slot.p, k_rec, n_kept, c->d_list3.as<int32_t>());
-        phi_launch_gather_i32(c->stream, (const int32_t *)c->d_u_uid.p, c->d_list3.as<int32_t>(), n_kept, tmp);
-        HIPCHK(hipMemcpyAsync(k_slot.data(), tmp, (size_t)n_kept * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        phi_launch_gather_i32(c->stream, c->d_rec_e0.as<int32_t>(), k_rec, n_kept, tmp);
-        HIPCHK(hipMemcpyAsync(k_e0.data(), tmp, (size_t)n_kept * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        phi_launch_gather_i32(c->stream, c->d_rec_e1.as<int32_t>(), k_rec, n_kept, tmp);
-        HIPCHK(hipMemcpyAsync(k_e1.data(), tmp, (size_t)n_kept * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        phi_launch_gather_u64(c->stream, c->d_rec_hash.as<uint64_t>(), k_rec, n_kept, (uint64_t *)tmp);
-        HIPCHK(hipMemcpyAsync(c->h_kept_hash.data(), tmp, (size_t)n_kept * 8, hipMemcpyDeviceToHost, c->stream));
+        phi_launch_gather_i32(c->stream, c->d_m_rec.as<int32_t>(), c->d_list.as<int32_t>(), n_kept, c->d_kept_rec.as<int32_t>());
+        PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)n_kept * 12));
+        phi_launch_anchor_triples(c->stream, c->d_kept_rec.as<int32_t>(), n_kept, c->d_rec_slot.as<uint32_t>(), c->d_u_uid.as<uint32_t>(),
+                                  c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>(), c->d_list2.as<int32_t>());
+        static_assert(sizeof(PhiAnchorHost) == 12, "PhiAnchorHost is the device triple");
+        HIPCHK(hipMemcpyAsync(c->h_kept.data(), c->d_list2.p, (size_t)n_kept * 12, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
     const int64_t filtered = (int64_t)sc[S_FILTERED], in_model = (int64_t)sc[S_INMODEL];
 
     tm.lap("anchors D2H");
-    c->h_kept.resize(n_kept);
-    c->h_dp.clear();
-    c->h_dp.reserve(n_kept);
+    // dp anchors (span >= 1 edge; single-vertex anchors are ignored, :795/:846), anchors per walk and the
+    // DP's per-anchor arrays: host threads over chunks of the kept list, order preserved
     c->h_n_anchors.assign(nw, 0);
+    std::vector<int32_t> a_e1;
+    std::vector<uint8_t> a_span;
     {
-        int32_t hw = 0;                                            // kept anchors come in walk order
-        for (int64_t i = 0; i < n_kept; i++) {
-            c->h_kept[i] = PhiAnchorHost{(uint32_t)k_slot[i], k_e0[i], k_e1[i]};
-            if (k_e0[i] < c->h_walk_off[hw] || k_e0[i] >= c->h_walk_off[hw + 1]) hw = phi_entry_walk(c, k_e0[i]);
-            c->h_n_anchors[hw]++;
-            if (k_e1[i] > k_e0[i]) c->h_dp.push_back(c->h_kept[i]);     // single-vertex anchors are ignored (:795/:846)
-        }
+        const int64_t chunk = (int64_t)1 << 16;
+        const int64_t n_chunks = (n_kept + chunk - 1) / chunk;
+        std::vector<int64_t> dp_cnt(n_chunks + 1, 0);
+        std::vector<std::vector<int32_t>> walk_cnt(phi_host_threads(), std::vector<int32_t>(nw, 0));
+        phi_parallel_chunks(n_kept, chunk, [&](int64_t lo, int64_t hi, int worker) {
+            int64_t n = 0;
+            int32_t hw = phi_entry_walk(c, c->h_kept[lo].e0);
+            for (int64_t i = lo; i < hi; i++) {
+                const PhiAnchorHost &k = c->h_kept[i];
+                n += k.e1 > k.e0;
+                while (k.e0 >= c->h_walk_off[hw + 1]) hw++;      // kept anchors come in walk order
+                walk_cnt[worker][hw]++;
+            }
+            dp_cnt[lo / chunk + 1] = n;
+        });
+        for (int64_t i = 0; i < n_chunks; i++) dp_cnt[i + 1] += dp_cnt[i];
+        for (const auto &wc : walk_cnt) for (int32_t h = 0; h < nw; h++) c->h_n_anchors[h] += wc[h];
+        const int64_t n_dp0 = dp_cnt[n_chunks];
+        c->h_dp.resize(n_dp0);
+        a_e1.resize(n_dp0);
+        a_span.resize(n_dp0);
+        PhiHostError herr;
+        phi_parallel_chunks(n_kept, chunk, [&](int64_t lo, int64_t hi, int) {
+            int64_t o = dp_cnt[lo / chunk];
+            for (int64_t i = lo; i < hi; i++) {
+                const PhiAnchorHost &k = c->h_kept[i];
+                if (k.e1 <= k.e0) continue;
+                if (k.e1 - k.e0 >= PHI_RCAP) { herr.set(PHI_ERR_DEVICE, "anchor spans %d edges (internal error)", k.e1 - k.e0); return; }
+                c->h_dp[o] = k;
+                a_e1[o] = k.e1;
+                a_span[o] = (uint8_t)(k.e1 - k.e0);
+                o++;
+            }
+        });
+        if (herr.failed()) return phi_fail(c, herr.code, "%s", herr.msg.c_str());
+        phi_parallel_chunks(n_dp0, chunk, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = std::max<int64_t>(lo, 1); i < hi; i++)
+                if (a_e1[i] < a_e1[i - 1]) { herr.set(PHI_ERR_DEVICE, "dp anchors not sorted by last entry (internal error)"); return; }
+        });
+        if (herr.failed()) return phi_fail(c, herr.code, "%s", herr.msg.c_str());
     }
     const int64_t n_dp = (int64_t)c->h_dp.size();
     // DP scores are int32 with -2^28 as "no state": a path scores at most one per anchor
@@ -309,14 +332,6 @@ int phi_solve_impl(phi_ctx *c)
     tm.lap("filter (GPU) + anchors D2H");
     // ---- 3. DP inputs
     {
-        std::vector<int32_t> a_e1(n_dp);
-        std::vector<uint8_t> a_span(n_dp);
-        for (int64_t i = 0; i < n_dp; i++) {
-            a_e1[i] = c->h_dp[i].e1;
-            a_span[i] = (uint8_t)(c->h_dp[i].e1 - c->h_dp[i].e0);
-            if (i && a_e1[i] < a_e1[i - 1]) return phi_fail(c, PHI_ERR_DEVICE, "dp anchors not sorted by last entry (internal error)");
-            if (c->h_dp[i].e1 - c->h_dp[i].e0 >= PHI_RCAP) return phi_fail(c, PHI_ERR_DEVICE, "anchor spans %d edges (internal error)", c->h_dp[i].e1 - c->h_dp[i].e0);
-        }
         PHICHK(phi_dev_ensure(c, c->d_a_e1, (size_t)std::max<int64_t>(n_dp, 1) * 4));
         PHICHK(phi_dev_ensure(c, c->d_g_span, (size_t)std::max<int64_t>(n_dp, 1)));
         PHICHK(phi_dev_ensure(c, c->d_a_weight, (size_t)std::max<int64_t>(n_dp, 1)));
