@@ -136,6 +136,19 @@ int phi_ctx_create(int device_id, phi_ctx **out)
         phi_dev_ensure(c, c->d_stripes, 2 * STRIPE_BYTES) || hipMemset(c->d_stripes.p, 0, 2 * STRIPE_BYTES) != hipSuccess) {
         (void)hipStreamDestroy(c->own_stream); delete c; return PHI_ERR_DEVICE;
     }
+    // the first pageable host-to-device copy of a process sets up the runtime's staging buffers
+    // (several ms): pay that here, once, not inside the first phi_set_graph
+    {
+        DevBuf warm;
+        std::vector<char> h((size_t)4 << 20, 0);
+        if (phi_dev_ensure(c, warm, h.size()) == PHI_OK) {
+            (void)hipMemcpyAsync(warm.p, h.data(), h.size(), hipMemcpyHostToDevice, c->stream);
+            (void)hipMemcpyAsync(h.data(), warm.p, h.size(), hipMemcpyDeviceToHost, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            dev_free(warm);
+        }
+        c->last_error.clear();
+    }
     *out = c;
     return PHI_OK;
 }
@@ -385,6 +398,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         }
     }
 
+    tm.lap("  dense step records");
     // ---- compact step stream of the event-driven DP (dp_events.hip): only the vertices where a
     //      recombination can enter or leave, or a walk starts or ends; in-edges count compact steps back
     c->dp_events = n_walks <= PHI_DP_EVENT_MAX_WALKS && !getenv("PHI_DP_DENSE");
@@ -421,6 +435,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             r[5] = ro[5];
         }
         for (int32_t v = 0; v < n_vtx; v++) cvtx[v] = c->h_cstep[topo_rank[v]];
+        tm.lap("  compact records");
         PHICHK(upload(c, c->d_k_rec, k_rec.data(), k_rec.size()));
         PHICHK(upload(c, c->d_k_in, k_in.data(), k_in.size()));
         PHICHK(upload(c, c->d_cvtx, cvtx.data(), cvtx.size()));
