@@ -104,10 +104,19 @@ int main(int argc, char *argv[])
     // The device context (HIP initialisation) and the reads file are prepared by two host threads
     // while this one parses the graph: the three are independent.
     phi_ctx *ctx = nullptr;
-    std::future<int> f_ctx = std::async(std::launch::async, [&]() { return phi_ctx_create(device, &ctx); });
+    const bool timing = getenv("PHI_TIMING") != nullptr;
+    std::future<int> f_ctx = std::async(std::launch::async, [&]() {
+        const int r = phi_ctx_create(device, &ctx);
+        if (timing) fprintf(stderr, "[phi timing] main: device context ready at %.3f s\n", realtime() - t0_real);
+        return r;
+    });
     phi_reads *rd = nullptr;
     char rerr[512] = "";
-    std::future<int> f_reads = std::async(std::launch::async, [&]() { return phi_reads_read(reads_file.c_str(), &rd, rerr, sizeof rerr); });
+    std::future<int> f_reads = std::async(std::launch::async, [&]() {
+        const int r = phi_reads_read(reads_file.c_str(), &rd, rerr, sizeof rerr);
+        if (timing) fprintf(stderr, "[phi timing] main: reads parsed at %.3f s\n", realtime() - t0_real);
+        return r;
+    });
 
     // ---- graph (main.cpp:101-115)
     phi_graph *g = nullptr;

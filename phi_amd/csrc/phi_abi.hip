@@ -690,15 +690,21 @@ int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_
     const int64_t n_bases = read_off[n_reads];
     if (n_bases > 0 && !bases) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads: bases is null");
     HIPCHK(hipSetDevice(c->device));
+    PhiStageTimer tm("add_reads");
     // the previous batch may still be reading the staging buffers
     HIPCHK(hipStreamSynchronize(c->stream));
+    tm.lap("wait for the stream");
     PHICHK(phi_dev_ensure(c, c->d_rbases, (size_t)std::max<int64_t>(n_bases, 1)));
     PHICHK(phi_dev_ensure(c, c->d_roff, (size_t)(n_reads + 1) * 8));
+    tm.lap("buffers");
     if (n_bases) HIPCHK(hipMemcpyAsync(c->d_rbases.p, bases, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_roff.p, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (tm.on) (void)hipStreamSynchronize(c->stream);
+    tm.lap("H2D");
     PHICHK(phi_add_reads_device(c, c->d_rbases.p, c->d_roff.p, n_reads, n_bases));
     // host buffers are borrowed for the call only
     HIPCHK(hipStreamSynchronize(c->stream));
+    tm.lap("sketch + probe");
     return PHI_OK;
 }
 
