@@ -672,3 +672,48 @@ def test_torch_views_of_device_buffers(oracle, ctx_factory):
     torch.cuda.synchronize()
     res = ctx.solve()
     assert res["spectrum_size"] == len(read_h) + 2
+
+
+# --------------------------------------------------------------------------- full size (BASELINE config C2)
+
+def test_full_size_properties_c2(ctx_factory):
+    """At the size the metric is quoted on (synMHC-49: 49 walks x 5.2 Mbp, 1x reads) no CPU checker
+    finishes in seconds; the domain's size-independent properties stand in: the read set is a SET of
+    canonical k-mers (order, strand, batching and repetition of reads change nothing), the solve
+    carries its own certificate (objective == proven bound, path value re-derived from the path on
+    the host), and the generator's truth walks come back."""
+    from phi_amd import synth
+    gk, rk = synth.CONFIGS["C2"]
+    g = synth.make_graph(**gk)
+    bases, off, truth = synth.make_reads(g, **rk)
+    A = g.arrays()
+
+    def solve(batches):
+        ctx = ctx_factory(k=31, w=25, threshold=1.0, recombination=100)
+        ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
+        for b, o in batches:
+            ctx.add_reads((b, o))
+        res = ctx.solve()
+        ctx.close()
+        hap = res["path_hap"]
+        walks = [int(x) for x in hap[np.r_[True, hap[1:] != hap[:-1]]]]
+        key = tuple(int(res[k]) for k in ("objective", "upper_bound", "optimal", "spectrum_size", "filtered", "n_in_model", "n_covered", "hap_len"))
+        return key, walks, res["n_anchors"].tolist(), res["n_minimizers"].tolist()
+
+    base = solve([(bases, off)])
+    assert base[0][2] == 1 and base[0][0] == base[0][1]              # proven optimal
+    assert base[1] == truth["walks"]                                  # the mosaic is recovered
+    # the same reads twice, and split in three batches
+    assert solve([(bases, off), (bases, off)]) == base
+    n = len(off) - 1
+    cuts = [0, n // 3, 2 * n // 3, n]
+    parts = [(bases[off[a]:off[b]], off[a:b + 1] - off[a]) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert solve(parts) == base
+    # every read reverse-complemented, read order reversed
+    comp = np.zeros(256, np.uint8)
+    comp[np.frombuffer(b"ACGT", np.uint8)] = np.frombuffer(b"TGCA", np.uint8)
+    rc = comp[bases][::-1].copy()                                      # reverses the read order as well
+    lens = np.diff(off)[::-1]
+    off_rc = np.zeros(len(off), np.int64)
+    np.cumsum(lens, out=off_rc[1:])
+    assert solve([(rc, off_rc)]) == base
