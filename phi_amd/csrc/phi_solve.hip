@@ -500,6 +500,8 @@ int phi_solve_impl(phi_ctx *c)
                 }
                 if (!covered) Z.insert(s);
             }
+            if (tm.on) fprintf(stderr, "[phi timing] solve:   run %d: DP value %lld + |S| %zu = bound %lld; path: exact %lld, %lld switches; doubly counted %zu, unused constants %zu\n",
+                               n_runs, (long long)val, S.size(), (long long)ub, (long long)true_val, (long long)n_sw, D.size(), Z.size());
             tm.lap("  path value, tighten sets");
             if (D.empty() && Z.empty()) { closed = true; break; }   // bound attained by this path
             // remember a branching candidate in canonical (first anchor) order
