@@ -282,6 +282,7 @@ int phi_solve_impl(phi_ctx *c)
     c->h_n_anchors.assign(nw, 0);
     std::vector<int32_t> a_e1;
     std::vector<uint8_t> a_span;
+    std::vector<int16_t> dp_walk;                              // walk of every dp anchor
     {
         const int64_t chunk = (int64_t)1 << 16;
         const int64_t n_chunks = (n_kept + chunk - 1) / chunk;
@@ -302,14 +303,18 @@ int phi_solve_impl(phi_ctx *c)
         for (const auto &wc : walk_cnt) for (int32_t h = 0; h < nw; h++) c->h_n_anchors[h] += wc[h];
         const int64_t n_dp0 = dp_cnt[n_chunks];
         c->h_dp.resize(n_dp0);
+        dp_walk.resize(n_dp0);
         a_e1.resize(n_dp0);
         a_span.resize(n_dp0);
         PhiHostError herr;
         phi_parallel_chunks(n_kept, chunk, [&](int64_t lo, int64_t hi, int) {
             int64_t o = dp_cnt[lo / chunk];
+            int32_t hw = phi_entry_walk(c, c->h_kept[lo].e0);
             for (int64_t i = lo; i < hi; i++) {
                 const PhiAnchorHost &k = c->h_kept[i];
+                while (k.e0 >= c->h_walk_off[hw + 1]) hw++;
                 if (k.e1 <= k.e0) continue;
+                dp_walk[o] = (int16_t)hw;
                 if (k.e1 - k.e0 >= PHI_RCAP) { herr.set(PHI_ERR_DEVICE, "anchor spans %d edges (internal error)", k.e1 - k.e0); return; }
                 c->h_dp[o] = k;
                 a_e1[o] = k.e1;
@@ -424,6 +429,15 @@ int phi_solve_impl(phi_ctx *c)
     };
 
     tm.lap("minimiser -> anchors map");
+    // Minimisers with two anchors on ONE walk (repeats along a haplotype) are what an additive DP counts
+    // twice on sight: start the relaxation with them in S instead of discovering them by a first run.
+    std::set<uint32_t> S0;
+    if (!getenv("PHI_NO_S0")) {
+        for (int64_t s = 0; s < n_ids; s++)
+            for (int32_t j = sa_off[s] + 1; j < sa_off[s + 1]; j++)
+                if (dp_walk[sa_idx[j]] == dp_walk[sa_idx[j - 1]]) { S0.insert((uint32_t)s); break; }
+        if (tm.on) fprintf(stderr, "[phi timing] solve: %zu minimisers repeat along a walk\n", S0.size());
+    }
     DpHost H;
     std::vector<uint8_t> wgt(n_dp, 1);
     std::vector<Seg> best_segs;
@@ -443,6 +457,7 @@ int phi_solve_impl(phi_ctx *c)
         std::map<uint32_t, std::vector<std::vector<int32_t>>> assign_clusters;
         for (auto &kv : assign) assign_clusters[kv.first] = clusters_of(kv.first);
         std::set<uint32_t> S;
+        if (node.assign.empty()) S = S0;
         std::set<std::set<uint32_t>> seenS;
         bool closed = false;
         int64_t node_ub = node.ub;
