@@ -519,35 +519,49 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     PHICHK(phi_dev_ensure(c, c->d_rec_slot, (size_t)nr * 4));
     PHICHK(phi_dev_ensure(c, c->d_rec_e0, (size_t)nr * 4));
     PHICHK(phi_dev_ensure(c, c->d_rec_e1, (size_t)nr * 4));
-    c->u_cap = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)c->n_rec));
-    PHICHK(phi_dev_ensure(c, c->d_u_keys, c->u_cap * 8));
-    PHICHK(phi_dev_ensure(c, c->d_u_rep, c->u_cap * 4));
-    phi_launch_fill_u64(c->stream, c->d_u_keys.as<uint64_t>(), (int64_t)c->u_cap, PHI_EMPTY_KEY);
-    phi_launch_fill_u32(c->stream, c->d_u_rep.as<uint32_t>(), (int64_t)c->u_cap, 0xFFFFFFFFu);
-    phi_launch_table_build(c->stream, c->d_rec_hash.as<uint64_t>(), c->n_rec, c->d_u_keys.as<uint64_t>(),
-                           c->d_u_rep.as<uint32_t>(), c->u_cap - 1, c->d_rec_slot.as<uint32_t>(),
-                           (uint32_t *)scalar(c, S_ERR));
-    // dense, rank-independent minimiser ids: rank of the first record of each hash in position order
+    // The table is sized by an estimate of the DISTINCT minimisers -- the walks of a pangenome share
+    // most of theirs, so 32x the records of an average walk (load ~3 %: read probes settle on the
+    // first slot) -- and only when that overflows by the records (2x, the worst case).
+    const uint64_t cap_full = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)c->n_rec));
+    uint64_t cap_try = pow2_at_least(std::max<uint64_t>(1024, 32 * (uint64_t)((c->n_rec + n_walks - 1) / n_walks)));
+    if (cap_try > cap_full) cap_try = cap_full;
     PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)nr));
-    phi_launch_rep_flags(c->stream, c->d_rec_slot.as<uint32_t>(), c->n_rec, c->d_u_rep.as<uint32_t>(),
-                         c->d_flags.as<uint8_t>());
-    PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), c->n_rec, c->d_m_rec, &c->n_unique));
-    // the final table is sized by the distinct minimisers, not by the records (table.hip): the
-    // records-sized one above only served to find the first record of every hash
+    for (;;) {
+        c->u_cap = cap_try;
+        PHICHK(phi_dev_ensure(c, c->d_u_keys, c->u_cap * 8));
+        PHICHK(phi_dev_ensure(c, c->d_u_rep, c->u_cap * 4));
+        phi_launch_fill_u64(c->stream, c->d_u_keys.as<uint64_t>(), (int64_t)c->u_cap, PHI_EMPTY_KEY);
+        phi_launch_fill_u32(c->stream, c->d_u_rep.as<uint32_t>(), (int64_t)c->u_cap, 0xFFFFFFFFu);
+        phi_launch_table_build(c->stream, c->d_rec_hash.as<uint64_t>(), c->n_rec, c->d_u_keys.as<uint64_t>(),
+                               c->d_u_rep.as<uint32_t>(), c->u_cap - 1, c->d_rec_slot.as<uint32_t>(),
+                               (uint32_t *)scalar(c, S_ERR));
+        // dense, rank-independent minimiser ids: rank of the first record of each hash in position order
+        phi_launch_rep_flags(c->stream, c->d_rec_slot.as<uint32_t>(), c->n_rec, c->d_u_rep.as<uint32_t>(),
+                             c->d_flags.as<uint8_t>());
+        PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), c->n_rec, c->d_m_rec, &c->n_unique));   // waits for the stream
+        uint32_t err = 0;
+        HIPCHK(hipMemcpy(&err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
+        if (!(err & PHI_KERR_TABLE_FULL) || cap_try == cap_full) break;
+        err &= ~PHI_KERR_TABLE_FULL;                     // the estimate was too small for this graph
+        HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
+        cap_try = cap_full;
+    }
     {
-        const uint64_t cap2 = pow2_at_least(std::max<uint64_t>(1024, 32 * (uint64_t)c->n_unique));
-        if (cap2 < c->u_cap) {
+        // wanted capacity: 32x the distinct keys; re-insert them (and look every record up again) when
+        // the table is more than a factor two away from it
+        const uint64_t want = pow2_at_least(std::max<uint64_t>(1024, 32 * (uint64_t)c->n_unique));
+        if (c->u_cap > 2 * want || 2 * c->u_cap < want) {
             DevBuf keys2, uid2;
-            PHICHK(phi_dev_ensure(c, keys2, cap2 * 8));
-            PHICHK(phi_dev_ensure(c, uid2, cap2 * 4));
-            phi_launch_fill_u64(c->stream, keys2.as<uint64_t>(), (int64_t)cap2, PHI_EMPTY_KEY);
+            PHICHK(phi_dev_ensure(c, keys2, want * 8));
+            PHICHK(phi_dev_ensure(c, uid2, want * 4));
+            phi_launch_fill_u64(c->stream, keys2.as<uint64_t>(), (int64_t)want, PHI_EMPTY_KEY);
             phi_launch_table_compact(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_hash.as<uint64_t>(), c->n_rec,
-                                     keys2.as<uint64_t>(), uid2.as<uint32_t>(), cap2 - 1, c->d_rec_slot.as<uint32_t>(),
+                                     keys2.as<uint64_t>(), uid2.as<uint32_t>(), want - 1, c->d_rec_slot.as<uint32_t>(),
                                      (uint32_t *)scalar(c, S_ERR));
             HIPCHK(hipStreamSynchronize(c->stream));
             dev_free(c->d_u_keys); dev_free(c->d_u_uid); dev_free(c->d_u_rep);
             c->d_u_keys = keys2; c->d_u_uid = uid2;
-            c->u_cap = cap2;
+            c->u_cap = want;
         } else {
             PHICHK(phi_dev_ensure(c, c->d_u_uid, c->u_cap * 4));
             phi_launch_slot_uid(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_slot.as<uint32_t>(),

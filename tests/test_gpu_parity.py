@@ -316,6 +316,30 @@ def test_walks_ending_inside_the_graph(oracle, ctx_factory):
         assert res["objective"] == m.brute_force()[0]
 
 
+@pytest.mark.parametrize("n", [40, 100])
+def test_walks_that_share_nothing(oracle, ctx_factory, n):
+    """Walks through private 400-bp branches: the walk-minimiser table's first sizing (32x the
+    records of an average walk) is too small -- with 40 walks it is re-inserted at a larger size, with
+    100 the first build overflows and falls back to the records-sized table."""
+    rng = np.random.default_rng(4040)
+
+    def rseq(m):
+        return bytes(rng.choice(list(b"ACGT"), size=m).tolist())
+    node_seq = [rseq(20)] + [rseq(400) for _ in range(n)] + [rseq(20)]
+    adj = [list(range(1, n + 1))] + [[n + 1] for _ in range(n)] + [[]]
+    g = oracle.Graph(seg_names=[f"s{i}" for i in range(n + 2)], node_seq=node_seq, adj=adj,
+                     paths=[[0, i + 1, n + 1] for i in range(n)], hap_names=[f"h{i}.0" for i in range(n)])
+    oracle.kahn(g)
+    reads = [g.node_seq[0] + g.node_seq[7][:200], g.node_seq[7][150:] + g.node_seq[n + 1], g.node_seq[23][50:300]]
+    ctx = ctx_factory(k=15, w=5, threshold=1.0, recombination=3)
+    _set_graph(ctx, g)
+    hist, n_distinct = ctx.walk_sharing(n)
+    assert hist[1] > 30 * hist[n]                              # almost everything is private to one walk
+    ctx.add_reads(reads)
+    st, res, m = _check_against_oracle(oracle, ctx, g, reads, 15, 5, 1.0, 3)
+    assert res["path_hap"][1] == 6 and res["n_switches"] == 0  # walk 6 carries branch vertex 7
+
+
 def test_walk_sharing_histogram(oracle, ctx_factory):
     """The reference's -d1 report (ILP_index.cpp:565-604): distinct walk minimisers by the number of
     walks they occur in, against a recount from the oracle's per-walk sketches."""
