@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <future>
 #include "phi_ctx.h"
 #include "phi_dev.h"
 
@@ -283,7 +284,166 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) c->h_in_src[cur[adj[x]]++] = u;
     }
 
+    // the kernels index with the walk entries: they must be in range before anything is launched
+    {
+        PhiHostError herr;
+        phi_parallel_chunks(n_entries, (int64_t)1 << 18, [&](int64_t lo, int64_t hi, int) {
+            uint32_t bad = 0;
+            for (int64_t e = lo; e < hi; e++) bad |= (uint32_t)walk_vtx[e] >= (uint32_t)n_vtx;
+            if (!bad) return;
+            for (int64_t e = lo; e < hi; e++)
+                if ((uint32_t)walk_vtx[e] >= (uint32_t)n_vtx) {
+                    const int32_t h = (int32_t)(std::upper_bound(walk_off, walk_off + n_walks + 1, e) - walk_off) - 1;
+                    herr.set(PHI_ERR_WALK, "walk %d holds vertex %d out of range", h, walk_vtx[e]);
+                    return;
+                }
+        });
+        if (herr.failed()) return phi_fail(c, herr.code, "%s", herr.msg.c_str());
+    }
     tm.lap("validate graph, copies");
+    // ---- the GPU side of the index (uploads, entry offsets, walk sketch, minimiser table) runs on its
+    //      own host thread while this one makes the pass over the walk entries below: neither needs
+    //      the other's results
+    auto gpu_part = [&]() -> int {
+        HIPCHK(hipSetDevice(c->device));
+        PhiStageTimer tg("set_graph");
+        PHICHK(upload(c, c->d_seq, c->h_seq.data(), c->h_seq.size()));
+        PHICHK(upload(c, c->d_seq_off, c->h_seq_off.data(), c->h_seq_off.size()));
+        PHICHK(upload(c, c->d_walk_vtx, walk_vtx, (size_t)n_entries));       // the caller's array: the host pass is still copying it
+        PHICHK(upload(c, c->d_walk_off, c->h_walk_off.data(), c->h_walk_off.size()));
+        // flat base offset of every walk entry: exclusive scan of the segment lengths, on the GPU
+        PHICHK(phi_dev_ensure(c, c->d_ebase, (size_t)(n_entries + 1) * 8));
+        PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)n_entries * 4));
+        phi_launch_entry_len(c->stream, c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(), n_entries, c->d_list3.as<int32_t>());
+        {
+            const int64_t nb = phi_scan_i32_num_blocks(n_entries);
+            PHICHK(phi_dev_ensure(c, c->d_scan_blk64, (size_t)nb * 8));
+            PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
+            phi_launch_scan_i64(c->stream, c->d_list3.as<int32_t>(), n_entries, c->d_ebase.as<int64_t>(), c->d_scan_blk64.as<int64_t>(),
+                                c->d_scan_blkoff.as<int64_t>());
+        }
+        PHICHK(upload(c, c->d_topo, c->h_topo.data(), c->h_topo.size()));
+        PHICHK(upload(c, c->d_in_off, c->h_in_off.data(), c->h_in_off.size()));
+        PHICHK(upload(c, c->d_in_src, c->h_in_src.data(), c->h_in_src.size()));
+
+        if (tg.on) (void)hipStreamSynchronize(c->stream);
+        tg.lap("[gpu thread] uploads + ebase scan");
+        // ---- stage 1a on the GPU: pack the walks, sketch them, build the minimiser table
+        HIPCHK(hipMemsetAsync(c->d_scalars.p, 0, S_N * 8, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_stripes.p, 0, 2 * STRIPE_BYTES, c->stream));
+        // bases of every walk from the scanned entry offsets
+        {
+            std::vector<int32_t> woff32(n_walks + 1);
+            for (int32_t h = 0; h <= n_walks; h++) woff32[h] = (int32_t)walk_off[h];
+            PHICHK(upload(c, c->d_list2, woff32.data(), woff32.size()));
+            PHICHK(phi_dev_ensure(c, c->d_list, (size_t)(n_walks + 1) * 8));
+            phi_launch_gather_u64(c->stream, c->d_ebase.as<uint64_t>(), c->d_list2.as<int32_t>(), n_walks + 1, c->d_list.as<uint64_t>());
+            c->h_walk_base.assign(n_walks + 1, 0);
+            HIPCHK(hipMemcpyAsync(c->h_walk_base.data(), c->d_list.p, (size_t)(n_walks + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        const int64_t run = c->h_walk_base[n_walks];
+        c->walk_bases = run;
+        const int64_t n_words = (run + 31) / 32;
+        PHICHK(phi_dev_ensure(c, c->d_wwords, (size_t)(n_words + 2) * 8));
+        PHICHK(phi_dev_ensure(c, c->d_wbad, (size_t)(n_words + 6) * 4));
+        phi_launch_pack_walks(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(),
+                              c->d_ebase.as<int64_t>(), n_entries, c->d_wwords.as<uint64_t>(), n_words,
+                              c->d_wbad.as<uint32_t>(), nullptr, (unsigned long long *)scalar(c, S_NBAD));
+        // bases outside ACGTacgt in the graph: keep a flat ASCII copy of the walks for the byte-wise path
+        const uint8_t *walk_ascii = nullptr;
+        {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            uint64_t n_bad = 0;
+            HIPCHK(hipMemcpy(&n_bad, scalar(c, S_NBAD), 8, hipMemcpyDeviceToHost));
+            if (n_bad) {
+                PHICHK(phi_dev_ensure(c, c->d_wascii, (size_t)run + 64));
+                HIPCHK(hipMemsetAsync(scalar(c, S_NBAD), 0, 8, c->stream));
+                phi_launch_pack_walks(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(),
+                                      c->d_ebase.as<int64_t>(), n_entries, c->d_wwords.as<uint64_t>(), n_words,
+                                      c->d_wbad.as<uint32_t>(), c->d_wascii.as<uint8_t>(), (unsigned long long *)scalar(c, S_NBAD));
+                walk_ascii = c->d_wascii.as<uint8_t>();
+            }
+        }
+        const size_t n_sw = (size_t)(run / 64 + 2);
+        PHICHK(phi_dev_ensure(c, c->d_wstarts, n_sw * 8));
+        HIPCHK(hipMemsetAsync(c->d_wstarts.p, 0, n_sw * 8, c->stream));
+        phi_launch_mark_starts(c->stream, c->d_list.as<int64_t>(), n_walks, c->d_wstarts.as<unsigned long long>());
+
+        PHICHK(sketch_records(c, c->d_wwords.as<uint64_t>(), c->d_wstarts.as<unsigned long long>(), run, c->k, c->w,
+                              walk_ascii, c->d_rec_hash, c->d_rec_pos, &c->n_rec));
+        if (c->n_rec >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk minimisers");
+        const int64_t nr = std::max<int64_t>(c->n_rec, 1);
+        PHICHK(phi_dev_ensure(c, c->d_rec_slot, (size_t)nr * 4));
+        PHICHK(phi_dev_ensure(c, c->d_rec_e0, (size_t)nr * 4));
+        PHICHK(phi_dev_ensure(c, c->d_rec_e1, (size_t)nr * 4));
+        // The table is sized by an estimate of the DISTINCT minimisers -- the walks of a pangenome share
+        // most of theirs, so 32x the records of an average walk (load ~3 %: read probes settle on the
+        // first slot) -- and only when that overflows by the records (2x, the worst case).
+        const uint64_t cap_full = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)c->n_rec));
+        uint64_t cap_try = pow2_at_least(std::max<uint64_t>(1024, 32 * (uint64_t)((c->n_rec + n_walks - 1) / n_walks)));
+        if (cap_try > cap_full) cap_try = cap_full;
+        PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)nr));
+        for (;;) {
+            c->u_cap = cap_try;
+            PHICHK(phi_dev_ensure(c, c->d_u_keys, c->u_cap * 8));
+            PHICHK(phi_dev_ensure(c, c->d_u_rep, c->u_cap * 4));
+            phi_launch_fill_u64(c->stream, c->d_u_keys.as<uint64_t>(), (int64_t)c->u_cap, PHI_EMPTY_KEY);
+            phi_launch_fill_u32(c->stream, c->d_u_rep.as<uint32_t>(), (int64_t)c->u_cap, 0xFFFFFFFFu);
+            phi_launch_table_build(c->stream, c->d_rec_hash.as<uint64_t>(), c->n_rec, c->d_u_keys.as<uint64_t>(),
+                                   c->d_u_rep.as<uint32_t>(), c->u_cap - 1, c->d_rec_slot.as<uint32_t>(),
+                                   (uint32_t *)scalar(c, S_ERR));
+            // dense, rank-independent minimiser ids: rank of the first record of each hash in position order
+            phi_launch_rep_flags(c->stream, c->d_rec_slot.as<uint32_t>(), c->n_rec, c->d_u_rep.as<uint32_t>(),
+                                 c->d_flags.as<uint8_t>());
+            PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), c->n_rec, c->d_m_rec, &c->n_unique));   // waits for the stream
+            uint32_t err = 0;
+            HIPCHK(hipMemcpy(&err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
+            if (!(err & PHI_KERR_TABLE_FULL) || cap_try == cap_full) break;
+            err &= ~PHI_KERR_TABLE_FULL;                     // the estimate was too small for this graph
+            HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
+            cap_try = cap_full;
+        }
+        {
+            // wanted capacity: 32x the distinct keys; re-insert them (and look every record up again) when
+            // the table is more than a factor two away from it
+            const uint64_t want = pow2_at_least(std::max<uint64_t>(1024, 32 * (uint64_t)c->n_unique));
+            if (c->u_cap > 2 * want || 2 * c->u_cap < want) {
+                DevBuf keys2, uid2;
+                PHICHK(phi_dev_ensure(c, keys2, want * 8));
+                PHICHK(phi_dev_ensure(c, uid2, want * 4));
+                phi_launch_fill_u64(c->stream, keys2.as<uint64_t>(), (int64_t)want, PHI_EMPTY_KEY);
+                phi_launch_table_compact(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_hash.as<uint64_t>(), c->n_rec,
+                                         keys2.as<uint64_t>(), uid2.as<uint32_t>(), want - 1, c->d_rec_slot.as<uint32_t>(),
+                                         (uint32_t *)scalar(c, S_ERR));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                dev_free(c->d_u_keys); dev_free(c->d_u_uid); dev_free(c->d_u_rep);
+                c->d_u_keys = keys2; c->d_u_uid = uid2;
+                c->u_cap = want;
+            } else {
+                PHICHK(phi_dev_ensure(c, c->d_u_uid, c->u_cap * 4));
+                phi_launch_slot_uid(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_slot.as<uint32_t>(),
+                                    c->d_u_uid.as<uint32_t>());
+            }
+        }
+        phi_launch_locate(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_ebase.as<int64_t>(), n_entries, c->k,
+                          c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>());
+        // records of each walk ("Number of Minimizers", ILP_index.cpp:563)
+        PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)(n_walks + 1) * 8));
+        phi_launch_lower_bound(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_list.as<int64_t>(), n_walks + 1,
+                               c->d_list2.as<int64_t>());
+        c->h_walk_rec_off.resize(n_walks + 1);
+        HIPCHK(hipMemcpyAsync(c->h_walk_rec_off.data(), c->d_list2.p, (size_t)(n_walks + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        PHICHK(phi_dev_ensure(c, c->d_hit, (size_t)(c->n_unique / 8 + 1) * 8));
+        HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)(c->n_unique / 8 + 1) * 8, c->stream));
+        HIPCHK(hipGetLastError());
+        PHICHK(phi_sync_check(c));
+        tg.lap("[gpu thread] walk sketch + table");
+        return PHI_OK;
+    };
+    std::future<int> gpu_future = std::async(std::launch::async, gpu_part);
+    // every early return below must first wait for that thread
+    struct Joiner { std::future<int> &f; ~Joiner() { if (f.valid()) f.wait(); } } joiner{gpu_future};
     // ---- one parallel pass over the walk entries (host threads over fixed chunks of entries):
     //   * walks follow edges of forward vertices (ILP_index.cpp:104-107 exits on reverse strand; an
     //     edge-less step would make the anchor's edge variables unconstrained, :799-815)
@@ -298,7 +458,6 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     // the step masks serve the every-vertex kernel only (dp.hip, more than 128 walks)
     const bool want_masks = !(n_walks <= PHI_DP_EVENT_MAX_WALKS && !getenv("PHI_DP_DENSE"));
     std::vector<unsigned long long> st_mask(want_masks ? (size_t)n_vtx * nw64 : 0, 0ull);
-    std::vector<int64_t> walk_len(n_walks, 0);
     {
         PhiHostError herr;
         int32_t *h_wv = c->h_walk_vtx.data();
@@ -311,17 +470,12 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             std::vector<int32_t> &cnt = cnt_priv[worker];
             if (cnt.empty()) cnt.assign(std::max<int64_t>(n_edges, 1), 0);
             int32_t h = (int32_t)(std::upper_bound(walk_off, walk_off + n_walks + 1, lo) - walk_off) - 1;
-            int64_t bases = 0;
             for (int64_t e = lo; e < hi; e++) {
-                while (e >= walk_off[h + 1]) {
-                    __atomic_fetch_add(&walk_len[h], bases, __ATOMIC_RELAXED);
-                    bases = 0; h++;
-                }
+                while (e >= walk_off[h + 1]) h++;
                 const int32_t u = walk_vtx[e];
                 if (u < 0 || u >= n_vtx) { herr.set(PHI_ERR_WALK, "walk %d holds vertex %d out of range", h, u); return; }
                 const int64_t len = seq_off[u + 1] - seq_off[u];
                 if (len == 0) { herr.set(PHI_ERR_UNSUPPORTED, "walk %d passes through empty segment %d", h, u); return; }
-                bases += len;
                 h_wv[e] = u;
                 if (want_masks) __atomic_fetch_or(&st_mask[(size_t)topo_rank[u] * nw64 + (h >> 6)], 1ull << (h & 63), __ATOMIC_RELAXED);
                 if (e + 1 < walk_off[h + 1]) {
@@ -336,7 +490,6 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                     cnt[x]++;
                 }
             }
-            __atomic_fetch_add(&walk_len[h], bases, __ATOMIC_RELAXED);
         });
         if (herr.failed()) return phi_fail(c, herr.code, "%s", herr.msg.c_str());
         phi_parallel_chunks(n_edges, (int64_t)1 << 14, [&](int64_t lo, int64_t hi, int) {
@@ -346,18 +499,14 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     }
     tm.lap("walk entries (threads)");
     bool start_interior = false, end_interior = false;
-    c->h_walk_base.assign(n_walks + 1, 0);
     for (int32_t h = 0; h < n_walks; h++) {
         if (indeg[walk_vtx[walk_off[h]]] > 0) start_interior = true;
         const int32_t last = walk_vtx[walk_off[h + 1] - 1];
         if (adj_off[last + 1] > adj_off[last]) end_interior = true;
-        c->h_walk_base[h + 1] = c->h_walk_base[h] + walk_len[h];
     }
     if (start_interior && end_interior)
         return phi_fail(c, PHI_ERR_UNSUPPORTED, "walks both start and end at interior vertices: the reference model "
                         "admits flow leak/spawn artefacts there (ILP_index.cpp:1330) that are not emulated");
-    const int64_t run = c->h_walk_base[n_walks];
-    c->walk_bases = run;
     for (int32_t u = 0; u < n_vtx; u++)
         for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) cont_total[u] += cnt_edge[x];
 
@@ -442,32 +591,19 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         HIPCHK(hipStreamSynchronize(c->stream));              // the vectors above go out of scope
     }
     tm.lap("DP step stream");
-    // ---- device copies
+    // ---- the GPU side has been running meanwhile
+    {
+        const int grc = gpu_future.get();
+        if (grc) return grc;
+    }
+    tm.lap("wait for the GPU thread");
+    // ---- device copies of what the host pass made
     PHICHK(upload(c, c->d_e_out, e_out.data(), e_out.size()));
     if (!c->dp_events) {                                       // the every-vertex stream serves dp.hip only
         PHICHK(upload(c, c->d_st_rec, st_rec.data(), st_rec.size()));
         PHICHK(upload(c, c->d_st_mask, st_mask.data(), st_mask.size()));
         PHICHK(upload(c, c->d_in_packed, in_packed.data(), in_packed.size()));
     }
-    PHICHK(upload(c, c->d_seq, c->h_seq.data(), c->h_seq.size()));
-    PHICHK(upload(c, c->d_seq_off, c->h_seq_off.data(), c->h_seq_off.size()));
-    PHICHK(upload(c, c->d_walk_vtx, c->h_walk_vtx.data(), c->h_walk_vtx.size()));
-    PHICHK(upload(c, c->d_walk_off, c->h_walk_off.data(), c->h_walk_off.size()));
-    // flat base offset of every walk entry: exclusive scan of the segment lengths, on the GPU
-    PHICHK(phi_dev_ensure(c, c->d_ebase, (size_t)(n_entries + 1) * 8));
-    PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)n_entries * 4));
-    phi_launch_entry_len(c->stream, c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(), n_entries, c->d_list3.as<int32_t>());
-    {
-        const int64_t nb = phi_scan_i32_num_blocks(n_entries);
-        PHICHK(phi_dev_ensure(c, c->d_scan_blk64, (size_t)nb * 8));
-        PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
-        phi_launch_scan_i64(c->stream, c->d_list3.as<int32_t>(), n_entries, c->d_ebase.as<int64_t>(), c->d_scan_blk64.as<int64_t>(),
-                            c->d_scan_blkoff.as<int64_t>());
-    }
-    PHICHK(upload(c, c->d_topo, c->h_topo.data(), c->h_topo.size()));
-    PHICHK(upload(c, c->d_in_off, c->h_in_off.data(), c->h_in_off.size()));
-    PHICHK(upload(c, c->d_in_src, c->h_in_src.data(), c->h_in_src.size()));
-
     // events of every walk: its entries on the compact steps
     if (c->dp_events) {
         PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)n_entries));
@@ -477,110 +613,10 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         phi_launch_event_off(c->stream, c->d_ev_e.as<int32_t>(), c->n_ev, c->d_walk_off.as<int64_t>(), n_walks,
                              c->d_ev_off.as<int64_t>());
     }
-    if (tm.on) (void)hipStreamSynchronize(c->stream);
-    if (tm.on) fprintf(stderr, "[phi timing] set_graph: %d vertices, %d compact steps, %lld entries, %lld events\n", n_vtx, c->n_k, (long long)n_entries, (long long)c->n_ev);
-    tm.lap("uploads + ebase scan");
-    // ---- stage 1a on the GPU: pack the walks, sketch them, build the minimiser table
-    HIPCHK(hipMemsetAsync(c->d_scalars.p, 0, S_N * 8, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_stripes.p, 0, 2 * STRIPE_BYTES, c->stream));
-    const int64_t n_words = (run + 31) / 32;
-    PHICHK(phi_dev_ensure(c, c->d_wwords, (size_t)(n_words + 2) * 8));
-    PHICHK(phi_dev_ensure(c, c->d_wbad, (size_t)(n_words + 6) * 4));
-    phi_launch_pack_walks(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(),
-                          c->d_ebase.as<int64_t>(), n_entries, c->d_wwords.as<uint64_t>(), n_words,
-                          c->d_wbad.as<uint32_t>(), nullptr, (unsigned long long *)scalar(c, S_NBAD));
-    // bases outside ACGTacgt in the graph: keep a flat ASCII copy of the walks for the byte-wise path
-    const uint8_t *walk_ascii = nullptr;
-    {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        uint64_t n_bad = 0;
-        HIPCHK(hipMemcpy(&n_bad, scalar(c, S_NBAD), 8, hipMemcpyDeviceToHost));
-        if (n_bad) {
-            PHICHK(phi_dev_ensure(c, c->d_wascii, (size_t)run + 64));
-            HIPCHK(hipMemsetAsync(scalar(c, S_NBAD), 0, 8, c->stream));
-            phi_launch_pack_walks(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(),
-                                  c->d_ebase.as<int64_t>(), n_entries, c->d_wwords.as<uint64_t>(), n_words,
-                                  c->d_wbad.as<uint32_t>(), c->d_wascii.as<uint8_t>(), (unsigned long long *)scalar(c, S_NBAD));
-            walk_ascii = c->d_wascii.as<uint8_t>();
-        }
-    }
-    const size_t n_sw = (size_t)(run / 64 + 2);
-    PHICHK(phi_dev_ensure(c, c->d_wstarts, n_sw * 8));
-    HIPCHK(hipMemsetAsync(c->d_wstarts.p, 0, n_sw * 8, c->stream));
-    std::vector<int64_t> wstart(n_walks + 1);
-    for (int32_t h = 0; h <= n_walks; h++) wstart[h] = c->h_walk_base[h];
-    PHICHK(upload(c, c->d_list, wstart.data(), wstart.size()));
-    phi_launch_mark_starts(c->stream, c->d_list.as<int64_t>(), n_walks, c->d_wstarts.as<unsigned long long>());
-
-    PHICHK(sketch_records(c, c->d_wwords.as<uint64_t>(), c->d_wstarts.as<unsigned long long>(), run, c->k, c->w,
-                          walk_ascii, c->d_rec_hash, c->d_rec_pos, &c->n_rec));
-    if (c->n_rec >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk minimisers");
-    const int64_t nr = std::max<int64_t>(c->n_rec, 1);
-    PHICHK(phi_dev_ensure(c, c->d_rec_slot, (size_t)nr * 4));
-    PHICHK(phi_dev_ensure(c, c->d_rec_e0, (size_t)nr * 4));
-    PHICHK(phi_dev_ensure(c, c->d_rec_e1, (size_t)nr * 4));
-    // The table is sized by an estimate of the DISTINCT minimisers -- the walks of a pangenome share
-    // most of theirs, so 32x the records of an average walk (load ~3 %: read probes settle on the
-    // first slot) -- and only when that overflows by the records (2x, the worst case).
-    const uint64_t cap_full = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)c->n_rec));
-    uint64_t cap_try = pow2_at_least(std::max<uint64_t>(1024, 32 * (uint64_t)((c->n_rec + n_walks - 1) / n_walks)));
-    if (cap_try > cap_full) cap_try = cap_full;
-    PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)nr));
-    for (;;) {
-        c->u_cap = cap_try;
-        PHICHK(phi_dev_ensure(c, c->d_u_keys, c->u_cap * 8));
-        PHICHK(phi_dev_ensure(c, c->d_u_rep, c->u_cap * 4));
-        phi_launch_fill_u64(c->stream, c->d_u_keys.as<uint64_t>(), (int64_t)c->u_cap, PHI_EMPTY_KEY);
-        phi_launch_fill_u32(c->stream, c->d_u_rep.as<uint32_t>(), (int64_t)c->u_cap, 0xFFFFFFFFu);
-        phi_launch_table_build(c->stream, c->d_rec_hash.as<uint64_t>(), c->n_rec, c->d_u_keys.as<uint64_t>(),
-                               c->d_u_rep.as<uint32_t>(), c->u_cap - 1, c->d_rec_slot.as<uint32_t>(),
-                               (uint32_t *)scalar(c, S_ERR));
-        // dense, rank-independent minimiser ids: rank of the first record of each hash in position order
-        phi_launch_rep_flags(c->stream, c->d_rec_slot.as<uint32_t>(), c->n_rec, c->d_u_rep.as<uint32_t>(),
-                             c->d_flags.as<uint8_t>());
-        PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), c->n_rec, c->d_m_rec, &c->n_unique));   // waits for the stream
-        uint32_t err = 0;
-        HIPCHK(hipMemcpy(&err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
-        if (!(err & PHI_KERR_TABLE_FULL) || cap_try == cap_full) break;
-        err &= ~PHI_KERR_TABLE_FULL;                     // the estimate was too small for this graph
-        HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
-        cap_try = cap_full;
-    }
-    {
-        // wanted capacity: 32x the distinct keys; re-insert them (and look every record up again) when
-        // the table is more than a factor two away from it
-        const uint64_t want = pow2_at_least(std::max<uint64_t>(1024, 32 * (uint64_t)c->n_unique));
-        if (c->u_cap > 2 * want || 2 * c->u_cap < want) {
-            DevBuf keys2, uid2;
-            PHICHK(phi_dev_ensure(c, keys2, want * 8));
-            PHICHK(phi_dev_ensure(c, uid2, want * 4));
-            phi_launch_fill_u64(c->stream, keys2.as<uint64_t>(), (int64_t)want, PHI_EMPTY_KEY);
-            phi_launch_table_compact(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_hash.as<uint64_t>(), c->n_rec,
-                                     keys2.as<uint64_t>(), uid2.as<uint32_t>(), want - 1, c->d_rec_slot.as<uint32_t>(),
-                                     (uint32_t *)scalar(c, S_ERR));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            dev_free(c->d_u_keys); dev_free(c->d_u_uid); dev_free(c->d_u_rep);
-            c->d_u_keys = keys2; c->d_u_uid = uid2;
-            c->u_cap = want;
-        } else {
-            PHICHK(phi_dev_ensure(c, c->d_u_uid, c->u_cap * 4));
-            phi_launch_slot_uid(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_slot.as<uint32_t>(),
-                                c->d_u_uid.as<uint32_t>());
-        }
-    }
-    phi_launch_locate(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_ebase.as<int64_t>(), n_entries, c->k,
-                      c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>());
-    // records of each walk ("Number of Minimizers", ILP_index.cpp:563)
-    PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)(n_walks + 1) * 8));
-    phi_launch_lower_bound(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_list.as<int64_t>(), n_walks + 1,
-                           c->d_list2.as<int64_t>());
-    c->h_walk_rec_off.resize(n_walks + 1);
-    HIPCHK(hipMemcpyAsync(c->h_walk_rec_off.data(), c->d_list2.p, (size_t)(n_walks + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    PHICHK(phi_dev_ensure(c, c->d_hit, (size_t)(c->n_unique / 8 + 1) * 8));
-    HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)(c->n_unique / 8 + 1) * 8, c->stream));
     HIPCHK(hipGetLastError());
     PHICHK(phi_sync_check(c));
-    tm.lap("walk sketch + table (GPU)");
+    if (tm.on) fprintf(stderr, "[phi timing] set_graph: %d vertices, %d compact steps, %lld entries, %lld events\n", n_vtx, c->n_k, (long long)n_entries, (long long)c->n_ev);
+    tm.lap("late uploads + event list");
     c->h_n_minimizers.resize(n_walks);
     for (int32_t h = 0; h < n_walks; h++) c->h_n_minimizers[h] = c->h_walk_rec_off[h + 1] - c->h_walk_rec_off[h];
 
