@@ -86,6 +86,18 @@ int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted)
     return PHI_OK;
 }
 
+int phi_pin_ensure(phi_ctx *c, size_t bytes)
+{
+    if (bytes <= c->h_pin_cap) return PHI_OK;
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    c->h_pin = nullptr; c->h_pin_cap = 0;
+    c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{};
+    const size_t want = bytes + bytes / 4;
+    if (hipHostMalloc(&c->h_pin, want, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; return phi_fail(c, PHI_ERR_NOMEM, "pinned host allocation of %zu bytes failed", want); }
+    c->h_pin_cap = want;
+    return PHI_OK;
+}
+
 // wait for the stream and translate the device error word
 int phi_sync_check(phi_ctx *c)
 {
@@ -156,6 +168,7 @@ int phi_ctx_create(int device_id, phi_ctx **out)
 
 void phi_ctx_destroy(phi_ctx *c)
 {
+    if (c && c->h_pin) { (void)hipSetDevice(c->device); (void)hipHostFree(c->h_pin); c->h_pin = nullptr; }
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -373,6 +386,10 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         PHICHK(sketch_records(c, c->d_wwords.as<uint64_t>(), c->d_wstarts.as<unsigned long long>(), run, c->k, c->w,
                               walk_ascii, c->d_rec_hash, c->d_rec_pos, &c->n_rec));
         if (c->n_rec >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk minimisers");
+        // the solve downloads its kept anchors (12 bytes each, usually a small fraction of the walk
+        // minimisers) into pinned memory: allocate it here, beside the host pass, not inside the solve
+        c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{};
+        (void)phi_pin_ensure(c, (size_t)(c->n_rec / 8 + 4096) * sizeof(PhiAnchorHost));
         const int64_t nr = std::max<int64_t>(c->n_rec, 1);
         PHICHK(phi_dev_ensure(c, c->d_rec_slot, (size_t)nr * 4));
         PHICHK(phi_dev_ensure(c, c->d_rec_e0, (size_t)nr * 4));

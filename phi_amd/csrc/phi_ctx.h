@@ -27,6 +27,16 @@ struct PhiAnchorHost {       // one dp anchor on the host (certificate / branch-
     int32_t e0, e1;          // first / last walk entry
 };
 
+// view of host anchors: the pinned download buffer, or an owned vector
+struct PhiAnchorSpan {
+    PhiAnchorHost *p = nullptr;
+    int64_t n = 0;
+    size_t size() const { return (size_t)n; }
+    PhiAnchorHost &operator[](int64_t i) const { return p[i]; }
+    PhiAnchorHost *begin() const { return p; }
+    PhiAnchorHost *end() const { return p + n; }
+};
+
 struct phi_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -82,7 +92,10 @@ struct phi_ctx {
     int64_t n_ev = 0;                                 // events
     std::vector<int32_t> h_cstep, h_kstep;            // topological step -> compact step (-1) and back
     DevBuf d_k_rec, d_k_in, d_cvtx, d_ev_e, d_ev_off, d_ev, d_cnt_end, d_cnt_start, d_off_end, d_off_start, d_scan_blk, d_scan_blk64, d_scan_blkoff;
-    std::vector<PhiAnchorHost> h_kept, h_dp;          // kept anchors; dp anchors (span >= 1 edge)
+    PhiAnchorSpan h_kept, h_dp;                       // kept anchors (in h_pin); dp anchors (span >= 1 edge: h_kept itself or h_dp_own)
+    std::vector<PhiAnchorHost> h_dp_own;
+    void *h_pin = nullptr;                            // pinned host buffer the kept anchors are downloaded into
+    size_t h_pin_cap = 0;
     std::vector<uint64_t> h_kept_hash;
     std::vector<int32_t> h_path_vtx, h_path_hap;
     std::vector<int64_t> h_n_minimizers, h_n_anchors;
@@ -182,6 +195,8 @@ int phi_fail(phi_ctx *c, int code, const char *fmt, ...);
 int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes);
 int phi_hip_check(phi_ctx *c, hipError_t e, const char *what);
 int phi_sync_check(phi_ctx *c);
+// pinned host buffer of at least `bytes` (contents are not kept)
+int phi_pin_ensure(phi_ctx *c, size_t bytes);
 // sums of the striped counters (waits for the stream)
 int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted);
 // flags[n] (0/1) -> ascending list of flagged indices (int32) in out

@@ -179,7 +179,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
 // dp anchors traversed by a path: calls f(anchor index)
 template <class F> static void for_covered(const phi_ctx *c, const std::vector<Seg> &segs, F f)
 {
-    const std::vector<PhiAnchorHost> &A = c->h_dp;            // sorted by e1
+    const PhiAnchorSpan &A = c->h_dp;                         // sorted by e1
     for (const Seg &s : segs) {
         auto lo = std::lower_bound(A.begin(), A.end(), s.es, [](const PhiAnchorHost &a, int32_t e) { return a.e1 < e; });
         for (auto it = lo; it != A.end() && it->e1 <= s.ee; ++it)
@@ -261,7 +261,9 @@ int phi_solve_impl(phi_ctx *c)
     tm.lap("filter kernels");
     // kept anchors to the host as (minimiser id, first entry, last entry) triples, gathered into
     // that layout on the GPU; their hashes stay behind (phi_kept_anchors fetches them on demand)
-    c->h_kept.resize(n_kept);
+    PHICHK(phi_pin_ensure(c, (size_t)std::max<int64_t>(n_kept, 1) * sizeof(PhiAnchorHost)));
+    c->h_kept = PhiAnchorSpan{static_cast<PhiAnchorHost *>(c->h_pin), n_kept};
+    c->h_dp = PhiAnchorSpan{};
     c->h_kept_hash.clear();
     PHICHK(phi_dev_ensure(c, c->d_kept_rec, (size_t)std::max<int64_t>(n_kept, 1) * 4));
     if (n_kept) {
@@ -270,7 +272,7 @@ int phi_solve_impl(phi_ctx *c)
         phi_launch_anchor_triples(c->stream, c->d_kept_rec.as<int32_t>(), n_kept, c->d_rec_slot.as<uint32_t>(), c->d_u_uid.as<uint32_t>(),
                                   c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>(), c->d_list2.as<int32_t>());
         static_assert(sizeof(PhiAnchorHost) == 12, "PhiAnchorHost is the device triple");
-        HIPCHK(hipMemcpyAsync(c->h_kept.data(), c->d_list2.p, (size_t)n_kept * 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_kept.p, c->d_list2.p, (size_t)n_kept * 12, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
@@ -302,7 +304,10 @@ int phi_solve_impl(phi_ctx *c)
         for (int64_t i = 0; i < n_chunks; i++) dp_cnt[i + 1] += dp_cnt[i];
         for (const auto &wc : walk_cnt) for (int32_t h = 0; h < nw; h++) c->h_n_anchors[h] += wc[h];
         const int64_t n_dp0 = dp_cnt[n_chunks];
-        c->h_dp.resize(n_dp0);
+        // usually every kept anchor spans an edge (vertices shorter than k): the dp list is the kept list
+        const bool same = n_dp0 == n_kept;
+        if (same) { c->h_dp_own.clear(); c->h_dp = c->h_kept; }
+        else { c->h_dp_own.resize(n_dp0); c->h_dp = PhiAnchorSpan{c->h_dp_own.data(), n_dp0}; }
         dp_walk.resize(n_dp0);
         a_e1.resize(n_dp0);
         a_span.resize(n_dp0);
@@ -316,7 +321,7 @@ int phi_solve_impl(phi_ctx *c)
                 if (k.e1 <= k.e0) continue;
                 dp_walk[o] = (int16_t)hw;
                 if (k.e1 - k.e0 >= PHI_RCAP) { herr.set(PHI_ERR_DEVICE, "anchor spans %d edges (internal error)", k.e1 - k.e0); return; }
-                c->h_dp[o] = k;
+                if (!same) c->h_dp[o] = k;
                 a_e1[o] = k.e1;
                 a_span[o] = (uint8_t)(k.e1 - k.e0);
                 o++;
