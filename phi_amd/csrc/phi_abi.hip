@@ -88,6 +88,7 @@ int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted)
 
 int phi_pin_ensure(phi_ctx *c, size_t bytes)
 {
+    if (c->pin_future.valid()) c->pin_future.wait();          // an allocation started by phi_set_graph
     if (bytes <= c->h_pin_cap) return PHI_OK;
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     c->h_pin = nullptr; c->h_pin_cap = 0;
@@ -168,6 +169,7 @@ int phi_ctx_create(int device_id, phi_ctx **out)
 
 void phi_ctx_destroy(phi_ctx *c)
 {
+    if (c && c->pin_future.valid()) c->pin_future.wait();
     if (c && c->h_pin) { (void)hipSetDevice(c->device); (void)hipHostFree(c->h_pin); c->h_pin = nullptr; }
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -256,6 +258,24 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     c->solved = false;
 
     PhiStageTimer tm("set_graph");
+    // the solve downloads its kept anchors (12 bytes each, a fraction of the walk entries) into pinned
+    // memory; pinning tens of MB takes 5-30 ms, so it happens on a thread of its own, from now on
+    if (c->pin_future.valid()) c->pin_future.wait();
+    {
+        int64_t ne = walk_off[n_walks];                      // not validated yet: clamp
+        ne = ne < 0 ? 0 : (ne > ((int64_t)1 << 31) ? ((int64_t)1 << 31) : ne);
+        const size_t want = ((size_t)ne / 4 + 4096) * sizeof(PhiAnchorHost);
+        if (want > c->h_pin_cap) {
+            c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{};
+            c->pin_future = std::async(std::launch::async, [c, want]() {
+                (void)hipSetDevice(c->device);
+                if (c->h_pin) (void)hipHostFree(c->h_pin);
+                c->h_pin = nullptr; c->h_pin_cap = 0;
+                void *p = nullptr;
+                if (hipHostMalloc(&p, want, hipHostMallocDefault) == hipSuccess) { c->h_pin = p; c->h_pin_cap = want; }
+            });
+        }
+    }
     // ---- validate and keep host copies
     if (seq_off[0] != 0 || adj_off[0] != 0 || walk_off[0] != 0) return phi_fail(c, PHI_ERR_INVALID, "offset arrays must start at 0");
     for (int32_t v = 0; v < n_vtx; v++)
@@ -386,10 +406,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         PHICHK(sketch_records(c, c->d_wwords.as<uint64_t>(), c->d_wstarts.as<unsigned long long>(), run, c->k, c->w,
                               walk_ascii, c->d_rec_hash, c->d_rec_pos, &c->n_rec));
         if (c->n_rec >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk minimisers");
-        // the solve downloads its kept anchors (12 bytes each, usually a small fraction of the walk
-        // minimisers) into pinned memory: allocate it here, beside the host pass, not inside the solve
         c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{};
-        (void)phi_pin_ensure(c, (size_t)(c->n_rec / 8 + 4096) * sizeof(PhiAnchorHost));
         const int64_t nr = std::max<int64_t>(c->n_rec, 1);
         PHICHK(phi_dev_ensure(c, c->d_rec_slot, (size_t)nr * 4));
         PHICHK(phi_dev_ensure(c, c->d_rec_e0, (size_t)nr * 4));
@@ -469,8 +486,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     if (n_walks > PHI_DP_MAX_WALKS) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than %d walks", PHI_DP_MAX_WALKS);
     c->dp_nw = phi_dp_num_waves(n_walks);
     const int nw64 = c->dp_nw;
-    c->h_walk_vtx.resize(n_entries);
-    std::vector<uint8_t> e_out(n_entries, 255);
+    PhiRawBuf<uint8_t> e_out;                                  // every entry is written by the pass below
+    if (!c->h_walk_vtx.resize(n_entries) || !e_out.resize(n_entries)) return phi_fail(c, PHI_ERR_NOMEM, "host allocation failed");
     std::vector<int32_t> cnt_edge(std::max<int64_t>(n_edges, 1), 0), cont_total(n_vtx, 0);
     // the step masks serve the every-vertex kernel only (dp.hip, more than 128 walks)
     const bool want_masks = !(n_walks <= PHI_DP_EVENT_MAX_WALKS && !getenv("PHI_DP_DENSE"));
@@ -505,6 +522,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                     if (x - adj_off[u] >= 255) { herr.set(PHI_ERR_UNSUPPORTED, "vertex %d has more than 254 out-edges", u); return; }
                     e_out[e] = (uint8_t)(x - adj_off[u]);
                     cnt[x]++;
+                } else {
+                    e_out[e] = 255;                        // the walk ends here
                 }
             }
         });

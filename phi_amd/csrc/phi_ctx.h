@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <future>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -25,6 +26,27 @@ struct DevBuf {
 struct PhiAnchorHost {       // one dp anchor on the host (certificate / branch-and-bound)
     uint32_t slot;           // minimiser identity: dense id (rank of first occurrence among the walk minimisers)
     int32_t e0, e1;          // first / last walk entry
+};
+
+// host array that is NOT value-initialised on allocation: the threads that fill it touch its pages
+// first (a std::vector would zero 38 MB on one thread before the threaded pass starts)
+template <class T> struct PhiRawBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PhiRawBuf() = default;
+    PhiRawBuf(const PhiRawBuf &) = delete;
+    PhiRawBuf &operator=(const PhiRawBuf &) = delete;
+    ~PhiRawBuf() { free(p); }
+    bool resize(size_t m)
+    {
+        free(p);
+        p = m ? static_cast<T *>(malloc(m * sizeof(T))) : nullptr;
+        n = p ? m : 0;
+        return m == 0 || p != nullptr;
+    }
+    size_t size() const { return n; }
+    T *data() const { return p; }
+    T &operator[](size_t i) const { return p[i]; }
 };
 
 // view of host anchors: the pinned download buffer, or an owned vector
@@ -52,7 +74,8 @@ struct phi_ctx {
     int32_t n_vtx = 0, n_walks = 0;
     std::vector<char> h_seq;
     std::vector<int64_t> h_seq_off, h_adj_off, h_walk_off, h_walk_base, h_in_off;   // h_walk_base: flat base offset of each walk
-    std::vector<int32_t> h_adj, h_walk_vtx, h_topo_rank, h_topo, h_in_src;
+    std::vector<int32_t> h_adj, h_topo_rank, h_topo, h_in_src;
+    PhiRawBuf<int32_t> h_walk_vtx;                    // host copy of the walk entries
     int64_t n_entries = 0, walk_bases = 0;
 
     // ---- graph, device side
@@ -96,6 +119,7 @@ struct phi_ctx {
     std::vector<PhiAnchorHost> h_dp_own;
     void *h_pin = nullptr;                            // pinned host buffer the kept anchors are downloaded into
     size_t h_pin_cap = 0;
+    std::future<void> pin_future;                     // its allocation, started by phi_set_graph on a thread of its own
     std::vector<uint64_t> h_kept_hash;
     std::vector<int32_t> h_path_vtx, h_path_hap;
     std::vector<int64_t> h_n_minimizers, h_n_anchors;
