@@ -86,6 +86,21 @@ int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted)
     return PHI_OK;
 }
 
+// |Sp_R| = hit flags set (read hashes that are walk minimisers) + size of the set of the others
+int phi_spectrum_count(phi_ctx *c, uint64_t *n_distinct)
+{
+    uint64_t in_set = 0, flagged = 0;
+    PHICHK(phi_read_counts(c, &in_set, nullptr));
+    if (c->n_unique > 0) {
+        HIPCHK(hipMemsetAsync(scalar(c, S_EXPORT), 0, 8, c->stream));
+        phi_launch_count_flags(c->stream, c->d_hit.as<uint8_t>(), c->n_unique, (unsigned long long *)scalar(c, S_EXPORT));
+        HIPCHK(hipMemcpyAsync(&flagged, scalar(c, S_EXPORT), 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *n_distinct = in_set + flagged;
+    return PHI_OK;
+}
+
 int phi_pin_ensure(phi_ctx *c, size_t bytes)
 {
     if (c->pin_future.valid()) c->pin_future.wait();          // an allocation started by phi_set_graph
@@ -415,7 +430,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         // most of theirs, so 32x the records of an average walk (load ~3 %: read probes settle on the
         // first slot) -- and only when that overflows by the records (2x, the worst case).
         const uint64_t cap_full = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)c->n_rec));
-        uint64_t cap_try = pow2_at_least(std::max<uint64_t>(1024, 32 * (uint64_t)((c->n_rec + n_walks - 1) / n_walks)));
+        const uint64_t UMULT = getenv("PHI_UMULT") ? (uint64_t)atoi(getenv("PHI_UMULT")) : 32;
+        uint64_t cap_try = pow2_at_least(std::max<uint64_t>(1024, UMULT * (uint64_t)((c->n_rec + n_walks - 1) / n_walks)));
         if (cap_try > cap_full) cap_try = cap_full;
         PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)nr));
         for (;;) {
@@ -441,7 +457,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         {
             // wanted capacity: 32x the distinct keys; re-insert them (and look every record up again) when
             // the table is more than a factor two away from it
-            const uint64_t want = pow2_at_least(std::max<uint64_t>(1024, 32 * (uint64_t)c->n_unique));
+            const uint64_t want = pow2_at_least(std::max<uint64_t>(1024, UMULT * (uint64_t)c->n_unique));
             if (c->u_cap > 2 * want || 2 * c->u_cap < want) {
                 DevBuf keys2, uid2;
                 PHICHK(phi_dev_ensure(c, keys2, want * 8));
@@ -689,7 +705,7 @@ static int sp_ensure(phi_ctx *c, int64_t est)
             phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)need, PHI_EMPTY_KEY);
             HIPCHK(hipMemsetAsync(sp_stripes(c), 0, STRIPE_BYTES, c->stream));
             phi_launch_spectrum_insert(c->stream, c->d_export.as<uint64_t>(), (int64_t)cnt, c->d_sp_keys.as<uint64_t>(),
-                                       c->sp_cap - 1, sp_stripes(c),
+                                       c->sp_cap - 1, sp_stripes(c), nullptr, 0, nullptr, nullptr,
                                        (uint32_t *)scalar(c, S_ERR));
         }
     }
@@ -812,7 +828,8 @@ int phi_reads_stats(phi_ctx *c, int64_t *n_reads, int64_t *n_bases, int64_t *n_e
     HIPCHK(hipSetDevice(c->device));
     PHICHK(phi_sync_check(c));
     uint64_t nd = 0, ne = 0;
-    PHICHK(phi_read_counts(c, &nd, &ne));
+    PHICHK(phi_read_counts(c, nullptr, &ne));
+    PHICHK(phi_spectrum_count(c, &nd));
     if (n_reads) *n_reads = c->reads_count;
     if (n_bases) *n_bases = c->reads_bases;
     if (n_emitted) *n_emitted = (int64_t)ne;
@@ -861,7 +878,8 @@ int phi_spectrum_import(phi_ctx *c, const void *d_hashes, int64_t n)
     PHICHK(phi_flush_reset(c));
     PHICHK(sp_ensure(c, n));
     phi_launch_spectrum_insert(c->stream, (const uint64_t *)d_hashes, n, c->d_sp_keys.as<uint64_t>(), c->sp_cap - 1,
-                               sp_stripes(c), (uint32_t *)scalar(c, S_ERR));
+                               sp_stripes(c), c->d_u_keys.as<uint64_t>(), c->u_cap - 1, c->d_u_uid.as<uint32_t>(),
+                               c->d_hit.as<uint8_t>(), (uint32_t *)scalar(c, S_ERR));
     HIPCHK(hipGetLastError());
     c->solved = false;
     return PHI_OK;

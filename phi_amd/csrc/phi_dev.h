@@ -48,10 +48,38 @@ PHI_HD uint64_t phi_revcomp(uint64_t f, int k)
 
 PHI_HD uint64_t phi_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
+// low 64 bits of a * c from three 32-bit multiplies (the quarter-rate instructions of the VALU):
+// one full 32x32 -> 64 product and the low halves of the two cross products
+PHI_HD uint64_t phi_mul64(uint64_t a, uint64_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32), clo = (uint32_t)c, chi = (uint32_t)(c >> 32);
+    const uint64_t t = (uint64_t)alo * clo;
+    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32) + alo * chi + ahi * clo;
+    // opaque to the optimiser: it would fold the shifts of a following rotate into further multiplies
+    asm("" : "+v"(lo), "+v"(hi));
+    return ((uint64_t)hi << 32) | lo;
+#else
+    return a * c;
+#endif
+}
+
+// h * 5 + c by shift and add (a 64-bit multiply-add would take the quarter-rate multiplier twice)
+PHI_HD uint64_t phi_x5_plus(uint64_t h, uint64_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t q = h << 2;
+    asm("" : "+v"(q));
+    return q + h + c;
+#else
+    return h * 5 + c;
+#endif
+}
+
 PHI_HD uint64_t phi_fmix64(uint64_t k)
 {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
-    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33; k = phi_mul64(k, 0xff51afd7ed558ccdull);
+    k ^= k >> 33; k = phi_mul64(k, 0xc4ceb9fe1a85ec53ull);
     k ^= k >> 33;
     return k;
 }
@@ -59,8 +87,13 @@ PHI_HD uint64_t phi_fmix64(uint64_t k)
 // 4 bases (8 bits, first base in the top two bits) -> 4 ASCII bytes, first base in byte 0.
 PHI_HD uint32_t phi_ascii4(uint32_t x)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t t = __umul24(x, 0x100401u);                            // x | x << 10 | x << 20, full rate
+    asm("" : "+v"(t));                                              // (keeps it a 24-bit multiply)
+#else
     uint32_t t = x | (x << 10);
     t = t | (x << 20);
+#endif
     const uint32_t sel = ((t << 4) | (x >> 6)) & 0x03030303u;      // byte j = code of base j
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_perm(0x54474341u, 0x54474341u, sel);    // "ACGT" byte lookup
@@ -87,24 +120,24 @@ PHI_HD uint64_t phi_murmur_lanes(uint64_t e0, uint64_t e1, uint64_t e2, uint64_t
     uint64_t t1, t2;                                               // tail lanes
     if (nblocks >= 1) {
         uint64_t k1 = e0, k2 = e1;
-        k1 *= c1; k1 = phi_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-        h1 = phi_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-        k2 *= c2; k2 = phi_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-        h2 = phi_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+        k1 = phi_mul64(k1, c1); k1 = phi_rotl64(k1, 31); k1 = phi_mul64(k1, c2); h1 ^= k1;
+        h1 = phi_rotl64(h1, 27); h1 += h2; h1 = phi_x5_plus(h1, 0x52dce729);
+        k2 = phi_mul64(k2, c2); k2 = phi_rotl64(k2, 33); k2 = phi_mul64(k2, c1); h2 ^= k2;
+        h2 = phi_rotl64(h2, 31); h2 += h1; h2 = phi_x5_plus(h2, 0x38495ab5);
         t1 = e2; t2 = e3;
     } else {
         t1 = e0; t2 = e1;
     }
     if (nblocks == 2) {                                            // k == 32: second full block
         uint64_t k1 = t1, k2 = t2;
-        k1 *= c1; k1 = phi_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-        h1 = phi_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-        k2 *= c2; k2 = phi_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-        h2 = phi_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+        k1 = phi_mul64(k1, c1); k1 = phi_rotl64(k1, 31); k1 = phi_mul64(k1, c2); h1 ^= k1;
+        h1 = phi_rotl64(h1, 27); h1 += h2; h1 = phi_x5_plus(h1, 0x52dce729);
+        k2 = phi_mul64(k2, c2); k2 = phi_rotl64(k2, 33); k2 = phi_mul64(k2, c1); h2 ^= k2;
+        h2 = phi_rotl64(h2, 31); h2 += h1; h2 = phi_x5_plus(h2, 0x38495ab5);
     } else {
         const int rem = k & 15;
-        if (rem > 8) { uint64_t k2 = t2; k2 *= c2; k2 = phi_rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
-        if (rem > 0) { uint64_t k1 = t1; k1 *= c1; k1 = phi_rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+        if (rem > 8) { uint64_t k2 = t2; k2 = phi_mul64(k2, c2); k2 = phi_rotl64(k2, 33); k2 = phi_mul64(k2, c1); h2 ^= k2; }
+        if (rem > 0) { uint64_t k1 = t1; k1 = phi_mul64(k1, c1); k1 = phi_rotl64(k1, 31); k1 = phi_mul64(k1, c2); h1 ^= k1; }
     }
     h1 ^= (uint64_t)k; h2 ^= (uint64_t)k;
     h1 += h2; h2 += h1;

@@ -90,7 +90,10 @@ void phi_launch_fill_u64(hipStream_t st, uint64_t *p, int64_t n, uint64_t v);
 void phi_launch_fill_u32(hipStream_t st, uint32_t *p, int64_t n, uint32_t v);
 // insert a list of hashes into the spectrum set (multi-GPU spectrum merge)
 void phi_launch_spectrum_insert(hipStream_t st, const uint64_t *hashes, int64_t n, uint64_t *sp_keys,
-                                uint64_t sp_mask, unsigned long long *sp_count, uint32_t *err);
+                                uint64_t sp_mask, unsigned long long *sp_count, const uint64_t *u_keys, uint64_t u_mask,
+                                const uint32_t *u_uid, uint8_t *hit, uint32_t *err);
+// *n_out += number of non-zero bytes of flags[0..n)
+void phi_launch_count_flags(hipStream_t st, const uint8_t *flags, int64_t n, unsigned long long *n_out);
 // compact the occupied slots of the spectrum set into a list; *n_out receives the count
 void phi_launch_spectrum_export(hipStream_t st, const uint64_t *sp_keys, int64_t cap, uint64_t *out,
                                 unsigned long long *n_out);

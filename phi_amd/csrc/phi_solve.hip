@@ -205,7 +205,7 @@ int phi_solve_impl(phi_ctx *c)
     uint64_t sc[S_N];
     HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
     uint64_t n_distinct = 0;
-    PHICHK(phi_read_counts(c, &n_distinct, nullptr));
+    PHICHK(phi_spectrum_count(c, &n_distinct));
     const int64_t spectrum = c->spectrum_override >= 0 ? c->spectrum_override : (c->sp_cap ? (int64_t)n_distinct : 0);
     const int64_t n_rec = c->n_rec;
     const int32_t nw = c->n_walks;

@@ -244,45 +244,42 @@ __device__ __forceinline__ int next_start_lds(const unsigned long long *s_bits, 
 // 32 bases starting at local base lb of the staged words, left-aligned
 __device__ __forceinline__ uint64_t lds_extract64(const uint64_t *s_words, int lb)
 {
-    const int wi = lb >> 5, s = (lb & 31) * 2;
-    const uint64_t hi = s_words[wi];
-    return s ? (hi << s) | (s_words[wi + 1] >> (64 - s)) : hi;
+    const int wi = lb >> 5, s = (lb & 31) * 2;                 // s <= 62: no special case for s == 0
+    return (s_words[wi] << s) | ((s_words[wi + 1] >> 1) >> (63 - s));
 }
 
 struct MinEnt { uint64_t v; int i; };
 // b lies to the right of a: ties go right (the reference's deque pops on >=, ILP_index.cpp:397)
 __device__ __forceinline__ MinEnt take_right(MinEnt a, MinEnt b) { return (b.v <= a.v) ? b : a; }
 
-// read spectrum insert + walk-minimiser table probe of one emitted read hash.  The first probe
-// of both tables (and the speculative id load) are issued back to back so that their round trips
-// overlap; at load factors <= 0.5 almost every hash settles on that first probe.
+// walk-minimiser table probe + read spectrum insert of one emitted read hash.  A hash found in the
+// walk table is recorded by its hit flag alone; the spectrum set (ILP_index.cpp:622-635) keeps only
+// the hashes absent from the table, so |Sp_R| = set flags + set size and most reads of a sample
+// that resembles the graph never pay the atomic.
 __device__ __forceinline__ void probe_tables(const PhiSketchArgs &A, uint64_t h, int &n_new)
 {
     if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return; }
-    uint64_t su = h & A.u_mask, ss = h & A.sp_mask;
+    uint64_t su = h & A.u_mask;
     const uint64_t key0 = A.u_keys[su];
-    const uint32_t uid0 = A.u_uid[su];
-    const unsigned long long prev0 = atomicCAS((unsigned long long *)&A.sp_keys[ss], PHI_EMPTY_KEY, h);
+    const uint32_t uid0 = A.u_uid[su];                 // speculative: same round trip as the key
     // walk-minimiser table: lookup, mark the minimiser as hit
-    if (key0 == h) A.hit[uid0] = 1;
-    else if (key0 != PHI_EMPTY_KEY) {
+    if (key0 == h) { A.hit[uid0] = 1; return; }
+    if (key0 != PHI_EMPTY_KEY) {
         for (int probes = 1; probes <= PHI_MAX_PROBE; probes++) {
             su = (su + 1) & A.u_mask;
             const uint64_t key = A.u_keys[su];
-            if (key == h) { A.hit[A.u_uid[su]] = 1; break; }
+            if (key == h) { A.hit[A.u_uid[su]] = 1; return; }
             if (key == PHI_EMPTY_KEY) break;
         }
     }
-    // read spectrum: open-addressed insert (ILP_index.cpp:622-635 keeps a set)
-    if (prev0 == PHI_EMPTY_KEY) n_new++;
-    else if (prev0 != h) {
-        for (int probes = 1;; probes++) {
-            ss = (ss + 1) & A.sp_mask;
-            const unsigned long long prev = atomicCAS((unsigned long long *)&A.sp_keys[ss], PHI_EMPTY_KEY, h);
-            if (prev == PHI_EMPTY_KEY) { n_new++; break; }
-            if (prev == h) break;
-            if (probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
-        }
+    // not a walk minimiser: open-addressed insert into the spectrum set
+    uint64_t ss = h & A.sp_mask;
+    for (int probes = 0;; probes++) {
+        const unsigned long long prev = atomicCAS((unsigned long long *)&A.sp_keys[ss], PHI_EMPTY_KEY, h);
+        if (prev == PHI_EMPTY_KEY) { n_new++; break; }
+        if (prev == h) break;
+        if (probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
+        ss = (ss + 1) & A.sp_mask;
     }
 }
 
@@ -388,9 +385,36 @@ __device__ __forceinline__ void slow_windows(const PhiSketchArgs &A, int64_t c0,
 #define SM(l) s_mp[(l) + ((l) >> 3)]   // one pad word per 8 entries: lane t reads entries 8t+i
                                         // = u64 index 9t+i: conflict-free for ds_read_b64
 
+// k-mer slots of one wave: every lane rolls P = ceil((WCH + w) / 64) consecutive k-mers and stores all
+// of them (the lanes past WCH + w write k-mers nobody reads), so the roll needs no per-store check
+__host__ __device__ static inline int phi_wave_mp_u64(int w)
+{
+    const int P = (WCH + w + 63) / 64;
+    return ((64 * P + 8) * 9) / 8 + 8;
+}
 __host__ __device__ static inline int phi_wave_region_u64(int w)
 {
-    return ((WCH + w + 8) * 9) / 8 + 8 + SWW + 2 * SBW + WCH / 2 + 4;
+    return phi_wave_mp_u64(w) + SWW + 2 * SBW + WCH / 2 + 8;
+}
+
+// minimum of two k-mer values below 2^62 (k <= 31) in one instruction: bit patterns with the two top
+// bits clear are non-negative finite doubles (never NaN or infinity), and IEEE order of non-negative
+// doubles is the unsigned order of their bit patterns; f64 denormals are kept by the kernels' mode
+// register (.amdhsa_float_denorm_mode_16_64 3), so the selected operand comes back unchanged
+__device__ __forceinline__ uint64_t min_u62(uint64_t a, uint64_t b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+    return (uint64_t)__double_as_longlong(r);
+}
+
+// the value one lane below (lane 0 gets `first`): DPP wave_shr:1, no LDS round trip
+__device__ __forceinline__ uint64_t wave_prev_u64(uint64_t v, uint64_t first, int lane)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+    const uint64_t p = ((uint64_t)hi << 32) | lo;
+    return lane == 0 ? first : p;
 }
 
 // inclusive prefix sum over the 64 lanes on the VALU (DPP row shifts + row broadcasts; __shfl_up
@@ -456,6 +480,7 @@ template <int MODE, bool WIDE, int KT, int WT>
 __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 {
     constexpr bool NEED_POS = MODE == PHI_MODE_WRITE;   // only the ordered write stores positions (ILP_index.cpp:423)
+    constexpr bool FMIN = !NEED_POS && KT > 0 && KT <= 31;   // values < 2^62: minima by v_min_f64
     extern __shared__ uint64_t s_dyn[];
 
     // read batches: the workgroups past the 2-bit ones take the byte-wise path (they leave at once
@@ -477,12 +502,12 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     const int span = w + k - 1;                           // bases under one window
     const bool have_bad = A.badbits != nullptr;
 
-    const int mp_words = ((M + 8) * 9) / 8 + 8;
-    uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w);   // k-mers; later candidate values, then hashes
-    uint64_t *s_words = s_mp + mp_words;
+    uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w);   // k-mers; later the window minima
+    uint64_t *s_words = s_mp + phi_wave_mp_u64(w);
     unsigned long long *s_bits = (unsigned long long *)(s_words + SWW);
     unsigned long long *s_bad = s_bits + SBW;
-    uint32_t *s_meta = (uint32_t *)(s_bad + SBW);
+    uint32_t *s_meta = (uint32_t *)(s_bad + SBW);         // WCH + 1 items + 8 trash slots
+    uint64_t *s_q = s_mp + lane * (Q + 1);                // SM(lane * Q + x) == s_q[x + (x >> 3)]
 
     // ---- phase 0: stage the chunk's packed words and bitmaps (the only global reads up to the
     //      output phase).  Local base lb <-> base c0-32+lb; local bit lp <-> base c0-64+lp.
@@ -515,10 +540,13 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
         const int l0 = lane * P;
         if (c0 >= 1 && c0 - 1 + (int64_t)P * 64 + k <= N) {
             // interior chunk (all but the first and last of a batch): every k-mer a lane touches
-            // exists, so the roll needs no per-position checks
+            // exists, so the roll needs no per-position checks, and every lane stores all P of its
+            // k-mers (the slots past M are spare).  Slot of l0+i: a0 + i + carry of (l0 & 7) + i.
             uint64_t F = lds_extract64(s_words, l0 + 31) >> (64 - 2 * k);
             uint64_t R = phi_revcomp(F, k);
             uint64_t nxt = lds_extract64(s_words, l0 + 31 + k);     // bases j+k .. j+k+31
+            uint64_t *s_p = s_mp + l0 + (l0 >> 3);
+            const int lo7 = l0 & 7;
 #pragma unroll
             for (int i = 0; i < P; i++) {
                 if (i) {
@@ -527,7 +555,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
                     F = ((F << 2) | b) & kmask;
                     R = (R >> 2) | ((3 - b) << (2 * k - 2));
                 }
-                if (l0 + i < M) SM(l0 + i) = F < R ? F : R;
+                s_p[i + ((lo7 + i) >> 3)] = FMIN ? min_u62(F, R) : (F < R ? F : R);
             }
         } else {
             const int l1 = min(l0 + P, M);
@@ -557,22 +585,44 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     }
     wave_sync();
 
-    // ---- phase 2: minima of windows la = lane*Q .. lane*Q+Q  (window la = m[la .. la+w))
+    // ---- phase 2: minima of windows la = lane*Q .. lane*Q+Q  (window la = m[la .. la+w)); the
+    //      k-mer of slot lane*Q + x is s_q[x + (x >> 3)]: constant offsets from one address
+#define SQ(x) s_q[(x) + ((x) >> 3)]
     uint64_t wv[Q + 1];
     int wp[Q + 1];
     {
         const int base = lane * Q;
-        if (WIDE) {
+        if (WIDE && FMIN) {
+            // values only (no positions): the rightmost-tie rule does not change a minimum's value
+            uint64_t L[Q];                        // L[i] = min of m[base+i .. base+Q)
+            L[Q - 1] = SQ(Q - 1);
+#pragma unroll
+            for (int i = Q - 2; i >= 0; i--) L[i] = min_u62(SQ(i), L[i + 1]);
+            uint64_t core = SQ(Q);
+#pragma unroll
+            for (int x = Q + 1; x < WT; x++) core = min_u62(core, SQ(x));
+            uint64_t Rr = 0;                      // min of m[base+w .. base+w+i)
+#pragma unroll
+            for (int i = 0; i <= Q; i++) {
+                uint64_t t = (i < Q) ? min_u62(L[i], core) : core;
+                if (i > 0) {
+                    const uint64_t e = SQ(WT + i - 1);
+                    Rr = (i == 1) ? e : min_u62(Rr, e);
+                    t = min_u62(t, Rr);
+                }
+                wv[i] = t; wp[i] = 0;
+            }
+        } else if (WIDE) {
             MinEnt L[Q + 1];                      // L[i] = min of m[base+i .. base+Q), ties right
             L[Q].v = 0; L[Q].i = -1;
 #pragma unroll
             for (int i = Q - 1; i >= 0; i--) {
-                MinEnt e; e.v = SM(base + i); e.i = NEED_POS ? base + i : 0;
+                MinEnt e; e.v = SQ(i); e.i = NEED_POS ? base + i : 0;
                 L[i] = (i == Q - 1) ? e : take_right(e, L[i + 1]);
             }
-            MinEnt core; core.v = SM(base + Q); core.i = NEED_POS ? base + Q : 0;
-            for (int x = base + Q + 1; x < base + w; x++) {
-                MinEnt e; e.v = SM(x); e.i = NEED_POS ? x : 0;
+            MinEnt core; core.v = SQ(Q); core.i = NEED_POS ? base + Q : 0;
+            for (int x = Q + 1; x < w; x++) {
+                MinEnt e; e.v = SQ(x); e.i = NEED_POS ? base + x : 0;
                 core = take_right(core, e);
             }
             MinEnt Rr; Rr.v = 0; Rr.i = -1;       // min of m[base+w .. base+w+i)
@@ -580,7 +630,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             for (int i = 0; i <= Q; i++) {
                 MinEnt t = (i < Q) ? take_right(L[i], core) : core;
                 if (i > 0) {
-                    MinEnt e; e.v = SM(base + w + i - 1); e.i = NEED_POS ? base + w + i - 1 : 0;
+                    MinEnt e; e.v = SQ(w + i - 1); e.i = NEED_POS ? base + w + i - 1 : 0;
                     Rr = (i == 1) ? e : take_right(Rr, e);
                     t = take_right(t, Rr);
                 }
@@ -589,9 +639,9 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
         } else {
 #pragma unroll
             for (int i = 0; i <= Q; i++) {
-                MinEnt t; t.v = SM(base + i); t.i = NEED_POS ? base + i : 0;
+                MinEnt t; t.v = SQ(i); t.i = NEED_POS ? base + i : 0;
                 for (int x = 1; x < w; x++) {
-                    MinEnt e; e.v = SM(base + i + x); e.i = NEED_POS ? base + i + x : 0;
+                    MinEnt e; e.v = SQ(i + x); e.i = NEED_POS ? base + i + x : 0;
                     t = take_right(t, e);
                 }
                 wv[i] = t.v; wp[i] = t.i;
@@ -692,56 +742,57 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     }
     wave_sync();                                          // every lane has read its k-mers
     {
-        // every lane stores all Q windows, the non-candidates into trash slots past the last
-        // candidate slot SM(WCH) (they may reach into s_words, dead since phase 1) and past
-        // s_meta[WCH - 1]: no divergent branch per window
-        int c = coff;
-        const int trash_v = WCH + 1 + ((WCH + 1) >> 3) + 1 + (lane & 31), trash_m = WCH + (lane & 7);
+        // the minimum of window slot s = lane*Q + i goes to SM(s) (constant offsets again); slot 0 is
+        // the window before the chunk's first
+        if (lane == 0) s_q[0] = wv[0];
+#pragma unroll
+        for (int i = 1; i <= Q; i++) SQ(i) = wv[i];
+        // item list: item 0 = the window before the chunk's first candidate (only its hash is needed),
+        // item 1 + c = candidate c.  Every lane stores all Q windows, the non-candidates into trash
+        // slots past the last item: no divergent branch per window
+        int c = coff + 1;
+        const int trash = WCH + 1 + (lane & 7);
 #pragma unroll
         for (int i = 1; i <= Q; i++) {
             const bool on = (cflag >> i) & 1u;
-            s_mp[on ? c + (c >> 3) : trash_v] = wv[i];
-            s_meta[on ? c : trash_m] = (uint32_t)(lane * Q + i) | ((uint32_t)wp[i] << 10) | ((fflag >> i) & 1u) << 31;
+            s_meta[on ? c : trash] = (uint32_t)(lane * Q + i) | ((uint32_t)wp[i] << 10) | ((fflag >> i) & 1u) << 31;
             c += on;
         }
-        // the window before the first candidate of the chunk (one lane)
-        if (coff == 0 && cflag) {
-            const int i1 = __ffs((int)cflag) - 1;
-#pragma unroll
-            for (int i = 1; i <= Q; i++) if (i == i1) SM(ncand) = wv[i - 1];
-        }
+        if (coff == 0 && cflag) s_meta[0] = (uint32_t)(lane * Q + __ffs((int)cflag) - 2);
     }
     wave_sync();
+#undef SQ
 
-    // ---- phase 4: hash candidates (and the predecessor value in slot ncand) on dense lanes, in
-    //      place: lane c reads and writes slot c only
-    if (ncand > 0)
-        for (int c = lane; c <= ncand; c += 64) SM(c) = phi_kmer_hash(SM(c), k);
-    wave_sync();
-
-    // ---- phase 5: hash-change test, ordered compaction, output
-    for (int r0 = 0; r0 < ncand; r0 += 64) {
-        const int c = r0 + lane;
-        bool emit = false;
-        uint64_t h = 0;
-        uint32_t meta = 0;
-        if (c < ncand) {
-            h = SM(c);
-            meta = s_meta[c];
-            const uint64_t hp = (meta >> 31) ? PHI_EMPTY_KEY : SM(c == 0 ? ncand : c - 1);
-            emit = h != hp;
-        }
-        const unsigned long long bal = __ballot(emit);
-        if (emit) {
-            const int rank = n_emit + __popcll(bal & ((1ull << lane) - 1));
-            if (MODE == PHI_MODE_WRITE) {
-                A.out_hash[out_base + rank] = h;
-                A.out_pos[out_base + rank] = c0 - 1 + (int64_t)((meta >> 10) & 0x3FFu);
-            } else if (MODE == PHI_MODE_PROBE) {
-                probe_tables(A, h, n_new);
+    // ---- phases 4 + 5: items on dense lanes, 64 per round: murmur3 of the item's minimum, the
+    //      hash-change test against the item before it (the lane below; lane 0 takes the last lane of
+    //      the round before), ordered compaction, output
+    if (ncand > 0) {
+        uint64_t carry = PHI_EMPTY_KEY;
+        for (int r0 = 0; r0 <= ncand; r0 += 64) {
+            const int t = r0 + lane;
+            const bool valid = t <= ncand;
+            uint32_t meta = 0;
+            uint64_t h = 0;
+            if (valid) {
+                meta = s_meta[t];
+                h = phi_kmer_hash(SM((int)(meta & 0x3FFu)), k);
             }
+            const uint64_t hp = wave_prev_u64(h, carry, lane);
+            carry = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), 63) << 32) |
+                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, 63);
+            const bool emit = valid && t >= 1 && ((meta >> 31) || h != hp);
+            const unsigned long long bal = __ballot(emit);
+            if (emit) {
+                const int rank = n_emit + __popcll(bal & ((1ull << lane) - 1));
+                if (MODE == PHI_MODE_WRITE) {
+                    A.out_hash[out_base + rank] = h;
+                    A.out_pos[out_base + rank] = c0 - 1 + (int64_t)((meta >> 10) & 0x3FFu);
+                } else if (MODE == PHI_MODE_PROBE) {
+                    probe_tables(A, h, n_new);
+                }
+            }
+            n_emit += __popcll(bal);
         }
-        n_emit += __popcll(bal);
     }
 
     if (MODE == PHI_MODE_COUNT) {

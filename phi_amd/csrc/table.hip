@@ -186,15 +186,30 @@ void phi_launch_share_hist(hipStream_t st, const uint64_t *keys, int64_t cap, co
         hipLaunchKernelGGL(phi_share_hist_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, st, keys, cap, n_walks_of, hist);
 }
 
+// u_keys != nullptr: a hash found in the walk-minimiser table sets its hit flag instead (the set holds
+// only hashes absent from the table, see probe_tables in sketch.hip)
 __global__ void __launch_bounds__(256) phi_spectrum_insert_kernel(const uint64_t *__restrict__ hashes, int64_t n,
                                                                   uint64_t *__restrict__ sp_keys, uint64_t sp_mask,
                                                                   unsigned long long *__restrict__ sp_count,
+                                                                  const uint64_t *__restrict__ u_keys, uint64_t u_mask,
+                                                                  const uint32_t *__restrict__ u_uid, uint8_t *__restrict__ hit,
                                                                   uint32_t *__restrict__ err)
 {
     int n_new = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t h = hashes[i];
         if (h == PHI_EMPTY_KEY) continue;
+        if (u_keys) {
+            bool found = false;
+            uint64_t su = h & u_mask;
+            for (int probes = 0; probes <= PHI_MAX_PROBE; probes++) {
+                const uint64_t key = u_keys[su];
+                if (key == h) { hit[u_uid[su]] = 1; found = true; break; }
+                if (key == PHI_EMPTY_KEY) break;
+                su = (su + 1) & u_mask;
+            }
+            if (found) continue;
+        }
         uint64_t slot = h & sp_mask;
         int probes = 0;
         for (;;) {
@@ -212,11 +227,29 @@ __global__ void __launch_bounds__(256) phi_spectrum_insert_kernel(const uint64_t
 }
 
 void phi_launch_spectrum_insert(hipStream_t st, const uint64_t *hashes, int64_t n, uint64_t *sp_keys,
-                                uint64_t sp_mask, unsigned long long *sp_count, uint32_t *err)
+                                uint64_t sp_mask, unsigned long long *sp_count, const uint64_t *u_keys, uint64_t u_mask,
+                                const uint32_t *u_uid, uint8_t *hit, uint32_t *err)
 {
     if (n > 0)
         hipLaunchKernelGGL(phi_spectrum_insert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, hashes, n, sp_keys,
-                           sp_mask, sp_count, err);
+                           sp_mask, sp_count, u_keys, u_mask, u_uid, hit, err);
+}
+
+// number of set hit flags (bytes != 0), added to *n_out
+__global__ void __launch_bounds__(256) phi_count_flags_kernel(const uint8_t *__restrict__ flags, int64_t n,
+                                                              unsigned long long *__restrict__ n_out)
+{
+    int cnt = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        cnt += flags[i] != 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(n_out, (unsigned long long)cnt);
+}
+
+void phi_launch_count_flags(hipStream_t st, const uint8_t *flags, int64_t n, unsigned long long *n_out)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_count_flags_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, flags, n, n_out);
 }
 
 __global__ void __launch_bounds__(256) phi_spectrum_export_kernel(const uint64_t *__restrict__ sp_keys, int64_t cap,

@@ -683,19 +683,25 @@ def test_torch_views_of_device_buffers(oracle, ctx_factory):
     assert n == len(uniq)
     assert np.array_equal(hit.cpu().numpy(), np.isin(uniq, read_h).astype(np.uint8))
     pdist.allreduce_hits(hit)                       # world size 1: a no-op that must not fail
-    # exported spectrum = the distinct read hashes
+    # exported spectrum = the distinct read hashes that are NOT walk minimisers (those are the hit
+    # flags): together they are the reference's Sp_R
     p, m = ctx.spectrum_export()
     sp = torch.as_tensor(pdist.DevArray(p, m, "<i8"), device="cuda").clone()
-    assert np.array_equal(np.sort(sp.cpu().numpy().view(np.uint64)), read_h)
+    assert np.array_equal(np.sort(sp.cpu().numpy().view(np.uint64)), read_h[~np.isin(read_h, uniq)])
+    assert ctx.reads_stats()["n_distinct"] == len(read_h)
     # importing a copy of it (what another rank would send) leaves the set unchanged
     ctx.spectrum_import(sp.data_ptr(), m)
     torch.cuda.synchronize()
     assert ctx.reads_stats()["n_distinct"] == len(read_h)
-    extra = torch.tensor([12345, 67890], dtype=torch.int64, device="cuda")
-    ctx.spectrum_import(extra.data_ptr(), 2)
+    # a foreign hash that is a walk minimiser sets its flag, any other joins the set
+    unseen = uniq[~np.isin(uniq, read_h)]
+    assert len(unseen) > 0
+    extra = torch.from_numpy(np.array([12345, 67890, unseen[0], read_h[0]], np.uint64).view(np.int64)).cuda()
+    ctx.spectrum_import(extra.data_ptr(), 4)
     torch.cuda.synchronize()
+    assert int(hit.cpu().numpy().sum()) == int(np.isin(uniq, read_h).sum()) + 1
     res = ctx.solve()
-    assert res["spectrum_size"] == len(read_h) + 2
+    assert res["spectrum_size"] == len(read_h) + 3
 
 
 # --------------------------------------------------------------------------- full size (BASELINE config C2)
