@@ -192,7 +192,7 @@ void phi_ctx_destroy(phi_ctx *c)
     DevBuf *all[] = {&c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_rbad, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
-                     &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
+                     &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
                      &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_kept_rec, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
@@ -427,10 +427,10 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         PHICHK(phi_dev_ensure(c, c->d_rec_e0, (size_t)nr * 4));
         PHICHK(phi_dev_ensure(c, c->d_rec_e1, (size_t)nr * 4));
         // The table is sized by an estimate of the DISTINCT minimisers -- the walks of a pangenome share
-        // most of theirs, so 32x the records of an average walk (load ~3 %: read probes settle on the
+        // most of theirs, so 8x the records of an average walk (load ~12 %: read probes settle on the
         // first slot) -- and only when that overflows by the records (2x, the worst case).
         const uint64_t cap_full = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)c->n_rec));
-        const uint64_t UMULT = getenv("PHI_UMULT") ? (uint64_t)atoi(getenv("PHI_UMULT")) : 32;
+        const uint64_t UMULT = 8;
         uint64_t cap_try = pow2_at_least(std::max<uint64_t>(1024, UMULT * (uint64_t)((c->n_rec + n_walks - 1) / n_walks)));
         if (cap_try > cap_full) cap_try = cap_full;
         PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)nr));
@@ -455,7 +455,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             cap_try = cap_full;
         }
         {
-            // wanted capacity: 32x the distinct keys; re-insert them (and look every record up again) when
+            // wanted capacity: 8x the distinct keys; re-insert them (and look every record up again) when
             // the table is more than a factor two away from it
             const uint64_t want = pow2_at_least(std::max<uint64_t>(1024, UMULT * (uint64_t)c->n_unique));
             if (c->u_cap > 2 * want || 2 * c->u_cap < want) {
@@ -476,6 +476,9 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                                     c->d_u_uid.as<uint32_t>());
             }
         }
+        PHICHK(phi_dev_ensure(c, c->d_u_kv, c->u_cap * 16));
+        phi_launch_table_pairs(c->stream, c->d_u_keys.as<uint64_t>(), c->d_u_uid.as<uint32_t>(), (int64_t)c->u_cap,
+                               c->d_u_kv.as<uint64_t>());
         phi_launch_locate(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_ebase.as<int64_t>(), n_entries, c->k,
                           c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>());
         // records of each walk ("Number of Minimizers", ILP_index.cpp:563)
@@ -757,7 +760,7 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     A.sp_keys = c->d_sp_keys.as<uint64_t>(); A.sp_mask = c->sp_cap - 1;
     A.sp_count = sp_stripes(c);
     A.n_emitted = emit_stripes(c);
-    A.u_keys = c->d_u_keys.as<uint64_t>(); A.u_uid = c->d_u_uid.as<uint32_t>(); A.u_mask = c->u_cap - 1;
+    A.u_kv = c->d_u_kv.as<uint64_t>(); A.u_mask = c->u_cap - 1;
     A.hit = c->d_hit.as<uint8_t>();
     A.err = (uint32_t *)scalar(c, S_ERR);
     A.batch_bad = batch_bad;                            // windows touching a base outside ACGT: byte-wise workgroups of the same launch

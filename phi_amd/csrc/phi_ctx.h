@@ -87,6 +87,7 @@ struct phi_ctx {
     int64_t n_rec = 0;
     std::vector<int64_t> h_walk_rec_off;              // record range of each walk
     DevBuf d_u_keys, d_u_rep, d_u_uid;                // walk-minimiser table: keys, first record, dense id
+    DevBuf d_u_kv;                                    // the same table as (key, id) pairs, for the read probes
     int64_t n_unique = 0;                             // distinct walk minimisers
     uint64_t u_cap = 0;
     DevBuf d_hit;                                     // uint8 per distinct walk minimiser

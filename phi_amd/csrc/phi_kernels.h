@@ -38,7 +38,7 @@ struct PhiSketchArgs {
     uint64_t *sp_keys; uint64_t sp_mask;   // read spectrum set
     unsigned long long *sp_count;          // [PHI_STRIPES][8] striped counter of new spectrum entries
     unsigned long long *n_emitted;         // [PHI_STRIPES][8] striped counter of emitted records
-    const uint64_t *u_keys; const uint32_t *u_uid; uint64_t u_mask;   // walk-minimiser table: slot -> dense id
+    const uint64_t *u_kv; uint64_t u_mask; // walk-minimiser table as (key, dense id) pairs: one 16-byte load per probe
     uint8_t *hit;                          // per distinct walk minimiser (dense id)
     uint32_t *err;
     // read batches: count of bases outside ACGTacgt of this batch (device scalar); when set, the PROBE
@@ -86,6 +86,8 @@ void phi_launch_share_count(hipStream_t st, const uint32_t *rec_slot, int64_t lo
 void phi_launch_share_hist(hipStream_t st, const uint64_t *keys, int64_t cap, const int32_t *n_walks_of, unsigned long long *hist);
 void phi_launch_slot_uid(hipStream_t st, const int32_t *rep_list, int64_t n_unique, const uint32_t *rec_slot,
                          uint32_t *u_uid);
+// (key, id) pairs of the walk-minimiser table for the read probes: kv[2s] = keys[s], kv[2s+1] = uid[s]
+void phi_launch_table_pairs(hipStream_t st, const uint64_t *keys, const uint32_t *uid, int64_t cap, uint64_t *kv);
 void phi_launch_fill_u64(hipStream_t st, uint64_t *p, int64_t n, uint64_t v);
 void phi_launch_fill_u32(hipStream_t st, uint32_t *p, int64_t n, uint32_t v);
 // insert a list of hashes into the spectrum set (multi-GPU spectrum merge)

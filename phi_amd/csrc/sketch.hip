@@ -260,16 +260,16 @@ __device__ __forceinline__ void probe_tables(const PhiSketchArgs &A, uint64_t h,
 {
     if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return; }
     uint64_t su = h & A.u_mask;
-    const uint64_t key0 = A.u_keys[su];
-    const uint32_t uid0 = A.u_uid[su];                 // speculative: same round trip as the key
+    const ulonglong2 *kv = reinterpret_cast<const ulonglong2 *>(A.u_kv);
+    const ulonglong2 e0 = kv[su];                      // key and dense id in one round trip
     // walk-minimiser table: lookup, mark the minimiser as hit
-    if (key0 == h) { A.hit[uid0] = 1; return; }
-    if (key0 != PHI_EMPTY_KEY) {
+    if (e0.x == h) { A.hit[(uint32_t)e0.y] = 1; return; }
+    if (e0.x != PHI_EMPTY_KEY) {
         for (int probes = 1; probes <= PHI_MAX_PROBE; probes++) {
             su = (su + 1) & A.u_mask;
-            const uint64_t key = A.u_keys[su];
-            if (key == h) { A.hit[A.u_uid[su]] = 1; return; }
-            if (key == PHI_EMPTY_KEY) break;
+            const ulonglong2 e = kv[su];
+            if (e.x == h) { A.hit[(uint32_t)e.y] = 1; return; }
+            if (e.x == PHI_EMPTY_KEY) break;
         }
     }
     // not a walk minimiser: open-addressed insert into the spectrum set

@@ -28,6 +28,21 @@ static inline unsigned grid_for(int64_t n, int tpb)
     return (unsigned)nb;
 }
 
+__global__ void __launch_bounds__(256) phi_table_pairs_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ uid,
+                                                              int64_t cap, ulonglong2 *__restrict__ kv)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i];
+        kv[i] = make_ulonglong2(key, key == PHI_EMPTY_KEY ? 0ull : (unsigned long long)uid[i]);
+    }
+}
+
+void phi_launch_table_pairs(hipStream_t st, const uint64_t *keys, const uint32_t *uid, int64_t cap, uint64_t *kv)
+{
+    if (cap > 0)
+        hipLaunchKernelGGL(phi_table_pairs_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, st, keys, uid, cap, (ulonglong2 *)kv);
+}
+
 void phi_launch_fill_u64(hipStream_t st, uint64_t *p, int64_t n, uint64_t v)
 {
     if (n > 0) hipLaunchKernelGGL(phi_fill_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, n, v);
