@@ -174,8 +174,10 @@ int phi_kept_anchors(phi_ctx *ctx, uint64_t *out_hash, int32_t *out_walk, int32_
                      int32_t *out_t1, int64_t cap, int64_t *n_out);
 
 /* Timing of the dominant kernel (the sketch kernel), measured with HIP events on the stream
- * the kernel is launched on.  phi_prof_enable(1) starts bracketing every sketch launch;
- * phi_prof_read returns the number of bracketed launches and their summed duration. */
+ * the kernel is launched on.  phi_prof_enable(n), n >= 1, starts bracketing every n-th sketch launch
+ * (a bracketed launch costs the stream a few microseconds more than a plain one, so a throughput
+ * measurement samples: n = 8); phi_prof_enable(0) stops.  phi_prof_read returns the number of
+ * bracketed launches, their summed duration and the bases they covered. */
 int phi_prof_enable(phi_ctx *ctx, int on);
 int phi_prof_read(phi_ctx *ctx, int64_t *n_launches, double *total_ms, int64_t *total_bases);
 

@@ -765,7 +765,7 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     A.err = (uint32_t *)scalar(c, S_ERR);
     A.batch_bad = batch_bad;                            // windows touching a base outside ACGT: byte-wise workgroups of the same launch
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (c->prof) {
+    if (c->prof && c->prof_period > 0 && (c->prof_seq++ % c->prof_period) == 0) {
         if (c->prof_used == c->prof_events.size()) {
             hipEvent_t a, b;
             HIPCHK(hipEventCreate(&a));
@@ -1060,6 +1060,8 @@ int phi_prof_enable(phi_ctx *c, int on)
 {
     if (!c) return PHI_ERR_INVALID;
     c->prof = on != 0;
+    c->prof_period = on > 0 ? on : 1;                   // on = n: every n-th sketch launch is bracketed
+    c->prof_seq = 0;
     if (c->prof) {
         // create the event pairs of the next launches now, not inside the region being timed
         HIPCHK(hipSetDevice(c->device));

@@ -132,6 +132,8 @@ struct phi_ctx {
     // ---- profiling of the sketch kernel
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    int prof_period = 1;                              // every prof_period-th sketch launch is bracketed
+    uint64_t prof_seq = 0;
     size_t prof_used = 0;
     int64_t prof_bases = 0;
     double prof_ms_done = 0.0;
