@@ -106,11 +106,13 @@ int phi_reads_stats(phi_ctx *ctx, int64_t *n_reads, int64_t *n_bases, int64_t *n
  *                       index = dense minimiser id (rank of the hash's first occurrence in walk
  *                       position order), identical on every rank for the same graph; valid until
  *                       the next phi_reset_reads / phi_set_graph on this context
- *   phi_spectrum_export this rank's distinct read hashes: device pointer to uint64[n]
- *                       (valid until the next call on this context)
- *   phi_spectrum_import insert another rank's exported hashes (a device buffer the caller owns)
- *                       so that the local set becomes the union; |Sp_R| (ILP_index.cpp:641)
- *                       is then the same on every rank
+ *   phi_spectrum_export this rank's distinct read hashes that are NOT walk minimisers (those that
+ *                       are, are exactly the set hit flags): device pointer to uint64[n] (valid
+ *                       until the next call on this context)
+ *   phi_spectrum_import merge another rank's exported hashes (a device buffer the caller owns): a
+ *                       hash that is a walk minimiser sets its hit flag, any other joins the local
+ *                       set; after the hit all-reduce and the imports |Sp_R| (ILP_index.cpp:641)
+ *                       = flags set + set size is the same on every rank
  *   phi_spectrum_set_size  alternatively, override |Sp_R| used in the log counters
  */
 int phi_hits_buffer(phi_ctx *ctx, void **d_hits, int64_t *n);
