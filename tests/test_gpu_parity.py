@@ -653,6 +653,52 @@ def test_synthetic_vs_highs_golden(oracle, ctx_factory):
         assert res["objective"] == case["objective"], (case, res["objective"], res["n_dp_runs"])
 
 
+def test_probe_low_complexity_at_default_k_w(oracle, ctx_factory):
+    """The (31, 25) instance takes window minima with v_min_f64 on the k-mer values' bit patterns: k-mers
+    that start with runs of A (top bits clear: zero and denormal doubles), poly-T (reverse complement 0),
+    tandem repeats (ties everywhere) must give the reference's hashes, hit flags and spectrum."""
+    import torch
+    from phi_amd import dist as pdist
+    rng = np.random.default_rng(3125)
+    k, w = 31, 25
+
+    def rseq(n):
+        return bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+    low = [b"A" * 90, b"T" * 75, b"AAAAAC" * 20, b"AT" * 60, b"A" * 40 + b"C" + b"A" * 40, b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAG" * 4,
+           b"C" * 64, b"ACGT" * 30]
+    g = random_graph(rng, n_sites=10, n_walks=5, seg_len=(60, 120), alt_len=(1, 8))
+    # splice the low-complexity blocks into backbone vertices of the graph
+    for i, blk in enumerate(low):
+        v = (3 * i) % len(g.node_seq)
+        g.node_seq[v] = g.node_seq[v][:len(g.node_seq[v]) // 2] + blk + g.node_seq[v][len(g.node_seq[v]) // 2:]
+    reads = mosaic_reads(rng, g, n_reads=120, read_len=150, n_seg=2)
+    reads += [blk + rseq(60) + blk for blk in low] + [rseq(40) + b"A" * 70 + rseq(45), b"A" * 200, b"T" * 200, b"AC" * 100]
+    ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=10)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads)
+    torch.cuda.synchronize()
+    walk_h = np.concatenate([oracle.sketch(b"".join(g.node_seq[v] for v in path), k, w)[0] for path in g.paths])
+    _, first = np.unique(walk_h, return_index=True)
+    uniq = walk_h[np.sort(first)]
+    per_read = [oracle.sketch(r, k, w)[0] for r in reads]
+    read_h = np.unique(np.concatenate(per_read))
+    st = ctx.reads_stats()
+    assert st["n_emitted"] == sum(len(x) for x in per_read)
+    assert st["n_distinct"] == len(read_h)
+    p, n = ctx.hits_buffer()
+    hit = torch.as_tensor(pdist.DevArray(p, n), device="cuda").cpu().numpy()
+    assert n == len(uniq)
+    assert np.array_equal(hit, np.isin(uniq, read_h).astype(np.uint8))
+    p, m = ctx.spectrum_export()
+    sp = torch.as_tensor(pdist.DevArray(p, m, "<i8"), device="cuda").clone().cpu().numpy().view(np.uint64)
+    assert np.array_equal(np.sort(sp), read_h[~np.isin(read_h, uniq)])
+    for h in range(len(g.paths)):
+        wh, wp = ctx.walk_minimizers(h)
+        eh, ep = oracle.sketch(b"".join(g.node_seq[v] for v in g.paths[h]), k, w)
+        assert np.array_equal(wh, eh) and np.array_equal(wp, ep)
+
+
 # --------------------------------------------------------------------------- torch / multi-GPU plumbing
 
 def test_torch_views_of_device_buffers(oracle, ctx_factory):
