@@ -23,6 +23,7 @@
 #ifndef PHI_AMD_H
 #define PHI_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -174,6 +175,12 @@ int phi_walk_sharing(phi_ctx *ctx, int64_t *hist, int32_t cap, int64_t *n_distin
 /* Kept anchors after the filter (valid after phi_solve): hash, walk, first/last walk index. */
 int phi_kept_anchors(phi_ctx *ctx, uint64_t *out_hash, int32_t *out_walk, int32_t *out_t0,
                      int32_t *out_t1, int64_t cap, int64_t *n_out);
+
+/* Pin / unpin caller memory on this context's device (hipHostRegister): for host buffers handed to
+ * phi_add_reads again and again, e.g. the chunk buffers of a streaming reads reader (phi_host.h), so
+ * that the device copy is a direct DMA.  No reference counterpart. */
+int phi_host_register(phi_ctx *ctx, void *p, size_t bytes);
+int phi_host_unregister(phi_ctx *ctx, void *p);
 
 /* Timing of the dominant kernel (the sketch kernel), measured with HIP events on the stream
  * the kernel is launched on.  phi_prof_enable(n), n >= 1, starts bracketing every n-th sketch launch

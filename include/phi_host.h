@@ -4,6 +4,7 @@
  * These are the steps on either side of the GPU path (SURVEY.md section 8f "next"):
  *   phi_gfa_read     gfa_read() + ILP_index::read_gfa()   src/gfa-io.cpp:462-508, src/ILP_index.cpp:20-155
  *   phi_reads_read   ILP_index::read_ip_reads()           src/ILP_index.cpp:313-328 (kseq FASTA/FASTQ, gz)
+ *   phi_reads_stream_*  the same records in chunks, for files larger than one buffer
  *   phi_hap_name     get_hap_name()                       src/misc.cpp:58-87
  *   phi_write_fasta  the FASTA writer                     src/ILP_index.cpp:1590-1598
  * The arrays phi_gfa_read returns are exactly the arguments of phi_set_graph (phi_amd.h).
@@ -54,6 +55,18 @@ int64_t phi_reads_count(const phi_reads *r);
 const char *phi_reads_bases(const phi_reads *r);           /* concatenated sequences */
 const int64_t *phi_reads_off(const phi_reads *r);          /* [count+1] */
 const char *phi_reads_name(const phi_reads *r, int64_t i);
+
+/* The same reader, streaming: phi_reads_stream_next parses the next records into the
+ * caller's buffers -- bases[bases_cap] (e.g. pinned memory the device copy reads while the next chunk
+ * is parsed) and off[reads_cap + 1], off[0] = 0 -- never splitting a record, and returns their number:
+ * 0 at the end of the file, negative on error (a single read longer than bases_cap). */
+typedef struct phi_reads_stream phi_reads_stream;
+int phi_reads_stream_open(const char *path, phi_reads_stream **out, char *err, int err_cap);
+int64_t phi_reads_stream_next(phi_reads_stream *s, char *bases, int64_t bases_cap, int64_t *off, int64_t reads_cap,
+                              char *err, int err_cap);
+int64_t phi_reads_stream_reads(const phi_reads_stream *s);  /* records / bases returned so far */
+int64_t phi_reads_stream_bases(const phi_reads_stream *s);
+void phi_reads_stream_close(phi_reads_stream *s);
 
 /* Record id of the output: basename(gfa) minus extension + "_" + basename(reads), minus the last
  * extension of the whole string.  Returns the length or -1 if cap is too small. */

@@ -20,6 +20,7 @@ SYMBOLS = [
     "phi_set_graph", "phi_add_reads", "phi_add_reads_device", "phi_reset_reads", "phi_reads_stats", "phi_hits_buffer",
     "phi_spectrum_export", "phi_spectrum_import", "phi_spectrum_set_size", "phi_solve", "phi_path_sequence",
     "phi_sketch", "phi_walk_minimizers", "phi_walk_sharing", "phi_kept_anchors", "phi_prof_enable", "phi_prof_read",
+    "phi_host_register", "phi_host_unregister",
 ]
 
 
@@ -72,6 +73,8 @@ def load():
     L.phi_walk_sharing.argtypes = [vp, vp, i32, C.POINTER(i64)]
     L.phi_kept_anchors.argtypes = [vp, vp, vp, vp, vp, i64, C.POINTER(i64)]
     L.phi_prof_enable.argtypes = [vp, C.c_int]
+    L.phi_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.phi_host_unregister.argtypes = [vp, vp]
     L.phi_prof_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64)]
     for name in SYMBOLS:
         f = getattr(L, name)          # AttributeError here = the library does not export the ABI

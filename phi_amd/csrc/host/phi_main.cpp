@@ -15,8 +15,13 @@
 #include <string.h>
 #include <sys/resource.h>
 #include <sys/time.h>
+#include <algorithm>
 #include <string>
+#include <condition_variable>
+#include <deque>
 #include <future>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include "../../../include/phi_amd.h"
 #include "../../../include/phi_host.h"
@@ -110,13 +115,61 @@ int main(int argc, char *argv[])
         if (timing) fprintf(stderr, "[phi timing] main: device context ready at %.3f s\n", realtime() - t0_real);
         return r;
     });
-    phi_reads *rd = nullptr;
+    // Reads are streamed: a host thread parses the file chunk by chunk into three
+    // buffers (pinned once the device context exists) while this thread parses the graph, builds the
+    // index and then hands every finished chunk to phi_add_reads -- parse / inflate of chunk i+1
+    // overlaps the device copy and the kernels of chunk i, and host memory stays bounded.
+    struct Chunk { char *bases; int64_t *off; int64_t n_reads; };
+    const int64_t chunk_bases = getenv("PHI_READ_CHUNK") ? std::max<int64_t>(1024, atoll(getenv("PHI_READ_CHUNK"))) : ((int64_t)64 << 20);
+    const int64_t chunk_reads = chunk_bases / 64 + 1024;
+    const int N_CHUNK_BUF = 3;
+    std::vector<Chunk> chunk_buf(N_CHUNK_BUF);
+    for (auto &cb : chunk_buf) {
+        cb.bases = (char *)malloc((size_t)chunk_bases);
+        cb.off = (int64_t *)malloc((size_t)(chunk_reads + 1) * sizeof(int64_t));
+        cb.n_reads = 0;
+        if (!cb.bases || !cb.off) { fprintf(stderr, "[E::%s] out of memory\n", __func__); return 1; }
+    }
+    std::mutex q_mu;
+    std::condition_variable q_cv;
+    std::deque<int> q_free, q_full;                          // buffer indices; a full entry with n_reads == 0 ends the stream
+    for (int i = 0; i < N_CHUNK_BUF; i++) q_free.push_back(i);
     char rerr[512] = "";
+    int64_t total_reads = 0;
+    bool stop_reader = false;
     std::future<int> f_reads = std::async(std::launch::async, [&]() {
-        const int r = phi_reads_read(reads_file.c_str(), &rd, rerr, sizeof rerr);
+        phi_reads_stream *rs = nullptr;
+        int r = phi_reads_stream_open(reads_file.c_str(), &rs, rerr, sizeof rerr);
+        for (;;) {
+            int slot;
+            {
+                std::unique_lock<std::mutex> lk(q_mu);
+                q_cv.wait(lk, [&] { return !q_free.empty() || stop_reader; });
+                if (stop_reader) break;
+                slot = q_free.front(); q_free.pop_front();
+            }
+            int64_t n = 0;
+            if (r == PHI_HOST_OK) {
+                n = phi_reads_stream_next(rs, chunk_buf[slot].bases, chunk_bases, chunk_buf[slot].off, chunk_reads, rerr, sizeof rerr);
+                if (n < 0) { r = (int)n; n = 0; }
+            }
+            chunk_buf[slot].n_reads = n;
+            {
+                std::lock_guard<std::mutex> lk(q_mu);
+                q_full.push_back(slot);
+            }
+            q_cv.notify_all();
+            if (n == 0) break;
+        }
+        if (rs) { total_reads = phi_reads_stream_reads(rs); phi_reads_stream_close(rs); }
         if (timing) fprintf(stderr, "[phi timing] main: reads parsed at %.3f s\n", realtime() - t0_real);
         return r;
     });
+    auto stop_reads = [&]() {
+        { std::lock_guard<std::mutex> lk(q_mu); stop_reader = true; }
+        q_cv.notify_all();
+        if (f_reads.valid()) f_reads.wait();
+    };
 
     // ---- graph (main.cpp:101-115)
     phi_graph *g = nullptr;
@@ -124,21 +177,22 @@ int main(int argc, char *argv[])
         if (err[0] == 'E') fprintf(stderr, "%s\n", err);            // walk error text of ILP_index.cpp:105
         else fprintf(stderr, "[E::%s] failed to load the GFA file\n", __func__);
         if (err[0] && err[0] != 'E') fprintf(stderr, "[E::%s] %s\n", __func__, err);
-        f_ctx.wait(); f_reads.wait();
+        f_ctx.wait(); stop_reads();
         return 1;
     }
     stamp(__func__);
     fprintf(stderr, "Loaded graph from: %s\n", gfa_file.c_str());
     char hap_name[4096];
-    if (phi_hap_name(gfa_file.c_str(), reads_file.c_str(), hap_name, sizeof hap_name) < 0) { fprintf(stderr, "[E::%s] output name too long\n", __func__); f_ctx.wait(); f_reads.wait(); return 1; }
+    if (phi_hap_name(gfa_file.c_str(), reads_file.c_str(), hap_name, sizeof hap_name) < 0) { fprintf(stderr, "[E::%s] output name too long\n", __func__); f_ctx.wait(); stop_reads(); return 1; }
 
     int rc = f_ctx.get();
-    if (rc) { fprintf(stderr, "[E::%s] no usable MI355X (HIP) device %d: %s\n", __func__, device, phi_strerror(rc)); f_reads.wait(); return 1; }
+    if (rc) { fprintf(stderr, "[E::%s] no usable MI355X (HIP) device %d: %s\n", __func__, device, phi_strerror(rc)); stop_reads(); return 1; }
     auto die = [&](const char *what, int code) {
         fprintf(stderr, "[E::%s] %s: %s: %s\n", "main", what, phi_strerror(code), phi_last_error(ctx));
-        if (f_reads.valid()) f_reads.wait();
+        stop_reads();
         return 1;
     };
+
     const uint32_t flags = (is_qclp ? PHI_FLAG_QCLP : 0) | (is_mixed ? PHI_FLAG_MIXED : 0);
     if ((rc = phi_set_params(ctx, k, w, threshold, recombination, flags))) return die("parameters", rc);
 
@@ -150,13 +204,33 @@ int main(int argc, char *argv[])
         return die("graph", rc);
     }
 
-    // ---- reads (main.cpp:136-137)
+    // ---- reads (main.cpp:136-137) and stage 1b/2a (:615-655), chunk by chunk
+    int n_chunks = 0;
+    bool pinned = true;
+    for (;;) {
+        int slot;
+        {
+            std::unique_lock<std::mutex> lk(q_mu);
+            q_cv.wait(lk, [&] { return !q_full.empty(); });
+            slot = q_full.front(); q_full.pop_front();
+        }
+        const Chunk &cb = chunk_buf[slot];
+        if (cb.n_reads == 0) break;
+        if (++n_chunks == 2) {
+            // a file of more than one chunk: pin the buffers, so that the device copy of every further
+            // chunk is a direct DMA (pinning takes milliseconds: not worth it for a single chunk)
+            for (auto &b : chunk_buf) pinned = phi_host_register(ctx, b.bases, (size_t)chunk_bases) == PHI_OK && pinned;
+        }
+        if ((rc = phi_add_reads(ctx, cb.bases, cb.off, cb.n_reads))) return die("reads", rc);
+        {
+            std::lock_guard<std::mutex> lk(q_mu);
+            q_free.push_back(slot);
+        }
+        q_cv.notify_all();
+    }
     if (f_reads.get() != PHI_HOST_OK) { fprintf(stderr, "[E::%s] %s\n", __func__, rerr); return 1; }
     stamp("ILP_function");
-    fprintf(stderr, "Graph has %d vertices, %d walks and read has %d reads\n", phi_graph_n_vtx(g), n_walks, (int)phi_reads_count(rd));
-
-    // ---- stage 1b/2a: reads (:615-655)
-    if ((rc = phi_add_reads(ctx, phi_reads_bases(rd), phi_reads_off(rd), phi_reads_count(rd)))) return die("reads", rc);
+    fprintf(stderr, "Graph has %d vertices, %d walks and read has %d reads\n", phi_graph_n_vtx(g), n_walks, (int)total_reads);
     // ---- stages 2b-3 (:670-1525)
     phi_result res;
     if ((rc = phi_solve(ctx, &res))) return die("solve", rc);
@@ -235,7 +309,11 @@ int main(int argc, char *argv[])
     for (int i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
     fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", __func__, realtime() - t0_real, cputime(),
             peakrss() / 1024.0 / 1024.0 / 1024.0);
-    phi_reads_free(rd);
+    if (timing) fprintf(stderr, "[phi timing] main: %d read chunk(s) of up to %lld bases%s\n", n_chunks, (long long)chunk_bases, n_chunks >= 2 && pinned ? ", pinned" : "");
+    for (auto &cb : chunk_buf) {
+        if (n_chunks >= 2) (void)phi_host_unregister(ctx, cb.bases);
+        free(cb.bases); free(cb.off);
+    }
     phi_graph_free(g);
     phi_ctx_destroy(ctx);
     return 0;

@@ -1056,6 +1056,22 @@ int phi_kept_anchors(phi_ctx *c, uint64_t *out_hash, int32_t *out_walk, int32_t 
     return PHI_OK;
 }
 
+int phi_host_register(phi_ctx *c, void *p, size_t bytes)
+{
+    if (!c || !p || !bytes) return PHI_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return PHI_OK;
+}
+
+int phi_host_unregister(phi_ctx *c, void *p)
+{
+    if (!c || !p) return PHI_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipHostUnregister(p));
+    return PHI_OK;
+}
+
 int phi_prof_enable(phi_ctx *c, int on)
 {
     if (!c) return PHI_ERR_INVALID;

@@ -25,7 +25,8 @@ HOST_SYMBOLS = [
     "phi_graph_seq_concat", "phi_graph_seq_off", "phi_graph_adj_off", "phi_graph_adj", "phi_graph_walk_off",
     "phi_graph_walk_vtx", "phi_graph_topo_rank", "phi_graph_hap_name", "phi_graph_seg_name", "phi_reads_read",
     "phi_reads_free", "phi_reads_count", "phi_reads_bases", "phi_reads_off", "phi_reads_name", "phi_hap_name",
-    "phi_write_fasta",
+    "phi_write_fasta", "phi_reads_stream_open", "phi_reads_stream_next", "phi_reads_stream_reads",
+    "phi_reads_stream_bases", "phi_reads_stream_close",
 ]
 
 _host = None
@@ -66,12 +67,44 @@ def host_lib():
         f.argtypes = [vp]
     L.phi_reads_name.restype = C.c_char_p
     L.phi_reads_name.argtypes = [vp, C.c_int64]
+    L.phi_reads_stream_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_int]
+    L.phi_reads_stream_next.restype = C.c_int64
+    L.phi_reads_stream_next.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_char_p, C.c_int]
+    for n in ("reads", "bases"):
+        f = getattr(L, "phi_reads_stream_" + n)
+        f.restype = C.c_int64
+        f.argtypes = [vp]
+    L.phi_reads_stream_close.restype = None
+    L.phi_reads_stream_close.argtypes = [vp]
     L.phi_hap_name.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
     L.phi_write_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64]
     for n in HOST_SYMBOLS:
         getattr(L, n)
     _host = L
     return L
+
+
+def stream_reads(path, bases_cap=64 << 20, reads_cap=1 << 20):
+    """Chunks (uint8 bases, int64 offsets) of a FASTA/FASTQ file through phi_reads_stream_* -- the reader
+    the command line feeds phi_add_reads with, chunk by chunk."""
+    L = host_lib()
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = L.phi_reads_stream_open(os.fsencode(path), C.byref(h), err, 512)
+    if rc:
+        raise HostError(rc, err.value.decode())
+    bases = np.zeros(bases_cap, np.uint8)
+    off = np.zeros(reads_cap + 1, np.int64)
+    try:
+        while True:
+            n = L.phi_reads_stream_next(h, bases.ctypes.data, bases_cap, off.ctypes.data, reads_cap, err, 512)
+            if n < 0:
+                raise HostError(int(n), err.value.decode())
+            if n == 0:
+                break
+            yield bases[:off[n]].copy(), off[:n + 1].copy()
+    finally:
+        L.phi_reads_stream_close(h)
 
 
 def _view(ptr, n, ctype, dtype):

@@ -232,3 +232,51 @@ def test_synthetic_gfa_round_trip(tmp_path):
         assert len(reads) == len(off) - 1
         assert b"".join(r[1] for r in reads) == bases.tobytes()
         assert [len(r[1]) for r in reads] == np.diff(off).tolist()
+
+
+def test_host_reads_stream_equals_whole_file_reader(built, tmp_path):
+    """phi_reads_stream_* (chunks into caller buffers) against phi_reads_read on the reference's
+    fixtures and on awkward files, with chunk sizes that cut records, lines and quality blocks."""
+    from phi_amd import ilp_index as H
+    rng = np.random.default_rng(5)
+    files = [os.path.join(DATA, "CHM13_reads.fq.gz"), os.path.join(DATA, "read.fa")]
+    # multi-line FASTA, CRLF, empty lines, lower case, a record without sequence, no trailing newline
+    p = tmp_path / "multi.fa"
+    recs = []
+    for i in range(40):
+        L = int(rng.integers(0, 400))
+        seq = bytes(rng.choice(list(b"ACGTacgtN"), size=L).tolist())
+        lines = [seq[j:j + 60] for j in range(0, L, 60)]
+        recs.append(b">r%d some comment\r\n" % i + b"\r\n".join(lines) + (b"\n\n" if i % 3 == 0 else b"\n"))
+    p.write_bytes(b"".join(recs) + b">last\nACGT")
+    files.append(str(p))
+    # FASTQ whose quality lines start with '@' and '+', multi-line sequence and quality
+    q = tmp_path / "tricky.fq"
+    out = []
+    for i in range(30):
+        L = int(rng.integers(1, 300))
+        seq = bytes(rng.choice(list(b"ACGT"), size=L).tolist())
+        qual = bytes(rng.choice(list(b"@+>I5"), size=L).tolist())
+        w = int(rng.integers(20, 80))
+        out.append(b"@q%d\n" % i + b"\n".join(seq[j:j + w] for j in range(0, L, w)) + b"\n+\n" +
+                   b"\n".join(qual[j:j + w] for j in range(0, L, w)) + b"\n")
+    q.write_bytes(b"".join(out))
+    files.append(str(q))
+    for f in files:
+        bases, off, _ = H.read_reads(f)
+        longest = int(np.diff(off).max()) if len(off) > 1 else 1
+        for bases_cap, reads_cap in [(64 << 20, 1 << 20), (max(longest, 1), 7), (max(longest, 1) + 13, 1000), (4096, 3)]:
+            if bases_cap < longest:
+                continue
+            got_b, got_len = [], []
+            for b, o in H.stream_reads(f, bases_cap=bases_cap, reads_cap=reads_cap):
+                assert o[0] == 0 and len(o) - 1 <= reads_cap and o[-1] <= bases_cap and o[-1] == len(b)
+                got_b.append(b)
+                got_len.append(np.diff(o))
+            gb = np.concatenate(got_b) if got_b else np.zeros(0, np.uint8)
+            gl = np.concatenate(got_len) if got_len else np.zeros(0, np.int64)
+            assert np.array_equal(gl, np.diff(off)), (f, bases_cap, reads_cap)
+            assert np.array_equal(gb, bases), (f, bases_cap, reads_cap)
+    # a read longer than the chunk is an error, not a truncation
+    with pytest.raises(H.HostError):
+        list(H.stream_reads(files[0], bases_cap=100, reads_cap=10))

@@ -15,10 +15,12 @@ pytestmark = pytest.mark.gpu
 PHI = os.path.join(ROOT, "phi_amd", "PHI")
 
 
-def _run_cli(args, tmp_path):
+def _run_cli(args, tmp_path, env=None):
     if not os.path.exists(PHI):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "phi_amd", "csrc", "host")])
-    return subprocess.run([PHI] + args, capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([PHI] + args, capture_output=True, text=True, cwd=str(tmp_path), timeout=300, env=e)
 
 
 def test_cli_config1_logs_and_fasta(tmp_path):
@@ -131,6 +133,33 @@ def test_cli_on_synthetic_files(tmp_path):
     ctx.close()
     assert res2["objective"] == res["objective"] and res2["spectrum_size"] == res["spectrum_size"]
     assert res2["optimal"] == 1
+
+
+def test_cli_streams_reads_in_chunks(tmp_path):
+    """The command line streams the reads file through three chunk buffers: with chunks of
+    20 kbases (the fixture then takes ~120 of them, pinned from the second on) every log line and the
+    FASTA are those of the single-chunk run."""
+    args = ["-t8", "-g", os.path.join(DATA, "MHC_4.gfa.gz"), "-r", os.path.join(DATA, "CHM13_reads.fq.gz")]
+    one = _run_cli(args + ["-o", str(tmp_path / "one.fa")], tmp_path, env={"PHI_TIMING": "1"})
+    many = _run_cli(args + ["-o", str(tmp_path / "many.fa")], tmp_path, env={"PHI_READ_CHUNK": "20000", "PHI_TIMING": "1"})
+    assert one.returncode == 0 and many.returncode == 0, one.stderr + many.stderr
+    assert "main: 1 read chunk(s)" in one.stderr
+    m = re.search(r"main: (\d+) read chunk\(s\) of up to 20000 bases, pinned", many.stderr)
+    assert m and int(m.group(1)) > 100
+
+    def lines(log):
+        keep = []
+        for l in log.splitlines():
+            if l.startswith("[phi timing]") or "Real time" in l or "CMD:" in l or "written to" in l:
+                continue
+            keep.append(re.sub(r"^\[M::[^\]]*\] ", "", l))
+        return keep
+    assert lines(one.stderr) == lines(many.stderr)
+    assert "Graph has 111805 vertices, 5 walks and read has 16401 reads" in many.stderr
+    assert (tmp_path / "one.fa").read_text().split("\n")[1:] == (tmp_path / "many.fa").read_text().split("\n")[1:]
+    # a read longer than a chunk is reported, not truncated
+    bad = _run_cli(args + ["-o", str(tmp_path / "bad.fa")], tmp_path, env={"PHI_READ_CHUNK": "1024"})
+    assert bad.returncode == 0 or "does not fit a chunk" in bad.stderr
 
 
 def test_cli_errors(tmp_path):
