@@ -59,6 +59,18 @@ static unsigned long long *sp_stripes(phi_ctx *c) { return c->d_stripes.as<unsig
 static unsigned long long *emit_stripes(phi_ctx *c) { return c->d_stripes.as<unsigned long long>() + PHI_STRIPES * 8; }
 #define STRIPE_BYTES ((size_t)PHI_STRIPES * 8 * 8)
 
+// off[0..n] = exclusive prefix sums of cnt[0..n): one workgroup for a few thousand items, the three-phase
+// scan beyond (the per-chunk counts of 250 Mbases of walks are half a million items: 1 ms in one workgroup)
+int phi_scan_counts_wide(phi_ctx *c, const int32_t *cnt, int64_t n, int64_t *off)
+{
+    if (n <= 8192) { phi_launch_scan_counts(c->stream, cnt, n, off); return PHI_OK; }
+    const int64_t nb = phi_scan_i32_num_blocks(n);
+    PHICHK(phi_dev_ensure(c, c->d_scan_blk64, (size_t)nb * 8));
+    PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
+    phi_launch_scan_i64(c->stream, cnt, n, off, c->d_scan_blk64.as<int64_t>(), c->d_scan_blkoff.as<int64_t>());
+    return PHI_OK;
+}
+
 // phi_reset_reads only notes the reset; the next read batch folds it into its preparation launch.
 // Everything else that looks at the spectrum, the hit vector or the counters calls this first.
 int phi_flush_reset(phi_ctx *c)
@@ -243,7 +255,7 @@ static int sketch_records(phi_ctx *c, const uint64_t *words, const unsigned long
     A.err = (uint32_t *)scalar(c, S_ERR);
     if (A.allslow) phi_launch_sketch_bytes(c->stream, PHI_MODE_COUNT, A, nullptr);
     else phi_launch_sketch(c->stream, PHI_MODE_COUNT, A);
-    phi_launch_scan_counts(c->stream, c->d_blk_cnt.as<int32_t>(), nb, c->d_blk_off.as<int64_t>());
+    PHICHK(phi_scan_counts_wide(c, c->d_blk_cnt.as<int32_t>(), nb, c->d_blk_off.as<int64_t>()));
     int64_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, c->d_blk_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

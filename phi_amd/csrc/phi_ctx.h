@@ -227,5 +227,6 @@ int phi_pin_ensure(phi_ctx *c, size_t bytes);
 // sums of the striped counters (waits for the stream)
 int phi_read_counts(phi_ctx *c, uint64_t *n_in_set, uint64_t *n_emitted);
 int phi_spectrum_count(phi_ctx *c, uint64_t *n_distinct);
+int phi_scan_counts_wide(phi_ctx *c, const int32_t *cnt, int64_t n, int64_t *off);
 // flags[n] (0/1) -> ascending list of flagged indices (int32) in out
 int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_t *n_out);

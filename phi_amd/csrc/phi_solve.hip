@@ -41,7 +41,7 @@ int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_
     PHICHK(phi_dev_ensure(c, c->d_blk_cnt, (size_t)nb * 4));
     PHICHK(phi_dev_ensure(c, c->d_blk_off, (size_t)(nb + 1) * 8));
     phi_launch_flag_count(c->stream, flags, n, c->d_blk_cnt.as<int32_t>());
-    phi_launch_scan_counts(c->stream, c->d_blk_cnt.as<int32_t>(), nb, c->d_blk_off.as<int64_t>());
+    PHICHK(phi_scan_counts_wide(c, c->d_blk_cnt.as<int32_t>(), nb, c->d_blk_off.as<int64_t>()));
     int64_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, c->d_blk_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

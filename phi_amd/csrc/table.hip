@@ -65,12 +65,17 @@ __global__ void __launch_bounds__(256) phi_table_build_kernel(const uint64_t *__
         uint64_t slot = h & u_mask;
         int probes = 0;
         for (;;) {
-            const unsigned long long prev = atomicCAS((unsigned long long *)&u_keys[slot], PHI_EMPTY_KEY, h);
+            // the walks of a pangenome share most minimisers: look before the atomic (a key, once
+            // written, never changes)
+            unsigned long long prev = __builtin_nontemporal_load((const unsigned long long *)&u_keys[slot]);
+            if (prev == PHI_EMPTY_KEY) prev = atomicCAS((unsigned long long *)&u_keys[slot], PHI_EMPTY_KEY, h);
             if (prev == PHI_EMPTY_KEY || prev == h) break;
             slot = (slot + 1) & u_mask;
             if (++probes > PHI_MAX_PROBE) { atomicOr(err, PHI_KERR_TABLE_FULL); break; }
         }
-        atomicMin(&u_rep[slot], (uint32_t)i);     // smallest record index: same on every rank
+        // smallest record index: same on every rank.  The stored value only falls, so a record that
+        // sees a smaller one already there has nothing to add
+        if (__builtin_nontemporal_load(&u_rep[slot]) > (uint32_t)i) atomicMin(&u_rep[slot], (uint32_t)i);
         rec_slot[i] = (uint32_t)slot;
     }
 }
