@@ -218,7 +218,7 @@ def main():
         "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {'reference graph' if args.config == 'C1syn' else 'synMHC-49 graph'} (seed {gk['seed']}, {g.n_walks} walks, {g.n_vtx} vertices{'' if args.config == 'C1syn' else ' <=30 bp'}, "
+        "config": {"workload": f"{args.config}: {'reference graph' if args.config == 'C1syn' else f'synMHC-{g.n_walks} graph'} (seed {gk['seed']}, {g.n_walks} walks, {g.n_vtx} vertices{'' if args.config == 'C1syn' else ' <=30 bp'}, "
                                f"{walk_bases / 1e6:.1f} Mbases of walks) + {n_reads} reads of mean {n_bases / max(1, n_reads):.0f} bp per GPU (seed {rk['seed']}, {n_bases / 1e6:.2f} Mbases)",
                    "k": K, "w": W, "R": 100, "reads_per_gpu_bases": n_bases, "parallelism": f"read-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
