@@ -923,9 +923,13 @@ static void launch_sketch_mode(hipStream_t st, unsigned nb, size_t lds, const Ph
 {
     // the reference's defaults (options.cpp:7-8) get a fully unrolled instance, except for the
     // ordered write whose position tracking would push it past 128 VGPRs
-    if (A.k == 31 && A.w == 25 && MODE != PHI_MODE_WRITE)
-        hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, true, 31, 25>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
-    else if (A.w > Q) hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, true, 0, 0>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
+    if constexpr (MODE != PHI_MODE_WRITE) {
+        if (A.k == 31 && A.w == 25) {
+            hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, true, 31, 25>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
+            return;
+        }
+    }
+    if (A.w > Q) hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, true, 0, 0>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
     else hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, false, 0, 0>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
 }
 

@@ -303,6 +303,7 @@ CONFIGS = {
     # config 5 at the MHC's length: the same 200 walks and 30x reads over a 5 Mbp backbone (what one GPU box
     # generates and holds in minutes; the DP takes the dense path of > 128 walks)
     "C5s": (dict(backbone_len=5_000_000, n_walks=200, seed=20001), dict(coverage=30.0, seed=20002)),
+    "C2w100": (dict(backbone_len=5_000_000, n_walks=100, seed=4901), dict(coverage=1.0, seed=4902)),
     # small variants for tests and smoke runs
     "tiny": (dict(backbone_len=60_000, n_walks=7, seed=11, max_sv=800), dict(coverage=2.0, seed=12)),
     "small": (dict(backbone_len=400_000, n_walks=16, seed=21, max_sv=2000), dict(coverage=1.0, seed=22)),
