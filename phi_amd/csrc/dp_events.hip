@@ -340,16 +340,21 @@ __device__ int32_t ev_count_inside(const PhiDpEventArgs &A, int64_t es, int64_t 
     return n;
 }
 
-template <int NW>   // waves in the workgroup (1 or 2)
+template <int NW>   // waves in the workgroup (1, 2 or 4)
 __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A)
 {
     constexpr int NT = NW * 64;
-    constexpr int D = NW == 1 ? 16 : 8;              // per-lane ring of event records
+    constexpr int D = NW == 1 ? 16 : NW == 2 ? 8 : 4;   // per-lane ring of event records
     constexpr int P = D / 2;                         // refill period in steps
+    // four waves: 160 KB of LDS hold queues of 16 runs (31 can be alive in theory, 2-3 are in practice: a
+    // deeper one raises PHI_KERR_DP_QUEUE and the caller reruns with dp.hip) and the tops of 512 steps
+    constexpr int QD = NW <= 2 ? 32 : 16;
+    constexpr int RNG = NW <= 2 ? RING : 512;
     __shared__ int4 s_rec[2][CHK][2];
-    __shared__ int4 s_top[RING];                    // packed tops of recent steps
+    __shared__ int4 s_top[RNG];                     // packed tops of recent steps
     __shared__ uint4 s_ev[D][3][NT];
-    __shared__ int32_t s_qs[32][NT], s_qE[32][NT], s_qK[32][NT];   // live young runs: start, value, key
+    __shared__ int32_t s_qs[QD][NT], s_qE[QD][NT], s_qK[QD][NT];   // live young runs: start, value, key
+    const int32_t q_limit = A.q_limit > 0 && A.q_limit < QD ? A.q_limit : (QD == 32 ? 32 : QD);
     __shared__ unsigned long long s_red[NW > 1 ? NW : 1];
     __shared__ int32_t s_oidx[NT];
 
@@ -434,10 +439,10 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
                     if (val > E || (val == E && (hh < Eh || (hh == Eh && src < Esrc)))) { E = val; Eh = hh; Esrc = src; }
                 };
                 const uint32_t b0 = (uint32_t)ra.z >> 8, b1 = (uint32_t)ra.w >> 8, b2 = (uint32_t)rb.x >> 8;
-                if (n_in <= 3 && (b0 | b1 | b2) < RING) {
-                    const int4 q0 = s_top[(k - b0) & (RING - 1)];
-                    const int4 q1 = s_top[(k - b1) & (RING - 1)];
-                    const int4 q2 = s_top[(k - b2) & (RING - 1)];
+                if (n_in <= 3 && (b0 | b1 | b2) < RNG) {
+                    const int4 q0 = s_top[(k - b0) & (RNG - 1)];
+                    const int4 q1 = s_top[(k - b1) & (RNG - 1)];
+                    const int4 q2 = s_top[(k - b2) & (RNG - 1)];
                     consider(q0, ra.z & 0xFF, k - (int32_t)b0);
                     if (n_in > 1) consider(q1, ra.w & 0xFF, k - (int32_t)b1);
                     if (n_in > 2) consider(q2, rb.x & 0xFF, k - (int32_t)b2);
@@ -446,7 +451,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
                         const int32_t p = j == 0 ? ra.z : j == 1 ? ra.w : j == 2 ? rb.x : A.k_in_packed[ra.y + j - 3];
                         const int32_t back = (int32_t)((uint32_t)p >> 8);
                         const int32_t src = k - back;
-                        const int4 q = back < RING ? s_top[src & (RING - 1)] : reinterpret_cast<const int4 *>(A.tops)[src];
+                        const int4 q = back < RNG ? s_top[src & (RNG - 1)] : reinterpret_cast<const int4 *>(A.tops)[src];
                         consider(q, p & 0xFF, src);
                     }
                 }
@@ -465,9 +470,9 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
                 const uint8_t *gb = reinterpret_cast<const uint8_t *>(&s_ev[sl][1][h]);
                 oidx = reinterpret_cast<const uint8_t *>(&s_ev[sl][2][h])[15];
                 // runs older than 30 entries: one scalar
-                while (qh != qt && t - s_qs[qh & 31][h] >= 31) {
-                    const int32_t key = s_qK[qh & 31][h];
-                    if (key > M) { M = key; sL = s_qs[qh & 31][h]; }
+                while (qh != qt && t - s_qs[qh & (QD - 1)][h] >= 31) {
+                    const int32_t key = s_qK[qh & (QD - 1)][h];
+                    if (key > M) { M = key; sL = s_qs[qh & (QD - 1)][h]; }
                     qh++;
                 }
                 // a run begins here: the walk start, or a recombination entry worth keeping
@@ -477,20 +482,21 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
                 if (newE > Emax) {
                     Emax = newE;
                     const int32_t key = newE - SB;
-                    while (qh != qt && s_qK[(qt - 1) & 31][h] < key) qt--;
-                    s_qs[qt & 31][h] = t; s_qE[qt & 31][h] = newE; s_qK[qt & 31][h] = key;
+                    while (qh != qt && s_qK[(qt - 1) & (QD - 1)][h] < key) qt--;
+                    if (qt - qh >= q_limit) { atomicOr(A.err, PHI_KERR_DP_QUEUE); qt--; }   // result void: the caller falls back
+                    s_qs[qt & (QD - 1)][h] = t; s_qE[qt & (QD - 1)][h] = newE; s_qK[qt & (QD - 1)][h] = key;
                     qt++;
                 }
                 if ((flags & PHI_DP_NEED_TOPS) || e == ee - 1) {
                     // oldest first, strict improvement: ties keep the older run
                     int32_t best = M > NEGK / 2 ? M + End : NEG, bs = sL;
                     for (int32_t j = qh; j != qt; j++) {
-                        const int32_t s = s_qs[j & 31][h];
+                        const int32_t s = s_qs[j & (QD - 1)][h];
                         const int a = t - s;
                         int32_t inside;
                         if (!ovf) inside = a < 16 ? gb[a] : reinterpret_cast<const uint8_t *>(&s_ev[sl][2][h])[a - 16];
                         else inside = ev_count_inside(A, eb + s, e);
-                        const int32_t val = s_qE[j & 31][h] + inside;
+                        const int32_t val = s_qE[j & (QD - 1)][h] + inside;
                         if (val > best) { best = val; bs = s; }
                     }
                     if (best > NEG / 2) { dmax = best; A.dmax[e] = best; A.bstart[e] = bs; }
@@ -547,7 +553,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
                 }
                 if (h == 0) {
                     const int4 q = ev_pack_tops(t1v, t1h, t1n, t2v, t2h);
-                    s_top[k & (RING - 1)] = q;
+                    s_top[k & (RNG - 1)] = q;
                     reinterpret_cast<int4 *>(A.tops)[k] = q;
                 }
                 if (NW > 1) __syncthreads();
@@ -811,5 +817,6 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
 void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A)
 {
     if (A.n_walks <= 64) hipLaunchKernelGGL(phi_dp_events_pc_kernel<2>, dim3(1), dim3(64 * 3), 0, st, A);
-    else hipLaunchKernelGGL(phi_dp_events_kernel<2>, dim3(1), dim3(128), 0, st, A);    // n_walks <= PHI_DP_EVENT_MAX_WALKS
+    else if (A.n_walks <= 128) hipLaunchKernelGGL(phi_dp_events_kernel<2>, dim3(1), dim3(128), 0, st, A);
+    else hipLaunchKernelGGL(phi_dp_events_kernel<4>, dim3(1), dim3(256), 0, st, A);    // n_walks <= PHI_DP_EVENT_MAX_WALKS
 }

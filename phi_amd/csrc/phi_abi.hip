@@ -521,7 +521,9 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     if (!c->h_walk_vtx.resize(n_entries) || !e_out.resize(n_entries)) return phi_fail(c, PHI_ERR_NOMEM, "host allocation failed");
     std::vector<int32_t> cnt_edge(std::max<int64_t>(n_edges, 1), 0), cont_total(n_vtx, 0);
     // the step masks serve the every-vertex kernel only (dp.hip, more than 128 walks)
-    const bool want_masks = !(n_walks <= PHI_DP_EVENT_MAX_WALKS && !getenv("PHI_DP_DENSE"));
+    // the every-vertex stream of dp.hip: beyond 256 walks, when asked for, and as the fallback of the
+    // four-wave event kernel (129-256 walks) whose per-lane queues are shallower than the worst case
+    const bool want_masks = !(n_walks <= PHI_DP_EVENT_SAFE_WALKS && !getenv("PHI_DP_DENSE"));
     std::vector<unsigned long long> st_mask(want_masks ? (size_t)n_vtx * nw64 : 0, 0ull);
     {
         PhiHostError herr;
@@ -666,7 +668,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     tm.lap("wait for the GPU thread");
     // ---- device copies of what the host pass made
     PHICHK(upload(c, c->d_e_out, e_out.data(), e_out.size()));
-    if (!c->dp_events) {                                       // the every-vertex stream serves dp.hip only
+    c->dp_dense_ready = want_masks;
+    if (want_masks) {                                          // the every-vertex stream serves dp.hip only
         PHICHK(upload(c, c->d_st_rec, st_rec.data(), st_rec.size()));
         PHICHK(upload(c, c->d_st_mask, st_mask.data(), st_mask.size()));
         PHICHK(upload(c, c->d_in_packed, in_packed.data(), in_packed.size()));

@@ -111,6 +111,7 @@ struct phi_ctx {
     DevBuf d_a_e1, d_g_off, d_g_span, d_a_weight;
     DevBuf d_dmax, d_bstart, d_top, d_ent, d_word;
     // event-driven DP (dp_events.hip)
+    bool dp_dense_ready = false;                      // the every-vertex stream of dp.hip is on the device (fallback of the 4-wave event kernel)
     bool dp_events = false;
     int32_t n_k = 0;                                  // compact steps
     int64_t n_ev = 0;                                 // events

@@ -18,6 +18,7 @@ enum { PHI_MODE_COUNT = 0, PHI_MODE_WRITE = 1, PHI_MODE_PROBE = 2 };
 #define PHI_KERR_SENTINEL 1u    // a minimiser hashed to the empty-slot sentinel
 #define PHI_KERR_TABLE_FULL 2u  // probe bound exceeded
 #define PHI_KERR_WALK_EDGE 4u   // consecutive walk vertices not joined by a graph edge
+#define PHI_KERR_DP_QUEUE 16u    // event DP: more live young runs on a lane than its queue holds
 
 struct PhiSketchArgs {
     const uint64_t *words;                 // packed bases (+2 padding words)
@@ -163,7 +164,8 @@ struct PhiDpArgs {
 void phi_launch_dp(hipStream_t st, const PhiDpArgs &A);
 
 // event-driven DP (dp_events.hip): up to PHI_DP_EVENT_MAX_WALKS walks
-#define PHI_DP_EVENT_MAX_WALKS 128
+#define PHI_DP_EVENT_MAX_WALKS 256
+#define PHI_DP_EVENT_SAFE_WALKS 128  // beyond: per-lane queues of 16 runs; a deeper one makes the caller fall back to dp.hip
 #define PHI_DP_LANE_ONLY 4      // compact-step flag: a walk starts or ends on the vertex (no ENTRY / TOPS work)
 struct PhiDpEventArgs {
     int32_t n_k, n_walks;                // compact steps (vertices with ENTRY / TOPS / a walk start or end)
@@ -182,6 +184,8 @@ struct PhiDpEventArgs {
     int32_t *dmax, *bstart;              // per entry, written at query events
     int32_t *tops;                       // [n_k] packed 16-byte tops
     int32_t *ent_src, *ent_h;            // per compact step
+    uint32_t *err;                       // PHI_KERR_DP_QUEUE
+    int32_t q_limit;                     // 0 = the kernel's queue depth; tests lower it to provoke the fallback
 };
 void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A);
 void phi_launch_event_flags(hipStream_t st, const int32_t *walk_vtx, int64_t n_entries, const int32_t *cvtx, uint8_t *flags);

@@ -89,6 +89,8 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
         A.dmax = d_dmax; A.bstart = d_bstart;
         A.tops = c->d_top.as<int32_t>();
         A.ent_src = d_ent_src; A.ent_h = d_ent_h;
+        A.err = (uint32_t *)(c->d_scalars.as<uint64_t>() + S_ERR);
+        A.q_limit = getenv("PHI_DP_QLIMIT") ? atoi(getenv("PHI_DP_QLIMIT")) : 0;      // tests: provoke the fallback
         phi_launch_dp_event_fill(c->stream, A, c->d_e_out.as<uint8_t>(), c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(),
                                  c->d_off_end.as<int32_t>(), c->d_off_start.as<int32_t>());
         if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("weights + per-run records"); }
@@ -116,8 +118,19 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
     H.ends.resize(c->n_walks);
     phi_launch_gather_i32(c->stream, d_dmax, c->d_walk_last.as<int32_t>(), c->n_walks, c->d_list3.as<int32_t>());
     HIPCHK(hipMemcpyAsync(H.ends.data(), c->d_list3.p, (size_t)c->n_walks * 4, hipMemcpyDeviceToHost, c->stream));
+    uint32_t kerr = 0;
+    if (events) HIPCHK(hipMemcpyAsync(&kerr, c->d_scalars.as<uint64_t>() + S_ERR, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     tr.lap("kernel");
+    if (kerr & PHI_KERR_DP_QUEUE) {
+        // a lane of the four-wave event kernel had more live runs than its queue holds: this graph takes
+        // the every-vertex kernel from now on
+        kerr &= ~PHI_KERR_DP_QUEUE;
+        HIPCHK(hipMemcpy(c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
+        if (!c->dp_dense_ready) return phi_fail(c, PHI_ERR_DEVICE, "event DP queue overflow without a dense fallback (internal error)");
+        c->dp_events = false;
+        return run_dp(c, wgt, H, value, segs);
+    }
     bool bulk = false;
     auto fetch_bulk = [&]() -> int {
         H.bstart.resize(ne); H.ent_u.resize(n_ent); H.ent_h.resize(n_ent);

@@ -419,7 +419,7 @@ def test_dense_and_event_dp_agree(oracle, ctx_factory, monkeypatch):
         assert out[("events", R)] == out[("dense", R)], (R, out)
 
 
-@pytest.mark.parametrize("seed,n_walks", [(1, 60), (2, 33), (3, 100)])
+@pytest.mark.parametrize("seed,n_walks", [(1, 60), (2, 33), (3, 100), (4, 200), (5, 256)])
 def test_dense_and_event_dp_agree_at_scale(oracle, ctx_factory, monkeypatch, seed, n_walks):
     """Two independent DP kernels (event-driven with prefix sums / every-vertex with a difference
     ring) on graphs with thousands of vertices and tens of walks: same objective, same proof."""
@@ -444,6 +444,36 @@ def test_dense_and_event_dp_agree_at_scale(oracle, ctx_factory, monkeypatch, see
     m = S.Model(g, st, R)
     obj, cov, nsw = m.objective(S.states_from_path(res["path_vtx"], res["path_hap"]))
     assert obj == res["objective"]
+
+
+def test_event_dp_queue_overflow_falls_back_to_dense(oracle, ctx_factory, monkeypatch):
+    """129-256 walks: the four-wave event kernel keeps 16 live runs per lane; a lane that needs more raises
+    PHI_KERR_DP_QUEUE and the solve reruns on the every-vertex kernel.  PHI_DP_QLIMIT=1 provokes it."""
+    rng = np.random.default_rng(777)
+    g = random_graph(rng, n_sites=300, n_walks=150, seg_len=(3, 20), alt_len=(1, 10), p_del=0.2)
+    reads = mosaic_reads(rng, g, n_reads=400, read_len=80, n_seg=4, err=0.01)
+    k, w, R = 11, 5, 3
+    out = {}
+    for mode in ("events", "fallback", "dense"):
+        if mode == "fallback":
+            monkeypatch.setenv("PHI_DP_QLIMIT", "1")
+        if mode == "dense":
+            monkeypatch.delenv("PHI_DP_QLIMIT")
+            monkeypatch.setenv("PHI_DP_DENSE", "1")
+        ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=R)
+        _set_graph(ctx, g)
+        ctx.add_reads(reads)
+        res = ctx.solve()
+        out[mode] = (res["objective"], res["upper_bound"], res["optimal"], res["n_in_model"], res["path_vtx"].tolist(), res["path_hap"].tolist())
+    monkeypatch.delenv("PHI_DP_DENSE")
+    assert out["events"][:4] == out["dense"][:4] == out["fallback"][:4], [o[:4] for o in out.values()]
+    assert out["fallback"] == out["dense"]                   # the fallback IS the dense kernel: same path
+    from oracle import solve_oracle as S
+    st = oracle.run_stage12(g, reads, k, w, 1.0)
+    m = S.Model(g, st, R)
+    for mode in ("events", "dense"):
+        obj, cov, nsw = m.objective(S.states_from_path(np.array(out[mode][4]), np.array(out[mode][5])))
+        assert obj == out[mode][0]
 
 
 def test_many_switches_backtrack(oracle, ctx_factory):
