@@ -69,6 +69,56 @@ void phi_launch_anchor_triples(hipStream_t st, const int32_t *rec, int64_t n, co
                            rec_e1, out);
 }
 
+// ------------------------------------------------------------------------- minimiser -> anchors (CSR)
+// The certificate on the host walks the anchors of each minimiser; grouping 10^6-10^7 anchors by
+// minimiser id is a scatter the GPU does in microseconds: count per id, scan (phi_launch_scan_i32),
+// scatter through atomic cursors, then put every short list in ascending anchor order (deterministic).
+__global__ void __launch_bounds__(256) phi_csr_count_kernel(const int32_t *__restrict__ triples, int64_t n, int64_t n_ids,
+                                                            int32_t *__restrict__ cnt, uint32_t *__restrict__ err)
+{
+    GRID_STRIDE(i, n) {
+        const uint32_t id = (uint32_t)triples[3 * i];
+        if ((int64_t)id >= n_ids) { atomicOr(err, PHI_KERR_CSR_ID); continue; }
+        atomicAdd(&cnt[id], 1);
+    }
+}
+__global__ void __launch_bounds__(256) phi_csr_scatter_kernel(const int32_t *__restrict__ triples, int64_t n, int64_t n_ids,
+                                                              const int32_t *__restrict__ off, int32_t *__restrict__ cur,
+                                                              int32_t *__restrict__ idx)
+{
+    GRID_STRIDE(i, n) {
+        const uint32_t id = (uint32_t)triples[3 * i];
+        if ((int64_t)id >= n_ids) continue;
+        idx[off[id] + atomicAdd(&cur[id], 1)] = (int32_t)i;
+    }
+}
+__global__ void __launch_bounds__(256) phi_csr_sort_kernel(const int32_t *__restrict__ off, int64_t n_ids, int32_t *__restrict__ idx)
+{
+    GRID_STRIDE(s, n_ids) {
+        const int32_t lo = off[s], n = off[s + 1] - lo;
+        for (int32_t a = 1; a < n; a++) {             // insertion sort: lists hold a few entries (at most walks x repeats)
+            const int32_t v = idx[lo + a];
+            int32_t b = a - 1;
+            while (b >= 0 && idx[lo + b] > v) { idx[lo + b + 1] = idx[lo + b]; b--; }
+            idx[lo + b + 1] = v;
+        }
+    }
+}
+
+void phi_launch_csr_count(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, int32_t *cnt, uint32_t *err)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_csr_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, triples, n, n_ids, cnt, err);
+}
+void phi_launch_csr_scatter(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, const int32_t *off, int32_t *cur,
+                            int32_t *idx)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_csr_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, triples, n, n_ids, off, cur, idx);
+}
+void phi_launch_csr_sort(hipStream_t st, const int32_t *off, int64_t n_ids, int32_t *idx)
+{
+    if (n_ids > 0) hipLaunchKernelGGL(phi_csr_sort_kernel, dim3(grid_for(n_ids, 256)), dim3(256), 0, st, off, n_ids, idx);
+}
+
 // ------------------------------------------------------------------------- locate
 // rec_e0/rec_e1: walk entries owning the first / last base of each minimiser's k-mer.
 __global__ void __launch_bounds__(256) phi_locate_kernel(const int64_t *__restrict__ rec_pos, int64_t n_rec,

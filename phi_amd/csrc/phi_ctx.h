@@ -105,6 +105,7 @@ struct phi_ctx {
 
     // ---- scratch for sketch passes and compaction
     DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2, d_list3, d_walk_last, d_kept_rec;
+    DevBuf d_sa_cnt, d_sa_cur, d_sa_off, d_sa_idx;    // minimiser -> anchors CSR, built on the GPU
 
     // ---- solve state
     DevBuf d_m_rec, d_m_group, d_g_keys, d_g_rep, d_g_cnt, d_slot_maxcnt, d_slot_multi;

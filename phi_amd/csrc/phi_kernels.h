@@ -18,6 +18,7 @@ enum { PHI_MODE_COUNT = 0, PHI_MODE_WRITE = 1, PHI_MODE_PROBE = 2 };
 #define PHI_KERR_SENTINEL 1u    // a minimiser hashed to the empty-slot sentinel
 #define PHI_KERR_TABLE_FULL 2u  // probe bound exceeded
 #define PHI_KERR_WALK_EDGE 4u   // consecutive walk vertices not joined by a graph edge
+#define PHI_KERR_CSR_ID 32u      // a minimiser id outside the table (internal error)
 #define PHI_KERR_DP_QUEUE 16u    // event DP: more live young runs on a lane than its queue holds
 
 struct PhiSketchArgs {
@@ -106,6 +107,11 @@ void phi_launch_spectrum_export(hipStream_t st, const uint64_t *sp_keys, int64_t
 void phi_launch_entry_len(hipStream_t st, const int64_t *seq_off, const int32_t *walk_vtx, int64_t n_entries, int32_t *len);
 void phi_launch_anchor_triples(hipStream_t st, const int32_t *rec, int64_t n, const uint32_t *rec_slot, const uint32_t *u_uid,
                                const int32_t *rec_e0, const int32_t *rec_e1, int32_t *out);
+// CSR minimiser id -> anchor indices of a triple list (id, e0, e1): cnt / cur zeroed by the caller, off from a scan of cnt
+void phi_launch_csr_count(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, int32_t *cnt, uint32_t *err);
+void phi_launch_csr_scatter(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, const int32_t *off, int32_t *cur,
+                            int32_t *idx);
+void phi_launch_csr_sort(hipStream_t st, const int32_t *off, int64_t n_ids, int32_t *idx);
 void phi_launch_locate(hipStream_t st, const int64_t *rec_pos, int64_t n_rec, const int64_t *ebase,
                        int64_t n_entries, int32_t k, int32_t *rec_e0, int32_t *rec_e1);
 void phi_launch_lower_bound(hipStream_t st, const int64_t *a, int64_t n, const int64_t *keys, int64_t m,

@@ -400,7 +400,33 @@ int phi_solve_impl(phi_ctx *c)
     // dp anchors of every minimiser (CSR over the dense minimiser ids), ascending anchor index
     const int64_t n_ids = c->n_unique;
     std::vector<int32_t> sa_off(n_ids + 1, 0), sa_idx(std::max<int64_t>(n_dp, 1));
-    {
+    const bool dp_is_kept = c->h_dp.p == c->h_kept.p && c->h_dp.size() == c->h_kept.size();
+    if (dp_is_kept && n_dp > 0) {
+        // the dp list is the kept list, whose triples are still on the device: count / scan / scatter /
+        // sort there (1-2 ms for 10^7 anchors; the host loop below takes 4 ms per million)
+        const int32_t *tri = c->d_list2.as<int32_t>();
+        PHICHK(phi_dev_ensure(c, c->d_sa_cnt, (size_t)(n_ids + 1) * 4));
+        PHICHK(phi_dev_ensure(c, c->d_sa_cur, (size_t)(n_ids + 1) * 4));
+        PHICHK(phi_dev_ensure(c, c->d_sa_off, (size_t)(n_ids + 2) * 4));
+        PHICHK(phi_dev_ensure(c, c->d_sa_idx, (size_t)n_dp * 4));
+        const int64_t nb = phi_scan_i32_num_blocks(n_ids);
+        PHICHK(phi_dev_ensure(c, c->d_scan_blk, (size_t)nb * 4));
+        PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
+        HIPCHK(hipMemsetAsync(c->d_sa_cnt.p, 0, (size_t)(n_ids + 1) * 4, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_sa_cur.p, 0, (size_t)(n_ids + 1) * 4, c->stream));
+        phi_launch_csr_count(c->stream, tri, n_dp, n_ids, c->d_sa_cnt.as<int32_t>(), (uint32_t *)scalar(c, S_ERR));
+        phi_launch_scan_i32(c->stream, c->d_sa_cnt.as<int32_t>(), n_ids, c->d_sa_off.as<int32_t>(), c->d_scan_blk.as<int32_t>(),
+                            c->d_scan_blkoff.as<int64_t>());
+        phi_launch_csr_scatter(c->stream, tri, n_dp, n_ids, c->d_sa_off.as<int32_t>(), c->d_sa_cur.as<int32_t>(), c->d_sa_idx.as<int32_t>());
+        phi_launch_csr_sort(c->stream, c->d_sa_off.as<int32_t>(), n_ids, c->d_sa_idx.as<int32_t>());
+        HIPCHK(hipMemcpyAsync(sa_off.data(), c->d_sa_off.p, (size_t)(n_ids + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(sa_idx.data(), c->d_sa_idx.p, (size_t)n_dp * 4, hipMemcpyDeviceToHost, c->stream));
+        uint32_t kerr = 0;
+        HIPCHK(hipMemcpyAsync(&kerr, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((kerr & PHI_KERR_CSR_ID) || sa_off[n_ids] != (int32_t)n_dp)
+            return phi_fail(c, PHI_ERR_DEVICE, "minimiser id out of range (internal error)");
+    } else {
         // (tried on host threads with atomic counters and per-list sorts: 7.5 ms against 4.3 ms for this loop)
         for (const PhiAnchorHost &a : c->h_dp) {
             if ((int64_t)a.slot >= n_ids) return phi_fail(c, PHI_ERR_DEVICE, "minimiser id out of range (internal error)");
