@@ -674,53 +674,68 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
     int4 lastq = make_int4(NEG, NEG, 0, 0);          // tops of the latest TOPS step, forwarded in registers
     int32_t lastk = -1;
 
+    // recombination entry into the vertex of one step record (uniform): value, walk and source step
+    auto eval_entry = [&](const int4 xa, const int4 xb, int32_t k, int32_t &E, int32_t &Eh, int32_t &Esrc) {
+        E = NEG; Eh = -1; Esrc = -1;
+        const int32_t flags = xa.x;
+        const int n_in = (flags >> 8) & 0xFF;
+        auto consider = [&](const int4 q, int32_t oj, int32_t src) {
+            const int32_t t1h = (q.z & 0x3FF) - 1, t1n = ((q.z >> 10) & 0x3FF) - 1, t2h = ((q.z >> 20) & 0x3FF) - 1;
+            const bool cont = t1n == oj;
+            const int32_t val = cont ? q.y : q.x, hh = cont ? t2h : t1h;
+            if (hh < 0) return;
+            if (val > E || (val == E && (hh < Eh || (hh == Eh && src < Esrc)))) { E = val; Eh = hh; Esrc = src; }
+        };
+        const uint32_t b0 = (uint32_t)xa.z >> 8, b1 = (uint32_t)xa.w >> 8, b2 = (uint32_t)xb.x >> 8;
+        if (n_in == 1 && b0 < RING) {
+            const int32_t src = k - (int32_t)b0;
+            const int4 q = src == lastk ? lastq : s_top[src & (RING - 1)];
+            const int32_t t1h = (q.z & 0x3FF) - 1, t1n = ((q.z >> 10) & 0x3FF) - 1, t2h = ((q.z >> 20) & 0x3FF) - 1;
+            const bool cont = t1n == (xa.z & 0xFF);
+            const int32_t hh = cont ? t2h : t1h;
+            if (hh >= 0) { E = cont ? q.y : q.x; Eh = hh; Esrc = k - (int32_t)b0; }
+        } else if (n_in <= 3 && (b0 | b1 | b2) < RING) {
+            const int4 q0 = s_top[(k - b0) & (RING - 1)];
+            const int4 q1 = s_top[(k - b1) & (RING - 1)];
+            const int4 q2 = s_top[(k - b2) & (RING - 1)];
+            consider(q0, xa.z & 0xFF, k - (int32_t)b0);
+            if (n_in > 1) consider(q1, xa.w & 0xFF, k - (int32_t)b1);
+            if (n_in > 2) consider(q2, xb.x & 0xFF, k - (int32_t)b2);
+        } else {
+            for (int j = 0; j < n_in; j++) {
+                const int32_t pk = j == 0 ? xa.z : j == 1 ? xa.w : j == 2 ? xb.x : A.k_in_packed[xa.y + j - 3];
+                const int32_t back = (int32_t)((uint32_t)pk >> 8);
+                const int32_t src = k - back;
+                // tops older than the ring come from HBM: the producers wrote them at least RING - 2P steps ago
+                const int4 q = back < RING ? s_top[src & (RING - 1)] : reinterpret_cast<const int4 *>(A.tops)[src];
+                consider(q, pk & 0xFF, src);
+            }
+        }
+        if (Eh >= 0) E -= A.cost;
+        if (h == 0) s_ent[k & (2 * P - 1)] = make_int2(Esrc, Eh);
+    };
+
     for (int p = 0; p < n_per; p++) {
         const int32_t k_end = min(n_k, (p + 1) * P);
-        for (int32_t k = p * P; k < k_end; k++) {
-            // record of the next step (past the last step: a stale record, never used)
+        for (int32_t k = p * P; k < k_end;) {
+            // records of the next two steps (past the last step: stale records, never used)
             const int4 na = s_rec[(k + 1) & (2 * CHK - 1)][0], nb = s_rec[(k + 1) & (2 * CHK - 1)][1];
-            const int32_t flags = ra.x;
-            const bool active = (int32_t)cA.x == k;
+            const int4 n2a = s_rec[(k + 2) & (2 * CHK - 1)][0], n2b = s_rec[(k + 2) & (2 * CHK - 1)][1];
+            // two alleles of one site (PHI_DP_PAIR: neither leaves states, no walk visits both): one iteration
+            const bool pair = (ra.x & PHI_DP_PAIR) && k + 1 < k_end;
+            const int32_t stepk = (int32_t)cA.x;
+            const bool second = pair && stepk == k + 1;
+            const bool active = stepk == k || second;
+            const int32_t flags = second ? na.x : ra.x;
 
-            // ---- recombination entry into this vertex (uniform)
+            // ---- recombination entry into this vertex (uniform per step)
             int32_t E = NEG, Eh = -1, Esrc = -1;
-            if (flags & PHI_DP_NEED_ENTRY) {
-                const int n_in = (flags >> 8) & 0xFF;
-                auto consider = [&](const int4 q, int32_t oj, int32_t src) {
-                    const int32_t t1h = (q.z & 0x3FF) - 1, t1n = ((q.z >> 10) & 0x3FF) - 1, t2h = ((q.z >> 20) & 0x3FF) - 1;
-                    const bool cont = t1n == oj;
-                    const int32_t val = cont ? q.y : q.x, hh = cont ? t2h : t1h;
-                    if (hh < 0) return;
-                    if (val > E || (val == E && (hh < Eh || (hh == Eh && src < Esrc)))) { E = val; Eh = hh; Esrc = src; }
-                };
-                const uint32_t b0 = (uint32_t)ra.z >> 8, b1 = (uint32_t)ra.w >> 8, b2 = (uint32_t)rb.x >> 8;
-                if (n_in == 1 && b0 < RING) {
-                    const int32_t src = k - (int32_t)b0;
-                    const int4 q = src == lastk ? lastq : s_top[src & (RING - 1)];
-                    const int32_t t1h = (q.z & 0x3FF) - 1, t1n = ((q.z >> 10) & 0x3FF) - 1, t2h = ((q.z >> 20) & 0x3FF) - 1;
-                    const bool cont = t1n == (ra.z & 0xFF);
-                    const int32_t hh = cont ? t2h : t1h;
-                    if (hh >= 0) { E = cont ? q.y : q.x; Eh = hh; Esrc = k - (int32_t)b0; }
-                } else if (n_in <= 3 && (b0 | b1 | b2) < RING) {
-                    const int4 q0 = s_top[(k - b0) & (RING - 1)];
-                    const int4 q1 = s_top[(k - b1) & (RING - 1)];
-                    const int4 q2 = s_top[(k - b2) & (RING - 1)];
-                    consider(q0, ra.z & 0xFF, k - (int32_t)b0);
-                    if (n_in > 1) consider(q1, ra.w & 0xFF, k - (int32_t)b1);
-                    if (n_in > 2) consider(q2, rb.x & 0xFF, k - (int32_t)b2);
-                } else {
-                    for (int j = 0; j < n_in; j++) {
-                        const int32_t pk = j == 0 ? ra.z : j == 1 ? ra.w : j == 2 ? rb.x : A.k_in_packed[ra.y + j - 3];
-                        const int32_t back = (int32_t)((uint32_t)pk >> 8);
-                        const int32_t src = k - back;
-                        // tops older than the ring come from HBM: the producers wrote them at least RING - 2P steps ago
-                        const int4 q = back < RING ? s_top[src & (RING - 1)] : reinterpret_cast<const int4 *>(A.tops)[src];
-                        consider(q, pk & 0xFF, src);
-                    }
-                }
-                if (Eh >= 0) E -= A.cost;
-                if (h == 0) s_ent[k & (2 * P - 1)] = make_int2(Esrc, Eh);
-            }
+            if (ra.x & PHI_DP_NEED_ENTRY) eval_entry(ra, rb, k, E, Eh, Esrc);
+            if (pair && (na.x & PHI_DP_NEED_ENTRY)) {
+                int32_t E1, Eh1, Esrc1;
+                eval_entry(na, nb, k + 1, E1, Eh1, Esrc1);
+                if (second) { E = E1; Eh = Eh1; Esrc = Esrc1; }
+            } else if (second) { E = NEG; Eh = -1; }
 
             int32_t dmax = NEG;
             int32_t oidx = 255;
@@ -777,8 +792,8 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                 if (vi < ve) cA = s_ev[vi & (D - 1)][0][h];
             }
 
-            // ---- best states leaving this vertex (as in dp.hip)
-            if (flags & PHI_DP_NEED_TOPS) {
+            // ---- best states leaving this vertex (as in dp.hip); never for a pair
+            if (!pair && (ra.x & PHI_DP_NEED_TOPS)) {
                 const bool leaving = active && oidx != 255 && dmax > NEG / 2;
                 int32_t t1v = NEG, t1h = -1, t1n = -1, t2v = NEG, t2h = -1;
                 if (__ballot(leaving && oidx > 1) == 0ull) {
@@ -807,7 +822,8 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                 lastk = k;
                 if (h == 0) s_top[k & (RING - 1)] = lastq;
             }
-            ra = na; rb = nb;
+            if (pair) { ra = n2a; rb = n2b; k += 2; }
+            else { ra = na; rb = nb; k += 1; }
         }
         s_vi[h] = vi;
         __syncthreads();                             // B_{p+1}

@@ -652,6 +652,27 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             }
             r[5] = ro[5];
         }
+        // two alleles of one site: consecutive in topological order, no edge between them (so no walk
+        // visits both), neither leaves recombination states -> the consumer takes them in one iteration
+        int64_t n_pairs = 0;
+        for (int32_t k = 0; k + 1 < c->n_k; k++) {
+            int32_t *r0 = &k_rec[(size_t)k * 8], *r1 = r0 + 8;
+            if ((r0[0] | r1[0]) & PHI_DP_NEED_TOPS) continue;
+            const int32_t s0 = c->h_kstep[k], s1 = c->h_kstep[k + 1];
+            if (s1 != s0 + 1) continue;
+            const int32_t v0 = c->h_topo[s0], v1 = c->h_topo[s1];
+            bool edge = false;
+            for (int64_t a = c->h_adj_off[v0]; a < c->h_adj_off[v0 + 1] && !edge; a++) edge = c->h_adj[a] == v1;
+            if (edge) continue;
+            r0[0] |= PHI_DP_PAIR;
+            n_pairs++;
+            k++;                                           // pairs do not overlap
+        }
+        if (tm.on) {
+            int64_t n_tops = 0, n_entry = 0;
+            for (int32_t k = 0; k < c->n_k; k++) { n_tops += (k_rec[(size_t)k * 8] & PHI_DP_NEED_TOPS) != 0; n_entry += (k_rec[(size_t)k * 8] & PHI_DP_NEED_ENTRY) != 0; }
+            fprintf(stderr, "[phi timing] set_graph: %d compact steps: %lld with TOPS, %lld with ENTRY, %lld pairs\n", c->n_k, (long long)n_tops, (long long)n_entry, (long long)n_pairs);
+        }
         for (int32_t v = 0; v < n_vtx; v++) cvtx[v] = c->h_cstep[topo_rank[v]];
         tm.lap("  compact records");
         PHICHK(upload(c, c->d_k_rec, k_rec.data(), k_rec.size()));

@@ -173,6 +173,8 @@ void phi_launch_dp(hipStream_t st, const PhiDpArgs &A);
 #define PHI_DP_EVENT_MAX_WALKS 256
 #define PHI_DP_EVENT_SAFE_WALKS 128  // beyond: per-lane queues of 16 runs; a deeper one makes the caller fall back to dp.hip
 #define PHI_DP_LANE_ONLY 4      // compact-step flag: a walk starts or ends on the vertex (no ENTRY / TOPS work)
+#define PHI_DP_PAIR 8           // compact-step flag: this step and the next have no TOPS and no walk in common
+                                // (two alleles of one site): the consumer may take them in one iteration
 struct PhiDpEventArgs {
     int32_t n_k, n_walks;                // compact steps (vertices with ENTRY / TOPS / a walk start or end)
     int64_t n_ev;                        // events = walk entries on those vertices
