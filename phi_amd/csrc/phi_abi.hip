@@ -11,7 +11,8 @@
 #include "phi_dev.h"
 
 // scalar slots in d_scalars (8 bytes each)
-enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_BATCHBAD2 = 7, S_N = 8 };
+enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_BATCHBAD2 = 7,
+       S_SPDIRTY = 8 /* .. 10: three rotating flags, see sp_dirty in phi_ctx.h */, S_N = 11 };
 
 int phi_fail(phi_ctx *c, int code, const char *fmt, ...)
 {
@@ -80,6 +81,9 @@ int phi_flush_reset(phi_ctx *c)
     if (c->sp_cap == 0 && c->n_unique == 0) return PHI_OK;
     phi_launch_reset_reads(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_hit.as<uint64_t>(),
                            c->n_unique / 8 + 1, c->d_stripes.as<uint64_t>(), 2 * PHI_STRIPES * 8);
+    // a whole-set reset that starts generation sp_gen + 1: zero the flag of the generation after it
+    HIPCHK(hipMemsetAsync(scalar(c, S_SPDIRTY + (int)((c->sp_gen + 2) % 3)), 0, 8, c->stream));
+    c->sp_gen++; c->log_chunks = 0; c->sp_full = false;
     return phi_hip_check(c, hipGetLastError(), "reset launch");
 }
 
@@ -201,7 +205,7 @@ void phi_ctx_destroy(phi_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_rbad, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
@@ -712,6 +716,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     for (int32_t h = 0; h < n_walks; h++) c->h_n_minimizers[h] = c->h_walk_rec_off[h + 1] - c->h_walk_rec_off[h];
 
     c->sp_cap = 0; c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
+    c->log_chunks = 0; c->sp_full = true;
     c->have_graph = true;
     return PHI_OK;
 }
@@ -724,6 +729,7 @@ static int sp_ensure(phi_ctx *c, int64_t est)
     if (c->sp_cap == 0) {
         PHICHK(phi_dev_ensure(c, c->d_sp_keys, need * 8));
         c->sp_cap = need;
+        c->sp_full = true;
         phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)need, PHI_EMPTY_KEY);
         HIPCHK(hipMemsetAsync(sp_stripes(c), 0, STRIPE_BYTES, c->stream));
     } else if (need > c->sp_cap) {
@@ -741,6 +747,7 @@ static int sp_ensure(phi_ctx *c, int64_t est)
             dev_free(c->d_sp_keys);
             PHICHK(phi_dev_ensure(c, c->d_sp_keys, need * 8));
             c->sp_cap = need;
+            c->sp_full = true;                               // the re-inserted keys are in no log
             phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)need, PHI_EMPTY_KEY);
             HIPCHK(hipMemsetAsync(sp_stripes(c), 0, STRIPE_BYTES, c->stream));
             phi_launch_spectrum_insert(c->stream, c->d_export.as<uint64_t>(), (int64_t)cnt, c->d_sp_keys.as<uint64_t>(),
@@ -782,9 +789,25 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
         P.badbits = c->d_rbad.as<uint32_t>();
         P.batch_bad = batch_bad;
         P.batch_bad_next = (unsigned long long *)scalar(c, c->bad_parity ? S_BATCHBAD : S_BATCHBAD2);
+        if (c->reset_pending) {
+            // this launch ends generation sp_gen: it empties the logged slots unless something was not logged
+            P.full = c->sp_full || !c->d_splog.p;
+            P.sp_log = c->d_splog.as<uint32_t>(); P.sp_log_cnt = c->d_splog_cnt.as<uint8_t>(); P.log_chunks = c->log_chunks;
+            P.sp_dirty = (const uint32_t *)scalar(c, S_SPDIRTY + (int)(c->sp_gen % 3));
+            P.sp_dirty_zero = (uint32_t *)scalar(c, S_SPDIRTY + (int)((c->sp_gen + 2) % 3));
+        }
         phi_launch_prep_reads(c->stream, P, c->reset_pending);
+        if (c->reset_pending) { c->sp_gen++; c->log_chunks = 0; c->sp_full = false; }
         c->reset_pending = false;
         c->bad_parity ^= 1;
+    }
+    // this batch's part of the insert log (a buffer that has to grow loses what it held)
+    const int64_t n_log_chunks = phi_sketch_num_blocks(n_bases);
+    if ((size_t)(c->log_chunks + n_log_chunks) * PHI_SPLOG * 4 > c->d_splog.cap || (size_t)(c->log_chunks + n_log_chunks) > c->d_splog_cnt.cap) {
+        if (c->log_chunks > 0) c->sp_full = true;
+        HIPCHK(hipStreamSynchronize(c->stream));             // the preparation launch above may read the old buffers
+        PHICHK(phi_dev_ensure(c, c->d_splog, (size_t)(c->log_chunks + n_log_chunks) * 2 * PHI_SPLOG * 4));
+        PHICHK(phi_dev_ensure(c, c->d_splog_cnt, (size_t)(c->log_chunks + n_log_chunks) * 2));
     }
     PhiSketchArgs A{};
     A.badbits = c->d_rbad.as<unsigned long long>();      // windows touching such bases take the byte-wise path
@@ -800,6 +823,9 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     A.hit = c->d_hit.as<uint8_t>();
     A.err = (uint32_t *)scalar(c, S_ERR);
     A.batch_bad = batch_bad;                            // windows touching a base outside ACGT: byte-wise workgroups of the same launch
+    A.sp_log = c->d_splog.as<uint32_t>(); A.sp_log_cnt = c->d_splog_cnt.as<uint8_t>(); A.log_base = c->log_chunks;
+    A.sp_dirty = (uint32_t *)scalar(c, S_SPDIRTY + (int)(c->sp_gen % 3));
+    c->log_chunks += n_log_chunks;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (c->prof && c->prof_period > 0 && (c->prof_seq++ % c->prof_period) == 0) {
         if (c->prof_used == c->prof_events.size()) {
@@ -916,6 +942,7 @@ int phi_spectrum_import(phi_ctx *c, const void *d_hashes, int64_t n)
     if (d_hashes == c->d_export.p) return phi_fail(c, PHI_ERR_INVALID, "phi_spectrum_import: pass a copy, not the export buffer");
     PHICHK(phi_flush_reset(c));
     PHICHK(sp_ensure(c, n));
+    c->sp_full = true;                                       // imported keys are in no log
     phi_launch_spectrum_insert(c->stream, (const uint64_t *)d_hashes, n, c->d_sp_keys.as<uint64_t>(), c->sp_cap - 1,
                                sp_stripes(c), c->d_u_keys.as<uint64_t>(), c->u_cap - 1, c->d_u_uid.as<uint32_t>(),
                                c->d_hit.as<uint8_t>(), (uint32_t *)scalar(c, S_ERR));

@@ -102,6 +102,14 @@ struct phi_ctx {
     // device scalars: [0] err(u32 in low half) [1] n_bad [2] sp_count [3] n_emitted [4..] scratch
     DevBuf d_scalars;
     DevBuf d_stripes;                                 // [2][PHI_STRIPES][8] u64: distinct read hashes, emitted records
+    // Log of the spectrum slots filled since the last reset (PHI_SPLOG per chunk): the next reset empties
+    // those instead of the whole set.  A generation of reads (between two resets) raises "its" dirty flag
+    // -- scalar S_SPDIRTY + sp_gen % 3 -- when something filled a slot without logging it; the reset that
+    // ends generation g reads flag g % 3 and zeroes flag (g + 2) % 3 for the generation after the next.
+    DevBuf d_splog, d_splog_cnt;
+    int64_t log_chunks = 0;                           // chunks logged in this generation
+    int64_t sp_gen = 0;
+    bool sp_full = true;                              // the next reset must empty the whole set (import, regrow, log too small)
 
     // ---- scratch for sketch passes and compaction
     DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2, d_list3, d_walk_last, d_kept_rec;

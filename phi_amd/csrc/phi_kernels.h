@@ -8,6 +8,7 @@
 #define PHI_MAX_W 256
 #define PHI_MAX_K 32
 #define PHI_MAX_PROBE 4096     // linear-probe bound of the open-addressed tables
+#define PHI_SPLOG 32            // logged spectrum inserts per chunk of 512 windows (31 hashes are emitted per chunk of short reads)
 #define PHI_STRIPES 256          // counters are striped over 256 cache lines: one hot address
                                  // serialises at ~12 ns per atomic (MI355X_MICROARCH.md "fanin")
 #define PHI_RCAP 32            // DP run-length states 0..31 (an anchor spans <= k-1 <= 31 edges)
@@ -47,6 +48,10 @@ struct PhiSketchArgs {
     // launch carries byte-wise workgroups behind its fast_blocks 2-bit ones (set by the launcher)
     const unsigned long long *batch_bad;
     unsigned fast_blocks;
+    // PHI_MODE_PROBE: log of the spectrum slots this batch fills (PHI_SPLOG entries per chunk, chunk
+    // log_base + i of the reads since the last reset) so that the next reset empties those slots instead
+    // of the whole table; *sp_dirty is raised when a chunk fills more, or the byte-wise path inserts
+    uint32_t *sp_log; uint8_t *sp_log_cnt; int64_t log_base; uint32_t *sp_dirty;
 };
 
 // sketch.hip
@@ -58,6 +63,8 @@ void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_se
 struct PhiPrepArgs {
     uint64_t *sp_keys; int64_t sp_cap; uint64_t *hit_words; int64_t n_hit_words;      // reset part
     uint64_t *stripes; int64_t n_stripe_words;
+    // sparse reset: the logged slots of log_chunks chunks, unless *sp_dirty or full; *sp_dirty_zero is zeroed
+    const uint32_t *sp_log; const uint8_t *sp_log_cnt; int64_t log_chunks; const uint32_t *sp_dirty; uint32_t *sp_dirty_zero; int32_t full;
     const int64_t *seq_off; int64_t n_seq; unsigned long long *starts; int64_t n_sw;   // bitmap part
     const uint8_t *bases; int64_t n; uint64_t *words; int64_t n_words; uint32_t *badbits;   // pack part
     unsigned long long *batch_bad, *batch_bad_next;

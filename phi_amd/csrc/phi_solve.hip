@@ -26,7 +26,8 @@
 #define HIPCHK(call) do { int rc_ = phi_hip_check(c, (call), #call); if (rc_) return rc_; } while (0)
 #define PHICHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
-enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_BATCHBAD2 = 7, S_N = 8 };
+enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_BATCHBAD2 = 7,
+       S_SPDIRTY = 8 /* .. 10: three rotating flags, see sp_dirty in phi_ctx.h */, S_N = 11 };
 static uint64_t *scalar(phi_ctx *c, int i) { return c->d_scalars.as<uint64_t>() + i; }
 static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 

@@ -123,9 +123,17 @@ static __device__ __forceinline__ void start_bitmap_word(int64_t j, const int64_
 static __device__ __forceinline__ void reset_reads_part(int64_t t, int64_t stride, uint64_t *__restrict__ sp_keys,
                                                         int64_t sp_cap, uint64_t *__restrict__ hit_words,
                                                         int64_t n_hit_words, uint64_t *__restrict__ stripes,
-                                                        int64_t n_stripe_words)
+                                                        int64_t n_stripe_words, const uint32_t *__restrict__ sp_log = nullptr,
+                                                        const uint8_t *__restrict__ sp_log_cnt = nullptr, int64_t log_chunks = 0,
+                                                        bool sparse = false)
 {
-    for (int64_t i = t; i < sp_cap; i += stride) sp_keys[i] = PHI_EMPTY_KEY;
+    if (sparse) {
+        // the set holds what the logged chunks put there and nothing else: empty those slots only
+        for (int64_t i = t; i < log_chunks * PHI_SPLOG; i += stride)
+            if ((int)(i & (PHI_SPLOG - 1)) < (int)sp_log_cnt[i / PHI_SPLOG]) sp_keys[sp_log[i]] = PHI_EMPTY_KEY;
+    } else {
+        for (int64_t i = t; i < sp_cap; i += stride) sp_keys[i] = PHI_EMPTY_KEY;
+    }
     for (int64_t i = t; i < n_hit_words; i += stride) hit_words[i] = 0;
     for (int64_t i = t; i < n_stripe_words; i += stride) stripes[i] = 0;
 }
@@ -146,10 +154,14 @@ __global__ void __launch_bounds__(256) phi_reset_reads_kernel(uint64_t *__restri
 __global__ void __launch_bounds__(256) phi_prep_reads_kernel(PhiPrepArgs P)
 {
     unsigned b = blockIdx.x;
-    if (b == 0 && threadIdx.x == 0) *P.batch_bad_next = 0;
+    if (b == 0 && threadIdx.x == 0) {
+        *P.batch_bad_next = 0;
+        if (P.reset_blocks && P.sp_dirty_zero) *P.sp_dirty_zero = 0;     // the flag of the reads after the next reset
+    }
     if (b < P.reset_blocks) {
+        const bool sparse = !P.full && P.sp_log && *P.sp_dirty == 0;
         reset_reads_part((int64_t)b * 256 + threadIdx.x, (int64_t)P.reset_blocks * 256, P.sp_keys, P.sp_cap, P.hit_words,
-                         P.n_hit_words, P.stripes, P.n_stripe_words);
+                         P.n_hit_words, P.stripes, P.n_stripe_words, P.sp_log, P.sp_log_cnt, P.log_chunks, sparse);
         return;
     }
     b -= P.reset_blocks;
@@ -256,19 +268,20 @@ __device__ __forceinline__ MinEnt take_right(MinEnt a, MinEnt b) { return (b.v <
 // walk table is recorded by its hit flag alone; the spectrum set (ILP_index.cpp:622-635) keeps only
 // the hashes absent from the table, so |Sp_R| = set flags + set size and most reads of a sample
 // that resembles the graph never pay the atomic.
-__device__ __forceinline__ void probe_tables(const PhiSketchArgs &A, uint64_t h, int &n_new)
+// returns the spectrum slot it filled, or -1
+__device__ __forceinline__ int64_t probe_tables(const PhiSketchArgs &A, uint64_t h, int &n_new)
 {
-    if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return; }
+    if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return -1; }
     uint64_t su = h & A.u_mask;
     const ulonglong2 *kv = reinterpret_cast<const ulonglong2 *>(A.u_kv);
     const ulonglong2 e0 = kv[su];                      // key and dense id in one round trip
     // walk-minimiser table: lookup, mark the minimiser as hit
-    if (e0.x == h) { A.hit[(uint32_t)e0.y] = 1; return; }
+    if (e0.x == h) { A.hit[(uint32_t)e0.y] = 1; return -1; }
     if (e0.x != PHI_EMPTY_KEY) {
         for (int probes = 1; probes <= PHI_MAX_PROBE; probes++) {
             su = (su + 1) & A.u_mask;
             const ulonglong2 e = kv[su];
-            if (e.x == h) { A.hit[(uint32_t)e.y] = 1; return; }
+            if (e.x == h) { A.hit[(uint32_t)e.y] = 1; return -1; }
             if (e.x == PHI_EMPTY_KEY) break;
         }
     }
@@ -276,11 +289,12 @@ __device__ __forceinline__ void probe_tables(const PhiSketchArgs &A, uint64_t h,
     uint64_t ss = h & A.sp_mask;
     for (int probes = 0;; probes++) {
         const unsigned long long prev = atomicCAS((unsigned long long *)&A.sp_keys[ss], PHI_EMPTY_KEY, h);
-        if (prev == PHI_EMPTY_KEY) { n_new++; break; }
+        if (prev == PHI_EMPTY_KEY) { n_new++; return (int64_t)ss; }
         if (prev == h) break;
         if (probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
         ss = (ss + 1) & A.sp_mask;
     }
+    return -1;
 }
 
 // ---------------------------------------------------------------------------------- byte-wise routine
@@ -369,7 +383,7 @@ __device__ __forceinline__ void slow_windows(const PhiSketchArgs &A, int64_t c0,
                 A.out_hash[out_base + rank] = h;
                 A.out_pos[out_base + rank] = pos;
             } else if (MODE == PHI_MODE_PROBE) {
-                probe_tables(A, h, n_new);
+                if (probe_tables(A, h, n_new) >= 0 && A.sp_dirty) atomicOr(A.sp_dirty, 1u);   // not logged: the next reset empties the whole set
             }
         }
         n_emit += __popcll(bal);
@@ -530,7 +544,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     const bool chunk_bad = have_bad && __ballot(my_bad != 0) != 0ull;   // wave-uniform
     wave_sync();
 
-    int n_emit = 0, n_new = 0;
+    int n_emit = 0, n_new = 0, n_log = 0;
     int64_t out_base = 0;
     if (MODE == PHI_MODE_WRITE) out_base = A.block_off[chunk];
 
@@ -782,14 +796,24 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, 63);
             const bool emit = valid && t >= 1 && ((meta >> 31) || h != hp);
             const unsigned long long bal = __ballot(emit);
+            int64_t filled = -1;
             if (emit) {
                 const int rank = n_emit + __popcll(bal & ((1ull << lane) - 1));
                 if (MODE == PHI_MODE_WRITE) {
                     A.out_hash[out_base + rank] = h;
                     A.out_pos[out_base + rank] = c0 - 1 + (int64_t)((meta >> 10) & 0x3FFu);
                 } else if (MODE == PHI_MODE_PROBE) {
-                    probe_tables(A, h, n_new);
+                    filled = probe_tables(A, h, n_new);
                 }
+            }
+            if (MODE == PHI_MODE_PROBE && A.sp_log) {
+                // the slots this chunk fills, for the next reset
+                const unsigned long long ib = __ballot(filled >= 0);
+                if (filled >= 0) {
+                    const int pos = n_log + __popcll(ib & ((1ull << lane) - 1));
+                    if (pos < PHI_SPLOG) A.sp_log[(A.log_base + chunk) * PHI_SPLOG + pos] = (uint32_t)filled;
+                }
+                n_log += __popcll(ib);
             }
             n_emit += __popcll(bal);
         }
@@ -798,6 +822,10 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     if (MODE == PHI_MODE_COUNT) {
         if (lane == 0) A.block_cnt[chunk] = n_emit;
     } else if (MODE == PHI_MODE_PROBE) {
+        if (A.sp_log && lane == 0) {
+            A.sp_log_cnt[A.log_base + chunk] = (uint8_t)(n_log < PHI_SPLOG ? n_log : PHI_SPLOG);
+            if (n_log > PHI_SPLOG) atomicOr(A.sp_dirty, 1u);
+        }
         // one atomic per wave for the number of new spectrum entries and emitted records
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) n_new += __shfl_xor(n_new, d, 64);

@@ -538,6 +538,71 @@ def test_run_cap_reports_a_proven_bound(oracle, ctx_factory):
     assert res["n_dp_runs"] <= 256
 
 
+def test_resets_empty_only_what_was_filled(oracle, ctx_factory):
+    """A reset folded into the next preparation launch empties the logged spectrum slots instead of the
+    whole set -- unless a chunk filled more slots than its log holds, the byte-wise path inserted, a list
+    was imported or the set was rebuilt, in which case it empties everything.  Generation after
+    generation, through each of those cases, the set and the flags must be exactly the batch's."""
+    import torch
+    from phi_amd import dist as pdist
+    rng = np.random.default_rng(99)
+    k, w = 15, 6
+    g = random_graph(rng, n_sites=40, n_walks=6, seg_len=(20, 60), alt_len=(1, 8))
+    walk_h = np.concatenate([oracle.sketch(b"".join(g.node_seq[v] for v in path), k, w)[0] for path in g.paths])
+    _, first = np.unique(walk_h, return_index=True)
+    uniq = walk_h[np.sort(first)]
+
+    def rseq(n):
+        return bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+    gens = [
+        ("graph reads", mosaic_reads(rng, g, n_reads=80, read_len=90, n_seg=2)),
+        ("foreign reads: every hash is inserted, far more than a chunk logs", [rseq(3000) for _ in range(6)]),
+        ("graph reads again", mosaic_reads(rng, g, n_reads=60, read_len=90, n_seg=2)),
+        ("reads with bytes outside ACGT: the byte-wise path inserts", [rseq(200) + b"N" + rseq(300) + b"nn" + rseq(150) for _ in range(5)]),
+        ("graph reads once more", mosaic_reads(rng, g, n_reads=70, read_len=90, n_seg=3)),
+        ("two batches in one generation", None),
+        ("after an import", mosaic_reads(rng, g, n_reads=30, read_len=90, n_seg=2)),
+        ("last", mosaic_reads(rng, g, n_reads=50, read_len=90, n_seg=2)),
+    ]
+    ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=5)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    _set_graph(ctx, g)
+    for name, reads in gens:
+        ctx.reset_reads()
+        if reads is None:
+            a = mosaic_reads(rng, g, n_reads=40, read_len=90, n_seg=2) + [rseq(500)]
+            b = mosaic_reads(rng, g, n_reads=40, read_len=90, n_seg=2) + [rseq(700)]
+            for part in (a, b):
+                off = np.zeros(len(part) + 1, np.int64)
+                np.cumsum([len(r) for r in part], out=off[1:])
+                d_b = torch.from_numpy(np.frombuffer(b"".join(part), np.uint8).copy()).cuda()
+                d_o = torch.from_numpy(off).cuda()
+                ctx.add_reads_device(d_b.data_ptr(), d_o.data_ptr(), len(part), int(off[-1]))
+                torch.cuda.synchronize()
+            reads = a + b
+        else:
+            off = np.zeros(len(reads) + 1, np.int64)
+            np.cumsum([len(r) for r in reads], out=off[1:])
+            d_b = torch.from_numpy(np.frombuffer(b"".join(reads), np.uint8).copy()).cuda()
+            d_o = torch.from_numpy(off).cuda()
+            ctx.add_reads_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), int(off[-1]))
+            torch.cuda.synchronize()
+        read_h = np.unique(np.concatenate([oracle.sketch(r, k, w)[0] for r in reads]))
+        st = ctx.reads_stats()
+        assert st["n_distinct"] == len(read_h), name
+        p, n = ctx.hits_buffer()
+        hit = torch.as_tensor(pdist.DevArray(p, n), device="cuda").cpu().numpy()
+        assert np.array_equal(hit, np.isin(uniq, read_h).astype(np.uint8)), name
+        p, m = ctx.spectrum_export()
+        sp = torch.as_tensor(pdist.DevArray(p, m, "<i8"), device="cuda").clone()
+        assert np.array_equal(np.sort(sp.cpu().numpy().view(np.uint64)), read_h[~np.isin(read_h, uniq)]), name
+        if name == "two batches in one generation":
+            extra = torch.from_numpy(np.array([111, 222, 333], np.uint64).view(np.int64)).cuda()
+            ctx.spectrum_import(extra.data_ptr(), 3)
+            torch.cuda.synchronize()
+            assert ctx.reads_stats()["n_distinct"] == len(read_h) + 3
+
+
 def test_reset_is_deferred_but_never_visible(oracle, ctx_factory):
     """phi_reset_reads is folded into the next batch's preparation launch; every observer in between
     (stats, hit vector, spectrum export, solve) must still see the reads forgotten."""
