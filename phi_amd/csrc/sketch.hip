@@ -297,6 +297,14 @@ __device__ __forceinline__ int64_t probe_tables(const PhiSketchArgs &A, uint64_t
     return -1;
 }
 
+// "something filled a spectrum slot without logging it": a flag thousands of waves may want to raise at
+// once (long noisy reads fill more slots per chunk than a chunk logs) -- look first, then a plain store:
+// atomics on one address serialise at ~12 ns each
+__device__ __forceinline__ void raise_sp_dirty(uint32_t *flag)
+{
+    if (__builtin_nontemporal_load(flag) == 0u) __builtin_nontemporal_store(1u, flag);
+}
+
 // ---------------------------------------------------------------------------------- byte-wise routine
 // Exact restatement on ASCII for windows the 2-bit path cannot take (ILP_index.cpp:330-357, 388-414).
 
@@ -383,7 +391,7 @@ __device__ __forceinline__ void slow_windows(const PhiSketchArgs &A, int64_t c0,
                 A.out_hash[out_base + rank] = h;
                 A.out_pos[out_base + rank] = pos;
             } else if (MODE == PHI_MODE_PROBE) {
-                if (probe_tables(A, h, n_new) >= 0 && A.sp_dirty) atomicOr(A.sp_dirty, 1u);   // not logged: the next reset empties the whole set
+                if (probe_tables(A, h, n_new) >= 0 && A.sp_dirty) raise_sp_dirty(A.sp_dirty);   // not logged: the next reset empties the whole set
             }
         }
         n_emit += __popcll(bal);
@@ -824,7 +832,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     } else if (MODE == PHI_MODE_PROBE) {
         if (A.sp_log && lane == 0) {
             A.sp_log_cnt[A.log_base + chunk] = (uint8_t)(n_log < PHI_SPLOG ? n_log : PHI_SPLOG);
-            if (n_log > PHI_SPLOG) atomicOr(A.sp_dirty, 1u);
+            if (n_log > PHI_SPLOG) raise_sp_dirty(A.sp_dirty);
         }
         // one atomic per wave for the number of new spectrum entries and emitted records
 #pragma unroll
