@@ -825,6 +825,7 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     A.batch_bad = batch_bad;                            // windows touching a base outside ACGT: byte-wise workgroups of the same launch
     A.sp_log = c->d_splog.as<uint32_t>(); A.sp_log_cnt = c->d_splog_cnt.as<uint8_t>(); A.log_base = c->log_chunks;
     A.sp_dirty = (uint32_t *)scalar(c, S_SPDIRTY + (int)(c->sp_gen % 3));
+    if (c->sp_cap > 0xFFFFFFFFull) { A.sp_log = nullptr; c->sp_full = true; }   // the log holds 32-bit slots
     c->log_chunks += n_log_chunks;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (c->prof && c->prof_period > 0 && (c->prof_seq++ % c->prof_period) == 0) {

@@ -268,20 +268,21 @@ __device__ __forceinline__ MinEnt take_right(MinEnt a, MinEnt b) { return (b.v <
 // walk table is recorded by its hit flag alone; the spectrum set (ILP_index.cpp:622-635) keeps only
 // the hashes absent from the table, so |Sp_R| = set flags + set size and most reads of a sample
 // that resembles the graph never pay the atomic.
-// returns the spectrum slot it filled, or -1
-__device__ __forceinline__ int64_t probe_tables(const PhiSketchArgs &A, uint64_t h, int &n_new)
+// returns the spectrum slot it filled, or PHI_NO_SLOT (the set has fewer than 2^32 slots)
+#define PHI_NO_SLOT 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t probe_tables(const PhiSketchArgs &A, uint64_t h, int &n_new)
 {
-    if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return -1; }
+    if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return PHI_NO_SLOT; }
     uint64_t su = h & A.u_mask;
     const ulonglong2 *kv = reinterpret_cast<const ulonglong2 *>(A.u_kv);
     const ulonglong2 e0 = kv[su];                      // key and dense id in one round trip
     // walk-minimiser table: lookup, mark the minimiser as hit
-    if (e0.x == h) { A.hit[(uint32_t)e0.y] = 1; return -1; }
+    if (e0.x == h) { A.hit[(uint32_t)e0.y] = 1; return PHI_NO_SLOT; }
     if (e0.x != PHI_EMPTY_KEY) {
         for (int probes = 1; probes <= PHI_MAX_PROBE; probes++) {
             su = (su + 1) & A.u_mask;
             const ulonglong2 e = kv[su];
-            if (e.x == h) { A.hit[(uint32_t)e.y] = 1; return -1; }
+            if (e.x == h) { A.hit[(uint32_t)e.y] = 1; return PHI_NO_SLOT; }
             if (e.x == PHI_EMPTY_KEY) break;
         }
     }
@@ -289,12 +290,12 @@ __device__ __forceinline__ int64_t probe_tables(const PhiSketchArgs &A, uint64_t
     uint64_t ss = h & A.sp_mask;
     for (int probes = 0;; probes++) {
         const unsigned long long prev = atomicCAS((unsigned long long *)&A.sp_keys[ss], PHI_EMPTY_KEY, h);
-        if (prev == PHI_EMPTY_KEY) { n_new++; return (int64_t)ss; }
+        if (prev == PHI_EMPTY_KEY) { n_new++; return (uint32_t)ss; }
         if (prev == h) break;
         if (probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
         ss = (ss + 1) & A.sp_mask;
     }
-    return -1;
+    return PHI_NO_SLOT;
 }
 
 // "something filled a spectrum slot without logging it": a flag thousands of waves may want to raise at
@@ -391,7 +392,7 @@ __device__ __forceinline__ void slow_windows(const PhiSketchArgs &A, int64_t c0,
                 A.out_hash[out_base + rank] = h;
                 A.out_pos[out_base + rank] = pos;
             } else if (MODE == PHI_MODE_PROBE) {
-                if (probe_tables(A, h, n_new) >= 0 && A.sp_dirty) raise_sp_dirty(A.sp_dirty);   // not logged: the next reset empties the whole set
+                if (probe_tables(A, h, n_new) != PHI_NO_SLOT && A.sp_dirty) raise_sp_dirty(A.sp_dirty);   // not logged: the next reset empties the whole set
             }
         }
         n_emit += __popcll(bal);
@@ -804,7 +805,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, 63);
             const bool emit = valid && t >= 1 && ((meta >> 31) || h != hp);
             const unsigned long long bal = __ballot(emit);
-            int64_t filled = -1;
+            uint32_t filled = PHI_NO_SLOT;
             if (emit) {
                 const int rank = n_emit + __popcll(bal & ((1ull << lane) - 1));
                 if (MODE == PHI_MODE_WRITE) {
@@ -816,10 +817,10 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             }
             if (MODE == PHI_MODE_PROBE && A.sp_log) {
                 // the slots this chunk fills, for the next reset
-                const unsigned long long ib = __ballot(filled >= 0);
-                if (filled >= 0) {
+                const unsigned long long ib = __ballot(filled != PHI_NO_SLOT);
+                if (filled != PHI_NO_SLOT) {
                     const int pos = n_log + __popcll(ib & ((1ull << lane) - 1));
-                    if (pos < PHI_SPLOG) A.sp_log[(A.log_base + chunk) * PHI_SPLOG + pos] = (uint32_t)filled;
+                    if (pos < PHI_SPLOG) A.sp_log[(A.log_base + chunk) * PHI_SPLOG + pos] = filled;
                 }
                 n_log += __popcll(ib);
             }
