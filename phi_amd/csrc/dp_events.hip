@@ -325,6 +325,36 @@ __device__ __forceinline__ void ev_wave_max2_i32(int32_t a, int32_t b, int32_t &
     mb = max(max(__builtin_amdgcn_readlane(b, 0), __builtin_amdgcn_readlane(b, 16)), max(__builtin_amdgcn_readlane(b, 32), __builtin_amdgcn_readlane(b, 48)));
 }
 
+// (score, walk) of a leaving state as one key: larger score first, then the lower walk id.  Scores lie
+// above NEG = -2^28, so the key is below 2^38: a positive (denormal) double bit pattern, whose IEEE order
+// is the integer order -- v_max_f64 reduces it, and the winner's walk comes out of the key (no ballot,
+// no find-first, no branches).  0 = no leaving state.
+__device__ __forceinline__ unsigned long long ev_key(int32_t val, int lane)
+{
+    return ((unsigned long long)(uint32_t)(val - NEG) << 8) | (unsigned long long)(255 - lane);
+}
+__device__ __forceinline__ unsigned long long ev_max_u53(unsigned long long a, unsigned long long b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+    return (unsigned long long)__double_as_longlong(r);
+}
+#define EV_DPP64(x, ctrl, rm, bc)                                                                                             \
+    (((unsigned long long)(uint32_t)__builtin_amdgcn_update_dpp((int)((x) >> 32), (int)((x) >> 32), ctrl, rm, 0xF, bc) << 32) | \
+     (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(x), (int)(uint32_t)(x), ctrl, rm, 0xF, bc))
+// wave maxima of two keys, the two DPP chains interleaved; the result is uniform (read from lane 63)
+__device__ __forceinline__ void ev_wave_max2_key(unsigned long long a, unsigned long long b, unsigned long long &ma, unsigned long long &mb)
+{
+    a = ev_max_u53(a, EV_DPP64(a, 0x121, 0xF, false)); b = ev_max_u53(b, EV_DPP64(b, 0x121, 0xF, false));   // row_ror:1
+    a = ev_max_u53(a, EV_DPP64(a, 0x122, 0xF, false)); b = ev_max_u53(b, EV_DPP64(b, 0x122, 0xF, false));   // row_ror:2
+    a = ev_max_u53(a, EV_DPP64(a, 0x124, 0xF, false)); b = ev_max_u53(b, EV_DPP64(b, 0x124, 0xF, false));   // row_ror:4
+    a = ev_max_u53(a, EV_DPP64(a, 0x128, 0xF, false)); b = ev_max_u53(b, EV_DPP64(b, 0x128, 0xF, false));   // row_ror:8
+    a = ev_max_u53(a, EV_DPP64(a, 0x142, 0xA, false)); b = ev_max_u53(b, EV_DPP64(b, 0x142, 0xA, false));   // row_bcast:15 into rows 1, 3
+    a = ev_max_u53(a, EV_DPP64(a, 0x143, 0xC, false)); b = ev_max_u53(b, EV_DPP64(b, 0x143, 0xC, false));   // row_bcast:31 into rows 2, 3
+    ma = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(a >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, 63);
+    mb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63);
+}
+
 __device__ __forceinline__ int4 ev_pack_tops(int32_t t1v, int32_t t1h, int32_t t1n, int32_t t2v, int32_t t2h)
 {
     return make_int4(t1v, t2v, (t1h + 1) | ((t1n + 1) << 10) | ((t2h + 1) << 20), 0);
@@ -799,14 +829,16 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                 if (__ballot(leaving && oidx > 1) == 0ull) {
                     // at most two out-edges in use (a bubble): best walk per edge, two independent reductions
                     const bool on0 = leaving && oidx == 0, on1 = leaving && oidx == 1;
-                    int32_t m0, m1;
-                    ev_wave_max2_i32(on0 ? dmax : NEG, on1 ? dmax : NEG, m0, m1);
-                    const int l0 = m0 > NEG / 2 ? __ffsll((long long)__ballot(on0 && dmax == m0)) - 1 : -1;
-                    const int l1 = m1 > NEG / 2 ? __ffsll((long long)__ballot(on1 && dmax == m1)) - 1 : -1;
-                    // top1: larger value, then the lower walk id; top2: the best on the other edge
-                    const bool first0 = l0 >= 0 && (l1 < 0 || m0 > m1 || (m0 == m1 && l0 < l1));
-                    if (first0) { t1v = m0; t1h = l0; t1n = 0; if (l1 >= 0) { t2v = m1; t2h = l1; } }
-                    else if (l1 >= 0) { t1v = m1; t1h = l1; t1n = 1; if (l0 >= 0) { t2v = m0; t2h = l0; } }
+                    unsigned long long K0, K1;
+                    ev_wave_max2_key(on0 ? ev_key(dmax, h) : 0ull, on1 ? ev_key(dmax, h) : 0ull, K0, K1);
+                    // top1: larger value, then the lower walk id (= the larger key); top2: the best on the other edge
+                    const bool first0 = K0 >= K1;
+                    const unsigned long long Kf = first0 ? K0 : K1, Ks = first0 ? K1 : K0;
+                    t1v = Kf ? (int32_t)(uint32_t)(Kf >> 8) + NEG : NEG;
+                    t1h = Kf ? 255 - (int32_t)(Kf & 255) : -1;
+                    t1n = Kf ? (first0 ? 0 : 1) : -1;
+                    t2v = Ks ? (int32_t)(uint32_t)(Ks >> 8) + NEG : NEG;
+                    t2h = Ks ? 255 - (int32_t)(Ks & 255) : -1;
                 } else {
                     const int32_t m1 = ev_wave_max_i32(leaving ? dmax : NEG);
                     if (m1 > NEG / 2) {
