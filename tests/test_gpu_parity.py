@@ -560,7 +560,7 @@ def test_resets_empty_only_what_was_filled(oracle, ctx_factory):
         ("graph reads again", mosaic_reads(rng, g, n_reads=60, read_len=90, n_seg=2)),
         ("reads with bytes outside ACGT: the byte-wise path inserts", [rseq(200) + b"N" + rseq(300) + b"nn" + rseq(150) for _ in range(5)]),
         ("graph reads once more", mosaic_reads(rng, g, n_reads=70, read_len=90, n_seg=3)),
-        ("two batches in one generation", None),
+        ("three batches in one generation", None),
         ("after an import", mosaic_reads(rng, g, n_reads=30, read_len=90, n_seg=2)),
         ("last", mosaic_reads(rng, g, n_reads=50, read_len=90, n_seg=2)),
     ]
@@ -572,14 +572,15 @@ def test_resets_empty_only_what_was_filled(oracle, ctx_factory):
         if reads is None:
             a = mosaic_reads(rng, g, n_reads=40, read_len=90, n_seg=2) + [rseq(500)]
             b = mosaic_reads(rng, g, n_reads=40, read_len=90, n_seg=2) + [rseq(700)]
-            for part in (a, b):
+            big = mosaic_reads(rng, g, n_reads=600, read_len=90, n_seg=2)      # outgrows the log buffer mid-generation
+            for part in (a, b, big):
                 off = np.zeros(len(part) + 1, np.int64)
                 np.cumsum([len(r) for r in part], out=off[1:])
                 d_b = torch.from_numpy(np.frombuffer(b"".join(part), np.uint8).copy()).cuda()
                 d_o = torch.from_numpy(off).cuda()
                 ctx.add_reads_device(d_b.data_ptr(), d_o.data_ptr(), len(part), int(off[-1]))
                 torch.cuda.synchronize()
-            reads = a + b
+            reads = a + b + big
         else:
             off = np.zeros(len(reads) + 1, np.int64)
             np.cumsum([len(r) for r in reads], out=off[1:])
@@ -596,7 +597,7 @@ def test_resets_empty_only_what_was_filled(oracle, ctx_factory):
         p, m = ctx.spectrum_export()
         sp = torch.as_tensor(pdist.DevArray(p, m, "<i8"), device="cuda").clone()
         assert np.array_equal(np.sort(sp.cpu().numpy().view(np.uint64)), read_h[~np.isin(read_h, uniq)]), name
-        if name == "two batches in one generation":
+        if name == "three batches in one generation":
             extra = torch.from_numpy(np.array([111, 222, 333], np.uint64).view(np.int64)).cuda()
             ctx.spectrum_import(extra.data_ptr(), 3)
             torch.cuda.synchronize()
