@@ -69,6 +69,55 @@ void phi_launch_anchor_triples(hipStream_t st, const int32_t *rec, int64_t n, co
                            rec_e1, out);
 }
 
+// ------------------------------------------------------------------------- walk entries -> out-edges
+// For every walk entry: the index of the graph edge the walk leaves its vertex by (255 = the walk ends
+// here), the number of walks crossing every edge, and (st_mask != null) the walks present on every
+// vertex -- what ILP_index::read_gfa keeps in `paths` / `haps` (ILP_index.cpp:85-113).  err[0] = first
+// failure: 1 empty segment, 2 step without a graph edge, 3 more than 254 out-edges; err[1..3] = walk, u, v.
+__global__ void __launch_bounds__(256) phi_walk_edges_kernel(const int32_t *__restrict__ walk_vtx, const int64_t *__restrict__ walk_off,
+                                                             int32_t n_walks, int64_t n_entries, const int64_t *__restrict__ adj_off,
+                                                             const int32_t *__restrict__ adj, const int64_t *__restrict__ seq_off,
+                                                             const int32_t *__restrict__ topo_rank, uint8_t *__restrict__ e_out,
+                                                             int32_t *__restrict__ cnt_edge, unsigned long long *__restrict__ st_mask,
+                                                             int32_t nw64, int32_t *__restrict__ err)
+{
+    GRID_STRIDE(e, n_entries) {
+        int32_t lo = 0, hi = n_walks;                  // walk of entry e: walk_off[lo] <= e < walk_off[lo + 1]
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (walk_off[mid] <= e) lo = mid; else hi = mid;
+        }
+        const int32_t h = lo;
+        const int32_t u = walk_vtx[e];
+        auto fail = [&](int32_t code, int32_t v) {
+            if (atomicCAS(&err[0], 0, code) == 0) { err[1] = h; err[2] = u; err[3] = v; }
+        };
+        if (seq_off[u + 1] == seq_off[u]) { fail(1, -1); e_out[e] = 255; continue; }
+        if (st_mask) atomicOr(&st_mask[(size_t)topo_rank[u] * nw64 + (h >> 6)], 1ull << (h & 63));
+        if (e + 1 < walk_off[h + 1]) {
+            const int32_t v = walk_vtx[e + 1];
+            int64_t x = adj_off[u];
+            const int64_t xe = adj_off[u + 1];
+            while (x < xe && adj[x] != v) x++;
+            if (x == xe) { fail(2, v); e_out[e] = 255; continue; }
+            if (x - adj_off[u] >= 255) { fail(3, v); e_out[e] = 255; continue; }
+            e_out[e] = (uint8_t)(x - adj_off[u]);
+            atomicAdd(&cnt_edge[x], 1);
+        } else {
+            e_out[e] = 255;
+        }
+    }
+}
+
+void phi_launch_walk_edges(hipStream_t st, const int32_t *walk_vtx, const int64_t *walk_off, int32_t n_walks, int64_t n_entries,
+                           const int64_t *adj_off, const int32_t *adj, const int64_t *seq_off, const int32_t *topo_rank,
+                           uint8_t *e_out, int32_t *cnt_edge, unsigned long long *st_mask, int32_t nw64, int32_t *err)
+{
+    if (n_entries > 0)
+        hipLaunchKernelGGL(phi_walk_edges_kernel, dim3(grid_for(n_entries, 256)), dim3(256), 0, st, walk_vtx, walk_off, n_walks,
+                           n_entries, adj_off, adj, seq_off, topo_rank, e_out, cnt_edge, st_mask, nw64, err);
+}
+
 // ------------------------------------------------------------------------- minimiser -> anchors (CSR)
 // The certificate on the host walks the anchors of each minimiser; grouping 10^6-10^7 anchors by
 // minimiser id is a scatter the GPU does in microseconds: count per id, scan (phi_launch_scan_i32),

@@ -205,7 +205,7 @@ void phi_ctx_destroy(phi_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_rbad, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
@@ -316,12 +316,6 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     const int64_t n_edges = adj_off[n_vtx], n_entries = walk_off[n_walks];
     if (n_entries >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk entries");
     c->n_vtx = n_vtx; c->n_walks = n_walks; c->n_entries = n_entries;
-    c->h_seq.assign(seq_concat, seq_concat + seq_off[n_vtx]);
-    c->h_seq_off.assign(seq_off, seq_off + n_vtx + 1);
-    c->h_adj_off.assign(adj_off, adj_off + n_vtx + 1);
-    c->h_adj.assign(adj, adj + n_edges);
-    c->h_walk_off.assign(walk_off, walk_off + n_walks + 1);
-    c->h_topo_rank.assign(topo_rank, topo_rank + n_vtx);
 
     // topological order from the ranks; every edge must go forward (acyclic GFA, README.md:70-75)
     c->h_topo.assign(n_vtx, -1);
@@ -338,15 +332,6 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             if (topo_rank[u] >= topo_rank[v]) return phi_fail(c, PHI_ERR_INVALID, "edge %d->%d goes backwards in topo_rank: graph must be acyclic", u, v);
             indeg[v]++;
         }
-    // reverse adjacency
-    c->h_in_off.assign(n_vtx + 1, 0);
-    for (int32_t v = 0; v < n_vtx; v++) c->h_in_off[v + 1] = c->h_in_off[v] + indeg[v];
-    c->h_in_src.resize(n_edges);
-    {
-        std::vector<int64_t> cur(c->h_in_off.begin(), c->h_in_off.end() - 1);
-        for (int32_t u = 0; u < n_vtx; u++)
-            for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) c->h_in_src[cur[adj[x]]++] = u;
-    }
 
     // the kernels index with the walk entries: they must be in range before anything is launched
     {
@@ -368,13 +353,76 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     // ---- the GPU side of the index (uploads, entry offsets, walk sketch, minimiser table) runs on its
     //      own host thread while this one makes the pass over the walk entries below: neither needs
     //      the other's results
+    if (n_walks > PHI_DP_MAX_WALKS) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than %d walks", PHI_DP_MAX_WALKS);
+    c->dp_nw = phi_dp_num_waves(n_walks);
+    const int nw64 = c->dp_nw;
+    if (!c->h_walk_vtx.resize(n_entries)) return phi_fail(c, PHI_ERR_NOMEM, "host allocation failed");
+    // host copy of the walk entries for the solve (38 MB at C2, 4 ms of page faults): a few threads of
+    // their own, joined before this call returns
+    std::future<void> wv_copy = std::async(std::launch::async, [&]() {
+        int32_t *dst = c->h_walk_vtx.data();
+        const int nt = 4;
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([=]() {
+                const int64_t lo = n_entries * t / nt, hi = n_entries * (t + 1) / nt;
+                memcpy(dst + lo, walk_vtx + lo, (size_t)(hi - lo) * 4);
+            });
+        for (auto &x : th) x.join();
+    });
+    struct CopyJoiner { std::future<void> &f; ~CopyJoiner() { if (f.valid()) f.wait(); } } copy_joiner{wv_copy};
+    std::vector<int32_t> cnt_edge(std::max<int64_t>(n_edges, 1), 0), cont_total(n_vtx, 0);
+    // the every-vertex stream of dp.hip: beyond 256 walks, when asked for, and as the fallback of the
+    // four-wave event kernel (129-256 walks) whose per-lane queues are shallower than the worst case
+    const bool want_masks = !(n_walks <= PHI_DP_EVENT_SAFE_WALKS && !getenv("PHI_DP_DENSE"));
+    // the walk-entry pass (out-edge of every entry, walks per edge, walks per vertex) runs on the GPU as soon
+    // as the walks are uploaded; its edge counts come back through this promise, the rest stays on the device
+    std::promise<int> edges_promise;
+    std::future<int> edges_future = edges_promise.get_future();
+    int32_t walk_err[4] = {0, 0, 0, 0};
     auto gpu_part = [&]() -> int {
+        // whatever happens, the host thread waiting for the edge counts is released
+        struct PromiseGuard { std::promise<int> &p; bool done = false; ~PromiseGuard() { if (!done) p.set_value(PHI_ERR_DEVICE); } } pg{edges_promise};
         HIPCHK(hipSetDevice(c->device));
         PhiStageTimer tg("set_graph");
-        PHICHK(upload(c, c->d_seq, c->h_seq.data(), c->h_seq.size()));
-        PHICHK(upload(c, c->d_seq_off, c->h_seq_off.data(), c->h_seq_off.size()));
+        // (from the caller's arrays: the host copies are made by the main thread meanwhile)
+        PHICHK(upload(c, c->d_seq, seq_concat, (size_t)seq_off[n_vtx]));
+        PHICHK(upload(c, c->d_seq_off, seq_off, (size_t)n_vtx + 1));
         PHICHK(upload(c, c->d_walk_vtx, walk_vtx, (size_t)n_entries));       // the caller's array: the host pass is still copying it
-        PHICHK(upload(c, c->d_walk_off, c->h_walk_off.data(), c->h_walk_off.size()));
+        PHICHK(upload(c, c->d_walk_off, walk_off, (size_t)n_walks + 1));
+        {
+            // the walk-entry pass: walks follow edges of forward vertices (ILP_index.cpp:104-107 exits on reverse
+            // strand; an edge-less step would leave an anchor's edge variables unconstrained, :799-815)
+            int rc = PHI_OK;
+            auto pass = [&]() -> int {
+                PHICHK(upload(c, c->d_adj_off, adj_off, (size_t)n_vtx + 1));
+                if (n_edges == 0) PHICHK(phi_dev_ensure(c, c->d_adj, 4));
+                else PHICHK(upload(c, c->d_adj, adj, (size_t)n_edges));
+                PHICHK(upload(c, c->d_topo_rank, topo_rank, (size_t)n_vtx));
+                PHICHK(phi_dev_ensure(c, c->d_e_out, (size_t)n_entries));
+                PHICHK(phi_dev_ensure(c, c->d_cnt_edge, cnt_edge.size() * 4));
+                PHICHK(phi_dev_ensure(c, c->d_walk_err, 16));
+                HIPCHK(hipMemsetAsync(c->d_cnt_edge.p, 0, cnt_edge.size() * 4, c->stream));
+                HIPCHK(hipMemsetAsync(c->d_walk_err.p, 0, 16, c->stream));
+                if (want_masks) {
+                    PHICHK(phi_dev_ensure(c, c->d_st_mask, (size_t)n_vtx * nw64 * 8));
+                    HIPCHK(hipMemsetAsync(c->d_st_mask.p, 0, (size_t)n_vtx * nw64 * 8, c->stream));
+                }
+                phi_launch_walk_edges(c->stream, c->d_walk_vtx.as<int32_t>(), c->d_walk_off.as<int64_t>(), n_walks, n_entries,
+                                      c->d_adj_off.as<int64_t>(), c->d_adj.as<int32_t>(), c->d_seq_off.as<int64_t>(),
+                                      c->d_topo_rank.as<int32_t>(), c->d_e_out.as<uint8_t>(), c->d_cnt_edge.as<int32_t>(),
+                                      want_masks ? c->d_st_mask.as<unsigned long long>() : nullptr, nw64, c->d_walk_err.as<int32_t>());
+                HIPCHK(hipMemcpyAsync(cnt_edge.data(), c->d_cnt_edge.p, cnt_edge.size() * 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipMemcpyAsync(walk_err, c->d_walk_err.p, 16, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                return PHI_OK;
+            };
+            rc = pass();
+            edges_promise.set_value(rc);
+            pg.done = true;
+            if (rc) return rc;
+            if (tg.on) tg.lap("[gpu thread] uploads + walk-entry pass");
+        }
         // flat base offset of every walk entry: exclusive scan of the segment lengths, on the GPU
         PHICHK(phi_dev_ensure(c, c->d_ebase, (size_t)(n_entries + 1) * 8));
         PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)n_entries * 4));
@@ -386,9 +434,6 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             phi_launch_scan_i64(c->stream, c->d_list3.as<int32_t>(), n_entries, c->d_ebase.as<int64_t>(), c->d_scan_blk64.as<int64_t>(),
                                 c->d_scan_blkoff.as<int64_t>());
         }
-        PHICHK(upload(c, c->d_topo, c->h_topo.data(), c->h_topo.size()));
-        PHICHK(upload(c, c->d_in_off, c->h_in_off.data(), c->h_in_off.size()));
-        PHICHK(upload(c, c->d_in_src, c->h_in_src.data(), c->h_in_src.size()));
 
         if (tg.on) (void)hipStreamSynchronize(c->stream);
         tg.lap("[gpu thread] uploads + ebase scan");
@@ -513,64 +558,36 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     std::future<int> gpu_future = std::async(std::launch::async, gpu_part);
     // every early return below must first wait for that thread
     struct Joiner { std::future<int> &f; ~Joiner() { if (f.valid()) f.wait(); } } joiner{gpu_future};
+    // ---- host copies of the graph and its reverse adjacency, while the GPU thread uploads
+    c->h_seq.assign(seq_concat, seq_concat + seq_off[n_vtx]);
+    c->h_seq_off.assign(seq_off, seq_off + n_vtx + 1);
+    c->h_adj_off.assign(adj_off, adj_off + n_vtx + 1);
+    c->h_adj.assign(adj, adj + n_edges);
+    c->h_walk_off.assign(walk_off, walk_off + n_walks + 1);
+    c->h_topo_rank.assign(topo_rank, topo_rank + n_vtx);
+    // reverse adjacency
+    c->h_in_off.assign(n_vtx + 1, 0);
+    for (int32_t v = 0; v < n_vtx; v++) c->h_in_off[v + 1] = c->h_in_off[v] + indeg[v];
+    c->h_in_src.resize(n_edges);
+    {
+        std::vector<int64_t> cur(c->h_in_off.begin(), c->h_in_off.end() - 1);
+        for (int32_t u = 0; u < n_vtx; u++)
+            for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) c->h_in_src[cur[adj[x]]++] = u;
+    }
+    tm.lap("host copies, reverse adjacency");
     // ---- one parallel pass over the walk entries (host threads over fixed chunks of entries):
     //   * walks follow edges of forward vertices (ILP_index.cpp:104-107 exits on reverse strand; an
     //     edge-less step would make the anchor's edge variables unconstrained, :799-815)
     //   * out-edge index of every entry, walks per edge (DP step stream, dp.hip)
     //   * mask of walks on every topological step, bases of every walk, host copy of the entries
-    if (n_walks > PHI_DP_MAX_WALKS) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than %d walks", PHI_DP_MAX_WALKS);
-    c->dp_nw = phi_dp_num_waves(n_walks);
-    const int nw64 = c->dp_nw;
-    PhiRawBuf<uint8_t> e_out;                                  // every entry is written by the pass below
-    if (!c->h_walk_vtx.resize(n_entries) || !e_out.resize(n_entries)) return phi_fail(c, PHI_ERR_NOMEM, "host allocation failed");
-    std::vector<int32_t> cnt_edge(std::max<int64_t>(n_edges, 1), 0), cont_total(n_vtx, 0);
-    // the step masks serve the every-vertex kernel only (dp.hip, more than 128 walks)
-    // the every-vertex stream of dp.hip: beyond 256 walks, when asked for, and as the fallback of the
-    // four-wave event kernel (129-256 walks) whose per-lane queues are shallower than the worst case
-    const bool want_masks = !(n_walks <= PHI_DP_EVENT_SAFE_WALKS && !getenv("PHI_DP_DENSE"));
-    std::vector<unsigned long long> st_mask(want_masks ? (size_t)n_vtx * nw64 : 0, 0ull);
     {
-        PhiHostError herr;
-        int32_t *h_wv = c->h_walk_vtx.data();
-        // walks per edge: all walks cross the same edges at about the same time, so every host
-        // thread counts into its own array (shared counters bounce between the cores)
-        const int n_workers = phi_host_threads();
-        std::vector<std::vector<int32_t>> cnt_priv(n_workers);
-        phi_parallel_chunks(n_entries, (int64_t)1 << 16, [&](int64_t lo, int64_t hi, int worker) {
-            if (herr.failed()) return;
-            std::vector<int32_t> &cnt = cnt_priv[worker];
-            if (cnt.empty()) cnt.assign(std::max<int64_t>(n_edges, 1), 0);
-            int32_t h = (int32_t)(std::upper_bound(walk_off, walk_off + n_walks + 1, lo) - walk_off) - 1;
-            for (int64_t e = lo; e < hi; e++) {
-                while (e >= walk_off[h + 1]) h++;
-                const int32_t u = walk_vtx[e];
-                if (u < 0 || u >= n_vtx) { herr.set(PHI_ERR_WALK, "walk %d holds vertex %d out of range", h, u); return; }
-                const int64_t len = seq_off[u + 1] - seq_off[u];
-                if (len == 0) { herr.set(PHI_ERR_UNSUPPORTED, "walk %d passes through empty segment %d", h, u); return; }
-                h_wv[e] = u;
-                if (want_masks) __atomic_fetch_or(&st_mask[(size_t)topo_rank[u] * nw64 + (h >> 6)], 1ull << (h & 63), __ATOMIC_RELAXED);
-                if (e + 1 < walk_off[h + 1]) {
-                    const int32_t v = walk_vtx[e + 1];
-                    if (v < 0 || v >= n_vtx) { herr.set(PHI_ERR_WALK, "walk %d holds vertex %d out of range", h, v); return; }
-                    int64_t x = adj_off[u];
-                    const int64_t xe = adj_off[u + 1];
-                    while (x < xe && adj[x] != v) x++;
-                    if (x == xe) { herr.set(PHI_ERR_WALK, "walk %d steps %d->%d without a graph edge", h, u, v); return; }
-                    if (x - adj_off[u] >= 255) { herr.set(PHI_ERR_UNSUPPORTED, "vertex %d has more than 254 out-edges", u); return; }
-                    e_out[e] = (uint8_t)(x - adj_off[u]);
-                    cnt[x]++;
-                } else {
-                    e_out[e] = 255;                        // the walk ends here
-                }
-            }
-        });
-        if (herr.failed()) return phi_fail(c, herr.code, "%s", herr.msg.c_str());
-        phi_parallel_chunks(n_edges, (int64_t)1 << 14, [&](int64_t lo, int64_t hi, int) {
-            for (const std::vector<int32_t> &cnt : cnt_priv)
-                if (!cnt.empty()) for (int64_t x = lo; x < hi; x++) cnt_edge[x] += cnt[x];
-        });
+        const int erc = edges_future.get();
+        if (erc) return erc;
+        if (walk_err[0] == 1) return phi_fail(c, PHI_ERR_UNSUPPORTED, "walk %d passes through empty segment %d", walk_err[1], walk_err[2]);
+        if (walk_err[0] == 2) return phi_fail(c, PHI_ERR_WALK, "walk %d steps %d->%d without a graph edge", walk_err[1], walk_err[2], walk_err[3]);
+        if (walk_err[0] == 3) return phi_fail(c, PHI_ERR_UNSUPPORTED, "vertex %d has more than 254 out-edges", walk_err[2]);
     }
-    tm.lap("walk entries (threads)");
+    tm.lap("walk entries: pass on the GPU");
     bool start_interior = false, end_interior = false;
     for (int32_t h = 0; h < n_walks; h++) {
         if (indeg[walk_vtx[walk_off[h]]] > 0) start_interior = true;
@@ -692,11 +709,9 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     }
     tm.lap("wait for the GPU thread");
     // ---- device copies of what the host pass made
-    PHICHK(upload(c, c->d_e_out, e_out.data(), e_out.size()));
     c->dp_dense_ready = want_masks;
     if (want_masks) {                                          // the every-vertex stream serves dp.hip only
         PHICHK(upload(c, c->d_st_rec, st_rec.data(), st_rec.size()));
-        PHICHK(upload(c, c->d_st_mask, st_mask.data(), st_mask.size()));
         PHICHK(upload(c, c->d_in_packed, in_packed.data(), in_packed.size()));
     }
     // events of every walk: its entries on the compact steps

@@ -114,6 +114,10 @@ void phi_launch_spectrum_export(hipStream_t st, const uint64_t *sp_keys, int64_t
 void phi_launch_entry_len(hipStream_t st, const int64_t *seq_off, const int32_t *walk_vtx, int64_t n_entries, int32_t *len);
 void phi_launch_anchor_triples(hipStream_t st, const int32_t *rec, int64_t n, const uint32_t *rec_slot, const uint32_t *u_uid,
                                const int32_t *rec_e0, const int32_t *rec_e1, int32_t *out);
+// walk entries -> out-edge index per entry, walks per edge, walks per vertex (see anchors.hip)
+void phi_launch_walk_edges(hipStream_t st, const int32_t *walk_vtx, const int64_t *walk_off, int32_t n_walks, int64_t n_entries,
+                           const int64_t *adj_off, const int32_t *adj, const int64_t *seq_off, const int32_t *topo_rank,
+                           uint8_t *e_out, int32_t *cnt_edge, unsigned long long *st_mask, int32_t nw64, int32_t *err);
 // CSR minimiser id -> anchor indices of a triple list (id, e0, e1): cnt / cur zeroed by the caller, off from a scan of cnt
 void phi_launch_csr_count(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, int32_t *cnt, uint32_t *err);
 void phi_launch_csr_scatter(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, const int32_t *off, int32_t *cur,
