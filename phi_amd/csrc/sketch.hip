@@ -101,11 +101,35 @@ __global__ void phi_mark_starts_kernel(const int64_t *__restrict__ seq_off, int6
 
 // Same bitmap, one whole word per lane: no memset, no atomics.  Word j covers bases [64j, 64j+64).
 static __device__ __forceinline__ void start_bitmap_word(int64_t j, const int64_t *__restrict__ seq_off, int64_t n_seq,
-                                                         unsigned long long *__restrict__ starts, int64_t n_sw)
+                                                         unsigned long long *__restrict__ starts, int64_t n_sw, int64_t total = 0)
 {
     if (j >= n_sw) return;
     const int64_t lo_b = j * 64, hi_b = lo_b + 64;
-    int64_t lo = 0, hi = n_seq;                       // first sequence with seq_off >= lo_b
+    // first sequence with seq_off >= lo_b (n_seq if none).  Reads are of similar lengths, so the answer
+    // lies close to lo_b / mean length: gallop away from that guess, then bisect the bracket (3-4
+    // dependent loads instead of log2(n_seq))
+    int64_t lo = 0, hi = n_seq;
+    if (total > 0 && n_seq > 64) {
+        int64_t g = (int64_t)((double)lo_b / (double)total * (double)n_seq);
+        g = g < 0 ? 0 : (g > n_seq - 1 ? n_seq - 1 : g);
+        if (seq_off[g] >= lo_b) {                      // answer <= g
+            hi = g;
+            int64_t step = 1;
+            while (hi - step >= 0) {
+                if (seq_off[hi - step] < lo_b) { lo = hi - step + 1; break; }
+                hi -= step;
+                step <<= 1;
+            }
+        } else {                                       // answer > g
+            lo = g + 1;
+            int64_t step = 1;
+            while (lo + step < n_seq) {
+                if (seq_off[lo + step] >= lo_b) { hi = lo + step; break; }
+                lo += step + 1;
+                step <<= 1;
+            }
+        }
+    }
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
         if (seq_off[mid] < lo_b) lo = mid + 1; else hi = mid;
@@ -166,7 +190,7 @@ __global__ void __launch_bounds__(256) phi_prep_reads_kernel(PhiPrepArgs P)
     }
     b -= P.reset_blocks;
     if (b < P.bitmap_blocks) {
-        start_bitmap_word((int64_t)b * 256 + threadIdx.x, P.seq_off, P.n_seq, P.starts, P.n_sw);
+        start_bitmap_word((int64_t)b * 256 + threadIdx.x, P.seq_off, P.n_seq, P.starts, P.n_sw, P.n);
         return;
     }
     b -= P.bitmap_blocks;
