@@ -177,11 +177,7 @@ __global__ void __launch_bounds__(256) phi_locate_kernel(const int64_t *__restri
 {
     GRID_STRIDE(i, n_rec) {
         const int64_t g = rec_pos[i];
-        int64_t lo = 0, hi = n_entries;                 // ebase[lo] <= g < ebase[hi]
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (ebase[mid] <= g) lo = mid; else hi = mid;
-        }
+        const int64_t lo = phi_locate_in(ebase, n_entries, g);   // ebase[lo] <= g < ebase[lo + 1]
         int64_t e1 = lo;
         const int64_t last = g + k - 1;
         while (ebase[e1 + 1] <= last) e1++;

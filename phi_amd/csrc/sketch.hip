@@ -220,13 +220,7 @@ __global__ void __launch_bounds__(256) phi_pack_walks_kernel(const uint8_t *__re
     uint64_t word = 0;
     uint32_t bad = 0;
     if (b0 < total) {
-        // last entry e with ebase[e] <= b0
-        int64_t lo = 0, hi = n_entries;           // invariant: ebase[lo] <= b0 < ebase[hi]
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (ebase[mid] <= b0) lo = mid; else hi = mid;
-        }
-        int64_t e = lo;
+        int64_t e = phi_locate_in(ebase, n_entries, b0);   // last entry e with ebase[e] <= b0
         int64_t eend = ebase[e + 1];
         const uint8_t *src = seq_concat + seq_off[walk_vtx[e]] - ebase[e];
         for (int j = 0; j < 32; j++) {
