@@ -433,10 +433,15 @@ __host__ __device__ static inline int phi_wave_mp_u64(int w)
     const int P = (WCH + w + 63) / 64;
     return ((64 * P + 8) * 9) / 8 + 8;
 }
-__host__ __device__ static inline int phi_wave_region_u64(int w)
+// items of one chunk: the window before its first candidate, its candidates, and one more per stretch of
+// windows the 2-bit path leaves to the byte-wise one (a stretch is longer than a window's span: the first
+// window after it carries its own predecessor, see phase 3); + 4 trash slots
+__host__ __device__ static inline int phi_wave_items(int w, int k) { return 1 + WCH + WCH / (w + k + 1) + 2; }
+__host__ __device__ static inline int phi_wave_region_u64(int w, int k)
 {
-    return phi_wave_mp_u64(w) + SWW + 2 * SBW + WCH / 2 + 8;
+    return phi_wave_mp_u64(w) + SWW + 2 * SBW + (phi_wave_items(w, k) + 4 + 1) / 2;
 }
+#define PHI_ITEM_NOEMIT 0x40000000u   // item flag: only its hash is needed (the window before a candidate)
 
 // minimum of two k-mer values below 2^62 (k <= 31) in one instruction: bit patterns with the two top
 // bits clear are non-negative finite doubles (never NaN or infinity), and IEEE order of non-negative
@@ -543,7 +548,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     const int span = w + k - 1;                           // bases under one window
     const bool have_bad = A.badbits != nullptr;
 
-    uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w);   // k-mers; later the window minima
+    uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w, k);   // k-mers; later the window minima
     uint64_t *s_words = s_mp + phi_wave_mp_u64(w);
     unsigned long long *s_bits = (unsigned long long *)(s_words + SWW);
     unsigned long long *s_bad = s_bits + SBW;
@@ -692,7 +697,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 
     // ---- phase 3: candidate windows of this lane: outputs i = 1..Q, window start a = c0-1+lane*Q+i
     //      (local bit of base a = la + 63 with la = lane*Q + i)
-    uint32_t cflag = 0, fflag = 0;
+    uint32_t cflag = 0, fflag = 0, pflag = 0;             // candidates; first windows; candidates that carry their predecessor
     {
         const int64_t a0 = c0 - 1 + (int64_t)lane * Q;
         const int lp0 = lane * Q + 63;                    // local bit of base a0
@@ -752,8 +757,17 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             for (int i = 1; i <= Q; i++) changed |= (uint32_t)(wv[i] != wv[i - 1]) << i;
             const uint32_t first = ((uint32_t)sb & ((1u << Q) - 1)) << 1;           // bit i <-> sb bit i-1
             const uint32_t in_batch = imax >= 1 ? ((2u << imax) - 2u) : 0u;        // bits 1 .. imax
-            cflag = in_batch & ~(uint32_t)blocked & ~(uint32_t)dirty & (first | changed) & ((2u << Q) - 2u);
+            // the first window after a stretch left to the byte-wise path: the candidate before it is not its
+            // predecessor window, so it becomes a candidate that carries its own predecessor (whose value
+            // is valid: a window that is not dirty has no such base under its predecessor either)
+            uint32_t reseed = 0;
+            if (chunk_bad) {
+                const uint32_t dall = (uint32_t)dirty | (uint32_t)range_has_bit(s_bad, lp0 - 1, lp0 + span - 1);   // bit 0: window 0
+                reseed = ~dall & (dall << 1);
+            }
+            cflag = in_batch & ~(uint32_t)blocked & ~(uint32_t)dirty & (first | changed | reseed) & ((2u << Q) - 2u);
             fflag = cflag & first;
+            pflag = cflag & reseed & ~first;
         } else {
             const int lim = lp0 + Q + span + 1;
             int ns = next_start_lds(s_bits, lp0 + 2, lim);
@@ -765,9 +779,11 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
                 if (valid && chunk_bad) valid = !range_has_bit(s_bad, lp - 1, lp + span - 1);
                 if (valid) {
                     const bool first = (s_bits[lp >> 6] >> (lp & 63)) & 1ull;
-                    if (first || wv[i] != wv[i - 1]) {
+                    const bool reseed = chunk_bad && !first && range_has_bit(s_bad, lp - 2, lp + span - 2);   // the window before is byte-wise
+                    if (first || reseed || wv[i] != wv[i - 1]) {
                         cflag |= 1u << i;
                         if (first) fflag |= 1u << i;
+                        if (reseed) pflag |= 1u << i;
                     }
                 }
             }
@@ -776,7 +792,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     // wave prefix sum of the per-lane candidate counts
     int ncand, coff;
     {
-        const int cnt = __popc(cflag);
+        const int cnt = __popc(cflag) + __popc(pflag);
         const int v = wave_scan_inclusive(cnt);
         ncand = __builtin_amdgcn_readlane(v, 63);
         coff = v - cnt;
@@ -792,14 +808,25 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
         // item 1 + c = candidate c.  Every lane stores all Q windows, the non-candidates into trash
         // slots past the last item: no divergent branch per window
         int c = coff + 1;
-        const int trash = WCH + 1 + (lane & 7);
+        const int trash = phi_wave_items(w, k) + (lane & 3);
+        if (!chunk_bad) {
 #pragma unroll
-        for (int i = 1; i <= Q; i++) {
-            const bool on = (cflag >> i) & 1u;
-            s_meta[on ? c : trash] = (uint32_t)(lane * Q + i) | ((uint32_t)wp[i] << 10) | ((fflag >> i) & 1u) << 31;
-            c += on;
+            for (int i = 1; i <= Q; i++) {
+                const bool on = (cflag >> i) & 1u;
+                s_meta[on ? c : trash] = (uint32_t)(lane * Q + i) | ((uint32_t)wp[i] << 10) | ((fflag >> i) & 1u) << 31;
+                c += on;
+            }
+        } else {
+            // (rare) a candidate after a byte-wise stretch is preceded by the window before it
+#pragma unroll
+            for (int i = 1; i <= Q; i++) {
+                if ((cflag >> i) & 1u) {
+                    if ((pflag >> i) & 1u) s_meta[c++] = (uint32_t)(lane * Q + i - 1) | PHI_ITEM_NOEMIT;
+                    s_meta[c++] = (uint32_t)(lane * Q + i) | ((uint32_t)wp[i] << 10) | ((fflag >> i) & 1u) << 31;
+                }
+            }
         }
-        if (coff == 0 && cflag) s_meta[0] = (uint32_t)(lane * Q + __ffs((int)cflag) - 2);
+        if (coff == 0 && cflag) s_meta[0] = (uint32_t)(lane * Q + __ffs((int)cflag) - 2) | PHI_ITEM_NOEMIT;
     }
     wave_sync();
 #undef SQ
@@ -821,7 +848,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             const uint64_t hp = wave_prev_u64(h, carry, lane);
             carry = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), 63) << 32) |
                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, 63);
-            const bool emit = valid && t >= 1 && ((meta >> 31) || h != hp);
+            const bool emit = valid && !(meta & PHI_ITEM_NOEMIT) && ((meta >> 31) || h != hp);
             const unsigned long long bal = __ballot(emit);
             uint32_t filled = PHI_NO_SLOT;
             if (emit) {
@@ -1000,7 +1027,7 @@ void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A0, hipEve
         A.fast_blocks = nb;
         nb += nb < 1024 ? nb : 1024;
     }
-    const size_t lds = (size_t)phi_wave_region_u64(A.w) * 8 * (TPB / 64);
+    const size_t lds = (size_t)phi_wave_region_u64(A.w, A.k) * 8 * (TPB / 64);
     if (mode == PHI_MODE_COUNT) launch_sketch_mode<PHI_MODE_COUNT>(st, nb, lds, A, t0, t1);
     else if (mode == PHI_MODE_WRITE) launch_sketch_mode<PHI_MODE_WRITE>(st, nb, lds, A, t0, t1);
     else launch_sketch_mode<PHI_MODE_PROBE>(st, nb, lds, A, t0, t1);

@@ -749,6 +749,43 @@ def test_synthetic_vs_highs_golden(oracle, ctx_factory):
         assert res["objective"] == case["objective"], (case, res["objective"], res["n_dp_runs"])
 
 
+def _probe_counts(ctx, reads):
+    import torch
+    ctx.reset_reads()
+    off = np.zeros(len(reads) + 1, np.int64)
+    np.cumsum([len(r) for r in reads], out=off[1:])
+    d_b = torch.from_numpy(np.frombuffer(b"".join(reads), np.uint8).copy()).cuda()
+    d_o = torch.from_numpy(off).cuda()
+    ctx.add_reads_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), int(off[-1]))
+    torch.cuda.synchronize()
+    return ctx.reads_stats()
+
+
+@pytest.mark.parametrize("k,w", [(2, 1), (5, 6), (4, 3), (3, 25), (31, 25), (7, 30), (21, 60)])
+def test_probe_minimiser_returns_to_its_value_across_a_base_outside_acgt(oracle, ctx_factory, k, w):
+    """Windows around a base outside ACGT go to the byte-wise path; the first 2-bit window after such a
+    stretch must be compared with ITS predecessor window, not with the last 2-bit candidate before the
+    stretch (`TTnTAa`, k=2, w=1: the last window's minimiser equals the first's, yet it is emitted)."""
+    import torch
+    rng = np.random.default_rng(100 * k + w)
+    g = random_graph(rng, n_sites=5, n_walks=3, seg_len=(5, 40), alt_len=(1, 8))
+    ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=5)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    _set_graph(ctx, g)
+    fixed = [b"TTnTAa", b"tAGcGGCGaCngCccGaaCacGggnCACCcncTCCnNGtNngacGgNGccNNaatgCCGCTga", b"ttaGaANcNTGgtTctG"]
+    for r in fixed:
+        if len(r) >= k + w - 1:
+            assert _probe_counts(ctx, [r])["n_emitted"] == len(oracle.sketch(r, k, w)[0]), r
+    # low-entropy sequences make a minimiser come back to an earlier value often
+    for trial in range(60):
+        alpha = [b"ACGTN", b"AACCGTn", b"ATN", b"ACGTNacgtn"][trial % 4]
+        reads = [bytes(rng.choice(list(alpha), size=int(rng.integers(k + w - 1, 700))).tolist()) for _ in range(int(rng.integers(1, 6)))]
+        per = [oracle.sketch(r, k, w)[0] for r in reads]
+        st = _probe_counts(ctx, reads)
+        assert st["n_emitted"] == sum(len(x) for x in per), (trial, reads)
+        assert st["n_distinct"] == len(np.unique(np.concatenate(per))), (trial, reads)
+
+
 def test_probe_low_complexity_at_default_k_w(oracle, ctx_factory):
     """The (31, 25) instance takes window minima with v_min_f64 on the k-mer values' bit patterns: k-mers
     that start with runs of A (top bits clear: zero and denormal doubles), poly-T (reverse complement 0),
