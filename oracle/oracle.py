@@ -311,6 +311,22 @@ def ref_parse_gfa(path) -> Graph:
     return G
 
 
+def ref_read_reads(path):
+    """(name, sequence) of every record as the reference's own kseq.h reads them (oracle/_ref)."""
+    R = ref()
+    sz = max(os.path.getsize(path) * 12 + 4096, 1 << 16)            # gzip expands
+    names = C.create_string_buffer(sz)
+    seqs = C.create_string_buffer(sz)
+    off = (C.c_int64 * (sz // 2 + 2))()
+    R.ref_read_reads.restype = C.c_int64
+    R.ref_read_reads.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(C.c_int64), C.c_int64]
+    n = R.ref_read_reads(os.fsencode(path), names, sz, seqs, sz, off, sz // 2 + 2)
+    if n < 0:
+        raise RuntimeError(f"reference kseq reader failed ({n})")
+    nm = names.raw.split(b"\0", n)[:n]
+    return [(nm[i], seqs.raw[off[i]:off[i + 1]]) for i in range(n)]
+
+
 def ref_hap_name(gfa_path: str, reads_path: str) -> str:
     buf = C.create_string_buffer(4096)
     n = ref().ref_get_hap_name(gfa_path.encode(), reads_path.encode(), buf, 4096)
@@ -337,30 +353,81 @@ def hap_name(gfa_path: str, reads_path: str) -> str:
 # ---------------------------------------------------------------------------- reads
 
 def read_reads(path):
-    """kseq-style FASTA/FASTQ reader: list of (name, sequence) (ILP_index.cpp:313-328)."""
-    out = []
+    """The reference's FASTA/FASTQ reading (ILP_index.cpp:313-328 over kseq.h:192-233) restated, malformed input
+    included: list of (name, sequence).  The next header is the next '>' or '@' byte wherever it stands; the name
+    ends at the first white space; sequence lines are kept as they are (a trailing CR goes when the string is
+    longer than one byte, kseq.h:146) and end at a line that starts with '>', '@' or '+'; empty lines are skipped;
+    after '+', whole lines are read as quality until they cover the sequence; a quality string of another length,
+    or none, ends the reading (kseq_read returns -2 and the caller's loop stops)."""
     with _open_text(path) as f:
-        lines = (raw.rstrip(b"\r\n") for raw in f)
-        line = next(lines, None)
-        while line is not None:
-            if line[:1] not in (b">", b"@"):            # hunt for the next header
-                line = next(lines, None)
+        data = f.read()
+    n = len(data)
+    pos = 0
+    out = []
+    last_char = 0
+
+    def line_into(buf: bytearray):
+        nonlocal pos
+        if pos >= n:
+            return -1
+        nl = data.find(b"\n", pos)
+        end = nl if nl >= 0 else n
+        buf += data[pos:end]
+        pos = end + 1 if nl >= 0 else n
+        if len(buf) > 1 and buf[-1] == 13:
+            del buf[-1]
+        return len(buf)
+
+    while True:
+        if last_char == 0:
+            while pos < n and data[pos] not in (62, 64):        # '>' '@'
+                pos += 1
+            if pos >= n:
+                break
+            last_char = data[pos]
+            pos += 1
+        # name: up to the first white space
+        if pos >= n:
+            break
+        i = pos
+        while i < n and data[i] not in b" \t\n\v\f\r":
+            i += 1
+        name = data[pos:i]
+        delim = data[i] if i < n else 0
+        pos = i + 1 if i < n else n
+        if delim != 10:
+            line_into(bytearray())                              # the comment
+        seq = bytearray()
+        c = -1
+        while True:
+            if pos >= n:
+                c = -1
+                break
+            c = data[pos]
+            pos += 1
+            if c in (62, 43, 64):                               # '>' '+' '@'
+                break
+            if c == 10:
                 continue
-            tok = line[1:].split()
-            name = tok[0] if tok else b""
-            seq = []
-            line = next(lines, None)
-            while line is not None and line[:1] not in (b">", b"@", b"+"):
-                seq.append(b"".join(line.split()))      # kseq keeps graphical characters only
-                line = next(lines, None)
-            s = b"".join(seq)
-            out.append((name, s))
-            if line is not None and line[:1] == b"+":   # FASTQ: skip as many quality bytes as bases
-                qlen = 0
-                line = next(lines, None)
-                while line is not None and qlen < len(s):
-                    qlen += len(line)
-                    line = next(lines, None)
+            seq.append(c)
+            line_into(seq)
+        if c in (62, 64):
+            last_char = c
+        if c != 43:
+            out.append((name, bytes(seq)))                       # FASTA (at the end of the file: the next turn stops)
+            continue
+        # FASTQ: the rest of the '+' line, then whole quality lines
+        nl = data.find(b"\n", pos)
+        if nl < 0:
+            break                                               # -2: no quality string
+        pos = nl + 1
+        qual = bytearray()
+        while line_into(qual) >= 0 and len(qual) < len(seq):
+            pass
+        last_char = 0
+        if len(qual) != len(seq):
+            break                                               # -2: quality of another length
+        out.append((name, bytes(seq)))
     return out
 
 

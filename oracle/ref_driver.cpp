@@ -13,6 +13,10 @@
 #include "gfa.h"            // /root/reference/src/gfa.h
 #include "MurmurHash3.h"    // /root/reference/src/MurmurHash3.h
 #include "PHIpriv.h"        // /root/reference/src/PHIpriv.h: declares get_hap_name (misc.cpp:58)
+#include <zlib.h>
+#include <vector>
+#include "kseq.h"           // /root/reference/src/kseq.h, instantiated exactly as ILP_index.cpp:8 does
+KSEQ_INIT(gzFile, gzread)
 
 extern "C" {
 
@@ -55,4 +59,27 @@ int ref_get_hap_name(const char *gfa_name, const char *reads_name, char *out, in
     return (int)name.size();
 }
 
+
+// ILP_index::read_ip_reads (ILP_index.cpp:313-328) on the reference's own kseq: every record's name and
+// sequence, NUL-separated, into caller buffers; returns the number of records (-1: cannot open, -2: too small)
+int64_t ref_read_reads(const char *fn, char *names, int64_t names_cap, char *seqs, int64_t seqs_cap, int64_t *seq_off, int64_t off_cap)
+{
+    gzFile fp = gzopen(fn, "r");
+    if (!fp) return -1;
+    kseq_t *seq = kseq_init(fp);
+    int64_t n = 0, nn = 0, ns = 0;
+    int l;
+    seq_off[0] = 0;
+    while ((l = kseq_read(seq)) >= 0) {
+        const int64_t ln = (int64_t)seq->name.l, ls = (int64_t)seq->seq.l;
+        if (nn + ln + 1 > names_cap || ns + ls > seqs_cap || n + 1 >= off_cap) { n = -2; break; }
+        memcpy(names + nn, seq->name.s, (size_t)ln); names[nn + ln] = 0; nn += ln + 1;
+        if (ls) memcpy(seqs + ns, seq->seq.s, (size_t)ls);
+        ns += ls;
+        seq_off[++n] = ns;
+    }
+    kseq_destroy(seq);
+    gzclose(fp);
+    return n;
+}
 }

@@ -1,8 +1,9 @@
 // reads_reader.cpp -- FASTA/FASTQ (plain or gzip) -> concatenated bases + offsets, the arguments
-// of phi_add_reads.  Own implementation of the record rules of kseq as the reference uses it
-// (src/ILP_index.cpp:313-328, src/kseq.h:192-233): a record starts at a line beginning with '>'
-// or '@', its name is the first word, sequence lines run until a line starting with '>', '@' or
-// '+'; after '+' as many quality characters as bases are skipped.  Also: output naming
+// of phi_add_reads.  Own implementation of kseq as the reference uses it (src/ILP_index.cpp:313-328,
+// src/kseq.h:192-233), down to its behaviour on malformed input: the next header is the next '>' or
+// '@' character wherever it stands, sequence lines are taken as they are and end at a line starting
+// with '>', '@' or '+', whole quality lines are read until they cover the sequence, and a quality
+// string of another length (or none) ends the reading of the file, as the reference's loop does.  Also: output naming
 // (src/misc.cpp:58-87) and the FASTA writer (src/ILP_index.cpp:1590-1598).
 #include <ctype.h>
 #include <stdarg.h>
@@ -33,51 +34,141 @@ static int fail(char *err, int cap, int code, const char *fmt, ...)
 }
 
 namespace {
-// the whole (possibly gzip-compressed) file in memory
-bool slurp(const char *path, std::vector<char> &buf)
-{
-    if (FILE *fp = fopen(path, "rb")) {
-        unsigned char magic[2] = {0, 0};
-        const size_t got = fread(magic, 1, 2, fp);
-        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(fp, 0, SEEK_END) == 0) {
-            const long sz = ftell(fp);
-            if (sz >= 0) {
-                rewind(fp);
-                buf.resize((size_t)sz);
-                const size_t n = sz ? fread(buf.data(), 1, (size_t)sz, fp) : 0;
-                fclose(fp);
-                buf.resize(n);
-                return true;
-            }
-        }
-        fclose(fp);
-    } else {
-        return false;
-    }
-    gzFile fp = gzopen(path, "r");
-    if (!fp) return false;
-    gzbuffer(fp, 1 << 20);
-    size_t len = 0;
-    buf.resize((size_t)1 << 22);
-    for (;;) {
-        if (buf.size() - len < ((size_t)1 << 20)) buf.resize(buf.size() * 2);
-        const int n = gzread(fp, buf.data() + len, (unsigned)std::min<size_t>(buf.size() - len, (size_t)1 << 30));
-        if (n <= 0) break;
-        len += (size_t)n;
-    }
-    gzclose(fp);
-    buf.resize(len);
-    return true;
-}
+// A byte source with kstream's two primitives (kseq.h:100-150): one character, or the rest of the line.
+struct ByteSrc {
+    FILE *fp = nullptr;                               // plain file ...
+    gzFile gz = nullptr;                              // ... or gzip
+    std::vector<char> buf;
+    size_t begin = 0, end = 0;
+    bool is_eof = false;
 
-// one line [p, e) of the buffer (without the newline / a trailing CR); returns the start of the next
-inline const char *next_line(const char *p, const char *end, const char *&e)
+    bool open(const char *path)
+    {
+        FILE *f = fopen(path, "rb");
+        if (!f) return false;
+        unsigned char magic[2] = {0, 0};
+        const size_t got = fread(magic, 1, 2, f);
+        buf.resize((size_t)4 << 20);
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            fclose(f);
+            gz = gzopen(path, "r");
+            if (!gz) return false;
+            gzbuffer(gz, 1 << 20);
+        } else {
+            rewind(f);
+            fp = f;
+        }
+        return true;
+    }
+    void close()
+    {
+        if (fp) fclose(fp);
+        if (gz) gzclose(gz);
+        fp = nullptr; gz = nullptr;
+    }
+    bool refill()                                     // false: nothing more to read
+    {
+        if (is_eof) return false;
+        begin = 0;
+        long n;
+        if (gz) n = gzread(gz, buf.data(), (unsigned)buf.size());
+        else n = (long)fread(buf.data(), 1, buf.size(), fp);
+        end = n > 0 ? (size_t)n : 0;
+        if (end < buf.size()) is_eof = true;
+        return end > 0;
+    }
+    int getc()
+    {
+        if (begin >= end && !refill()) return -1;
+        return (unsigned char)buf[begin++];
+    }
+    // the bytes up to the next '\n' (consumed, not stored) appended to out; -1 when the source was already
+    // exhausted.  As ks_getuntil2(KS_SEP_LINE): a trailing '\r' is dropped when the string is longer than 1.
+    long line(std::vector<char> &out)
+    {
+        if (begin >= end && is_eof) return -1;
+        for (;;) {
+            if (begin >= end && !refill()) break;
+            const char *p = buf.data() + begin;
+            const char *nl = (const char *)memchr(p, '\n', end - begin);
+            const size_t n = nl ? (size_t)(nl - p) : end - begin;
+            out.insert(out.end(), p, p + n);
+            begin += n + (nl ? 1 : 0);
+            if (nl) break;
+        }
+        if (out.size() > 1 && out.back() == '\r') out.pop_back();
+        return (long)out.size();
+    }
+    // the same for a string whose bytes are not kept: len / last byte stand for it
+    long line_len(size_t &len, int &last)
+    {
+        if (begin >= end && is_eof) return -1;
+        for (;;) {
+            if (begin >= end && !refill()) break;
+            const char *p = buf.data() + begin;
+            const char *nl = (const char *)memchr(p, '\n', end - begin);
+            const size_t n = nl ? (size_t)(nl - p) : end - begin;
+            if (n) { len += n; last = (unsigned char)p[n - 1]; }
+            begin += n + (nl ? 1 : 0);
+            if (nl) break;
+        }
+        if (len > 1 && last == '\r') { len--; last = 0; }
+        return (long)len;
+    }
+    // the bytes up to the next white space (ks_getuntil with KS_SEP_SPACE); *dret = the delimiter
+    long word(std::string &out, int *dret)
+    {
+        out.clear();
+        *dret = 0;
+        if (begin >= end && is_eof) return -1;
+        for (;;) {
+            if (begin >= end && !refill()) break;
+            size_t i = begin;
+            while (i < end && !isspace((unsigned char)buf[i])) i++;
+            out.append(buf.data() + begin, i - begin);
+            const bool hit = i < end;
+            if (hit) *dret = (unsigned char)buf[i];
+            begin = i + 1;
+            if (hit) break;
+        }
+        return (long)out.size();
+    }
+};
+
+// kseq_read (kseq.h:192-233) as the reference instantiates it (ILP_index.cpp:8): >= 0 length of the
+// sequence, -1 end of file, -2 quality string missing or of another length (the caller stops reading:
+// ILP_index.cpp:322).  Sequence lines are taken as they are (no filtering), empty lines skipped.
+struct KseqState {
+    int last_char = 0;
+    std::string name, comment_sink;
+    std::vector<char> seq, sink;
+};
+long kseq_next(ByteSrc &ks, KseqState &st)
 {
-    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-    e = nl ? nl : end;
-    const char *nx = nl ? nl + 1 : end;
-    if (e > p && e[-1] == '\r') e--;
-    return nx;
+    int c;
+    if (st.last_char == 0) {                          // jump to the next header character, wherever it is
+        while ((c = ks.getc()) != -1 && c != '>' && c != '@') {}
+        if (c == -1) return -1;
+        st.last_char = c;
+    }
+    st.seq.clear();
+    if (ks.word(st.name, &c) < 0) return -1;
+    if (c != '\n') { st.sink.clear(); ks.line(st.sink); }     // the comment
+    while ((c = ks.getc()) != -1 && c != '>' && c != '+' && c != '@') {
+        if (c == '\n') continue;                      // empty line
+        st.seq.push_back((char)c);
+        ks.line(st.seq);                              // the rest of the line
+    }
+    if (c == '>' || c == '@') st.last_char = c;
+    if (c != '+') return (long)st.seq.size();         // FASTA
+    while ((c = ks.getc()) != -1 && c != '\n') {}     // the rest of the '+' line
+    if (c == -1) return -2;
+    size_t ql = 0;
+    int qlast = 0;
+    while (ks.line_len(ql, qlast) >= 0 && ql < st.seq.size()) {}
+    st.last_char = 0;
+    if (ql != st.seq.size()) return -2;
+    return (long)st.seq.size();
 }
 }  // namespace
 
@@ -87,130 +178,37 @@ int phi_reads_read(const char *path, phi_reads **out, char *err, int err_cap)
 {
     if (!path || !out) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "null argument");
     *out = nullptr;
-    std::vector<char> buf;
-    if (!slurp(path, buf)) return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to open the reads file %s", path);
+    ByteSrc ks;
+    if (!ks.open(path)) return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to open the reads file %s", path);
     phi_reads *r = new phi_reads();
-    r->bases.resize(buf.size());                      // the bases are a subset of the file's bytes
-    char *bases = r->bases.data();
-    size_t nb = 0;
-    const char *p = buf.data(), *const end = buf.data() + buf.size();
-    const char *e = p;
-    bool have = p < end;
-    const char *line = p;
-    if (have) p = next_line(p, end, e);
-    auto advance = [&]() { have = p < end; line = p; if (have) p = next_line(p, end, e); };
-    while (have) {
-        if (e == line || (line[0] != '>' && line[0] != '@')) { advance(); continue; }
-        const char *b = line + 1;
-        while (b < e && !isspace((unsigned char)*b)) b++;
+    KseqState st;
+    while (kseq_next(ks, st) >= 0) {                  // (:322: any negative value ends the loop)
         r->name_off.push_back((int64_t)r->names.size());
-        r->names.insert(r->names.end(), line + 1, b);
+        r->names.insert(r->names.end(), st.name.begin(), st.name.end());
         r->names.push_back('\0');
-        const size_t start = nb;
-        advance();
-        while (have && (e == line || (line[0] != '>' && line[0] != '@' && line[0] != '+'))) {
-            const size_t n = (size_t)(e - line);
-            memcpy(bases + nb, line, n);
-            unsigned bad = 0;
-            for (size_t i = 0; i < n; i++) bad |= (unsigned)((unsigned char)line[i] - 33) > 93u;   // not isgraph
-            if (bad) {
-                size_t k = nb;
-                for (size_t i = 0; i < n; i++) if (isgraph((unsigned char)line[i])) bases[k++] = line[i];
-                nb = k;
-            } else nb += n;
-            advance();
-        }
-        const size_t len = nb - start;
-        r->off.push_back((int64_t)nb);
-        if (have && line[0] == '+') {                 // FASTQ: skip the quality block
-            size_t q = 0;
-            advance();
-            while (have && q < len) { q += (size_t)(e - line); advance(); }
-        }
+        r->bases.insert(r->bases.end(), st.seq.begin(), st.seq.end());
+        r->off.push_back((int64_t)r->bases.size());
     }
-    r->bases.resize(nb);
+    ks.close();
     *out = r;
     return PHI_HOST_OK;
 }
 
-// ---- streaming reader: the same record rules as phi_reads_read, one line at a time,
-//      so that a reads file of any size goes through fixed buffers the caller owns (pinned, for the
-//      device copy) while the chunk before is on the GPU.
+// ---- streaming reader: the same records, a chunk at a time into buffers the caller owns
+//      (pinned, for the device copy) while the chunk before is on the GPU.
 struct phi_reads_stream {
-    FILE *fp = nullptr;                               // plain file ...
-    gzFile gz = nullptr;                              // ... or gzip
-    std::vector<char> ibuf;                           // file bytes not yet parsed: [pos, fill)
-    size_t pos = 0, fill = 0;
-    bool eof = false;
-    int state = 0;                                    // 0 between records, 1 in sequence lines, 2 in quality lines
-    size_t rec_len = 0, qual = 0;                     // bases of the open record; quality characters skipped so far
-    std::vector<char> carry;                          // bases of the open record parsed during an earlier call
+    ByteSrc ks;
+    KseqState st;
+    bool pending = false, done = false;               // st.seq holds a record that did not fit the chunk before
     int64_t total_reads = 0, total_bases = 0;
 };
-
-namespace {
-// more file bytes behind the unparsed tail; false at end of file
-bool stream_fill(phi_reads_stream *s)
-{
-    if (s->eof) return false;
-    if (s->pos > 0) {
-        memmove(s->ibuf.data(), s->ibuf.data() + s->pos, s->fill - s->pos);
-        s->fill -= s->pos;
-        s->pos = 0;
-    }
-    if (s->fill == s->ibuf.size()) s->ibuf.resize(s->ibuf.size() * 2);        // a line longer than the buffer
-    const size_t room = s->ibuf.size() - s->fill;
-    long n;
-    if (s->gz) n = gzread(s->gz, s->ibuf.data() + s->fill, (unsigned)std::min<size_t>(room, (size_t)1 << 30));
-    else n = (long)fread(s->ibuf.data() + s->fill, 1, room, s->fp);
-    if (n <= 0) { s->eof = true; return false; }
-    s->fill += (size_t)n;
-    return true;
-}
-
-// the next complete line [b, e) (newline and a trailing CR stripped); false when the file is exhausted
-bool stream_line(phi_reads_stream *s, const char *&b, const char *&e)
-{
-    for (;;) {
-        const char *base = s->ibuf.data();
-        const char *nl = s->fill > s->pos ? (const char *)memchr(base + s->pos, '\n', s->fill - s->pos) : nullptr;
-        if (nl) {
-            b = base + s->pos; e = nl;
-            s->pos = (size_t)(nl - base) + 1;
-            if (e > b && e[-1] == '\r') e--;
-            return true;
-        }
-        if (stream_fill(s)) continue;
-        if (s->fill > s->pos) {                       // last line without a newline
-            b = s->ibuf.data() + s->pos; e = s->ibuf.data() + s->fill;
-            s->pos = s->fill;
-            if (e > b && e[-1] == '\r') e--;
-            return true;
-        }
-        return false;
-    }
-}
-}  // namespace
 
 int phi_reads_stream_open(const char *path, phi_reads_stream **out, char *err, int err_cap)
 {
     if (!path || !out) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "null argument");
     *out = nullptr;
-    FILE *fp = fopen(path, "rb");
-    if (!fp) return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to open the reads file %s", path);
-    unsigned char magic[2] = {0, 0};
-    const size_t got = fread(magic, 1, 2, fp);
     phi_reads_stream *s = new phi_reads_stream();
-    s->ibuf.resize((size_t)8 << 20);
-    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-        fclose(fp);
-        s->gz = gzopen(path, "r");
-        if (!s->gz) { delete s; return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to open the reads file %s", path); }
-        gzbuffer(s->gz, 1 << 20);
-    } else {
-        rewind(fp);
-        s->fp = fp;
-    }
+    if (!s->ks.open(path)) { delete s; return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to open the reads file %s", path); }
     *out = s;
     return PHI_HOST_OK;
 }
@@ -219,74 +217,25 @@ int64_t phi_reads_stream_next(phi_reads_stream *s, char *bases, int64_t bases_ca
                               char *err, int err_cap)
 {
     if (!s || !bases || !off || bases_cap <= 0 || reads_cap <= 0) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "bad arguments");
-    size_t nb = 0, rec_start = 0;
-    int64_t n = 0;
+    int64_t n = 0, nb = 0;
     off[0] = 0;
-    if (!s->carry.empty()) {                          // the record that did not fit the chunk before
-        if ((int64_t)s->carry.size() > bases_cap)
+    while (n < reads_cap && !s->done) {
+        if (!s->pending) {
+            if (kseq_next(s->ks, s->st) < 0) { s->done = true; break; }
+            s->pending = true;
+        }
+        const int64_t len = (int64_t)s->st.seq.size();
+        if (len > bases_cap)
             return fail(err, err_cap, PHI_HOST_ERR_INVALID, "a read of more than %lld bases does not fit a chunk", (long long)bases_cap);
-        memcpy(bases, s->carry.data(), s->carry.size());
-        nb = s->carry.size();
-        s->carry.clear();
-    }
-    auto finish_record = [&]() {
-        off[++n] = (int64_t)nb;
+        if (nb + len > bases_cap) break;              // goes into the next chunk
+        if (len) memcpy(bases + nb, s->st.seq.data(), (size_t)len);
+        nb += len;
+        off[++n] = nb;
+        s->pending = false;
         s->total_reads++;
-        s->total_bases += (int64_t)s->rec_len;
-        rec_start = nb;
-    };
-    const char *b, *e;
-    for (;;) {
-        if (n == reads_cap) return n;                 // only between records (state 0 or 2)
-        if (!stream_line(s, b, e)) {
-            if (s->state == 1) { s->state = 0; finish_record(); }
-            return n;
-        }
-        if (s->state == 2) {                          // quality block: as many characters as bases (kseq.h:221-230)
-            s->qual += (size_t)(e - b);
-            if (s->qual >= s->rec_len) s->state = 0;
-            continue;
-        }
-        if (s->state == 1) {
-            if (e == b || (b[0] != '>' && b[0] != '@' && b[0] != '+')) {          // a sequence line
-                const size_t ln = (size_t)(e - b);
-                if (nb + ln > (size_t)bases_cap) {
-                    // chunk full inside a record: hand back the finished records, keep this one's bases
-                    if (n == 0)
-                        return fail(err, err_cap, PHI_HOST_ERR_INVALID, "a read of more than %lld bases does not fit a chunk", (long long)bases_cap);
-                    s->carry.assign(bases + rec_start, bases + nb);
-                    s->pos = (size_t)(b - s->ibuf.data());       // this line is parsed again by the next call
-                    return n;
-                }
-                char *dst = bases + nb;
-                memcpy(dst, b, ln);
-                unsigned bad = 0;
-                for (size_t i = 0; i < ln; i++) bad |= (unsigned)((unsigned char)b[i] - 33) > 93u;       // not isgraph
-                size_t kept = ln;
-                if (bad) {
-                    kept = 0;
-                    for (size_t i = 0; i < ln; i++) if (isgraph((unsigned char)b[i])) dst[kept++] = b[i];
-                }
-                nb += kept;
-                s->rec_len += kept;
-                continue;
-            }
-            s->state = 0;
-            finish_record();
-            if (b[0] == '+') {
-                s->qual = 0;
-                s->state = s->rec_len > 0 ? 2 : 0;
-                continue;
-            }
-            // a header line ends the record and opens the next: fall through
-        }
-        if (e > b && (b[0] == '>' || b[0] == '@')) {
-            if (n == reads_cap) { s->pos = (size_t)(b - s->ibuf.data()); return n; }
-            s->state = 1;
-            s->rec_len = 0;
-            rec_start = nb;
-        }
+        s->total_bases += len;
     }
+    return n;
 }
 
 int64_t phi_reads_stream_reads(const phi_reads_stream *s) { return s ? s->total_reads : 0; }
@@ -295,8 +244,7 @@ int64_t phi_reads_stream_bases(const phi_reads_stream *s) { return s ? s->total_
 void phi_reads_stream_close(phi_reads_stream *s)
 {
     if (!s) return;
-    if (s->fp) fclose(s->fp);
-    if (s->gz) gzclose(s->gz);
+    s->ks.close();
     delete s;
 }
 

@@ -6,6 +6,9 @@
   gfa_flatten.json      segments / arcs / walks of test/test.gfa as the REFERENCE's gfa_read() parses
                         them, flattened as ILP_index::read_gfa does; plus digests for test/MHC_4.gfa.gz
   hap_names.json        outputs of the reference's get_hap_name() (misc.cpp:58-87)
+  kseq_vectors.json     small FASTA / FASTQ texts, well-formed and malformed, with the records the REFERENCE's
+                        own kseq.h returns for them (kseq_read loop of ILP_index.cpp:313-328) and digests
+                        for test/CHM13_reads.fq.gz
   counters.json         NOT regenerated here: the counters the reference logged on its own fixtures,
                         recorded in SURVEY.md section 8(c) (the ILP_index.cpp TU needs gurobi_c++.h,
                         absent from this image, so it cannot be rebuilt)
@@ -53,6 +56,47 @@ def main():
                     ("graph", "reads"), ("dir.d/graph.gfa", "dir.e/reads")]:
         names.append({"gfa": gfa, "reads": rd, "name": O.ref_hap_name(gfa, rd)})
     json.dump(names, open(os.path.join(HERE, "hap_names.json"), "w"), indent=1)
+
+    # kseq: texts + what the reference's reader returns
+    import tempfile
+    texts = [
+        b">a\nACGT\n>b desc\nAC\nGT\n\nTT\n", b"@r\nACGT\n+\nIIII\n@s x\nAC\nGT\n+s\nII\nII\n",
+        b"@r0\r\nAC\r\nGT\r\n+r0\r\n!>\r\n!#\r\n@r1\r\nNatNT\r\n+r1\r\nI~>I~\r\n",
+        b"@r5 c\n\n+\n@r6\nAC\n+\nII\n",                     # empty sequence: its quality loop eats the next header, then -2
+        b"@a\nACGT\n+\nII\n@b\nAC\n+\nII\n",                 # short quality: reading stops
+        b"@a\nACGT\n+\n@III\n@b\nAC\n+\n+I\n",               # quality lines that start with '@' and '+'
+        b"junk @x >y\n>a\nAC GT\tA\n>b\n\r\nAC\n",           # header bytes inside a line, white space kept, a CR-only line
+        b">a\nACGT", b"@a\nACGT\n+", b"@a\nACGT\n+\n", b">\nAC\n> x\nGG\n", b"", b"\n\n", b">a\n>b\n>c\nA\n",
+        b">a\nAC\n+\nII\n>b\nGG\n", b"@a\nAC\r\n+\r\nI\r\n",
+    ]
+    rnd2 = random.Random(7)
+    for _ in range(40):                                            # random mixtures of the same ingredients
+        parts = []
+        for i in range(rnd2.randrange(1, 6)):
+            L = rnd2.choice([0, 1, 3, rnd2.randrange(1, 90)])
+            seq = bytes(rnd2.choice(b"ACGTNacgt") for _ in range(L))
+            w = rnd2.randrange(3, 40)
+            lines = [seq[j:j + w] for j in range(0, L, w)] or ([b""] if rnd2.random() < 0.5 else [])
+            nl = b"\r\n" if rnd2.random() < 0.2 else b"\n"
+            if rnd2.random() < 0.5:
+                q = bytes(rnd2.choice(b"@+>I5#") for _ in range(L if rnd2.random() < 0.8 else max(L - 1, 0)))
+                parts.append(nl.join([b"@n%d c" % i] + lines + [b"+"] + [q[j:j + w] for j in range(0, len(q), w)]) + nl)
+            else:
+                parts.append(nl.join([b">n%d" % i] + lines) + nl)
+        t = b"".join(parts)
+        if rnd2.random() < 0.3:
+            t = t[:rnd2.randrange(0, len(t) + 1)]
+        texts.append(t)
+    kv = []
+    with tempfile.TemporaryDirectory() as td:
+        for t in texts:
+            fn = os.path.join(td, "k.fq")
+            open(fn, "wb").write(t)
+            kv.append({"text_hex": t.hex(), "records": [[a.decode("latin1"), b.hex()] for a, b in O.ref_read_reads(fn)]})
+    recs = O.ref_read_reads(os.path.join(data, "CHM13_reads.fq.gz"))
+    chm = {"n": len(recs), "sha256_names": hashlib.sha256(b"\0".join(a for a, _ in recs)).hexdigest(),
+           "sha256_seqs": hashlib.sha256(b"\0".join(b for _, b in recs)).hexdigest()}
+    json.dump({"texts": kv, "CHM13_reads.fq.gz": chm}, open(os.path.join(HERE, "kseq_vectors.json"), "w"), indent=0)
 
 
 if __name__ == "__main__":

@@ -133,7 +133,10 @@ def test_host_reads_reader(built, oracle, tmp_path):
     bases, off, names = H.read_reads(str(p))
     raw = bases.tobytes()
     assert names == ["a", "b", "c", "q1", "q2"]
-    assert [raw[off[i]:off[i + 1]] for i in range(5)] == [b"ACGTACGT", b"", b"TT", b"GGCC", b"AACC"]
+    # (kseq keeps a sequence line as it is: the blank inside "AC GT" stays, kseq.h:209-213)
+    assert [raw[off[i]:off[i + 1]] for i in range(5)] == [b"ACGTAC GT", b"", b"TT", b"GGCC", b"AACC"]
+    if oracle.ref_available():
+        assert oracle.ref_read_reads(str(p)) == oracle.read_reads(str(p))
     assert [(n.decode(), s) for n, s in oracle.read_reads(str(p))] == list(zip(names, [raw[off[i]:off[i + 1]] for i in range(5)]))
 
 
@@ -280,3 +283,34 @@ def test_host_reads_stream_equals_whole_file_reader(built, tmp_path):
     # a read longer than the chunk is an error, not a truncation
     with pytest.raises(H.HostError):
         list(H.stream_reads(files[0], bases_cap=100, reads_cap=10))
+
+
+def test_reads_readers_on_the_reference_kseq_vectors(built, oracle, tmp_path):
+    """tests/golden/kseq_vectors.json: FASTA / FASTQ texts, well-formed and malformed, with the records the
+    reference's own kseq.h returns (make_golden.py).  The oracle's restatement, phi_reads_read and the streaming
+    reader must return exactly those -- including where kseq gives up (a quality string of another length ends
+    the file) and what it keeps (white space inside a sequence line, a CR on an otherwise empty first line)."""
+    from phi_amd import ilp_index as H
+    gold = json.load(open(os.path.join(GOLDEN, "kseq_vectors.json")))
+    for i, v in enumerate(gold["texts"]):
+        p = tmp_path / f"k{i}.fq"
+        p.write_bytes(bytes.fromhex(v["text_hex"]))
+        want = [(a.encode("latin1"), bytes.fromhex(b)) for a, b in v["records"]]
+        assert oracle.read_reads(str(p)) == want, (i, v["text_hex"])
+        bases, off, names = H.read_reads(str(p))
+        assert [(names[j].encode("latin1"), bytes(bases[off[j]:off[j + 1]])) for j in range(len(names))] == want, (i, v["text_hex"])
+        longest = max([len(b) for _, b in want] + [1])
+        for cap, rc in ((longest, 1), (longest + 5, 3), (1 << 16, 1 << 10)):
+            got = []
+            for b, o in H.stream_reads(str(p), bases_cap=cap, reads_cap=rc):
+                got += [bytes(b[o[j]:o[j + 1]]) for j in range(len(o) - 1)]
+            assert got == [b for _, b in want], (i, cap, rc)
+    c = gold["CHM13_reads.fq.gz"]
+    recs = oracle.read_reads(os.path.join(DATA, "CHM13_reads.fq.gz"))
+    assert len(recs) == c["n"]
+    assert hashlib.sha256(b"\0".join(a for a, _ in recs)).hexdigest() == c["sha256_names"]
+    assert hashlib.sha256(b"\0".join(b for _, b in recs)).hexdigest() == c["sha256_seqs"]
+    bases, off, names = H.read_reads(os.path.join(DATA, "CHM13_reads.fq.gz"))
+    assert hashlib.sha256(b"\0".join(bytes(bases[off[j]:off[j + 1]]) for j in range(len(names)))).hexdigest() == c["sha256_seqs"]
+    if oracle.ref_available():                         # and, where it is built, the reference's reader itself
+        assert oracle.ref_read_reads(os.path.join(DATA, "read.fa")) == oracle.read_reads(os.path.join(DATA, "read.fa"))
