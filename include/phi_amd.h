@@ -125,7 +125,8 @@ typedef struct {
     /* ---- solve (ILP_index.cpp:776-1418) */
     int64_t objective;          /* max  #covered minimisers - 2*(R/2)*#recombinations          */
     int64_t upper_bound;        /* proven bound; optimal iff upper_bound == objective           */
-    int32_t optimal;            /* 1 when proven optimal                                        */
+    int32_t optimal;            /* 1 when proven optimal; 0 when the search ran out of its budget (256 DP
+                                   runs, then two more seconds): the path is feasible, the bound proven */
     int32_t n_dp_runs;          /* DP launches used (1 = certificate closed at the root)        */
     int64_t n_covered;          /* minimisers with >=1 anchor fully traversed (sum of z_i)      */
     /* ---- decode (:1431-1525) */

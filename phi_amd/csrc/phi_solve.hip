@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <set>
 #include <unordered_map>
@@ -498,7 +499,17 @@ int phi_solve_impl(phi_ctx *c)
     std::vector<Seg> best_segs;
     int64_t incumbent = INT64_MIN, global_ub = INT64_MIN;
     int n_runs = 0;
-    const int max_runs = 256;
+    // branch and bound is finite and exact; it is given 256 DP runs whatever they cost, and beyond them as
+    // many as fit into two seconds (small graphs with short k, where a minimiser repeats everywhere, take
+    // thousands of runs of some tens of microseconds)
+    const int max_runs = 256, hard_runs = 1 << 16;
+    const double extra_budget_s = 2.0;
+    const auto bb_t0 = std::chrono::steady_clock::now();
+    auto out_of_runs = [&]() {
+        if (n_runs < max_runs) return false;
+        if (n_runs >= hard_runs) return true;
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - bb_t0).count() > extra_budget_s;
+    };
     bool exhausted = false;
     std::vector<Node> stack;
     stack.push_back(Node{});
@@ -519,7 +530,7 @@ int phi_solve_impl(phi_ctx *c)
         uint32_t branch_slot = 0;
         bool have_branch = false;
         for (int iter = 0; iter < 8 && !closed; iter++) {
-            if (n_runs >= max_runs) { exhausted = true; break; }
+            if (out_of_runs()) { exhausted = true; break; }
             // weights of this relaxation
             std::fill(wgt.begin(), wgt.end(), 1);
             for (uint32_t s : S) for (int32_t a : anchors_of(s)) wgt[a] = 0;

@@ -35,9 +35,18 @@ while time.time() < t_end:
                 try: reads += mosaic_reads(rng, g, n_reads=int(rng.integers(1, 60)), read_len=int(rng.integers(20, 400)), n_seg=2, err=float(rng.choice([0, 0.01, 0.05])))
                 except Exception: pass
             for _ in range(int(rng.integers(0, 6))):
-                L = int(rng.choice([0, 1, k - 1, k, k + w - 1, k + w, int(rng.integers(1, 4000))]))
+                L = int(rng.choice([0, 1, k - 1, k, k + w - 1, k + w, int(rng.integers(1, 4000)), int(rng.integers(4000, 60000))]))
                 alpha = b"ACGT" if rng.random() < 0.7 else b"ACGTNacgtn"
-                reads.append(bytes(rng.choice(list(alpha), size=max(L, 0)).tolist()))
+                r = rng.choice(list(alpha), size=max(L, 0))
+                if L > 200 and rng.random() < 0.5:             # long clean stretches with a few bases outside ACGT: chunk seams, reseeds
+                    r = rng.choice(list(b"ACGT"), size=L)
+                    for q in rng.integers(0, L, size=int(rng.integers(1, 12))):
+                        r[q] = ord("N")
+                if L > 100 and rng.random() < 0.3:             # low entropy: minimisers come back to earlier values
+                    r = rng.choice(list(b"AAC"), size=L)
+                    for q in rng.integers(0, L, size=int(rng.integers(0, 8))):
+                        r[q] = ord("n")
+                reads.append(bytes(r.tolist()))
             if not reads: reads = [b"ACGT" * 30]
             off = np.zeros(len(reads) + 1, np.int64); np.cumsum([len(r) for r in reads], out=off[1:])
             if off[-1] == 0: continue

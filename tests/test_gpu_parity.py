@@ -509,8 +509,9 @@ def test_many_switches_backtrack(oracle, ctx_factory):
 
 
 def test_run_cap_reports_a_proven_bound(oracle, ctx_factory):
-    """A hard instance (R = 0, eight walks, short repeats) can exhaust the cap of 256 DP runs: the
-    result then says optimal = 0 and carries a finite bound that the feasible path respects."""
+    """A hard instance (R = 0, eight walks, short repeats) can exhaust the run budget (256 DP runs, then as
+    many as fit into two more seconds): the result then says optimal = 0 and carries a finite bound that
+    the feasible path respects."""
     from oracle import solve_oracle as S
     rng = np.random.default_rng(321)
     g = random_graph(rng, n_sites=400, n_walks=8, seg_len=(8, 16), alt_len=(3, 6), p_del=0.0)
@@ -535,7 +536,8 @@ def test_run_cap_reports_a_proven_bound(oracle, ctx_factory):
     assert obj == res["objective"]
     assert res["objective"] <= res["upper_bound"] <= res["n_in_model"]
     assert res["optimal"] == (res["objective"] == res["upper_bound"])
-    assert res["n_dp_runs"] <= 256
+    assert res["n_dp_runs"] <= 65536
+    assert res["optimal"] == 1 or res["n_dp_runs"] >= 256      # gives up only after 256 runs and two more seconds
 
 
 def test_resets_empty_only_what_was_filled(oracle, ctx_factory):
