@@ -887,6 +887,51 @@ def test_torch_views_of_device_buffers(oracle, ctx_factory):
 
 # --------------------------------------------------------------------------- full size (BASELINE config C2)
 
+@pytest.mark.parametrize("seed", range(6))
+def test_two_read_shards_merge_to_the_single_context_result(oracle, ctx_factory, seed):
+    """The multi-GPU exchange on one GPU: two contexts score one half of the reads each, their hit vectors are
+    OR-ed in place (what the RCCL all-reduce(MAX) does) and their spectrum lists exchanged
+    (phi_spectrum_export / _import); both must then solve to what one context with all the reads gives."""
+    import torch
+    from phi_amd import dist as pdist
+    rng = np.random.default_rng(4200 + seed)
+    k, w = int(rng.choice([5, 9, 15])), int(rng.integers(2, 7))
+    g = random_graph(rng, n_sites=int(rng.integers(10, 40)), n_walks=int(rng.integers(2, 8)), seg_len=(4, 30), alt_len=(1, 8), p_del=0.2)
+    reads = mosaic_reads(rng, g, n_reads=int(rng.integers(20, 120)), read_len=int(rng.integers(k + w + 4, 90)), n_seg=3, err=0.02)
+    reads += [bytes(rng.choice(list(b"ACGTN"), size=200).tolist()) for _ in range(3)]      # foreign reads: spectrum-only hashes
+    R, T = int(rng.choice([0, 2, 5, 100])), float(rng.choice([1.0, 0.6]))
+    cut = len(reads) // 2
+
+    def make(rs):
+        c = ctx_factory(k=k, w=w, threshold=T, recombination=R)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        _set_graph(c, g)
+        c.add_reads(rs)
+        return c
+    whole, a, b = make(reads), make(reads[:cut]), make(reads[cut:])
+    want = whole.solve()
+    # exchange: hit vectors (in place) and spectrum lists
+    views = []
+    for c in (a, b):
+        p, n = c.hits_buffer()
+        views.append(torch.as_tensor(pdist.DevArray(p, n), device="cuda"))
+    merged = torch.maximum(views[0], views[1])
+    views[0].copy_(merged); views[1].copy_(merged)
+    lists = []
+    for c in (a, b):
+        p, m = c.spectrum_export()
+        lists.append(torch.as_tensor(pdist.DevArray(p, m, "<i8"), device="cuda").clone() if m else torch.zeros(0, dtype=torch.int64, device="cuda"))
+    if lists[1].numel(): a.spectrum_import(lists[1].data_ptr(), lists[1].numel())
+    if lists[0].numel(): b.spectrum_import(lists[0].data_ptr(), lists[0].numel())
+    torch.cuda.synchronize()
+    for c in (a, b):
+        got = c.solve()
+        for key in ("objective", "upper_bound", "optimal", "spectrum_size", "filtered", "retained", "n_in_model", "n_covered", "n_switches"):
+            assert got[key] == want[key], (key, got[key], want[key])
+        assert np.array_equal(got["n_anchors"], want["n_anchors"])
+        assert np.array_equal(got["path_vtx"], want["path_vtx"]) and np.array_equal(got["path_hap"], want["path_hap"])
+
+
 def test_full_size_properties_c2(ctx_factory):
     """At the size the metric is quoted on (synMHC-49: 49 walks x 5.2 Mbp, 1x reads) no CPU checker
     finishes in seconds; the domain's size-independent properties stand in: the read set is a SET of
