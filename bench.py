@@ -78,7 +78,8 @@ def main():
         __graft_entry__.ensure_built()                         # a checkout without built libraries (no fallback exists)
     else:
         t_wait = time.time()
-        while not os.path.exists(os.path.join(ROOT, "phi_amd", "libphi_amd.so")) and time.time() - t_wait < 600:
+        libs = [os.path.join(ROOT, "phi_amd", n) for n in ("libphi_amd.so", "libphi_host.so")]
+        while not all(os.path.exists(p) for p in libs) and time.time() - t_wait < 600:
             time.sleep(1.0)                                    # rank 0 is building
     import phi_amd
     from phi_amd import dist as pdist

@@ -46,7 +46,9 @@ def build_device(force=False):
         objs.append(o)
     lib = os.path.join(ROOT, "phi_amd", "libphi_amd.so")
     if force or _stale(lib, objs):
-        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs)
+        tmp = f"{lib}.{os.getpid()}.tmp"                    # other ranks wait for `lib` to appear: never half-written
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs)
+        os.replace(tmp, lib)
     return lib
 
 
