@@ -1,6 +1,6 @@
 """Randomised agreement of the DP kernels: event-driven (1 consumer wave / 2 waves / 4 waves, by walk count)
 against the every-vertex kernel (PHI_DP_DENSE=1) on random graphs.
-Usage (GPU box): python tests/fuzz/fuzz_dp_kernels.py SEED SECONDS MIN_WALKS MAX_WALKS"""
+Usage (GPU box): python tests/fuzz/fuzz_dp_kernels.py SEED SECONDS [MIN_WALKS MAX_WALKS]  (default 2 257: all three kernels)"""
 import os, sys, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -9,7 +9,7 @@ import phi_amd
 from graphgen import random_graph, mosaic_reads
 import test_gpu_parity as T
 seed0 = int(sys.argv[1]); t_end = time.time() + float(sys.argv[2])
-lo_w, hi_w = int(sys.argv[3]), int(sys.argv[4])
+lo_w, hi_w = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (2, 257)
 s = seed0 * 100000; n = 0
 while time.time() < t_end:
     s += 1
