@@ -121,12 +121,35 @@ int phi_spectrum_export(phi_ctx *ctx, void **d_hashes, int64_t *n);
 int phi_spectrum_import(phi_ctx *ctx, const void *d_hashes, int64_t n);
 int phi_spectrum_set_size(phi_ctx *ctx, int64_t global_size);
 
+/*
+ * The same exchange done by the library itself with RCCL over xGMI (librccl is loaded on first use).
+ * One context per GPU -- one process per GPU, or one host thread per GPU in one process (the `PHI
+ * --devices 0,1,..` mode) -- all holding the same graph and parameters, each fed its own shard of reads.
+ *   phi_comm_unique_id      ncclGetUniqueId: 128 bytes made by one rank and handed to the others out of
+ *                           band (a file, MPI, a torch.distributed store, shared memory between threads)
+ *   phi_comm_init           ncclCommInitRank on the context's device: collective over the n_ranks contexts
+ *   phi_comm_allreduce_hits step 1 alone: ncclAllReduce(MAX, uint8) of the hit vector in place, on the
+ *                           context's stream, asynchronous (what a job times per read set)
+ *   phi_comm_exchange       the whole exchange, once per job after the rank's last read batch: step 1, then
+ *                           ncclAllGather of the sizes and of the padded lists of phi_spectrum_export, and
+ *                           the import of every other rank's list.  Afterwards the hit vector, |Sp_R| and so
+ *                           phi_solve's result are identical on every rank.
+ *   phi_comm_destroy        also done by phi_ctx_destroy
+ */
+#define PHI_COMM_ID_BYTES 128
+int phi_comm_unique_id(void *id_out, size_t cap);
+int phi_comm_init(phi_ctx *ctx, const void *id, int32_t rank, int32_t n_ranks);
+int phi_comm_info(const phi_ctx *ctx, int32_t *rank, int32_t *n_ranks);
+int phi_comm_allreduce_hits(phi_ctx *ctx);
+int phi_comm_exchange(phi_ctx *ctx);
+int phi_comm_destroy(phi_ctx *ctx);
+
 typedef struct {
     /* ---- solve (ILP_index.cpp:776-1418) */
     int64_t objective;          /* max  #covered minimisers - 2*(R/2)*#recombinations          */
     int64_t upper_bound;        /* proven bound; optimal iff upper_bound == objective           */
-    int32_t optimal;            /* 1 when proven optimal; 0 when the search ran out of its budget (256 DP
-                                   runs, then two more seconds): the path is feasible, the bound proven */
+    int32_t optimal;            /* 1 when proven optimal; 0 when the search ran out of its budget of DP runs
+                                   (phi_set_solve_budget): the path is feasible, the bound proven */
     int32_t n_dp_runs;          /* DP launches used (1 = certificate closed at the root)        */
     int64_t n_covered;          /* minimisers with >=1 anchor fully traversed (sum of z_i)      */
     /* ---- decode (:1431-1525) */
@@ -145,6 +168,12 @@ typedef struct {
     int64_t retained;           /* spectrum_size - filtered                                     */
     int64_t n_in_model;         /* minimisers with a z_i ("% Minimizers are in ILP")            */
 } phi_result;
+
+/* Budget of the exact search behind phi_solve, counted in DP runs (never in wall-clock time: the same
+ * input gives the same result and the same `optimal` flag on every run).  The reference's
+ * model.optimize() (ILP_index.cpp:1412-1418) sets no limit; max_dp_runs <= 0 means the same here.
+ * Default 65536.  Almost every input closes at the root in 1-3 runs. */
+int phi_set_solve_budget(phi_ctx *ctx, int64_t max_dp_runs);
 
 /* Stages 2b-3 of ILP_function (:670-1525): filter, exact solve, decode.  Replaces
  * model.optimize() (:1418) with a max-plus DP + optimality certificate. */

@@ -48,6 +48,13 @@ def lib():
         L.orc_run.argtypes = [C.c_int32, C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                               C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float]
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_stage_seconds.restype = C.c_double
+        L.orc_stage_seconds.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads.restype = None
+        L.orc_max_threads.restype = C.c_int
+        L.orc_sketch_reads.restype = C.c_int64
+        L.orc_sketch_reads.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]
         for name in ("spectrum_size", "filtered", "retained", "n_in_model", "n_kept"):
             f = getattr(L, "orc_" + name)
             f.restype = C.c_int64

@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 #include <ctype.h>
 
 /* ------------------------------------------------------------------ hash */
@@ -133,6 +134,20 @@ int64_t orc_sketch(const char *seq_in, int64_t len, int k, int w,
     return n;
 }
 
+/* Threads of the OpenMP loops below (the reference's -t, main.cpp:60; its loops: ILP_index.cpp:559, :617). */
+void orc_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
+int orc_max_threads(void) { return omp_get_max_threads(); }
+
+/* compute_hashes over a batch of reads (ILP_index.cpp:617-621): returns the emitted minimisers. */
+int64_t orc_sketch_reads(const char *reads_concat, const int64_t *read_off, int64_t n_reads, int k, int w)
+{
+    int64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : total)
+    for (int64_t r = 0; r < n_reads; r++)
+        total += orc_sketch(reads_concat + read_off[r], read_off[r + 1] - read_off[r], k, w, 0, 0, 0);
+    return total;
+}
+
 /* ------------------------------------------------------------------ stages 1-2 driver */
 
 typedef struct {
@@ -156,6 +171,7 @@ typedef struct {
     int64_t *m_off;             /* [n_walks+1] */
     uint64_t *m_hash;
     int64_t *m_pos;
+    double stage_s[4];          /* wall seconds: walk sketch, read sketch + spectrum, anchors, filter */
 } orc_result_t;
 
 static int cmp_u64(const void *a, const void *b)
@@ -224,9 +240,13 @@ orc_result_t *orc_run(int32_t n_vtx, const char *seq_concat, const int64_t *seq_
     int64_t *node_len = (int64_t *)malloc(8 * (size_t)(n_vtx > 0 ? n_vtx : 1));
     for (int32_t v = 0; v < n_vtx; v++) node_len[v] = seq_off[v + 1] - seq_off[v];
 
-    /* ---- stage 1a: walks (index_kmers) */
-    int64_t m_cap = 0, m_n = 0;
+    double t_stage = omp_get_wtime();
+    /* ---- stage 1a: walks (index_kmers), one OpenMP task per walk as ILP_index.cpp:559 */
+    int64_t m_n = 0;
     int64_t **wbase = (int64_t **)calloc((size_t)n_walks, sizeof(int64_t *));
+    uint64_t **wh = (uint64_t **)calloc((size_t)n_walks, sizeof(uint64_t *));
+    int64_t **wp = (int64_t **)calloc((size_t)n_walks, sizeof(int64_t *));
+#pragma omp parallel for schedule(dynamic, 1)
     for (int32_t h = 0; h < n_walks; h++) {
         int64_t nv = walk_off[h + 1] - walk_off[h];
         const int32_t *wv = walk_vtx + walk_off[h];
@@ -239,33 +259,41 @@ orc_result_t *orc_run(int32_t n_vtx, const char *seq_concat, const int64_t *seq_
         for (int64_t i = 0; i < nv; i++)
             memcpy(hap + base[i], seq_concat + seq_off[wv[i]], (size_t)node_len[wv[i]]);
         int64_t n = orc_sketch(hap, L, k, w, 0, 0, 0);
-        if (m_n + n > m_cap) {
-            m_cap = (m_n + n) * 2 + 1024;
-            R->m_hash = (uint64_t *)realloc(R->m_hash, 8 * (size_t)m_cap);
-            R->m_pos = (int64_t *)realloc(R->m_pos, 8 * (size_t)m_cap);
-        }
-        orc_sketch(hap, L, k, w, R->m_hash + m_n, R->m_pos + m_n, n);
+        wh[h] = (uint64_t *)malloc(8 * (size_t)(n + 1));
+        wp[h] = (int64_t *)malloc(8 * (size_t)(n + 1));
+        orc_sketch(hap, L, k, w, wh[h], wp[h], n);
         R->n_minimizers[h] = n;
-        m_n += n;
-        R->m_off[h + 1] = m_n;
         free(hap);
     }
-
-    /* ---- stage 1b: reads (compute_hashes) + spectrum (:615-638) */
-    int64_t sp_cap = 1 << 16, sp_n = 0;
-    uint64_t *sp = (uint64_t *)malloc(8 * (size_t)sp_cap);
-    for (int64_t r = 0; r < n_reads; r++) {
-        int64_t L = read_off[r + 1] - read_off[r];
-        int64_t n = orc_sketch(reads_concat + read_off[r], L, k, w, 0, 0, 0);
-        if (sp_n + n > sp_cap) { sp_cap = (sp_n + n) * 2; sp = (uint64_t *)realloc(sp, 8 * (size_t)sp_cap); }
-        orc_sketch(reads_concat + read_off[r], L, k, w, sp + sp_n, 0, n);
-        sp_n += n;
+    for (int32_t h = 0; h < n_walks; h++) { m_n += R->n_minimizers[h]; R->m_off[h + 1] = m_n; }
+    R->m_hash = (uint64_t *)malloc(8 * (size_t)(m_n + 1));
+    R->m_pos = (int64_t *)malloc(8 * (size_t)(m_n + 1));
+    for (int32_t h = 0; h < n_walks; h++) {
+        memcpy(R->m_hash + R->m_off[h], wh[h], 8 * (size_t)R->n_minimizers[h]);
+        memcpy(R->m_pos + R->m_off[h], wp[h], 8 * (size_t)R->n_minimizers[h]);
+        free(wh[h]); free(wp[h]);
     }
+    free(wh); free(wp);
+
+    R->stage_s[0] = omp_get_wtime() - t_stage; t_stage = omp_get_wtime();
+    /* ---- stage 1b: reads (compute_hashes, OpenMP over reads as :617) + spectrum (:615-638) */
+    int64_t *r_off = (int64_t *)calloc((size_t)n_reads + 1, 8);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t r = 0; r < n_reads; r++)
+        r_off[r + 1] = orc_sketch(reads_concat + read_off[r], read_off[r + 1] - read_off[r], k, w, 0, 0, 0);
+    for (int64_t r = 0; r < n_reads; r++) r_off[r + 1] += r_off[r];
+    int64_t sp_n = r_off[n_reads];
+    uint64_t *sp = (uint64_t *)malloc(8 * (size_t)(sp_n + 1));
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t r = 0; r < n_reads; r++)
+        orc_sketch(reads_concat + read_off[r], read_off[r + 1] - read_off[r], k, w, sp + r_off[r], 0, r_off[r + 1] - r_off[r]);
+    free(r_off);
     qsort(sp, (size_t)sp_n, 8, cmp_u64);
     int64_t u = 0;
     for (int64_t i = 0; i < sp_n; i++) if (i == 0 || sp[i] != sp[i - 1]) sp[u++] = sp[i];
     R->spectrum = sp; R->spectrum_size = u;
 
+    R->stage_s[1] = omp_get_wtime() - t_stage; t_stage = omp_get_wtime();
     /* ---- stage 2a: anchors (compute_anchors, :495-526 + :645-655) */
     int64_t a_cap = 1 << 16, a_n = 0;
     anc_t *anc = (anc_t *)malloc(sizeof(anc_t) * (size_t)a_cap);
@@ -291,6 +319,7 @@ orc_result_t *orc_run(int32_t n_vtx, const char *seq_concat, const int64_t *seq_
     }
     qsort(anc, (size_t)a_n, sizeof(anc_t), cmp_anc);     /* Anchor_hits[r][h][k] order */
 
+    R->stage_s[2] = omp_get_wtime() - t_stage; t_stage = omp_get_wtime();
     /* ---- stage 2b: filter (:670-722) */
     R->a_r = (int32_t *)malloc(4 * (size_t)(a_n + 1)); R->a_h = (int32_t *)malloc(4 * (size_t)(a_n + 1));
     R->a_t0 = (int32_t *)malloc(4 * (size_t)(a_n + 1)); R->a_t1 = (int32_t *)malloc(4 * (size_t)(a_n + 1));
@@ -329,6 +358,7 @@ orc_result_t *orc_run(int32_t n_vtx, const char *seq_concat, const int64_t *seq_
         }
         s = e;
     }
+    R->stage_s[3] = omp_get_wtime() - t_stage;
     R->n_kept = kept;
     R->filtered = filtered;
     R->retained = u - filtered;           /* ids without anchors count as retained, :721 */
@@ -350,6 +380,7 @@ void orc_free(orc_result_t *R)
 }
 
 /* plain getters so the ctypes side never depends on struct layout */
+double orc_stage_seconds(const orc_result_t *R, int i) { return (i >= 0 && i < 4) ? R->stage_s[i] : 0.0; }
 int64_t orc_spectrum_size(const orc_result_t *R) { return R->spectrum_size; }
 const uint64_t *orc_spectrum(const orc_result_t *R) { return R->spectrum; }
 int64_t orc_filtered(const orc_result_t *R) { return R->filtered; }

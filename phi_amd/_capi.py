@@ -13,6 +13,7 @@ PHI_OK = 0
 PHI_ERR_INVALID, PHI_ERR_NOMEM, PHI_ERR_DEVICE, PHI_ERR_STATE = -1, -2, -3, -4
 PHI_ERR_UNSUPPORTED, PHI_ERR_WALK, PHI_ERR_OVERFLOW = -5, -6, -7
 PHI_FLAG_QCLP, PHI_FLAG_MIXED = 1, 2
+PHI_COMM_ID_BYTES = 128
 
 # every symbol include/phi_amd.h declares
 SYMBOLS = [
@@ -20,7 +21,8 @@ SYMBOLS = [
     "phi_set_graph", "phi_add_reads", "phi_add_reads_device", "phi_reset_reads", "phi_reads_stats", "phi_hits_buffer",
     "phi_spectrum_export", "phi_spectrum_import", "phi_spectrum_set_size", "phi_solve", "phi_path_sequence",
     "phi_sketch", "phi_walk_minimizers", "phi_walk_sharing", "phi_kept_anchors", "phi_prof_enable", "phi_prof_read",
-    "phi_host_register", "phi_host_unregister",
+    "phi_host_register", "phi_host_unregister", "phi_set_solve_budget",
+    "phi_comm_unique_id", "phi_comm_init", "phi_comm_info", "phi_comm_allreduce_hits", "phi_comm_exchange", "phi_comm_destroy",
 ]
 
 
@@ -67,6 +69,13 @@ def load():
     L.phi_spectrum_import.argtypes = [vp, vp, i64]
     L.phi_spectrum_set_size.argtypes = [vp, i64]
     L.phi_solve.argtypes = [vp, C.POINTER(PhiResult)]
+    L.phi_set_solve_budget.argtypes = [vp, i64]
+    L.phi_comm_unique_id.argtypes = [vp, C.c_size_t]
+    L.phi_comm_init.argtypes = [vp, vp, i32, i32]
+    L.phi_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.phi_comm_allreduce_hits.argtypes = [vp]
+    L.phi_comm_exchange.argtypes = [vp]
+    L.phi_comm_destroy.argtypes = [vp]
     L.phi_path_sequence.argtypes = [vp, vp, i64]
     L.phi_sketch.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64)]
     L.phi_walk_minimizers.argtypes = [vp, i32, vp, vp, i64, C.POINTER(i64)]

@@ -103,7 +103,40 @@ class Context:
     def spectrum_set_size(self, n):
         self._chk(self._L.phi_spectrum_set_size(self._h, n))
 
+    # ------------------------------------------------------------------ RCCL inside the library
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes (ncclUniqueId) made by one rank; the others receive them out of band."""
+        L = _capi.load()
+        buf = C.create_string_buffer(_capi.PHI_COMM_ID_BYTES)
+        rc = L.phi_comm_unique_id(buf, _capi.PHI_COMM_ID_BYTES)
+        if rc:
+            raise PhiError(rc, "phi_comm_unique_id failed (librccl missing?)")
+        return buf.raw
+
+    def comm_init(self, uid, rank, n_ranks):
+        assert len(uid) == _capi.PHI_COMM_ID_BYTES
+        self._chk(self._L.phi_comm_init(self._h, C.c_char_p(uid), rank, n_ranks))
+
+    def comm_info(self):
+        r, n = C.c_int32(), C.c_int32()
+        self._chk(self._L.phi_comm_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def comm_allreduce_hits(self):
+        self._chk(self._L.phi_comm_allreduce_hits(self._h))
+
+    def comm_exchange(self):
+        self._chk(self._L.phi_comm_exchange(self._h))
+
+    def comm_destroy(self):
+        self._chk(self._L.phi_comm_destroy(self._h))
+
     # ------------------------------------------------------------------ solve
+    def set_solve_budget(self, max_dp_runs):
+        """DP runs the exact search may use (<= 0: no limit, as the reference's model.optimize())."""
+        self._chk(self._L.phi_set_solve_budget(self._h, int(max_dp_runs)))
+
     def solve(self):
         r = _capi.PhiResult()
         self._chk(self._L.phi_solve(self._h, C.byref(r)))

@@ -3,6 +3,11 @@
 // the C ABI of include/phi_amd.h (HIP kernels on one MI355X).  Own implementation.
 //
 //   ./PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta> [-k -w -R -q -m -T -t -d -N -c]
+//         [--device N | --devices 0,1,..] [--dp-budget RUNS]
+//
+// --devices: one context and one host thread per GPU; every GPU builds the full index, the read chunks are
+// handed out through a work queue (the shards balance themselves), the library's RCCL exchange (phi_comm_*)
+// merges hit vectors and spectra once, and the first GPU solves and reports.
 //
 // Flag semantics (main.cpp:38-95): -q (IQP/ILP), -m (mixed/integer), -N (naive expanded graph)
 // choose between formulations with the same optimum; they are accepted and mapped onto the one
@@ -16,6 +21,8 @@
 #include <sys/resource.h>
 #include <sys/time.h>
 #include <algorithm>
+#include <atomic>
+#include <functional>
 #include <string>
 #include <condition_variable>
 #include <deque>
@@ -75,9 +82,11 @@ int main(int argc, char *argv[])
 {
     int k = 31, w = 25, n_threads = 4, recombination = 100, is_qclp = 1, is_naive = 0, is_mixed = 1, debug = 0, help = 0;
     int device = 0, max_occ = 5000;
+    std::vector<int> devices;                                 // --devices: one context (and host thread) per GPU
+    long long dp_budget = -1;                                 // --dp-budget: DP runs of the exact search (default: the library's)
     float threshold = 1.0f;
     std::string gfa_file, reads_file, hap_file;
-    static struct option long_options[] = {{"version", no_argument, 0, 300}, {"device", required_argument, 0, 301}, {0, 0, 0, 0}};
+    static struct option long_options[] = {{"version", no_argument, 0, 300}, {"device", required_argument, 0, 301}, {"dp-budget", required_argument, 0, 302}, {"devices", required_argument, 0, 303}, {0, 0, 0, 0}};
     int c;
     // main.cpp:38 declares -h with an argument; a bare -h falls into the usage branch either way
     while ((c = getopt_long(argc, argv, "x:d:c:l:s:m:R:q:T:N:h:k:w:t:g:r:o:DS", long_options, nullptr)) >= 0) {
@@ -97,6 +106,18 @@ int main(int argc, char *argv[])
         else if (c == 'h' || c == '?') help = 1;
         else if (c == 300) { fprintf(stderr, "PHI version: %s\n", PHI_VERSION); return 0; }
         else if (c == 301) device = atoi(optarg);
+        else if (c == 302) dp_budget = atoll(optarg);
+        else if (c == 303) {                                   // --devices 0,1,2,...: shard the reads over these GPUs
+            devices.clear();
+            for (const char *p = optarg; *p;) {
+                char *end = nullptr;
+                const long d = strtol(p, &end, 10);
+                if (end == p || d < 0) { fprintf(stderr, "[E::main] --devices takes a comma-separated list of GPU ordinals\n"); return 1; }
+                devices.push_back((int)d);
+                p = *end == ',' ? end + 1 : end;
+                if (*end && *end != ',') { fprintf(stderr, "[E::main] --devices takes a comma-separated list of GPU ordinals\n"); return 1; }
+            }
+        }
     }
     (void)max_occ; (void)is_naive; (void)n_threads;
     if (argc < 2 || gfa_file.empty() || reads_file.empty() || hap_file.empty() || help) {
@@ -108,11 +129,21 @@ int main(int argc, char *argv[])
 
     // The device context (HIP initialisation) and the reads file are prepared by two host threads
     // while this one parses the graph: the three are independent.
-    phi_ctx *ctx = nullptr;
+    if (devices.empty()) devices.push_back(device);
+    const int n_dev = (int)devices.size();
+    for (int i = 0; i < n_dev; i++)
+        for (int j = 0; j < i; j++)
+            if (devices[i] == devices[j]) { fprintf(stderr, "[E::main] --devices names GPU %d twice\n", devices[i]); return 1; }
+    std::vector<phi_ctx *> ctxs((size_t)n_dev, nullptr);
     const bool timing = getenv("PHI_TIMING") != nullptr;
     std::future<int> f_ctx = std::async(std::launch::async, [&]() {
-        const int r = phi_ctx_create(device, &ctx);
-        if (timing) fprintf(stderr, "[phi timing] main: device context ready at %.3f s\n", realtime() - t0_real);
+        // one host thread per GPU (each context initialises its own device)
+        std::vector<std::future<int>> fs;
+        for (int i = 0; i < n_dev; i++)
+            fs.push_back(std::async(std::launch::async, [&, i]() { return phi_ctx_create(devices[(size_t)i], &ctxs[(size_t)i]); }));
+        int r = 0;
+        for (auto &f : fs) { const int ri = f.get(); if (ri && !r) r = ri; }
+        if (timing) fprintf(stderr, "[phi timing] main: %d device context(s) ready at %.3f s\n", n_dev, realtime() - t0_real);
         return r;
     });
     // Reads are streamed: a host thread parses the file chunk by chunk into three
@@ -122,7 +153,7 @@ int main(int argc, char *argv[])
     struct Chunk { char *bases; int64_t *off; int64_t n_reads; };
     const int64_t chunk_bases = getenv("PHI_READ_CHUNK") ? std::max<int64_t>(1024, atoll(getenv("PHI_READ_CHUNK"))) : ((int64_t)64 << 20);
     const int64_t chunk_reads = chunk_bases / 64 + 1024;
-    const int N_CHUNK_BUF = 3;
+    const int N_CHUNK_BUF = 2 + n_dev;                       // one in flight per GPU, two with the parser
     std::vector<Chunk> chunk_buf(N_CHUNK_BUF);
     for (auto &cb : chunk_buf) {
         cb.bases = (char *)malloc((size_t)chunk_bases);
@@ -186,48 +217,77 @@ int main(int argc, char *argv[])
     if (phi_hap_name(gfa_file.c_str(), reads_file.c_str(), hap_name, sizeof hap_name) < 0) { fprintf(stderr, "[E::%s] output name too long\n", __func__); f_ctx.wait(); stop_reads(); return 1; }
 
     int rc = f_ctx.get();
-    if (rc) { fprintf(stderr, "[E::%s] no usable MI355X (HIP) device %d: %s\n", __func__, device, phi_strerror(rc)); stop_reads(); return 1; }
-    auto die = [&](const char *what, int code) {
-        fprintf(stderr, "[E::%s] %s: %s: %s\n", "main", what, phi_strerror(code), phi_last_error(ctx));
+    if (rc) { fprintf(stderr, "[E::%s] no usable MI355X (HIP) device %d: %s\n", __func__, devices[0], phi_strerror(rc)); stop_reads(); return 1; }
+    phi_ctx *ctx = ctxs[0];                                   // the context that solves and reports
+    auto die_on = [&](phi_ctx *cx, const char *what, int code) {
+        fprintf(stderr, "[E::%s] %s: %s: %s\n", "main", what, phi_strerror(code), phi_last_error(cx));
         stop_reads();
         return 1;
     };
+    auto die = [&](const char *what, int code) { return die_on(ctx, what, code); };
+    // rc of the first device thread that failed, with its context
+    auto run_on_all = [&](const char *what, const std::function<int(int, phi_ctx *)> &fn) -> int {
+        if (n_dev == 1) { const int r = fn(0, ctx); return r ? die(what, r) : 0; }
+        std::vector<std::future<int>> fs;
+        for (int i = 0; i < n_dev; i++) fs.push_back(std::async(std::launch::async, [&, i]() { return fn(i, ctxs[(size_t)i]); }));
+        int bad = -1, brc = 0;
+        for (int i = 0; i < n_dev; i++) { const int r = fs[(size_t)i].get(); if (r && bad < 0) { bad = i; brc = r; } }
+        if (bad >= 0) {
+            if (brc == PHI_ERR_WALK) fprintf(stderr, "Error: %s\n", phi_last_error(ctxs[(size_t)bad]));
+            return die_on(ctxs[(size_t)bad], what, brc);
+        }
+        return 0;
+    };
 
     const uint32_t flags = (is_qclp ? PHI_FLAG_QCLP : 0) | (is_mixed ? PHI_FLAG_MIXED : 0);
-    if ((rc = phi_set_params(ctx, k, w, threshold, recombination, flags))) return die("parameters", rc);
+    // the read shards of a multi-GPU run are merged by the library's own RCCL exchange (phi_comm_*)
+    unsigned char comm_id[PHI_COMM_ID_BYTES];
+    if (n_dev > 1 && (rc = phi_comm_unique_id(comm_id, sizeof comm_id))) { fprintf(stderr, "[E::main] RCCL is not available: %s\n", phi_strerror(rc)); stop_reads(); return 1; }
 
-    // ---- stage 1a: walks (ILP_index.cpp:556-611), while the reads are still being parsed
+    // ---- stage 1a: walks (ILP_index.cpp:556-611) on every GPU, while the reads are still being parsed
     const int32_t n_walks = phi_graph_n_walks(g);
-    if ((rc = phi_set_graph(ctx, phi_graph_n_vtx(g), phi_graph_seq_concat(g), phi_graph_seq_off(g), phi_graph_adj_off(g),
-                            phi_graph_adj(g), n_walks, phi_graph_walk_off(g), phi_graph_walk_vtx(g), phi_graph_topo_rank(g)))) {
-        if (rc == PHI_ERR_WALK) fprintf(stderr, "Error: %s\n", phi_last_error(ctx));
-        return die("graph", rc);
-    }
+    if (run_on_all("graph", [&](int i, phi_ctx *cx) -> int {
+            int r = phi_set_params(cx, k, w, threshold, recombination, flags);
+            if (!r && dp_budget >= 0) r = phi_set_solve_budget(cx, dp_budget);
+            if (!r) r = phi_set_graph(cx, phi_graph_n_vtx(g), phi_graph_seq_concat(g), phi_graph_seq_off(g), phi_graph_adj_off(g),
+                                      phi_graph_adj(g), n_walks, phi_graph_walk_off(g), phi_graph_walk_vtx(g), phi_graph_topo_rank(g));
+            if (r == PHI_ERR_WALK && n_dev == 1) fprintf(stderr, "Error: %s\n", phi_last_error(cx));
+            if (!r && n_dev > 1) r = phi_comm_init(cx, comm_id, i, n_dev);
+            return r;
+        })) return 1;
 
-    // ---- reads (main.cpp:136-137) and stage 1b/2a (:615-655), chunk by chunk
-    int n_chunks = 0;
-    bool pinned = true;
-    for (;;) {
-        int slot;
-        {
-            std::unique_lock<std::mutex> lk(q_mu);
-            q_cv.wait(lk, [&] { return !q_full.empty(); });
-            slot = q_full.front(); q_full.pop_front();
-        }
-        const Chunk &cb = chunk_buf[slot];
-        if (cb.n_reads == 0) break;
-        if (++n_chunks == 2) {
-            // a file of more than one chunk: pin the buffers, so that the device copy of every further
-            // chunk is a direct DMA (pinning takes milliseconds: not worth it for a single chunk)
-            for (auto &b : chunk_buf) pinned = phi_host_register(ctx, b.bases, (size_t)chunk_bases) == PHI_OK && pinned;
-        }
-        if ((rc = phi_add_reads(ctx, cb.bases, cb.off, cb.n_reads))) return die("reads", rc);
-        {
-            std::lock_guard<std::mutex> lk(q_mu);
-            q_free.push_back(slot);
-        }
-        q_cv.notify_all();
-    }
+    // ---- reads (main.cpp:136-137) and stage 1b/2a (:615-655), chunk by chunk: every GPU takes the next
+    //      finished chunk (a work queue: the shards balance themselves), then the one exchange of the job
+    std::atomic<int> n_chunks{0};
+    std::atomic<bool> pinned{true};
+    std::once_flag pin_once;
+    if (run_on_all("reads", [&](int, phi_ctx *cx) -> int {
+            for (;;) {
+                int slot;
+                {
+                    std::unique_lock<std::mutex> lk(q_mu);
+                    q_cv.wait(lk, [&] { return !q_full.empty(); });
+                    slot = q_full.front();
+                    if (chunk_buf[(size_t)slot].n_reads == 0) break;          // end of the stream: left in the queue for the other GPUs
+                    q_full.pop_front();
+                }
+                const Chunk &cb = chunk_buf[(size_t)slot];
+                if (++n_chunks >= 2)
+                    // a file of more than one chunk: pin the buffers, so that the device copy of every further
+                    // chunk is a direct DMA (pinning takes milliseconds: not worth it for a single chunk)
+                    std::call_once(pin_once, [&]() {
+                        for (auto &b : chunk_buf) if (phi_host_register(cx, b.bases, (size_t)chunk_bases) != PHI_OK) pinned = false;
+                    });
+                const int r = phi_add_reads(cx, cb.bases, cb.off, cb.n_reads);
+                if (r) return r;
+                {
+                    std::lock_guard<std::mutex> lk(q_mu);
+                    q_free.push_back(slot);
+                }
+                q_cv.notify_all();
+            }
+            return n_dev > 1 ? phi_comm_exchange(cx) : PHI_OK;
+        })) return 1;
     if (f_reads.get() != PHI_HOST_OK) { fprintf(stderr, "[E::%s] %s\n", __func__, rerr); return 1; }
     stamp("ILP_function");
     fprintf(stderr, "Graph has %d vertices, %d walks and read has %d reads\n", phi_graph_n_vtx(g), n_walks, (int)total_reads);
@@ -309,12 +369,20 @@ int main(int argc, char *argv[])
     for (int i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
     fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", __func__, realtime() - t0_real, cputime(),
             peakrss() / 1024.0 / 1024.0 / 1024.0);
-    if (timing) fprintf(stderr, "[phi timing] main: %d read chunk(s) of up to %lld bases%s\n", n_chunks, (long long)chunk_bases, n_chunks >= 2 && pinned ? ", pinned" : "");
+    if (timing) fprintf(stderr, "[phi timing] main: %d read chunk(s) of up to %lld bases%s on %d GPU(s)\n", n_chunks.load(), (long long)chunk_bases, n_chunks >= 2 && pinned ? ", pinned" : "", n_dev);
     for (auto &cb : chunk_buf) {
         if (n_chunks >= 2) (void)phi_host_unregister(ctx, cb.bases);
         free(cb.bases); free(cb.off);
     }
     phi_graph_free(g);
-    phi_ctx_destroy(ctx);
+    for (phi_ctx *cx : ctxs) phi_ctx_destroy(cx);
+    if (!res.optimal) {
+        // the reference returns only what model.optimize() proved (ILP_index.cpp:1418): an unproven path is
+        // written (it is feasible and within the printed bound) but the exit status says so
+        fprintf(stderr, "[W::main] the path written is NOT proven optimal: the exact search used its budget of %d DP runs "
+                        "(objective %lld, proven upper bound %lld); raise it with --dp-budget N (0 = no limit)\n",
+                res.n_dp_runs, (long long)res.objective, (long long)res.upper_bound);
+        return 3;
+    }
     return 0;
 }

@@ -203,6 +203,7 @@ void phi_ctx_destroy(phi_ctx *c)
     if (c && c->pin_future.valid()) c->pin_future.wait();
     if (c && c->h_pin) { (void)hipSetDevice(c->device); (void)hipHostFree(c->h_pin); c->h_pin = nullptr; }
     if (!c) return;
+    (void)phi_comm_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
@@ -974,6 +975,14 @@ int phi_spectrum_set_size(phi_ctx *c, int64_t global_size)
     return PHI_OK;
 }
 
+int phi_set_solve_budget(phi_ctx *c, int64_t max_dp_runs)
+{
+    if (!c) return PHI_ERR_INVALID;
+    c->solve_budget = max_dp_runs > 0x7FFFFFFF ? 0x7FFFFFFF : max_dp_runs;
+    c->solved = false;
+    return PHI_OK;
+}
+
 int phi_solve(phi_ctx *c, phi_result *out)
 {
     if (!c || !out) return PHI_ERR_INVALID;
@@ -1139,7 +1148,7 @@ int phi_host_register(phi_ctx *c, void *p, size_t bytes)
 {
     if (!c || !p || !bytes) return PHI_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterPortable));   // every GPU of a --devices run copies from it
     return PHI_OK;
 }
 

@@ -59,8 +59,11 @@ struct PhiAnchorSpan {
     PhiAnchorHost *end() const { return p + n; }
 };
 
+struct PhiComm;               // phi_comm.hip: the RCCL communicator of a multi-GPU job
+
 struct phi_ctx {
     int device = 0;
+    PhiComm *comm = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string last_error;
 
@@ -68,6 +71,7 @@ struct phi_ctx {
     int32_t k = 31, w = 25, recombination = 100;
     float threshold = 1.0f;
     uint32_t flags = PHI_FLAG_QCLP | PHI_FLAG_MIXED;
+    int64_t solve_budget = (int64_t)1 << 16;          // DP runs the exact search may use (phi_set_solve_budget); <= 0 = no limit
 
     // ---- graph, host side (decode, validation)
     bool have_graph = false;

@@ -17,7 +17,6 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
-#include <chrono>
 #include <map>
 #include <set>
 #include <unordered_map>
@@ -499,17 +498,11 @@ int phi_solve_impl(phi_ctx *c)
     std::vector<Seg> best_segs;
     int64_t incumbent = INT64_MIN, global_ub = INT64_MIN;
     int n_runs = 0;
-    // branch and bound is finite and exact; it is given 256 DP runs whatever they cost, and beyond them as
-    // many as fit into two seconds (small graphs with short k, where a minimiser repeats everywhere, take
-    // thousands of runs of some tens of microseconds)
-    const int max_runs = 256, hard_runs = 1 << 16;
-    const double extra_budget_s = 2.0;
-    const auto bb_t0 = std::chrono::steady_clock::now();
-    auto out_of_runs = [&]() {
-        if (n_runs < max_runs) return false;
-        if (n_runs >= hard_runs) return true;
-        return std::chrono::duration<double>(std::chrono::steady_clock::now() - bb_t0).count() > extra_budget_s;
-    };
+    // branch and bound is finite and exact.  The reference's model.optimize() (ILP_index.cpp:1412-1418) has no
+    // limit; this search has a budget counted in DP runs (phi_set_solve_budget, default 65536; <= 0 = none), never
+    // in wall-clock time: the same input gives the same `optimal` flag on every run and every machine.
+    const int64_t max_runs = c->solve_budget;
+    auto out_of_runs = [&]() { return max_runs > 0 && n_runs >= max_runs; };
     bool exhausted = false;
     std::vector<Node> stack;
     stack.push_back(Node{});

@@ -169,3 +169,62 @@ def test_cli_errors(tmp_path):
     assert r.returncode == 1 and "failed to load the GFA file" in r.stderr
     r = _run_cli(["--version"], tmp_path)
     assert r.returncode == 0 and "PHI version" in r.stderr
+
+
+def _write_gfa(g, path):
+    """oracle.Graph -> GFA 1.1 text (S / L 0M / W), segment names as the graph holds them."""
+    with open(path, "wb") as f:
+        f.write(b"H\tVN:Z:1.1\n")
+        for name, s in zip(g.seg_names, g.node_seq):
+            f.write(b"S\t%s\t%s\n" % (name.encode(), s))
+        for u, targets in enumerate(g.adj):
+            for v in targets:
+                f.write(b"L\t%s\t+\t%s\t+\t0M\n" % (g.seg_names[u].encode(), g.seg_names[v].encode()))
+        for h, p in enumerate(g.paths):
+            sample, _, hap = g.hap_names[h].rpartition(".")
+            f.write(b"W\t%s\t%s\tchr\t0\t%d\t%s\n" % (sample.encode(), hap.encode(), sum(len(g.node_seq[v]) for v in p),
+                                                     b"".join(b">" + g.seg_names[v].encode() for v in p)))
+
+
+def test_cli_devices_list_and_run_budget(tmp_path, oracle):
+    """--devices with one ordinal takes the multi-GPU code path's plumbing (context list, work queue) and
+    gives the default run's output; --dp-budget counts DP runs: a hard instance (R = 0, eight walks, short
+    repeats) stopped after 3 runs is written but the exit status (3) and a warning say it is not proven."""
+    import numpy as np
+    from graphgen import random_graph
+    args = ["-g", os.path.join(DATA, "MHC_4.gfa.gz"), "-r", os.path.join(DATA, "CHM13_reads.fq.gz")]
+    a = _run_cli(args + ["-o", str(tmp_path / "a.fa")], tmp_path)
+    b = _run_cli(args + ["-o", str(tmp_path / "b.fa"), "--devices", "0"], tmp_path)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert (tmp_path / "a.fa").read_text() == (tmp_path / "b.fa").read_text()
+    bad = _run_cli(args + ["-o", str(tmp_path / "c.fa"), "--devices", "0,0"], tmp_path)
+    assert bad.returncode == 1 and "twice" in bad.stderr
+    # the hard instance of test_run_budget_is_deterministic_and_reports_a_proven_bound, from files
+    rng = np.random.default_rng(321)
+    g = random_graph(rng, n_sites=400, n_walks=8, seg_len=(8, 16), alt_len=(3, 6), p_del=0.0)
+    succ = {v: sorted(t) for v, t in enumerate(g.adj)}
+    v, truth, site = g.paths[0][0], [], 0
+    while True:
+        truth.append(v)
+        nx = succ[v]
+        if not nx:
+            break
+        v = nx[site % 2] if len(nx) == 2 else nx[0]
+        site += len(nx) == 2
+    hap = b"".join(g.node_seq[x] for x in truth)
+    gfa, rd = str(tmp_path / "hard.gfa"), str(tmp_path / "hard.fa")
+    _write_gfa(g, gfa)
+    with open(rd, "wb") as f:
+        for i, s in enumerate(rng.integers(0, len(hap) - 60, size=700)):
+            f.write(b">r%d\n%s\n" % (i, hap[s:s + 60]))
+    base = ["-g", gfa, "-r", rd, "-k7", "-w2", "-R0"]
+    few = [_run_cli(base + ["-o", str(tmp_path / f"few{i}.fa"), "--dp-budget", "3"], tmp_path) for i in range(2)]
+    full = _run_cli(base + ["-o", str(tmp_path / "full.fa")], tmp_path)
+    assert full.returncode == 0, full.stderr
+    if "after 1 DP run" not in full.stderr and few[0].returncode != 0:
+        for r in few:
+            assert r.returncode == 3 and "NOT proven optimal" in r.stderr and "--dp-budget" in r.stderr
+        assert (tmp_path / "few0.fa").read_text() == (tmp_path / "few1.fa").read_text()      # reproducible
+        assert (tmp_path / "few0.fa").read_text().startswith(">hard_hard LN:")
+    else:
+        assert few[0].returncode == 0

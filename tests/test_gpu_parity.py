@@ -508,10 +508,11 @@ def test_many_switches_backtrack(oracle, ctx_factory):
     assert res["n_switches"] > 64, res["n_switches"]
 
 
-def test_run_cap_reports_a_proven_bound(oracle, ctx_factory):
-    """A hard instance (R = 0, eight walks, short repeats) can exhaust the run budget (256 DP runs, then as
-    many as fit into two more seconds): the result then says optimal = 0 and carries a finite bound that
-    the feasible path respects."""
+def test_run_budget_is_deterministic_and_reports_a_proven_bound(oracle, ctx_factory):
+    """A hard instance (R = 0, eight walks, short repeats) needs many DP runs.  The budget of the exact search
+    is counted in DP runs (phi_set_solve_budget), never in wall-clock time: with a small budget the result says
+    optimal = 0, carries a finite proven bound the feasible path respects, and is the SAME on every run; with
+    the default budget the instance is proven, and the proven optimum lies inside every earlier bound."""
     from oracle import solve_oracle as S
     rng = np.random.default_rng(321)
     g = random_graph(rng, n_sites=400, n_walks=8, seg_len=(8, 16), alt_len=(3, 6), p_del=0.0)
@@ -526,18 +527,78 @@ def test_run_cap_reports_a_proven_bound(oracle, ctx_factory):
         site += len(nx) == 2
     hap = b"".join(g.node_seq[x] for x in truth)
     reads = [hap[a:a + 60] for a in rng.integers(0, len(hap) - 60, size=700)]
-    ctx = ctx_factory(k=7, w=2, threshold=1.0, recombination=0)
-    _set_graph(ctx, g)
-    ctx.add_reads(reads)
-    res = ctx.solve()
     st = oracle.run_stage12(g, reads, 7, 2, 1.0)
     m = S.Model(g, st, 0)
-    obj, cov, nsw = m.objective(S.states_from_path(res["path_vtx"], res["path_hap"]))
-    assert obj == res["objective"]
-    assert res["objective"] <= res["upper_bound"] <= res["n_in_model"]
-    assert res["optimal"] == (res["objective"] == res["upper_bound"])
-    assert res["n_dp_runs"] <= 65536
-    assert res["optimal"] == 1 or res["n_dp_runs"] >= 256      # gives up only after 256 runs and two more seconds
+
+    def run(budget):
+        ctx = ctx_factory(k=7, w=2, threshold=1.0, recombination=0)
+        if budget is not None:
+            ctx.set_solve_budget(budget)
+        _set_graph(ctx, g)
+        ctx.add_reads(reads)
+        res = ctx.solve()
+        obj, cov, nsw = m.objective(S.states_from_path(res["path_vtx"], res["path_hap"]))
+        assert obj == res["objective"]
+        assert res["objective"] <= res["upper_bound"] <= res["n_in_model"]
+        assert res["optimal"] == (res["objective"] == res["upper_bound"])
+        return res
+
+    full = run(None)                                            # default budget: 65536 runs
+    assert full["n_dp_runs"] <= 65536
+    small = [run(3) for _ in range(3)]
+    for r in small:
+        assert r["n_dp_runs"] <= 3
+        for key in ("objective", "upper_bound", "optimal", "n_dp_runs", "n_covered", "n_switches"):
+            assert r[key] == small[0][key], key
+        assert np.array_equal(r["path_vtx"], small[0]["path_vtx"]) and np.array_equal(r["path_hap"], small[0]["path_hap"])
+        assert r["objective"] <= full["objective"] <= r["upper_bound"] or not full["optimal"]
+    if full["n_dp_runs"] > 3:
+        assert small[0]["optimal"] == 0                         # it really ran out of its budget
+    # the same budget again on one context after a reset
+    ctx = ctx_factory(k=7, w=2, threshold=1.0, recombination=0)
+    ctx.set_solve_budget(0)                                     # no limit, as model.optimize()
+    _set_graph(ctx, g)
+    ctx.add_reads(reads)
+    unl = ctx.solve()
+    assert unl["optimal"] == 1 and unl["objective"] >= full["objective"]
+
+
+def test_rccl_communicator_inside_the_library(oracle, ctx_factory):
+    """phi_comm_*: librccl loaded by the library, ncclCommInitRank on the context's device, the hit-vector
+    all-reduce and the spectrum all-gather on the context's stream.  One GPU here, so a communicator of one
+    rank: the exchange must leave the result exactly as it was (the N > 1 arithmetic is the export / import
+    pair of test_two_read_shards_merge_to_the_single_context_result and tests/test_cpu_dist.py)."""
+    import phi_amd
+    rng = np.random.default_rng(2)
+    g = random_graph(rng, n_sites=12, n_walks=5, seg_len=(10, 40))
+    reads = mosaic_reads(rng, g, n_reads=80, read_len=40, n_seg=3, err=0.02) + [bytes(rng.choice(list(b"ACGT"), size=300).tolist())]
+    ctx = ctx_factory(k=9, w=5, threshold=1.0, recombination=4)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads)
+    before = ctx.solve()
+    uid = phi_amd.Context.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    assert ctx.comm_info() == (0, 1)
+    with pytest.raises(phi_amd.PhiError) as e:
+        ctx.comm_exchange()                                     # no communicator yet
+    assert e.value.status == phi_amd.PHI_ERR_STATE
+    ctx.comm_init(uid, 0, 1)
+    assert ctx.comm_info() == (0, 1)
+    with pytest.raises(phi_amd.PhiError):
+        ctx.comm_init(uid, 0, 1)                                # one communicator per context
+    ctx.comm_allreduce_hits()
+    ctx.comm_exchange()
+    after = ctx.solve()
+    st, res, m = _check_against_oracle(oracle, ctx, g, reads, 9, 5, 1.0, 4)
+    for key in ("objective", "spectrum_size", "filtered", "n_in_model", "n_covered"):
+        assert before[key] == after[key] == res[key]
+    # a second generation of reads through the same communicator
+    ctx.reset_reads()
+    ctx.add_reads(reads[:40])
+    ctx.comm_exchange()
+    _check_against_oracle(oracle, ctx, g, reads[:40], 9, 5, 1.0, 4)
+    ctx.comm_destroy()
+    assert ctx.comm_info() == (0, 1)
 
 
 def test_resets_empty_only_what_was_filled(oracle, ctx_factory):
