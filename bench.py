@@ -4,7 +4,7 @@
 Metric (BASELINE.json): read Gbases/s scored on the 49-haplotype MHC graph, plus end-to-end
 seconds.  The real graph cannot be built offline, so the workload is SURVEY.md 8(d)'s
 deterministic stand-in "synMHC-49" (config C2: 49 walks x ~5.15 Mbp, nodes <= 30 bp, 1x 150-bp
-reads).  One STEP = one scoring pass of the read batch, reads already resident in HBM:
+reads).  One STEP = one scoring pass of a rank's read set, reads already resident in HBM:
     reset spectrum/hits -> 2-bit pack -> (w,k)-minimiser sketch + murmur3 -> spectrum insert +
     probe of the walk-minimiser table   [+ RCCL all-reduce(MAX) of the hit vector when N > 1]
 The graph index (walk sketch + table) is built once before the timed region and the exact solve
@@ -14,16 +14,26 @@ The graph index (walk sketch + table) is built once before the timed region and 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU; every rank holds the full graph index and its own shard of reads
-(weak scaling: each rank scores one C2-sized read set per step, drawn with its own seed).  The path
-has ONE exchange per job: the hit vector (one byte per distinct walk minimiser) is
-a running OR over the batches a rank has scored, so it is all-reduced (MAX, RCCL over xGMI) once,
-after the rank's last batch -- inside the timed region, after the K steps.  No collective per step.
+N > 1: one process per GPU; every rank holds the full graph index and a shard of reads.  The path
+has ONE exchange per read set: the hit vector (one byte per distinct walk
+minimiser) is all-reduced (MAX) by the library's own RCCL communicator (phi_comm_*, include/phi_amd.h)
+on the stream the kernels run on -- once per step, inside the timed region, since a step is a whole
+read set.  The once-per-job merge of the read hashes that are not walk minimisers (it only feeds log
+counters) runs with the solve.  Two scalings:
+    --scaling weak    (default; `value`)  every rank scores its own C2-sized read set per step;
+    --scaling strong  ONE read set (--strong-config, default C3: 10x reads) is cut into N contiguous
+                      shards balanced by bases (phi_amd.dist.shard_bounds); a step is shard score +
+                      all-reduce, value = the set's bases / step time.
+Whichever is chosen for `value`, the other is measured in the same run with fewer steps and reported
+under "strong_scaling" / "weak_scaling".
 """
 import argparse
+import ctypes
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -35,26 +45,85 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(reads_concat, read_off, k, w, budget_s=12.0):
-    """Oracle (scalar string-based port of compute_hashes) on the host cores: checker code timed as
-    the CPU baseline, never part of the measured GPU path."""
+def _host_threads():
+    """Threads for the CPU baseline: the cores this process may use, at most the box's CPU share of one
+    GPU (16) unless PHI_BASELINE_THREADS says otherwise."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("PHI_BASELINE_THREADS", "16"))))
+
+
+def cpu_baseline(g_arrays, reads_concat, read_off, k, w, budget_s=6.0):
+    """The oracle (scalar string-based port of compute_hashes / index_kmers / compute_anchors / the filter,
+    with the reference's OpenMP loops) on the host cores: checker code timed as the CPU baseline on a bounded
+    sample, never part of the measured GPU path.  Reads sketch at -t1 and -t<threads>, then stages 1-2 of
+    the whole configuration at -t<threads> (the reference parallelises the walk sketch over walks and the
+    read sketch over reads, ILP_index.cpp:559,617; match and filter are timed as one-thread restatements)."""
     from oracle import oracle as O
     L = O.lib()
     raw = reads_concat.tobytes()
-    n = len(read_off) - 1
+    off = np.ascontiguousarray(read_off, np.int64)
+    n_reads, n_bases = len(off) - 1, int(off[-1])
+    nt = _host_threads()
+
+    def leg(threads, budget):
+        L.orc_set_threads(threads)
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            L.orc_sketch_reads(raw, off.ctypes.data, n_reads, k, w)
+            done += n_bases
+            if time.perf_counter() - t0 > budget:
+                break
+        dt = time.perf_counter() - t0
+        return done / dt / 1e9, done, dt
+    v1, d1, t1 = leg(1, budget_s)
+    vn, dn, tn = leg(nt, budget_s)
+    out = {"value": vn, "unit": "Gbases/s", "cores": nt, "kind": "port",
+           "sample": f"read sketch (oracle/phi_oracle.c orc_sketch_reads, OpenMP over reads as ILP_index.cpp:617): "
+                     f"{dn / 1e6:.0f} Mbases of the same 150-bp synthetic reads in {tn:.1f} s on {nt} threads; "
+                     f"{d1 / 1e6:.0f} Mbases in {t1:.1f} s on 1 thread",
+           "value_1core": v1}
+    # stages 1-2 of the whole configuration (walk sketch, read sketch + spectrum, anchors, filter)
+    L.orc_set_threads(nt)
+    A = g_arrays
     t0 = time.perf_counter()
-    done = 0
-    r = 0
-    while True:
-        a, b = int(read_off[r]), int(read_off[r + 1])
-        L.orc_sketch(raw[a:b], b - a, k, w, None, None, 0)
-        done += b - a
-        r = (r + 1) % n
-        if (r & 1023) == 0 and time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": done / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
-            "sample": f"{done / 1e6:.1f} Mbases of the same 150-bp synthetic reads, oracle/phi_oracle.c orc_sketch, {dt:.1f} s"}
+    h = L.orc_run(len(A["seq_off"]) - 1, A["seq_concat"].tobytes(), A["seq_off"].ctypes.data, len(A["walk_off"]) - 1,
+                  A["walk_off"].ctypes.data, A["walk_vtx"].ctypes.data, raw, off.ctypes.data, n_reads, k, w,
+                  ctypes.c_float(1.0))
+    t_all = time.perf_counter() - t0
+    st = [L.orc_stage_seconds(h, i) for i in range(4)]
+    L.orc_free(h)
+    walk_bases = int((A["seq_off"][A["walk_vtx"] + 1] - A["seq_off"][A["walk_vtx"]]).sum())
+    out["stages"] = {"threads": nt, "walk_sketch_s": st[0], "read_sketch_spectrum_s": st[1], "anchors_s": st[2],
+                     "filter_s": st[3], "total_s": t_all, "walk_gbases_per_s": walk_bases / max(st[0], 1e-9) / 1e9,
+                     "note": "whole configuration, oracle orc_run; the Gurobi solve of the reference cannot run here (BASELINE.md quotes its published times)"}
+    return out
+
+
+def file_to_fasta(g, bases, off, k, w):
+    """Wall clock of the drop-in command line on this configuration's files (GFA 1.1 + FASTA on a tmpfs-like
+    temp dir): `PHI -g -r -o` from process start to FASTA close, parse and H2D included."""
+    from phi_amd import synth
+    phi = os.path.join(ROOT, "phi_amd", "PHI")
+    if not os.path.exists(phi):
+        return None
+    with tempfile.TemporaryDirectory(prefix="phi_bench_") as d:
+        gfa, rd, fa = os.path.join(d, "g.gfa"), os.path.join(d, "r.fa"), os.path.join(d, "out.fa")
+        synth.write_gfa(g, gfa)
+        synth.write_reads(bases, off, rd)
+        best = None
+        for _ in range(2):                                     # second run: page cache warm, as a user's rerun
+            t0 = time.perf_counter()
+            r = subprocess.run([phi, "-g", gfa, "-r", rd, "-o", fa, "-k", str(k), "-w", str(w)], capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": r.stderr[-300:]}
+            best = dt if best is None else min(best, dt)
+        return {"seconds": best, "gfa_mb": os.path.getsize(gfa) / 1e6, "reads_mb": os.path.getsize(rd) / 1e6,
+                "note": "best of 2 runs of phi_amd/PHI on uncompressed files, whole process wall clock"}
 
 
 def main():
@@ -63,11 +132,14 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C2", help="workload of phi_amd.synth.CONFIGS, or C1syn (reference MHC_4 graph + generator reads)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--strong-config", default="C3", help="read set that --scaling strong shards (same graph as --config)")
     ap.add_argument("--prof-period", type=int, default=8,
                     help="every n-th sketch launch of the timed region carries the HIP events of roofline.kernel_avg_ms "
                          "(a bracketed launch costs the stream ~5 us more than a plain one; 1 = every launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the second scaling mode, the H2D-inclusive rate and the command-line run")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N > 1 on ONE GPU for testing: every rank uses cuda:0 and the exchange goes through gloo on the host")
     args = ap.parse_args()
@@ -105,6 +177,7 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ctl_dev = "cpu" if (world > 1 and args.rehearse_gloo) else dev      # where control-plane tensors of torch.distributed live
 
     K, W = 31, 25
     t0 = time.perf_counter()
@@ -113,12 +186,14 @@ def main():
         gk = dict(seed="tests/golden/data/MHC_4.gfa.gz")
         g = synth.graph_from_gfa(os.path.join(ROOT, "tests", "golden", "data", "MHC_4.gfa.gz"))
         rk = dict(coverage=1.0, seed=4102, n_mosaic=2)
+        strong_rk = dict(coverage=10.0, seed=4103, n_mosaic=2)
     else:
         gk, rk = synth.CONFIGS[args.config]
         g = synth.make_graph(**gk)
+        strong_rk = dict(synth.CONFIGS[args.strong_config][1]) if args.strong_config in synth.CONFIGS else dict(rk)
     rk = dict(rk)
     if rank:
-        rk["sample_seed"] = rk["seed"] + 1000 * rank           # each rank scores its own reads of the same sample
+        rk["sample_seed"] = rk["seed"] + 1000 * rank           # weak scaling: each rank scores its own reads of the same sample
     bases, off, truth = synth.make_reads(g, **rk)
     t_gen = time.perf_counter() - t0
     n_reads, n_bases = len(off) - 1, int(off[-1])
@@ -139,49 +214,103 @@ def main():
     t_index = time.perf_counter() - t0
     walk_bases = int((A["seq_off"][A["walk_vtx"] + 1] - A["seq_off"][A["walk_vtx"]]).sum())
 
-    d_bases = torch.from_numpy(bases).to(dev)
-    d_off = torch.from_numpy(off).to(dev)
-    def step():
-        ctx.reset_reads()
-        ctx.add_reads_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases)
+    # the library's own RCCL communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes
+    use_lib_comm = world > 1 and not args.rehearse_gloo
+    if use_lib_comm:
+        box = [phi_amd.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(box[0], rank, world)
 
-    def exchange():
-        # the job's one data-path collective: all-reduce (MAX) of the hit vector, in place
-        if world > 1:
+    def allreduce_hits():
+        # the one data-path collective of a read set: all-reduce (MAX) of the hit vector, in place
+        if use_lib_comm:
+            ctx.comm_allreduce_hits()
+        elif world > 1:
             hit_ptr, n_unique = ctx.hits_buffer()
+            stream.synchronize()
             pdist.allreduce_hits(torch.as_tensor(pdist.DevArray(hit_ptr, n_unique), device=dev))
 
+    def make_step(d_b, d_o, nr, nb):
+        def step():
+            ctx.reset_reads()
+            ctx.add_reads_device(d_b.data_ptr(), d_o.data_ptr(), nr, nb)
+            allreduce_hits()
+        return step
+
+    def timed(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=ctl_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # ---- read sets on the device: this rank's own set (weak) and its shard of the common set (strong)
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    weak_step = make_step(d_bases, d_off, n_reads, n_bases)
+    need_strong = args.scaling == "strong" or not args.no_extra_legs
+    strong = None
+    if need_strong:
+        sb, so, _ = synth.make_reads(g, **strong_rk)            # the same set on every rank
+        lo, hi = pdist.shard_bounds(so, world, rank)
+        sh_off = (so[lo:hi + 1] - so[lo]).astype(np.int64)
+        sh_bases = sb[int(so[lo]):int(so[hi])]
+        strong = dict(total_bases=int(so[-1]), total_reads=len(so) - 1, n_reads=hi - lo, n_bases=int(sh_off[-1]),
+                      d_b=torch.from_numpy(np.ascontiguousarray(sh_bases)).to(dev), d_o=torch.from_numpy(sh_off).to(dev))
+        strong["step"] = make_step(strong["d_b"], strong["d_o"], strong["n_reads"], strong["n_bases"])
+
     # clock ramp: a fresh box runs its first launches at idle clocks (a third slower for the first tens
-    # of milliseconds); untimed, before the W warmup steps
+    # of milliseconds); untimed, before the W warmup steps (no collective inside: ranks need not agree on its length)
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.25:
         for _ in range(50):
-            step()
+            ctx.reset_reads()
+            ctx.add_reads_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases)
         torch.cuda.synchronize()
+
+    primary_step = weak_step if args.scaling == "weak" else strong["step"]
     for _ in range(args.warmup):
-        step()
-    exchange()                                                 # warms RCCL up as well
+        primary_step()
     ctx.prof_read()                                            # drop warmup timings
-    ctx.prof_enable(args.prof_period)                               # every n-th sketch launch carries timing events
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    exchange()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(args.prof_period)                          # every n-th sketch launch carries timing events
+    elapsed = timed(primary_step, args.steps, 0)
     ctx.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_gloo else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     n_launch, kern_ms, kern_bases = ctx.prof_read()
     stats = ctx.reads_stats()
     density = stats["n_emitted"] / max(1, stats["n_bases"])
+    ms_per_step = elapsed / args.steps * 1e3
+    step_bases = n_bases * world if args.scaling == "weak" else strong["total_bases"]
+    value = step_bases * args.steps / elapsed / 1e9
+
+    # ---- the other scaling mode, in the same run, with fewer steps
+    other = None
+    if not args.no_extra_legs:
+        o_steps, o_warm = max(5, args.steps // 4), max(2, args.warmup // 4)
+        if args.scaling == "weak":
+            el = timed(strong["step"], o_steps, o_warm)
+            other = ("strong_scaling", {"value": strong["total_bases"] * o_steps / el / 1e9, "unit": "Gbases/s", "ms_per_step": el / o_steps * 1e3, "steps": o_steps,
+                                        "workload": f"{args.strong_config} reads: ONE set of {strong['total_reads']} reads, {strong['total_bases'] / 1e6:.2f} Mbases, cut into {world} shard(s) balanced by bases; "
+                                                    f"step = reset + shard score + hit all-reduce; value = set bases / step time",
+                                        "shard_bases_this_rank": strong["n_bases"]})
+        else:
+            el = timed(weak_step, o_steps, o_warm)
+            other = ("weak_scaling", {"value": n_bases * world * o_steps / el / 1e9, "unit": "Gbases/s", "ms_per_step": el / o_steps * 1e3, "steps": o_steps,
+                                      "workload": f"{args.config} reads: every rank its own set of {n_bases / 1e6:.2f} Mbases per step + hit all-reduce"})
+        # leave the context holding the primary read set for the solve below
+        primary_step()
+        torch.cuda.synchronize()
 
     # ---- the rest of the job, once: spectrum merge (N > 1), filter + exact solve
     t_solve = None
@@ -189,56 +318,96 @@ def main():
     if not args.no_solve:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pdist.merge_spectrum_into(ctx, dev)
+        if use_lib_comm:
+            ctx.comm_exchange()                                # hit all-reduce (idempotent) + spectrum all-gather / import
+        else:
+            pdist.merge_spectrum_into(ctx, dev)
         res = ctx.solve()
         torch.cuda.synchronize()
         t_solve = time.perf_counter() - t0
         if world > 1:
-            o = torch.tensor([res["objective"], -res["objective"]], dtype=torch.int64, device="cpu" if args.rehearse_gloo else dev)
+            o = torch.tensor([res["objective"], -res["objective"], res["spectrum_size"], -res["spectrum_size"]], dtype=torch.int64, device=ctl_dev)
             dist.all_reduce(o, op=dist.ReduceOp.MAX)
             assert int(o[0].item()) == -int(o[1].item()), "ranks disagree on the objective"
+            assert int(o[2].item()) == -int(o[3].item()), "ranks disagree on the spectrum size"
+        assert res["optimal"] == 1, "the quoted configuration must be solved to proven optimality"
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = n_bases * world * args.steps / elapsed / 1e9
-    b_alg = 1.5 + 24.0 * density
+    # ---- roofline of the dominant kernel.  Algorithmic bytes per base, split by the kernel that
+    #      moves them: the preparation launch reads the ASCII base and writes the packed one (1.25 B); the sketch
+    #      kernel reads the packed base (0.25 B), and per emitted minimiser (density d) writes an 8-byte hash-sized
+    #      record's worth and probes 16 bytes (24 d).
+    b_prep, b_sketch = 1.25, 0.25 + 24.0 * density
+    b_alg = b_prep + b_sketch
     kern_avg_ms = kern_ms / max(1, n_launch)
-    achieved = (kern_bases / max(1, n_launch)) * b_alg / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0
+    launch_bases = kern_bases / max(1, n_launch)
+    achieved = launch_bases * b_alg / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0
+    per_rank_bases = n_bases if args.scaling == "weak" else strong["n_bases"]
+    step_frac = per_rank_bases * b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     # HBM bytes per launch from PMC counters: measured in a separate rocprofv3 run (bench.py cannot
     # profile itself) and kept, with the commands, under profiles/
-    traffic = None
+    traffic, traffic_source = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if tj.get("config") == args.config:
+        if tj.get("config") == args.config and args.scaling == "weak":
             traffic = tj["bytes_per_launch"]
+            traffic_source = tj.get("source", "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE run of this command in an earlier session, not this run")
     except (OSError, ValueError, KeyError):
         pass
 
     out = {
-        "metric": "read Gbases/s scored (49-hap MHC graph stand-in synMHC-49)",
+        "metric": "read Gbases/s scored (49-hap MHC graph stand-in synMHC-49); reads resident in HBM, parsing and H2D excluded",
         "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{args.config}: {'reference graph' if args.config == 'C1syn' else f'synMHC-{g.n_walks} graph'} (seed {gk['seed']}, {g.n_walks} walks, {g.n_vtx} vertices{'' if args.config == 'C1syn' else ' <=30 bp'}, "
-                               f"{walk_bases / 1e6:.1f} Mbases of walks) + {n_reads} reads of mean {n_bases / max(1, n_reads):.0f} bp per GPU (seed {rk['seed']}, {n_bases / 1e6:.2f} Mbases)",
-                   "k": K, "w": W, "R": 100, "reads_per_gpu_bases": n_bases, "parallelism": f"read-shard x{world}"},
+                               f"{walk_bases / 1e6:.1f} Mbases of walks) + " +
+                               (f"{n_reads} reads of mean {n_bases / max(1, n_reads):.0f} bp per GPU (seed {rk['seed']}, {n_bases / 1e6:.2f} Mbases)" if args.scaling == "weak" else
+                                f"ONE set of {strong['total_reads']} reads ({args.strong_config}, {strong['total_bases'] / 1e6:.2f} Mbases) in {world} shard(s)"),
+                   "k": K, "w": W, "R": 100, "reads_per_gpu_bases": per_rank_bases, "parallelism": f"read-shard x{world}",
+                   "exchange": "none (1 GPU)" if world == 1 else ("gloo through the host (rehearsal)" if args.rehearse_gloo else "RCCL all-reduce(MAX, uint8) of the hit vector per step, inside libphi_amd.so")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "phi_sketch_kernel<PHI_MODE_PROBE>", "kernel_avg_ms": kern_avg_ms,
                      "kernel_launches": n_launch, "kernel_timed_every": args.prof_period, "bytes_per_base_algorithmic": b_alg, "minimiser_density": density,
-                     "kernel_gbases_per_s": (kern_bases / max(1, n_launch)) / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0},
+                     "bytes_per_base_by_kernel": {"phi_prep_reads_kernel": b_prep, "phi_sketch_kernel": b_sketch},
+                     "kernel_own_frac": (launch_bases * b_sketch / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if n_launch else 0.0,
+                     "step_frac": step_frac,
+                     "note": "achieved/frac price the sketch kernel's time against ALL algorithmic bytes of a base (SURVEY 8d formula); kernel_own_frac prices it against "
+                             "the bytes that kernel itself moves; step_frac = all algorithmic bytes / whole step time (every launch of the step)",
+                     "kernel_gbases_per_s": launch_bases / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0},
         "index_build_s": t_index, "graph_gbases_per_s": walk_bases / t_index / 1e9,
         "solve_s": t_solve, "end_to_end_s": (t_index + ms_per_step * 1e-3 + t_solve) if t_solve is not None else None,
         "synthetic_gen_s": t_gen,
     }
+    if other is not None:
+        out[other[0]] = other[1]
     if res is not None:
         out["result"] = {k_: int(res[k_]) for k_ in ("objective", "upper_bound", "optimal", "n_dp_runs", "n_covered",
                                                       "recombination_count", "n_switches", "spectrum_size", "filtered",
                                                       "n_in_model", "hap_len")}
         out["result"]["truth_walks"] = truth["walks"]
-        out["result"]["path_walks"] = [int(x) for x in res["path_hap"][np.r_[True, res["path_hap"][1:] != res["path_hap"][:-1]]]]
+        ph = res["path_hap"]
+        out["result"]["path_walks"] = [int(x) for x in ph[np.r_[True, ph[1:] != ph[:-1]]]] if len(ph) else []
+
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        # PCIe-inclusive rate: the same read set handed over as HOST buffers (pinned) through phi_add_reads
+        hb = np.ascontiguousarray(bases)
+        ctx._chk(ctx._L.phi_host_register(ctx._h, hb.ctypes.data, hb.nbytes))
+        reps = max(3, min(20, int(2e8 // max(n_bases, 1))))
+        for _ in range(2):
+            ctx.reset_reads(); ctx.add_reads((hb, off))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.reset_reads(); ctx.add_reads((hb, off))
+        torch.cuda.synchronize()
+        out["h2d_inclusive_gbases_per_s"] = n_bases * reps / (time.perf_counter() - t0) / 1e9
+        ctx._chk(ctx._L.phi_host_unregister(ctx._h, hb.ctypes.data))
+        out["file_to_fasta"] = file_to_fasta(g, bases, off, K, W)
+        out["file_to_fasta_s"] = (out["file_to_fasta"] or {}).get("seconds")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(bases, off, K, W)
+        out["cpu_baseline"] = cpu_baseline(A, bases, off, K, W)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

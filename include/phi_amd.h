@@ -16,7 +16,7 @@
  *     re-entrant either: src/main.cpp:136-140).
  *
  * Limits (PHI_ERR_UNSUPPORTED / PHI_ERR_INVALID beyond them): k <= 32, w <= 256, at most 512 walks,
- * fewer than 2^31 walk entries and walk minimisers, fewer than 2^27 anchors in the model, at most
+ * fewer than 2^31 walk entries, minimisers of the distinct walk contexts and anchors in the model, at most
  * 254 out-edges and 255 recombination in-edges per vertex, no walk through a segment without
  * sequence, no graph whose walks both start and end at interior vertices.
  */
@@ -172,7 +172,8 @@ typedef struct {
 /* Budget of the exact search behind phi_solve, counted in DP runs (never in wall-clock time: the same
  * input gives the same result and the same `optimal` flag on every run).  The reference's
  * model.optimize() (ILP_index.cpp:1412-1418) sets no limit; max_dp_runs <= 0 means the same here.
- * Default 65536.  Almost every input closes at the root in 1-3 runs. */
+ * Default 4096 (minutes at most on a 49-walk MHC graph, seconds on small ones).  Almost every input closes at the
+ * root in 1-3 runs; what does not are graphs where short k-mers repeat all over (k <= 8). */
 int phi_set_solve_budget(phi_ctx *ctx, int64_t max_dp_runs);
 
 /* Stages 2b-3 of ILP_function (:670-1525): filter, exact solve, decode.  Replaces
@@ -192,6 +193,21 @@ int phi_path_sequence(phi_ctx *ctx, char *buf, int64_t cap);
 int phi_sketch(phi_ctx *ctx, const char *bases, const int64_t *seq_off, int64_t n_seq, int32_t k,
                int32_t w, uint64_t *out_hash, int64_t *out_pos, int32_t *out_seq, int64_t cap,
                int64_t *n_out);
+/*
+ * What phi_set_graph built.  The reference sketches every walk on its own (ILP_index.cpp:559-573); here walk
+ * entries with the same context (the base before, the vertex, the next w+k-2 bases of the walk) form a class
+ * that is sketched once (graph-side de-duplication): n_classes classes laid out in class_bases bases of "class
+ * space" stand for walk_bases bases of walks, n_class_records minimiser records for n_walk_minimizers.
+ * sketch_gpu_ms = GPU time from the first class kernel to the last class record (HIP events on the stream).
+ */
+typedef struct {
+    int64_t n_entries, walk_bases;
+    int64_t n_classes, class_bases, n_class_records;
+    int64_t n_walk_minimizers, n_distinct_minimizers;
+    double sketch_gpu_ms;
+} phi_index_info;
+int phi_index_stats(phi_ctx *ctx, phi_index_info *out);
+
 /* Minimisers of walk h found by phi_set_graph, sorted by position. */
 int phi_walk_minimizers(phi_ctx *ctx, int32_t walk, uint64_t *out_hash, int64_t *out_pos,
                         int64_t cap, int64_t *n_out);

@@ -43,6 +43,12 @@ class Context:
 
     # ------------------------------------------------------------------ configuration
     def set_stream(self, hip_stream):
+        """Run this context's work on the caller's HIP stream (its handle as an integer); None restores the
+        context's private stream.  The null stream has handle 0 and cannot be named through the C ABI (NULL
+        means "private stream" there), so 0 is refused instead of silently selecting a stream that is not
+        ordered against the caller's work: create an explicit stream (torch.cuda.Stream()) and pass that."""
+        if hip_stream is not None and int(hip_stream) == 0:
+            raise ValueError("the null stream (handle 0) cannot be shared with a context: pass an explicit stream, or None for the private one")
         self._chk(self._L.phi_set_stream(self._h, C.c_void_p(hip_stream)))
 
     def set_params(self, k=31, w=25, threshold=1.0, recombination=100, flags=_capi.PHI_FLAG_QCLP | _capi.PHI_FLAG_MIXED):
@@ -61,6 +67,12 @@ class Context:
         self.n_vtx, self.n_walks = len(seq_off) - 1, len(walk_off) - 1
         self._chk(self._L.phi_set_graph(self._h, self.n_vtx, _ptr(buf), _ptr(seq_off), _ptr(adj_off), _ptr(adj),
                                         self.n_walks, _ptr(walk_off), _ptr(walk_vtx), _ptr(top_rank)))
+
+    def index_stats(self):
+        """Sizes of the de-duplicated walk index (classes of walk entries with equal context) and its GPU time."""
+        r = _capi.PhiIndexInfo()
+        self._chk(self._L.phi_index_stats(self._h, C.byref(r)))
+        return {n: getattr(r, n) for n, _ in _capi.PhiIndexInfo._fields_}
 
     # ------------------------------------------------------------------ reads
     def add_reads(self, seqs):

@@ -27,48 +27,6 @@ static inline unsigned grid_for(int64_t n, int tpb)
 #define GRID_STRIDE(i, n) \
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
-// ------------------------------------------------------------------------- entry lengths
-// bases of every walk entry (their exclusive scan is ebase, the flat base offset of the entry)
-__global__ void __launch_bounds__(256) phi_entry_len_kernel(const int64_t *__restrict__ seq_off,
-                                                            const int32_t *__restrict__ walk_vtx, int64_t n_entries,
-                                                            int32_t *__restrict__ len)
-{
-    GRID_STRIDE(e, n_entries) {
-        const int32_t v = walk_vtx[e];
-        len[e] = (int32_t)(seq_off[v + 1] - seq_off[v]);
-    }
-}
-
-void phi_launch_entry_len(hipStream_t st, const int64_t *seq_off, const int32_t *walk_vtx, int64_t n_entries, int32_t *len)
-{
-    if (n_entries <= 0) return;
-    hipLaunchKernelGGL(phi_entry_len_kernel, dim3(grid_for(n_entries, 256)), dim3(256), 0, st, seq_off, walk_vtx, n_entries, len);
-}
-
-// ------------------------------------------------------------------------- anchors for the host
-// out[3i..3i+2] = (dense minimiser id, first entry, last entry) of kept record rec[i]
-__global__ void __launch_bounds__(256) phi_anchor_triples_kernel(const int32_t *__restrict__ rec, int64_t n,
-                                                                 const uint32_t *__restrict__ rec_slot,
-                                                                 const uint32_t *__restrict__ u_uid,
-                                                                 const int32_t *__restrict__ rec_e0,
-                                                                 const int32_t *__restrict__ rec_e1, int32_t *__restrict__ out)
-{
-    GRID_STRIDE(i, n) {
-        const int32_t r = rec[i];
-        out[3 * i + 0] = (int32_t)u_uid[rec_slot[r]];
-        out[3 * i + 1] = rec_e0[r];
-        out[3 * i + 2] = rec_e1[r];
-    }
-}
-
-void phi_launch_anchor_triples(hipStream_t st, const int32_t *rec, int64_t n, const uint32_t *rec_slot, const uint32_t *u_uid,
-                               const int32_t *rec_e0, const int32_t *rec_e1, int32_t *out)
-{
-    if (n > 0)
-        hipLaunchKernelGGL(phi_anchor_triples_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, rec, n, rec_slot, u_uid, rec_e0,
-                           rec_e1, out);
-}
-
 // ------------------------------------------------------------------------- walk entries -> out-edges
 // For every walk entry: the index of the graph edge the walk leaves its vertex by (255 = the walk ends
 // here), the number of walks crossing every edge, and (st_mask != null) the walks present on every
@@ -166,54 +124,6 @@ void phi_launch_csr_scatter(hipStream_t st, const int32_t *triples, int64_t n, i
 void phi_launch_csr_sort(hipStream_t st, const int32_t *off, int64_t n_ids, int32_t *idx)
 {
     if (n_ids > 0) hipLaunchKernelGGL(phi_csr_sort_kernel, dim3(grid_for(n_ids, 256)), dim3(256), 0, st, off, n_ids, idx);
-}
-
-// ------------------------------------------------------------------------- locate
-// rec_e0/rec_e1: walk entries owning the first / last base of each minimiser's k-mer.
-__global__ void __launch_bounds__(256) phi_locate_kernel(const int64_t *__restrict__ rec_pos, int64_t n_rec,
-                                                         const int64_t *__restrict__ ebase, int64_t n_entries,
-                                                         int32_t k, int32_t *__restrict__ rec_e0,
-                                                         int32_t *__restrict__ rec_e1)
-{
-    GRID_STRIDE(i, n_rec) {
-        const int64_t g = rec_pos[i];
-        const int64_t lo = phi_locate_in(ebase, n_entries, g);   // ebase[lo] <= g < ebase[lo + 1]
-        int64_t e1 = lo;
-        const int64_t last = g + k - 1;
-        while (ebase[e1 + 1] <= last) e1++;
-        rec_e0[i] = (int32_t)lo;
-        rec_e1[i] = (int32_t)e1;
-    }
-}
-
-void phi_launch_locate(hipStream_t st, const int64_t *rec_pos, int64_t n_rec, const int64_t *ebase,
-                       int64_t n_entries, int32_t k, int32_t *rec_e0, int32_t *rec_e1)
-{
-    if (n_rec > 0)
-        hipLaunchKernelGGL(phi_locate_kernel, dim3(grid_for(n_rec, 256)), dim3(256), 0, st, rec_pos, n_rec, ebase,
-                           n_entries, k, rec_e0, rec_e1);
-}
-
-// out[j] = number of elements of the sorted array a[0..n) that are < keys[j]
-__global__ void phi_lower_bound_kernel(const int64_t *__restrict__ a, int64_t n, const int64_t *__restrict__ keys,
-                                       int64_t m, int64_t *__restrict__ out)
-{
-    GRID_STRIDE(j, m) {
-        const int64_t key = keys[j];
-        int64_t lo = 0, hi = n;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (a[mid] < key) lo = mid + 1; else hi = mid;
-        }
-        out[j] = lo;
-    }
-}
-
-void phi_launch_lower_bound(hipStream_t st, const int64_t *a, int64_t n, const int64_t *keys, int64_t m,
-                            int64_t *out)
-{
-    if (m > 0)
-        hipLaunchKernelGGL(phi_lower_bound_kernel, dim3(grid_for(m, 64)), dim3(64), 0, st, a, n, keys, m, out);
 }
 
 // ------------------------------------------------------------------------- ordered compaction
@@ -341,7 +251,7 @@ __global__ void __launch_bounds__(256) phi_group_count_kernel(PhiFilterArgs A, i
         const int32_t r = A.m_rec[j];
         const int32_t gs = A.m_group[j];
         if (!same_group(A, r, A.g_rep[gs])) { atomicOr(A.err, PHI_KERR_FP_COLLISION); continue; }
-        atomicAdd(&A.g_cnt[gs], 1u);
+        atomicAdd(&A.g_cnt[gs], (uint32_t)A.cls_mult[A.rec_cls[r]]);   // every walk entry of the class carries this anchor (:686-689)
     }
 }
 

@@ -206,12 +206,12 @@ void phi_ctx_destroy(phi_ctx *c)
     (void)phi_comm_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_ebase, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_rbad, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
                      &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
-                     &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_kept_rec, &c->d_m_rec, &c->d_m_group,
+                     &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_bstart, &c->d_k_rec, &c->d_k_in, &c->d_cvtx, &c->d_ev_e, &c->d_ev_off, &c->d_ev,
                      &c->d_cnt_end, &c->d_cnt_start, &c->d_off_end, &c->d_off_start, &c->d_scan_blk, &c->d_scan_blk64, &c->d_scan_blkoff, &c->d_top,
@@ -275,6 +275,171 @@ static int sketch_records(phi_ctx *c, const uint64_t *words, const unsigned long
     *n_out = total;
     return PHI_OK;
 }
+
+
+}  // extern "C" (helpers below are C++)
+
+// Classes of walk entries with equal context, their sketch in class space and the class records
+// (contexts.hip).  Leaves d_vlen, d_ent_cls, d_cls_*, d_rec_{hash,cls,rel,e0,e1}, n_cls, n_rec,
+// h_walk_base / walk_bases.  Runs on the context's stream; called by the GPU thread of phi_set_graph.
+static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_entries)
+{
+    PhiStageTimer tg("set_graph");
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    HIPCHK(hipEventCreate(&ev0));
+    HIPCHK(hipEventCreate(&ev1));
+    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{ev0, ev1};
+    HIPCHK(hipEventRecord(ev0, c->stream));
+    PHICHK(phi_dev_ensure(c, c->d_vlen, (size_t)n_vtx * 4));
+    phi_launch_vlen(c->stream, c->d_seq_off.as<int64_t>(), n_vtx, c->d_vlen.as<int32_t>());
+    // bases of every walk (flat base offset of each walk: the positions phi_walk_minimizers reports are walk-relative)
+    PHICHK(phi_dev_ensure(c, c->d_list, (size_t)(n_walks + 1) * 8));
+    HIPCHK(hipMemsetAsync(c->d_list.p, 0, (size_t)(n_walks + 1) * 8, c->stream));
+    phi_launch_walk_bases(c->stream, c->d_walk_vtx.as<int32_t>(), c->d_vlen.as<int32_t>(), c->d_walk_off.as<int64_t>(), n_walks, n_entries,
+                          c->d_list.as<unsigned long long>());
+    c->h_walk_base.assign(n_walks + 1, 0);
+    HIPCHK(hipMemcpyAsync(c->h_walk_base.data() + 1, c->d_list.p, (size_t)n_walks * 8, hipMemcpyDeviceToHost, c->stream));
+
+    // ---- classes: table of context fingerprints, verified entry by entry
+    PHICHK(phi_dev_ensure(c, c->d_ent_cls, (size_t)n_entries * 4));
+    PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)n_entries));
+    DevBuf t_keys, t_rep, t_mult;
+    struct Guard { DevBuf &a, &b, &d; ~Guard() { dev_free(a); dev_free(b); dev_free(d); } } guard{t_keys, t_rep, t_mult};
+    PhiClassArgs A{};
+    A.walk_vtx = c->d_walk_vtx.as<int32_t>(); A.walk_off = c->d_walk_off.as<int64_t>(); A.n_walks = n_walks; A.n_entries = n_entries;
+    A.vlen = c->d_vlen.as<int32_t>(); A.seq = c->d_seq.as<uint8_t>(); A.seq_off = c->d_seq_off.as<int64_t>();
+    A.tail_need = c->w + c->k - 2;
+    A.ent_slot = c->d_ent_cls.as<uint32_t>();
+    A.err = (uint32_t *)scalar(c, S_ERR);
+    // a pangenome has a few contexts per vertex; walks that share nothing have one per entry
+    const uint64_t cap_max = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)n_entries));
+    uint64_t cap = std::min(cap_max, pow2_at_least(std::max<uint64_t>(1024, 4 * (uint64_t)n_vtx)));
+    for (int attempt = 0;; attempt++) {
+        PHICHK(phi_dev_ensure(c, t_keys, cap * 8));
+        PHICHK(phi_dev_ensure(c, t_rep, cap * 4));
+        PHICHK(phi_dev_ensure(c, t_mult, cap * 4));
+        A.t_keys = t_keys.as<uint64_t>(); A.t_rep = t_rep.as<uint32_t>(); A.t_mult = t_mult.as<uint32_t>(); A.t_mask = cap - 1;
+        A.seed = 0x13198A2E03707344ull + 0x9E3779B97F4A7C15ull * (uint64_t)attempt;
+        phi_launch_fill_u64(c->stream, A.t_keys, (int64_t)cap, PHI_EMPTY_KEY);
+        phi_launch_fill_u32(c->stream, A.t_rep, (int64_t)cap, 0xFFFFFFFFu);
+        HIPCHK(hipMemsetAsync(A.t_mult, 0, cap * 4, c->stream));
+        phi_launch_class_insert(c->stream, A);
+        uint32_t err = 0;
+        HIPCHK(hipMemcpyAsync(&err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (err & PHI_KERR_TABLE_FULL) {
+            if (cap == cap_max) return phi_fail(c, PHI_ERR_OVERFLOW, "walk-context table overflow (internal error)");
+            cap = std::min(cap_max, cap * 8);
+            err &= ~PHI_KERR_TABLE_FULL;
+            HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
+            attempt--;
+            continue;
+        }
+        phi_launch_class_verify(c->stream, A, c->d_flags.as<uint8_t>());
+        HIPCHK(hipMemcpyAsync(&err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!(err & PHI_KERR_FP_COLLISION)) break;
+        if (attempt >= 7) return phi_fail(c, PHI_ERR_DEVICE, "walk-context fingerprints collide under 8 seeds (internal error)");
+        err &= ~PHI_KERR_FP_COLLISION;
+        HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
+    }
+    for (int32_t h = 0; h < n_walks; h++) c->h_walk_base[h + 1] += c->h_walk_base[h];
+    c->walk_bases = c->h_walk_base[n_walks];
+    // classes in the order of their representatives (smallest entry): the same on every rank
+    PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_entries, c->d_cls_rep, &c->n_cls));
+    const int64_t nc = c->n_cls;
+    PHICHK(phi_dev_ensure(c, c->d_cls_mult, (size_t)nc * 4));
+    PHICHK(phi_dev_ensure(c, c->d_cls_left, (size_t)nc));
+    PHICHK(phi_dev_ensure(c, c->d_cls_base, (size_t)(nc + 1) * 8));
+    PHICHK(phi_dev_ensure(c, c->d_cls_rec_off, (size_t)(nc + 1) * 4));
+    // (the rep slot array t_rep is reused as slot -> class id)
+    phi_launch_class_ids(c->stream, c->d_cls_rep.as<int32_t>(), nc, A.ent_slot, n_entries, A.t_mult, A.t_rep, c->d_cls_mult.as<int32_t>(),
+                         c->d_ent_cls.as<int32_t>());
+    PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)nc * 4));
+    phi_launch_class_len(c->stream, A, c->d_cls_rep.as<int32_t>(), nc, c->d_list3.as<int32_t>(), c->d_cls_left.as<uint8_t>());
+    {
+        const int64_t nb = phi_scan_i32_num_blocks(nc);
+        PHICHK(phi_dev_ensure(c, c->d_scan_blk64, (size_t)nb * 8));
+        PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
+        phi_launch_scan_i64(c->stream, c->d_list3.as<int32_t>(), nc, c->d_cls_base.as<int64_t>(), c->d_scan_blk64.as<int64_t>(),
+                            c->d_scan_blkoff.as<int64_t>());
+    }
+    int64_t run = 0;
+    HIPCHK(hipMemcpyAsync(&run, c->d_cls_base.as<int64_t>() + nc, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->cls_bases = run;
+    if (tg.on) fprintf(stderr, "[phi timing] set_graph: %lld entries in %lld classes, %lld bases of class space for %lld bases of walks\\n",
+                       (long long)n_entries, (long long)nc, (long long)run, (long long)c->walk_bases);
+    tg.lap("[gpu thread]   classes");
+
+    // ---- class space: packed bases, start bitmap, sketch
+    const int64_t n_words = (run + 31) / 32;
+    PHICHK(phi_dev_ensure(c, c->d_wwords, (size_t)(n_words + 2) * 8));
+    PHICHK(phi_dev_ensure(c, c->d_wbad, (size_t)(n_words + 6) * 4));
+    auto pack = [&](uint8_t *ascii) {
+        phi_launch_pack_classes(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(), c->d_vlen.as<int32_t>(),
+                                c->d_cls_rep.as<int32_t>(), c->d_cls_left.as<uint8_t>(), c->d_cls_base.as<int64_t>(), nc,
+                                c->d_wwords.as<uint64_t>(), n_words, c->d_wbad.as<uint32_t>(), ascii, (unsigned long long *)scalar(c, S_NBAD));
+    };
+    pack(nullptr);
+    // bases outside ACGTacgt in the graph: keep a flat ASCII copy of class space for the byte-wise path
+    const uint8_t *cls_ascii = nullptr;
+    {
+        uint64_t n_bad = 0;
+        HIPCHK(hipMemcpyAsync(&n_bad, scalar(c, S_NBAD), 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (n_bad) {
+            PHICHK(phi_dev_ensure(c, c->d_wascii, (size_t)run + 64));
+            HIPCHK(hipMemsetAsync(scalar(c, S_NBAD), 0, 8, c->stream));
+            pack(c->d_wascii.as<uint8_t>());
+            cls_ascii = c->d_wascii.as<uint8_t>();
+        }
+    }
+    const size_t n_sw = (size_t)(run / 64 + 2);
+    PHICHK(phi_dev_ensure(c, c->d_wstarts, n_sw * 8));
+    HIPCHK(hipMemsetAsync(c->d_wstarts.p, 0, n_sw * 8, c->stream));
+    phi_launch_mark_starts(c->stream, c->d_cls_base.as<int64_t>(), nc, c->d_wstarts.as<unsigned long long>());
+    int64_t n_raw = 0;
+    DevBuf raw_hash;
+    struct Guard1 { DevBuf &a; ~Guard1() { dev_free(a); } } guard1{raw_hash};
+    PHICHK(sketch_records(c, c->d_wwords.as<uint64_t>(), c->d_wstarts.as<unsigned long long>(), run, c->k, c->w, cls_ascii, raw_hash,
+                          c->d_rec_pos, &n_raw));
+    if (n_raw >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 minimisers in the distinct walk contexts");
+    tg.lap("[gpu thread]   class-space pack + sketch");
+
+    // ---- raw records -> class records (the left base's own window dropped)
+    const int64_t nr0 = std::max<int64_t>(n_raw, 1);
+    DevBuf r_cls, r_rel, r_e0, r_e1;
+    struct Guard4 { DevBuf &a, &b, &d, &e; ~Guard4() { dev_free(a); dev_free(b); dev_free(d); dev_free(e); } } guard4{r_cls, r_rel, r_e0, r_e1};
+    PHICHK(phi_dev_ensure(c, r_cls, (size_t)nr0 * 4));
+    PHICHK(phi_dev_ensure(c, r_rel, (size_t)nr0 * 4));
+    PHICHK(phi_dev_ensure(c, r_e0, (size_t)nr0 * 4));
+    PHICHK(phi_dev_ensure(c, r_e1, (size_t)nr0 * 4));
+    PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)std::max<int64_t>(nr0, n_entries)));
+    phi_launch_class_rec(c->stream, c->d_rec_pos.as<int64_t>(), n_raw, c->d_cls_base.as<int64_t>(), nc, c->d_cls_rep.as<int32_t>(),
+                         c->d_cls_left.as<uint8_t>(), c->d_walk_vtx.as<int32_t>(), c->d_vlen.as<int32_t>(), c->k, c->d_flags.as<uint8_t>(),
+                         r_cls.as<int32_t>(), r_rel.as<int32_t>(), r_e0.as<int32_t>(), r_e1.as<int32_t>());
+    PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_raw, c->d_list2, &c->n_rec));
+    const int64_t nr = std::max<int64_t>(c->n_rec, 1);
+    PHICHK(phi_dev_ensure(c, c->d_rec_hash, (size_t)nr * 8));
+    PHICHK(phi_dev_ensure(c, c->d_rec_cls, (size_t)nr * 4));
+    PHICHK(phi_dev_ensure(c, c->d_rec_rel, (size_t)nr * 4));
+    PHICHK(phi_dev_ensure(c, c->d_rec_e0, (size_t)nr * 4));
+    PHICHK(phi_dev_ensure(c, c->d_rec_e1, (size_t)nr * 4));
+    phi_launch_class_rec_gather(c->stream, c->d_list2.as<int32_t>(), c->n_rec, raw_hash.as<uint64_t>(), r_cls.as<int32_t>(), r_rel.as<int32_t>(),
+                                r_e0.as<int32_t>(), r_e1.as<int32_t>(), c->d_rec_hash.as<uint64_t>(), c->d_rec_cls.as<int32_t>(),
+                                c->d_rec_rel.as<int32_t>(), c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>());
+    phi_launch_class_rec_off(c->stream, c->d_rec_cls.as<int32_t>(), c->n_rec, nc, c->d_cls_rec_off.as<int32_t>());
+    HIPCHK(hipEventRecord(ev1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                  // the temporaries above go out of scope
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    c->index_gpu_ms = ms;
+    HIPCHK(hipGetLastError());
+    return PHI_OK;
+}
+
+extern "C" {
 
 int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64_t *seq_off, const int64_t *adj_off,
                   const int32_t *adj, int32_t n_walks, const int64_t *walk_off, const int32_t *walk_vtx,
@@ -424,80 +589,24 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             if (rc) return rc;
             if (tg.on) tg.lap("[gpu thread] uploads + walk-entry pass");
         }
-        // flat base offset of every walk entry: exclusive scan of the segment lengths, on the GPU
-        PHICHK(phi_dev_ensure(c, c->d_ebase, (size_t)(n_entries + 1) * 8));
-        PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)n_entries * 4));
-        phi_launch_entry_len(c->stream, c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(), n_entries, c->d_list3.as<int32_t>());
-        {
-            const int64_t nb = phi_scan_i32_num_blocks(n_entries);
-            PHICHK(phi_dev_ensure(c, c->d_scan_blk64, (size_t)nb * 8));
-            PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
-            phi_launch_scan_i64(c->stream, c->d_list3.as<int32_t>(), n_entries, c->d_ebase.as<int64_t>(), c->d_scan_blk64.as<int64_t>(),
-                                c->d_scan_blkoff.as<int64_t>());
-        }
-
-        if (tg.on) (void)hipStreamSynchronize(c->stream);
-        tg.lap("[gpu thread] uploads + ebase scan");
-        // ---- stage 1a on the GPU: pack the walks, sketch them, build the minimiser table
+        if (walk_err[0]) return PHI_OK;                        // the main thread reports it; nothing below may index with such walks
+        // ---- stage 1a on the GPU (ILP_index.cpp:559-573), de-duplicated: classes of walk entries with equal
+        //      context, one sketch per class, the minimiser table from the class records (contexts.hip)
         HIPCHK(hipMemsetAsync(c->d_scalars.p, 0, S_N * 8, c->stream));
         HIPCHK(hipMemsetAsync(c->d_stripes.p, 0, 2 * STRIPE_BYTES, c->stream));
-        // bases of every walk from the scanned entry offsets
-        {
-            std::vector<int32_t> woff32(n_walks + 1);
-            for (int32_t h = 0; h <= n_walks; h++) woff32[h] = (int32_t)walk_off[h];
-            PHICHK(upload(c, c->d_list2, woff32.data(), woff32.size()));
-            PHICHK(phi_dev_ensure(c, c->d_list, (size_t)(n_walks + 1) * 8));
-            phi_launch_gather_u64(c->stream, c->d_ebase.as<uint64_t>(), c->d_list2.as<int32_t>(), n_walks + 1, c->d_list.as<uint64_t>());
-            c->h_walk_base.assign(n_walks + 1, 0);
-            HIPCHK(hipMemcpyAsync(c->h_walk_base.data(), c->d_list.p, (size_t)(n_walks + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-        }
-        const int64_t run = c->h_walk_base[n_walks];
-        c->walk_bases = run;
-        const int64_t n_words = (run + 31) / 32;
-        PHICHK(phi_dev_ensure(c, c->d_wwords, (size_t)(n_words + 2) * 8));
-        PHICHK(phi_dev_ensure(c, c->d_wbad, (size_t)(n_words + 6) * 4));
-        phi_launch_pack_walks(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(),
-                              c->d_ebase.as<int64_t>(), n_entries, c->d_wwords.as<uint64_t>(), n_words,
-                              c->d_wbad.as<uint32_t>(), nullptr, (unsigned long long *)scalar(c, S_NBAD));
-        // bases outside ACGTacgt in the graph: keep a flat ASCII copy of the walks for the byte-wise path
-        const uint8_t *walk_ascii = nullptr;
-        {
-            HIPCHK(hipStreamSynchronize(c->stream));
-            uint64_t n_bad = 0;
-            HIPCHK(hipMemcpy(&n_bad, scalar(c, S_NBAD), 8, hipMemcpyDeviceToHost));
-            if (n_bad) {
-                PHICHK(phi_dev_ensure(c, c->d_wascii, (size_t)run + 64));
-                HIPCHK(hipMemsetAsync(scalar(c, S_NBAD), 0, 8, c->stream));
-                phi_launch_pack_walks(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(),
-                                      c->d_ebase.as<int64_t>(), n_entries, c->d_wwords.as<uint64_t>(), n_words,
-                                      c->d_wbad.as<uint32_t>(), c->d_wascii.as<uint8_t>(), (unsigned long long *)scalar(c, S_NBAD));
-                walk_ascii = c->d_wascii.as<uint8_t>();
-            }
-        }
-        const size_t n_sw = (size_t)(run / 64 + 2);
-        PHICHK(phi_dev_ensure(c, c->d_wstarts, n_sw * 8));
-        HIPCHK(hipMemsetAsync(c->d_wstarts.p, 0, n_sw * 8, c->stream));
-        phi_launch_mark_starts(c->stream, c->d_list.as<int64_t>(), n_walks, c->d_wstarts.as<unsigned long long>());
-
-        PHICHK(sketch_records(c, c->d_wwords.as<uint64_t>(), c->d_wstarts.as<unsigned long long>(), run, c->k, c->w,
-                              walk_ascii, c->d_rec_hash, c->d_rec_pos, &c->n_rec));
-        if (c->n_rec >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk minimisers");
+        PHICHK(build_classes(c, n_vtx, n_walks, n_entries));
         c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{};
+        if (tg.on) (void)hipStreamSynchronize(c->stream);
+        tg.lap("[gpu thread] classes + class sketch");
         const int64_t nr = std::max<int64_t>(c->n_rec, 1);
         PHICHK(phi_dev_ensure(c, c->d_rec_slot, (size_t)nr * 4));
-        PHICHK(phi_dev_ensure(c, c->d_rec_e0, (size_t)nr * 4));
-        PHICHK(phi_dev_ensure(c, c->d_rec_e1, (size_t)nr * 4));
-        // The table is sized by an estimate of the DISTINCT minimisers -- the walks of a pangenome share
-        // most of theirs, so 8x the records of an average walk (load ~12 %: read probes settle on the
-        // first slot) -- and only when that overflows by the records (2x, the worst case).
+        // The table is built over the class records (nearly all distinct) at twice their number, then
+        // re-inserted at 8x the distinct keys (load ~12 %: read probes settle on the first slot).
         const uint64_t cap_full = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)c->n_rec));
         const uint64_t UMULT = 8;
-        uint64_t cap_try = pow2_at_least(std::max<uint64_t>(1024, UMULT * (uint64_t)((c->n_rec + n_walks - 1) / n_walks)));
-        if (cap_try > cap_full) cap_try = cap_full;
         PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)nr));
-        for (;;) {
-            c->u_cap = cap_try;
+        {
+            c->u_cap = cap_full;
             PHICHK(phi_dev_ensure(c, c->d_u_keys, c->u_cap * 8));
             PHICHK(phi_dev_ensure(c, c->d_u_rep, c->u_cap * 4));
             phi_launch_fill_u64(c->stream, c->d_u_keys.as<uint64_t>(), (int64_t)c->u_cap, PHI_EMPTY_KEY);
@@ -505,16 +614,10 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             phi_launch_table_build(c->stream, c->d_rec_hash.as<uint64_t>(), c->n_rec, c->d_u_keys.as<uint64_t>(),
                                    c->d_u_rep.as<uint32_t>(), c->u_cap - 1, c->d_rec_slot.as<uint32_t>(),
                                    (uint32_t *)scalar(c, S_ERR));
-            // dense, rank-independent minimiser ids: rank of the first record of each hash in position order
+            // dense, rank-independent minimiser ids: rank of the first class record of each hash
             phi_launch_rep_flags(c->stream, c->d_rec_slot.as<uint32_t>(), c->n_rec, c->d_u_rep.as<uint32_t>(),
                                  c->d_flags.as<uint8_t>());
-            PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), c->n_rec, c->d_m_rec, &c->n_unique));   // waits for the stream
-            uint32_t err = 0;
-            HIPCHK(hipMemcpy(&err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
-            if (!(err & PHI_KERR_TABLE_FULL) || cap_try == cap_full) break;
-            err &= ~PHI_KERR_TABLE_FULL;                     // the estimate was too small for this graph
-            HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
-            cap_try = cap_full;
+            PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), c->n_rec, c->d_u_replist, &c->n_unique));   // waits for the stream
         }
         {
             // wanted capacity: 8x the distinct keys; re-insert them (and look every record up again) when
@@ -522,33 +625,36 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             const uint64_t want = pow2_at_least(std::max<uint64_t>(1024, UMULT * (uint64_t)c->n_unique));
             if (c->u_cap > 2 * want || 2 * c->u_cap < want) {
                 DevBuf keys2, uid2;
+                struct Guard { DevBuf &a, &b; ~Guard() { dev_free(a); dev_free(b); } } guard{keys2, uid2};   // error paths below
                 PHICHK(phi_dev_ensure(c, keys2, want * 8));
                 PHICHK(phi_dev_ensure(c, uid2, want * 4));
                 phi_launch_fill_u64(c->stream, keys2.as<uint64_t>(), (int64_t)want, PHI_EMPTY_KEY);
-                phi_launch_table_compact(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_hash.as<uint64_t>(), c->n_rec,
+                phi_launch_table_compact(c->stream, c->d_u_replist.as<int32_t>(), c->n_unique, c->d_rec_hash.as<uint64_t>(), c->n_rec,
                                          keys2.as<uint64_t>(), uid2.as<uint32_t>(), want - 1, c->d_rec_slot.as<uint32_t>(),
                                          (uint32_t *)scalar(c, S_ERR));
                 HIPCHK(hipStreamSynchronize(c->stream));
                 dev_free(c->d_u_keys); dev_free(c->d_u_uid); dev_free(c->d_u_rep);
                 c->d_u_keys = keys2; c->d_u_uid = uid2;
+                keys2 = DevBuf{}; uid2 = DevBuf{};           // ownership moved
                 c->u_cap = want;
             } else {
                 PHICHK(phi_dev_ensure(c, c->d_u_uid, c->u_cap * 4));
-                phi_launch_slot_uid(c->stream, c->d_m_rec.as<int32_t>(), c->n_unique, c->d_rec_slot.as<uint32_t>(),
+                phi_launch_slot_uid(c->stream, c->d_u_replist.as<int32_t>(), c->n_unique, c->d_rec_slot.as<uint32_t>(),
                                     c->d_u_uid.as<uint32_t>());
             }
         }
         PHICHK(phi_dev_ensure(c, c->d_u_kv, c->u_cap * 16));
         phi_launch_table_pairs(c->stream, c->d_u_keys.as<uint64_t>(), c->d_u_uid.as<uint32_t>(), (int64_t)c->u_cap,
                                c->d_u_kv.as<uint64_t>());
-        phi_launch_locate(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_ebase.as<int64_t>(), n_entries, c->k,
-                          c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>());
-        // records of each walk ("Number of Minimizers", ILP_index.cpp:563)
-        PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)(n_walks + 1) * 8));
-        phi_launch_lower_bound(c->stream, c->d_rec_pos.as<int64_t>(), c->n_rec, c->d_list.as<int64_t>(), n_walks + 1,
-                               c->d_list2.as<int64_t>());
-        c->h_walk_rec_off.resize(n_walks + 1);
-        HIPCHK(hipMemcpyAsync(c->h_walk_rec_off.data(), c->d_list2.p, (size_t)(n_walks + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        // records of each walk ("Number of Minimizers", ILP_index.cpp:563) = sum over its entries of their class's records
+        {
+            PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)(n_walks + 1) * 8));
+            HIPCHK(hipMemsetAsync(c->d_list2.p, 0, (size_t)(n_walks + 1) * 8, c->stream));
+            phi_launch_walk_rec_counts(c->stream, c->d_ent_cls.as<int32_t>(), c->d_cls_rec_off.as<int32_t>(), c->d_walk_off.as<int64_t>(),
+                                       n_walks, n_entries, c->d_list2.as<unsigned long long>());
+            c->h_n_minimizers.assign(n_walks, 0);
+            HIPCHK(hipMemcpyAsync(c->h_n_minimizers.data(), c->d_list2.p, (size_t)n_walks * 8, hipMemcpyDeviceToHost, c->stream));
+        }
         PHICHK(phi_dev_ensure(c, c->d_hit, (size_t)(c->n_unique / 8 + 1) * 8));
         HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)(c->n_unique / 8 + 1) * 8, c->stream));
         HIPCHK(hipGetLastError());
@@ -728,8 +834,6 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     PHICHK(phi_sync_check(c));
     if (tm.on) fprintf(stderr, "[phi timing] set_graph: %d vertices, %d compact steps, %lld entries, %lld events\n", n_vtx, c->n_k, (long long)n_entries, (long long)c->n_ev);
     tm.lap("late uploads + event list");
-    c->h_n_minimizers.resize(n_walks);
-    for (int32_t h = 0; h < n_walks; h++) c->h_n_minimizers[h] = c->h_walk_rec_off[h + 1] - c->h_walk_rec_off[h];
 
     c->sp_cap = 0; c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
     c->log_chunks = 0; c->sp_full = true;
@@ -1072,16 +1176,57 @@ int phi_walk_minimizers(phi_ctx *c, int32_t walk, uint64_t *out_hash, int64_t *o
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_walk_minimizers before phi_set_graph");
     if (walk < 0 || walk >= c->n_walks) return phi_fail(c, PHI_ERR_INVALID, "walk out of range");
     HIPCHK(hipSetDevice(c->device));
-    const int64_t lo = c->h_walk_rec_off[walk], n = c->h_walk_rec_off[walk + 1] - lo;
+    const int64_t n = c->h_n_minimizers[walk];
     *n_out = n;
     if (cap < n || n == 0) return PHI_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (out_hash) HIPCHK(hipMemcpy(out_hash, c->d_rec_hash.as<uint64_t>() + lo, (size_t)n * 8, hipMemcpyDeviceToHost));
-    if (out_pos) {
-        HIPCHK(hipMemcpy(out_pos, c->d_rec_pos.as<int64_t>() + lo, (size_t)n * 8, hipMemcpyDeviceToHost));
-        const int64_t base = c->h_walk_base[walk];
-        for (int64_t i = 0; i < n; i++) out_pos[i] -= base;
+    // the records of a walk are never stored: expand the classes of its entries, in entry order
+    const int64_t e_lo = c->h_walk_off[walk], e_hi = c->h_walk_off[walk + 1], ne = e_hi - e_lo;
+    DevBuf lens, base, oh, op;
+    struct Guard { DevBuf &a, &b, &d, &e; ~Guard() { dev_free(a); dev_free(b); dev_free(d); dev_free(e); } } guard{lens, base, oh, op};
+    PHICHK(phi_dev_ensure(c, lens, (size_t)ne * 4));
+    PHICHK(phi_dev_ensure(c, base, (size_t)(ne + 1) * 8));
+    PHICHK(phi_dev_ensure(c, oh, (size_t)n * 8));
+    PHICHK(phi_dev_ensure(c, op, (size_t)n * 8));
+    phi_launch_entry_len_range(c->stream, c->d_walk_vtx.as<int32_t>(), c->d_vlen.as<int32_t>(), e_lo, ne, lens.as<int32_t>());
+    {
+        const int64_t nb = phi_scan_i32_num_blocks(ne);
+        PHICHK(phi_dev_ensure(c, c->d_scan_blk64, (size_t)nb * 8));
+        PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
+        phi_launch_scan_i64(c->stream, lens.as<int32_t>(), ne, base.as<int64_t>(), c->d_scan_blk64.as<int64_t>(), c->d_scan_blkoff.as<int64_t>());
     }
+    PhiExpandArgs X{};
+    X.ent_cls = c->d_ent_cls.as<int32_t>(); X.e_lo = e_lo; X.e_hi = e_hi;
+    X.cls_rec_off = c->d_cls_rec_off.as<int32_t>(); X.cls_rep = c->d_cls_rep.as<int32_t>();
+    X.rec_hash = c->d_rec_hash.as<uint64_t>(); X.rec_rel = c->d_rec_rel.as<int32_t>(); X.ent_base = base.as<int64_t>();
+    X.out_hash = oh.as<uint64_t>(); X.out_pos = op.as<int64_t>();
+    const int64_t nb = phi_expand_num_blocks(ne);
+    PHICHK(phi_dev_ensure(c, c->d_blk_cnt, (size_t)nb * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_off, (size_t)(nb + 1) * 8));
+    X.block_cnt = c->d_blk_cnt.as<int32_t>(); X.block_off = c->d_blk_off.as<int64_t>();
+    phi_launch_expand_count(c->stream, X);
+    PHICHK(phi_scan_counts_wide(c, c->d_blk_cnt.as<int32_t>(), nb, c->d_blk_off.as<int64_t>()));
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, c->d_blk_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (total != n) return phi_fail(c, PHI_ERR_DEVICE, "walk %d expands to %lld records, counted %lld (internal error)", walk, (long long)total, (long long)n);
+    phi_launch_expand_write(c->stream, X, 0);
+    HIPCHK(hipGetLastError());
+    if (out_hash) HIPCHK(hipMemcpyAsync(out_hash, oh.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (out_pos) HIPCHK(hipMemcpyAsync(out_pos, op.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PHI_OK;
+}
+
+int phi_index_stats(phi_ctx *c, phi_index_info *out)
+{
+    if (!c || !out) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_index_stats before phi_set_graph");
+    out->n_entries = c->n_entries; out->walk_bases = c->walk_bases;
+    out->n_classes = c->n_cls; out->class_bases = c->cls_bases; out->n_class_records = c->n_rec;
+    out->n_walk_minimizers = 0;
+    for (int64_t m : c->h_n_minimizers) out->n_walk_minimizers += m;
+    out->n_distinct_minimizers = c->n_unique;
+    out->sketch_gpu_ms = c->index_gpu_ms;
     return PHI_OK;
 }
 
@@ -1101,8 +1246,8 @@ int phi_walk_sharing(phi_ctx *c, int64_t *hist, int32_t cap, int64_t *n_distinct
         if ((rc = phi_hip_check(c, hipMemsetAsync(cnt.p, 0, c->u_cap * 4, c->stream), "memset"))) break;
         if ((rc = phi_hip_check(c, hipMemsetAsync(dh.p, 0, (size_t)(c->n_walks + 1) * 8, c->stream), "memset"))) break;
         for (int32_t h = 0; h < c->n_walks; h++)
-            phi_launch_share_count(c->stream, c->d_rec_slot.as<uint32_t>(), c->h_walk_rec_off[h], c->h_walk_rec_off[h + 1], h,
-                                   last.as<int32_t>(), cnt.as<int32_t>());
+            phi_launch_share_count_cls(c->stream, c->d_ent_cls.as<int32_t>(), c->h_walk_off[h], c->h_walk_off[h + 1], c->d_cls_rec_off.as<int32_t>(),
+                                       c->d_rec_slot.as<uint32_t>(), h, last.as<int32_t>(), cnt.as<int32_t>());
         phi_launch_share_hist(c->stream, c->d_u_keys.as<uint64_t>(), (int64_t)c->u_cap, cnt.as<int32_t>(),
                               dh.as<unsigned long long>());
         if ((rc = phi_hip_check(c, hipGetLastError(), "launch"))) break;
@@ -1128,10 +1273,13 @@ int phi_kept_anchors(phi_ctx *c, uint64_t *out_hash, int32_t *out_walk, int32_t 
         // the hashes stayed on the device (phi_solve does not need them): fetch them now
         HIPCHK(hipSetDevice(c->device));
         c->h_kept_hash.resize(n);
-        PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)n * 8));
-        phi_launch_gather_u64(c->stream, c->d_rec_hash.as<uint64_t>(), c->d_kept_rec.as<int32_t>(), n, c->d_list2.as<uint64_t>());
-        HIPCHK(hipMemcpyAsync(c->h_kept_hash.data(), c->d_list2.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        // hash of a dense minimiser id = hash of its first class record
+        std::vector<uint64_t> id_hash((size_t)c->n_unique);
+        PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)std::max<int64_t>(c->n_unique, 1) * 8));
+        phi_launch_gather_u64(c->stream, c->d_rec_hash.as<uint64_t>(), c->d_u_replist.as<int32_t>(), c->n_unique, c->d_list2.as<uint64_t>());
+        HIPCHK(hipMemcpyAsync(id_hash.data(), c->d_list2.p, (size_t)c->n_unique * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        for (int64_t i = 0; i < n; i++) c->h_kept_hash[i] = id_hash[c->h_kept[i].slot];
     }
     for (int64_t i = 0; i < n; i++) {
         const PhiAnchorHost &a = c->h_kept[i];

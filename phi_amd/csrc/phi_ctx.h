@@ -71,7 +71,7 @@ struct phi_ctx {
     int32_t k = 31, w = 25, recombination = 100;
     float threshold = 1.0f;
     uint32_t flags = PHI_FLAG_QCLP | PHI_FLAG_MIXED;
-    int64_t solve_budget = (int64_t)1 << 16;          // DP runs the exact search may use (phi_set_solve_budget); <= 0 = no limit
+    int64_t solve_budget = 4096;                      // DP runs the exact search may use (phi_set_solve_budget); <= 0 = no limit
 
     // ---- graph, host side (decode, validation)
     bool have_graph = false;
@@ -83,14 +83,20 @@ struct phi_ctx {
     int64_t n_entries = 0, walk_bases = 0;
 
     // ---- graph, device side
-    DevBuf d_seq, d_seq_off, d_walk_vtx, d_walk_off, d_ebase, d_topo, d_in_off, d_in_src;
+    DevBuf d_seq, d_seq_off, d_walk_vtx, d_walk_off, d_topo, d_in_off, d_in_src;
     DevBuf d_e_out, d_st_rec, d_st_mask, d_in_packed;  // DP step stream (dp.hip)
     int dp_nw = 1;                                    // waves of the DP workgroup
-    DevBuf d_wwords, d_wstarts, d_wbad, d_wascii;     // packed walk sequences, start bitmap, non-ACGT mask, flat ASCII (only if needed)
-    DevBuf d_rec_hash, d_rec_pos, d_rec_slot, d_rec_e0, d_rec_e1;   // walk minimiser records
+    DevBuf d_wwords, d_wstarts, d_wbad, d_wascii;     // class space (contexts.hip): packed bases, start bitmap, non-ACGT mask, flat ASCII (only if needed)
+    // graph-side de-duplication: walk entries of equal context form a class that is sketched once
+    DevBuf d_vlen;                                    // bases of every vertex
+    DevBuf d_ent_cls;                                 // class of every walk entry
+    DevBuf d_cls_rep, d_cls_left, d_cls_mult, d_cls_base, d_cls_rec_off;   // per class: representative entry, has a left base, entries, first base in class space, first record
+    int64_t n_cls = 0, cls_bases = 0;
+    double index_gpu_ms = 0.0;                        // GPU time of the walk sketch (classes, class-space sketch, table): phi_index_stats
+    // class records: (hash, class, position relative to the vertex, first / last entry of the representative under the k-mer, table slot)
+    DevBuf d_rec_hash, d_rec_pos, d_rec_cls, d_rec_rel, d_rec_slot, d_rec_e0, d_rec_e1;
     int64_t n_rec = 0;
-    std::vector<int64_t> h_walk_rec_off;              // record range of each walk
-    DevBuf d_u_keys, d_u_rep, d_u_uid;                // walk-minimiser table: keys, first record, dense id
+    DevBuf d_u_keys, d_u_rep, d_u_uid, d_u_replist;   // walk-minimiser table: keys, first record, dense id; dense id -> first record
     DevBuf d_u_kv;                                    // the same table as (key, id) pairs, for the read probes
     int64_t n_unique = 0;                             // distinct walk minimisers
     uint64_t u_cap = 0;
@@ -116,7 +122,7 @@ struct phi_ctx {
     bool sp_full = true;                              // the next reset must empty the whole set (import, regrow, log too small)
 
     // ---- scratch for sketch passes and compaction
-    DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2, d_list3, d_walk_last, d_kept_rec;
+    DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2, d_list3, d_walk_last;
     DevBuf d_adj_off, d_adj, d_topo_rank, d_cnt_edge, d_walk_err;   // the walk-entry pass on the GPU (phi_walk_edges_kernel)
     DevBuf d_sa_cnt, d_sa_cur, d_sa_off, d_sa_idx;    // minimiser -> anchors CSR, built on the GPU
 

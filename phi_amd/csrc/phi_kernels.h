@@ -74,9 +74,6 @@ void phi_launch_prep_reads(hipStream_t st, PhiPrepArgs P, bool with_reset);
 void phi_launch_sketch_bytes(hipStream_t st, int mode, const PhiSketchArgs &A, const unsigned long long *batch_bad);
 void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, uint64_t *hit_words, int64_t n_hit_words,
                             uint64_t *stripes, int64_t n_stripe_words);
-void phi_launch_pack_walks(hipStream_t st, const uint8_t *seq_concat, const int64_t *seq_off,
-                           const int32_t *walk_vtx, const int64_t *ebase, int64_t n_entries, uint64_t *words,
-                           int64_t n_words, uint32_t *badbits, uint8_t *ascii, unsigned long long *n_bad);
 int64_t phi_sketch_num_blocks(int64_t n_bases);
 void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void phi_launch_scan_counts(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off);
@@ -90,8 +87,6 @@ void phi_launch_rep_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_re
                           uint8_t *flags);
 void phi_launch_table_compact(hipStream_t st, const int32_t *rep_list, int64_t n_unique, const uint64_t *rec_hash, int64_t n_rec,
                               uint64_t *keys, uint32_t *uid, uint64_t mask, uint32_t *rec_slot, uint32_t *err);
-void phi_launch_share_count(hipStream_t st, const uint32_t *rec_slot, int64_t lo, int64_t hi, int32_t walk, int32_t *last_walk,
-                            int32_t *n_walks_of);
 void phi_launch_share_hist(hipStream_t st, const uint64_t *keys, int64_t cap, const int32_t *n_walks_of, unsigned long long *hist);
 void phi_launch_slot_uid(hipStream_t st, const int32_t *rep_list, int64_t n_unique, const uint32_t *rec_slot,
                          uint32_t *u_uid);
@@ -109,11 +104,57 @@ void phi_launch_count_flags(hipStream_t st, const uint8_t *flags, int64_t n, uns
 void phi_launch_spectrum_export(hipStream_t st, const uint64_t *sp_keys, int64_t cap, uint64_t *out,
                                 unsigned long long *n_out);
 
+// contexts.hip: graph-side de-duplication (entries of equal context form a class, sketched once)
+struct PhiClassArgs {
+    const int32_t *walk_vtx; const int64_t *walk_off; int32_t n_walks; int64_t n_entries;
+    const int32_t *vlen; const uint8_t *seq; const int64_t *seq_off;
+    int32_t tail_need;                     // w + k - 2: bases of a window beyond its first
+    uint64_t seed;
+    uint64_t *t_keys; uint32_t *t_rep; uint32_t *t_mult; uint64_t t_mask;   // class table: fingerprint, smallest entry, entries
+    uint32_t *ent_slot;                    // per entry: its table slot
+    uint32_t *err;
+};
+struct PhiExpandArgs {
+    const int32_t *ent_cls; int64_t e_lo, e_hi;
+    const int32_t *cls_rec_off; const int32_t *cls_rep;
+    const uint8_t *sel; const int32_t *sel_cnt;          // optional: selected records, and their number per class
+    int32_t *block_cnt; const int64_t *block_off;
+    // kind 0: minimisers of one walk
+    const uint64_t *rec_hash; const int32_t *rec_rel; const int64_t *ent_base; uint64_t *out_hash; int64_t *out_pos;
+    // kind 1: anchors (dense minimiser id, first entry, last entry)
+    const uint32_t *rec_slot; const uint32_t *u_uid; const int32_t *rec_e0; const int32_t *rec_e1; int32_t *out_tri;
+};
+void phi_launch_vlen(hipStream_t st, const int64_t *seq_off, int64_t n_vtx, int32_t *vlen);
+void phi_launch_walk_bases(hipStream_t st, const int32_t *walk_vtx, const int32_t *vlen, const int64_t *walk_off, int32_t n_walks,
+                           int64_t n_entries, unsigned long long *out);
+void phi_launch_walk_rec_counts(hipStream_t st, const int32_t *ent_cls, const int32_t *cls_rec_off, const int64_t *walk_off,
+                                int32_t n_walks, int64_t n_entries, unsigned long long *out);
+void phi_launch_class_insert(hipStream_t st, const PhiClassArgs &A);
+void phi_launch_class_verify(hipStream_t st, const PhiClassArgs &A, uint8_t *is_rep);
+void phi_launch_class_ids(hipStream_t st, const int32_t *cls_rep, int64_t n_cls, const uint32_t *ent_slot, int64_t n_entries,
+                          const uint32_t *t_mult, uint32_t *t_cid, int32_t *cls_mult, int32_t *ent_cls);
+void phi_launch_class_len(hipStream_t st, const PhiClassArgs &A, const int32_t *cls_rep, int64_t n_cls, int32_t *cls_len, uint8_t *cls_left);
+void phi_launch_pack_classes(hipStream_t st, const uint8_t *seq, const int64_t *seq_off, const int32_t *walk_vtx, const int32_t *vlen,
+                             const int32_t *cls_rep, const uint8_t *cls_left, const int64_t *cls_base, int64_t n_cls, uint64_t *words,
+                             int64_t n_words, uint32_t *badbits, uint8_t *ascii, unsigned long long *n_bad);
+void phi_launch_class_rec(hipStream_t st, const int64_t *raw_pos, int64_t n_raw, const int64_t *cls_base, int64_t n_cls,
+                          const int32_t *cls_rep, const uint8_t *cls_left, const int32_t *walk_vtx, const int32_t *vlen, int32_t k,
+                          uint8_t *keep, int32_t *r_cls, int32_t *r_rel, int32_t *r_e0, int32_t *r_e1);
+void phi_launch_class_rec_gather(hipStream_t st, const int32_t *idx, int64_t n, const uint64_t *raw_hash, const int32_t *r_cls,
+                                 const int32_t *r_rel, const int32_t *r_e0, const int32_t *r_e1, uint64_t *o_hash, int32_t *o_cls,
+                                 int32_t *o_rel, int32_t *o_e0, int32_t *o_e1);
+void phi_launch_class_rec_off(hipStream_t st, const int32_t *rec_cls, int64_t n_rec, int64_t n_cls, int32_t *off);
+int64_t phi_expand_num_blocks(int64_t n_entries);
+void phi_launch_expand_count(hipStream_t st, const PhiExpandArgs &A);
+void phi_launch_expand_write(hipStream_t st, const PhiExpandArgs &A, int kind);
+void phi_launch_class_sel_count(hipStream_t st, const uint8_t *sel, const int32_t *cls_rec_off, int64_t n_cls, int32_t *sel_cnt);
+void phi_launch_mark_list(hipStream_t st, const int32_t *list, const int32_t *through, int64_t n, uint8_t *sel);
+void phi_launch_share_count_cls(hipStream_t st, const int32_t *ent_cls, int64_t e_lo, int64_t e_hi, const int32_t *cls_rec_off,
+                                const uint32_t *rec_slot, int32_t walk, int32_t *last_walk, int32_t *n_walks_of);
+void phi_launch_entry_len_range(hipStream_t st, const int32_t *walk_vtx, const int32_t *vlen, int64_t e_lo, int64_t n, int32_t *lens);
+
 // anchors.hip
 #define PHI_KERR_FP_COLLISION 8u   // two different vertex lists share a fingerprint: reseed
-void phi_launch_entry_len(hipStream_t st, const int64_t *seq_off, const int32_t *walk_vtx, int64_t n_entries, int32_t *len);
-void phi_launch_anchor_triples(hipStream_t st, const int32_t *rec, int64_t n, const uint32_t *rec_slot, const uint32_t *u_uid,
-                               const int32_t *rec_e0, const int32_t *rec_e1, int32_t *out);
 // walk entries -> out-edge index per entry, walks per edge, walks per vertex (see anchors.hip)
 void phi_launch_walk_edges(hipStream_t st, const int32_t *walk_vtx, const int64_t *walk_off, int32_t n_walks, int64_t n_entries,
                            const int64_t *adj_off, const int32_t *adj, const int64_t *seq_off, const int32_t *topo_rank,
@@ -123,10 +164,6 @@ void phi_launch_csr_count(hipStream_t st, const int32_t *triples, int64_t n, int
 void phi_launch_csr_scatter(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, const int32_t *off, int32_t *cur,
                             int32_t *idx);
 void phi_launch_csr_sort(hipStream_t st, const int32_t *off, int64_t n_ids, int32_t *idx);
-void phi_launch_locate(hipStream_t st, const int64_t *rec_pos, int64_t n_rec, const int64_t *ebase,
-                       int64_t n_entries, int32_t k, int32_t *rec_e0, int32_t *rec_e1);
-void phi_launch_lower_bound(hipStream_t st, const int64_t *a, int64_t n, const int64_t *keys, int64_t m,
-                            int64_t *out);
 int64_t phi_compact_num_blocks(int64_t n);
 void phi_launch_flag_count(hipStream_t st, const uint8_t *flags, int64_t n, int32_t *block_cnt);
 void phi_launch_flag_write(hipStream_t st, const uint8_t *flags, int64_t n, const int64_t *block_off, int32_t *out);
@@ -134,8 +171,9 @@ void phi_launch_match_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_
                             const uint8_t *hit, uint8_t *flags);
 
 struct PhiFilterArgs {
-    const uint32_t *rec_slot; const int32_t *rec_e0; const int32_t *rec_e1;   // per walk record
+    const uint32_t *rec_slot; const int32_t *rec_e0; const int32_t *rec_e1;   // per class record (entries of the class representative)
     const int32_t *walk_vtx;
+    const int32_t *rec_cls; const int32_t *cls_mult;   // class of a record, walk entries in a class (its multiplicity)
     const int32_t *m_rec;                          // matched records (ascending)
     uint64_t *g_keys; int32_t *g_rep; uint32_t *g_cnt; uint64_t g_mask; uint64_t seed;   // group table
     int32_t *m_group;                              // group slot of each matched anchor

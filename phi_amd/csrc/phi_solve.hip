@@ -234,8 +234,11 @@ int phi_solve_impl(phi_ctx *c)
     tm.lap("match + compact");
     // ---- 2. shared-anchor filter (:670-743)
     PhiFilterArgs F{};
+    // (over the CLASS records of contexts.hip: a record stands for cls_mult walk entries; its vertex list is read
+    //  at the class representative's entries)
     F.rec_slot = c->d_rec_slot.as<uint32_t>(); F.rec_e0 = c->d_rec_e0.as<int32_t>(); F.rec_e1 = c->d_rec_e1.as<int32_t>();
     F.walk_vtx = c->d_walk_vtx.as<int32_t>();
+    F.rec_cls = c->d_rec_cls.as<int32_t>(); F.cls_mult = c->d_cls_mult.as<int32_t>();
     F.m_rec = c->d_m_rec.as<int32_t>();
     const uint64_t g_cap = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)n_matched));
     PHICHK(phi_dev_ensure(c, c->d_g_keys, g_cap * 8));
@@ -274,23 +277,45 @@ int phi_solve_impl(phi_ctx *c)
     PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)std::max<int64_t>(std::max(n_matched, n_rec), 1)));
     PHICHK(phi_dev_ensure(c, c->d_flags2, (size_t)std::max<int64_t>(n_matched, 1)));
     phi_launch_kept_flags(c->stream, F, n_matched, c->d_flags.as<uint8_t>(), c->d_flags2.as<uint8_t>());
-    int64_t n_kept = 0;
-    PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_matched, c->d_list, &n_kept));
+    int64_t n_kept_rec = 0, n_kept = 0;
+    PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_matched, c->d_list, &n_kept_rec));
     tm.lap("filter kernels");
-    // kept anchors to the host as (minimiser id, first entry, last entry) triples, gathered into
-    // that layout on the GPU; their hashes stay behind (phi_kept_anchors fetches them on demand)
-    PHICHK(phi_pin_ensure(c, (size_t)std::max<int64_t>(n_kept, 1) * sizeof(PhiAnchorHost)));
-    c->h_kept = PhiAnchorSpan{static_cast<PhiAnchorHost *>(c->h_pin), n_kept};
-    c->h_dp = PhiAnchorSpan{};
-    c->h_kept_hash.clear();
-    PHICHK(phi_dev_ensure(c, c->d_kept_rec, (size_t)std::max<int64_t>(n_kept, 1) * 4));
-    if (n_kept) {
-        phi_launch_gather_i32(c->stream, c->d_m_rec.as<int32_t>(), c->d_list.as<int32_t>(), n_kept, c->d_kept_rec.as<int32_t>());
-        PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)n_kept * 12));
-        phi_launch_anchor_triples(c->stream, c->d_kept_rec.as<int32_t>(), n_kept, c->d_rec_slot.as<uint32_t>(), c->d_u_uid.as<uint32_t>(),
-                                  c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>(), c->d_list2.as<int32_t>());
-        static_assert(sizeof(PhiAnchorHost) == 12, "PhiAnchorHost is the device triple");
-        HIPCHK(hipMemcpyAsync(c->h_kept.p, c->d_list2.p, (size_t)n_kept * 12, hipMemcpyDeviceToHost, c->stream));
+    // The kept class records are expanded into the anchors of the model: every walk entry of a record's class
+    // carries one, (minimiser id, first entry, last entry), in entry order = position order along the walks.
+    // They go to the host as triples; their hashes stay behind (phi_kept_anchors derives them from the ids).
+    {
+        const int64_t nr = std::max<int64_t>(n_rec, 1);
+        PHICHK(phi_dev_ensure(c, c->d_flags2, (size_t)std::max<int64_t>(nr, n_matched)));
+        HIPCHK(hipMemsetAsync(c->d_flags2.p, 0, (size_t)nr, c->stream));
+        phi_launch_mark_list(c->stream, c->d_list.as<int32_t>(), c->d_m_rec.as<int32_t>(), n_kept_rec, c->d_flags2.as<uint8_t>());
+        PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)std::max<int64_t>(c->n_cls, (int64_t)nw) * 4));
+        phi_launch_class_sel_count(c->stream, c->d_flags2.as<uint8_t>(), c->d_cls_rec_off.as<int32_t>(), c->n_cls, c->d_list3.as<int32_t>());
+        PhiExpandArgs X{};
+        X.ent_cls = c->d_ent_cls.as<int32_t>(); X.e_lo = 0; X.e_hi = c->n_entries;
+        X.cls_rec_off = c->d_cls_rec_off.as<int32_t>(); X.cls_rep = c->d_cls_rep.as<int32_t>();
+        X.sel = c->d_flags2.as<uint8_t>(); X.sel_cnt = c->d_list3.as<int32_t>();
+        X.rec_slot = c->d_rec_slot.as<uint32_t>(); X.u_uid = c->d_u_uid.as<uint32_t>();
+        X.rec_e0 = c->d_rec_e0.as<int32_t>(); X.rec_e1 = c->d_rec_e1.as<int32_t>();
+        const int64_t nb = phi_expand_num_blocks(c->n_entries);
+        PHICHK(phi_dev_ensure(c, c->d_blk_cnt, (size_t)nb * 4));
+        PHICHK(phi_dev_ensure(c, c->d_blk_off, (size_t)(nb + 1) * 8));
+        X.block_cnt = c->d_blk_cnt.as<int32_t>(); X.block_off = c->d_blk_off.as<int64_t>();
+        phi_launch_expand_count(c->stream, X);
+        PHICHK(phi_scan_counts_wide(c, c->d_blk_cnt.as<int32_t>(), nb, c->d_blk_off.as<int64_t>()));
+        HIPCHK(hipMemcpyAsync(&n_kept, c->d_blk_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (n_kept >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 anchors in the model");
+        PHICHK(phi_pin_ensure(c, (size_t)std::max<int64_t>(n_kept, 1) * sizeof(PhiAnchorHost)));
+        c->h_kept = PhiAnchorSpan{static_cast<PhiAnchorHost *>(c->h_pin), n_kept};
+        c->h_dp = PhiAnchorSpan{};
+        c->h_kept_hash.clear();
+        if (n_kept) {
+            PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)n_kept * 12));
+            X.out_tri = c->d_list2.as<int32_t>();
+            phi_launch_expand_write(c->stream, X, 1);
+            static_assert(sizeof(PhiAnchorHost) == 12, "PhiAnchorHost is the device triple");
+            HIPCHK(hipMemcpyAsync(c->h_kept.p, c->d_list2.p, (size_t)n_kept * 12, hipMemcpyDeviceToHost, c->stream));
+        }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
@@ -354,9 +379,23 @@ int phi_solve_impl(phi_ctx *c)
     }
     const int64_t n_dp = (int64_t)c->h_dp.size();
     // DP scores are int32 with -2^28 as "no state": a path scores at most one per anchor
-    if (n_dp >= ((int64_t)1 << 27)) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^27 anchors in the model");
+    if (n_dp >= ((int64_t)1 << 27)) {
+        // a path is on one walk at every vertex, so it scores at most sum over vertices of the most anchors that
+        // end there on one walk: that sum, not the number of anchors, has to stay inside the DP's score range
+        std::vector<int32_t> vmax((size_t)c->n_vtx, 0);
+        for (int64_t i = 0; i < n_dp;) {
+            int64_t j = i;
+            while (j < n_dp && a_e1[j] == a_e1[i]) j++;
+            int32_t &m = vmax[c->h_walk_vtx[a_e1[i]]];
+            m = std::max<int32_t>(m, (int32_t)std::min<int64_t>(j - i, INT32_MAX));
+            i = j;
+        }
+        int64_t bound = 0;
+        for (int32_t m : vmax) bound += m;
+        if (bound >= ((int64_t)1 << 27)) return phi_fail(c, PHI_ERR_UNSUPPORTED, "a path could score %lld >= 2^27 anchors", (long long)bound);
+    }
 
-    if (tm.on) fprintf(stderr, "[phi timing] solve: n_rec %lld matched %lld kept %lld dp %lld\n", (long long)n_rec, (long long)n_matched, (long long)n_kept, (long long)n_dp);
+    if (tm.on) fprintf(stderr, "[phi timing] solve: class records %lld, matched %lld, kept %lld -> anchors kept %lld, dp %lld\n", (long long)n_rec, (long long)n_matched, (long long)n_kept_rec, (long long)n_kept, (long long)n_dp);
     tm.lap("filter (GPU) + anchors D2H");
     // ---- 3. DP inputs
     {
@@ -499,7 +538,7 @@ int phi_solve_impl(phi_ctx *c)
     int64_t incumbent = INT64_MIN, global_ub = INT64_MIN;
     int n_runs = 0;
     // branch and bound is finite and exact.  The reference's model.optimize() (ILP_index.cpp:1412-1418) has no
-    // limit; this search has a budget counted in DP runs (phi_set_solve_budget, default 65536; <= 0 = none), never
+    // limit; this search has a budget counted in DP runs (phi_set_solve_budget, default 4096; <= 0 = none), never
     // in wall-clock time: the same input gives the same `optimal` flag on every run and every machine.
     const int64_t max_runs = c->solve_budget;
     auto out_of_runs = [&]() { return max_runs > 0 && n_runs >= max_runs; };

@@ -197,53 +197,6 @@ __global__ void __launch_bounds__(256) phi_prep_reads_kernel(PhiPrepArgs P)
     pack_ascii_word((int64_t)b * 256 + threadIdx.x, P.bases, P.n, P.words, P.n_words, P.badbits, P.batch_bad);
 }
 
-// Walk sequences gathered straight into packed words: lane -> 32 bases of the flat walk space.
-// ebase[e] = flat base offset of walk entry e (monotone, ebase[n_entries] = total bases).
-// ascii (optional): the same bases as a flat ASCII buffer, for the byte-wise routine.
-__global__ void __launch_bounds__(256) phi_pack_walks_kernel(const uint8_t *__restrict__ seq_concat,
-                                                             const int64_t *__restrict__ seq_off,
-                                                             const int32_t *__restrict__ walk_vtx,
-                                                             const int64_t *__restrict__ ebase, int64_t n_entries,
-                                                             uint64_t *__restrict__ words, int64_t n_words,
-                                                             uint32_t *__restrict__ badbits, uint8_t *__restrict__ ascii,
-                                                             unsigned long long *__restrict__ n_bad)
-{
-    const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (wi >= n_words + 4) return;
-    if (wi >= n_words) {
-        if (wi < n_words + 2) words[wi] = 0;
-        if (badbits) badbits[wi] = 0;
-        return;
-    }
-    const int64_t total = ebase[n_entries];
-    const int64_t b0 = wi * 32;
-    uint64_t word = 0;
-    uint32_t bad = 0;
-    if (b0 < total) {
-        int64_t e = phi_locate_in(ebase, n_entries, b0);   // last entry e with ebase[e] <= b0
-        int64_t eend = ebase[e + 1];
-        const uint8_t *src = seq_concat + seq_off[walk_vtx[e]] - ebase[e];
-        for (int j = 0; j < 32; j++) {
-            const int64_t b = b0 + j;
-            uint32_t c = 'A';
-            if (b < total) {
-                while (b >= eend) {               // skip to the entry that owns base b
-                    e++;
-                    eend = ebase[e + 1];
-                    src = seq_concat + seq_off[walk_vtx[e]] - ebase[e];
-                }
-                c = src[b];
-                bad |= (uint32_t)(!phi_is_acgt(c)) << j;
-                if (ascii) ascii[b] = (uint8_t)c;
-            }
-            word = (word << 2) | phi_code(c);
-        }
-    }
-    words[wi] = word;
-    if (badbits) badbits[wi] = bad;
-    if (bad) atomicAdd(n_bad, (unsigned long long)__popc(bad));
-}
-
 // ---------------------------------------------------------------------------------- helpers
 
 // Lanes of one wave exchange data through LDS without a workgroup barrier: LDS instructions of a
@@ -983,16 +936,6 @@ void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, u
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(phi_reset_reads_kernel, dim3((unsigned)nb), dim3(256), 0, st, sp_keys, sp_cap, hit_words,
                        n_hit_words, stripes, n_stripe_words);
-}
-
-void phi_launch_pack_walks(hipStream_t st, const uint8_t *seq_concat, const int64_t *seq_off,
-                           const int32_t *walk_vtx, const int64_t *ebase, int64_t n_entries, uint64_t *words,
-                           int64_t n_words, uint32_t *badbits, uint8_t *ascii, unsigned long long *n_bad)
-{
-    if (n_words <= 0) return;
-    const int64_t nb = (n_words + 4 + 255) / 256;
-    hipLaunchKernelGGL(phi_pack_walks_kernel, dim3((unsigned)nb), dim3(256), 0, st, seq_concat, seq_off, walk_vtx,
-                       ebase, n_entries, words, n_words, badbits, ascii, n_bad);
 }
 
 // number of per-wave chunks (= entries of block_cnt / block_off)

@@ -170,19 +170,6 @@ void phi_launch_table_compact(hipStream_t st, const int32_t *rep_list, int64_t n
                            rec_slot, err);
 }
 
-// -d1 histogram of the reference (ILP_index.cpp:565-604): number of walks every distinct walk
-// minimiser occurs in.  One launch per walk (records of a walk are contiguous): the first record of
-// (slot, walk) bumps the slot's walk count.
-__global__ void __launch_bounds__(256) phi_share_count_kernel(const uint32_t *__restrict__ rec_slot, int64_t lo, int64_t hi,
-                                                              int32_t walk, int32_t *__restrict__ last_walk,
-                                                              int32_t *__restrict__ n_walks_of)
-{
-    for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t s = rec_slot[i];
-        if (atomicExch(&last_walk[s], walk) != walk) atomicAdd(&n_walks_of[s], 1);
-    }
-}
-
 // hist[c] += 1 for every slot of the table that holds a key and occurs in c walks
 __global__ void __launch_bounds__(256) phi_share_hist_kernel(const uint64_t *__restrict__ keys, int64_t cap,
                                                              const int32_t *__restrict__ n_walks_of,
@@ -190,14 +177,6 @@ __global__ void __launch_bounds__(256) phi_share_hist_kernel(const uint64_t *__r
 {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (int64_t)gridDim.x * blockDim.x)
         if (keys[s] != PHI_EMPTY_KEY) atomicAdd(&hist[n_walks_of[s]], 1ull);
-}
-
-void phi_launch_share_count(hipStream_t st, const uint32_t *rec_slot, int64_t lo, int64_t hi, int32_t walk, int32_t *last_walk,
-                            int32_t *n_walks_of)
-{
-    if (hi > lo)
-        hipLaunchKernelGGL(phi_share_count_kernel, dim3(grid_for(hi - lo, 256)), dim3(256), 0, st, rec_slot, lo, hi, walk,
-                           last_walk, n_walks_of);
 }
 
 void phi_launch_share_hist(hipStream_t st, const uint64_t *keys, int64_t cap, const int32_t *n_walks_of, unsigned long long *hist)

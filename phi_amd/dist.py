@@ -70,9 +70,13 @@ def merge_spectrum_into(ctx, device):
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return
     rank = dist.get_rank()
+    # the tensors below are made on torch's current stream, the imports run on the context's: unless the
+    # caller bound both to one explicit stream they are not ordered, so wait on both sides
+    torch.cuda.current_stream().synchronize()
     p, n = ctx.spectrum_export()
     mine = torch.as_tensor(DevArray(p, n, "<i8"), device=device).clone() if n else torch.zeros(0, dtype=torch.int64, device=device)
     parts = gather_spectra(mine)
+    torch.cuda.current_stream().synchronize()          # the gathered lists are complete before another stream reads them
     for r, t in enumerate(parts):
         if r != rank and t.numel():
             t = t.contiguous()

@@ -18,7 +18,8 @@ while time.time() < t_end:
     k = int(rng.choice([31, 31, 31, int(rng.integers(1, 33))])); w = int(rng.choice([25, 25, int(rng.integers(1, 70))]))
     g = random_graph(rng, n_sites=int(rng.integers(3, 40)), n_walks=int(rng.integers(1, 9)), seg_len=(1, int(rng.integers(5, 120))), alt_len=(1, int(rng.integers(2, 40))))
     ctx = phi_amd.Context(0); ctx.set_params(k=k, w=w, threshold=1.0, recombination=5)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    _st = torch.cuda.Stream(); torch.cuda.set_stream(_st)
+    ctx.set_stream(_st.cuda_stream)
     A = g.arrays()
     try:
         ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
