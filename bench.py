@@ -89,6 +89,9 @@ def cpu_baseline(g_arrays, reads_concat, read_off, k, w, budget_s=6.0):
     # stages 1-2 of the whole configuration (walk sketch, read sketch + spectrum, anchors, filter)
     L.orc_set_threads(nt)
     A = g_arrays
+    if len(A["walk_vtx"]) > 50_000_000:
+        out["stages"] = {"note": "skipped: this configuration's walks take the scalar port minutes (see the C2 line for the per-stage times)"}
+        return out
     t0 = time.perf_counter()
     h = L.orc_run(len(A["seq_off"]) - 1, A["seq_concat"].tobytes(), A["seq_off"].ctypes.data, len(A["walk_off"]) - 1,
                   A["walk_off"].ctypes.data, A["walk_vtx"].ctypes.data, raw, off.ctypes.data, n_reads, k, w,
@@ -181,7 +184,16 @@ def main():
 
     K, W = 31, 25
     t0 = time.perf_counter()
-    if args.config == "C1syn":
+    native = args.config in synth.NATIVE_CONFIGS
+    if native:
+        # chromosome-scale configurations come from the native generator (libphi_synth.so): counter-based, so every
+        # rank makes its own reads -- its own set (weak) or its shard of the common set (strong) -- without the others'
+        gk, s_seed, n_mosaic, r_seed, cov = synth.NATIVE_CONFIGS[args.config]
+        g = synth.NativeGraph(**gk)
+        truth = g.sample(s_seed, n_mosaic)
+        rk = dict(seed=r_seed)
+        bases, off = g.reads(r_seed + 1000 * rank, 0, g.n_reads(cov))
+    elif args.config == "C1syn":
         # the reference's own graph (test/MHC_4.gfa.gz, 5 walks) with the generator's reads
         gk = dict(seed="tests/golden/data/MHC_4.gfa.gz")
         g = synth.graph_from_gfa(os.path.join(ROOT, "tests", "golden", "data", "MHC_4.gfa.gz"))
@@ -191,10 +203,11 @@ def main():
         gk, rk = synth.CONFIGS[args.config]
         g = synth.make_graph(**gk)
         strong_rk = dict(synth.CONFIGS[args.strong_config][1]) if args.strong_config in synth.CONFIGS else dict(rk)
-    rk = dict(rk)
-    if rank:
-        rk["sample_seed"] = rk["seed"] + 1000 * rank           # weak scaling: each rank scores its own reads of the same sample
-    bases, off, truth = synth.make_reads(g, **rk)
+    if not native:
+        rk = dict(rk)
+        if rank:
+            rk["sample_seed"] = rk["seed"] + 1000 * rank       # weak scaling: each rank scores its own reads of the same sample
+        bases, off, truth = synth.make_reads(g, **rk)
     t_gen = time.perf_counter() - t0
     n_reads, n_bases = len(off) - 1, int(off[-1])
 
@@ -212,7 +225,11 @@ def main():
     ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
     torch.cuda.synchronize()
     t_index = time.perf_counter() - t0
-    walk_bases = int((A["seq_off"][A["walk_vtx"] + 1] - A["seq_off"][A["walk_vtx"]]).sum())
+    index_info = ctx.index_stats()
+    walk_bases = index_info["walk_bases"]
+    # graph-side de-duplication: walk bases indexed per second of GPU time of the class sketch
+    index_info["sketch_gbases_per_s"] = walk_bases / max(index_info["sketch_gpu_ms"], 1e-6) / 1e6
+    index_info["dedup_factor_bases"] = walk_bases / max(1, index_info["class_bases"])
 
     # the library's own RCCL communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes
     use_lib_comm = world > 1 and not args.rehearse_gloo
@@ -262,20 +279,29 @@ def main():
     weak_step = make_step(d_bases, d_off, n_reads, n_bases)
     need_strong = args.scaling == "strong" or not args.no_extra_legs
     strong = None
-    if need_strong:
+    if need_strong and native:
+        # the common set is the configuration's own read set; this rank makes only its shard of it
+        tot = g.n_reads(cov)
+        lo, hi = tot * rank // world, tot * (rank + 1) // world
+        sh_bases, sh_off = g.reads(r_seed, lo, hi)
+        strong = dict(total_bases=tot * 150, total_reads=tot, n_reads=hi - lo, n_bases=int(sh_off[-1]),
+                      d_b=torch.from_numpy(sh_bases).to(dev), d_o=torch.from_numpy(sh_off).to(dev))
+        args.strong_config = args.config
+    elif need_strong:
         sb, so, _ = synth.make_reads(g, **strong_rk)            # the same set on every rank
         lo, hi = pdist.shard_bounds(so, world, rank)
         sh_off = (so[lo:hi + 1] - so[lo]).astype(np.int64)
         sh_bases = sb[int(so[lo]):int(so[hi])]
         strong = dict(total_bases=int(so[-1]), total_reads=len(so) - 1, n_reads=hi - lo, n_bases=int(sh_off[-1]),
                       d_b=torch.from_numpy(np.ascontiguousarray(sh_bases)).to(dev), d_o=torch.from_numpy(sh_off).to(dev))
+    if need_strong:
         strong["step"] = make_step(strong["d_b"], strong["d_o"], strong["n_reads"], strong["n_bases"])
 
     # clock ramp: a fresh box runs its first launches at idle clocks (a third slower for the first tens
     # of milliseconds); untimed, before the W warmup steps (no collective inside: ranks need not agree on its length)
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.25:
-        for _ in range(50):
+        for _ in range(50 if n_bases < 5e7 else 1):
             ctx.reset_reads()
             ctx.add_reads_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases)
         torch.cuda.synchronize()
@@ -360,7 +386,7 @@ def main():
         "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {'reference graph' if args.config == 'C1syn' else f'synMHC-{g.n_walks} graph'} (seed {gk['seed']}, {g.n_walks} walks, {g.n_vtx} vertices{'' if args.config == 'C1syn' else ' <=30 bp'}, "
+        "config": {"workload": f"{args.config}: {'reference graph' if args.config == 'C1syn' else (f'native syn-{g.n_walks} graph' if native else f'synMHC-{g.n_walks} graph')} (seed {gk['seed']}, {g.n_walks} walks, {g.n_vtx} vertices{'' if args.config == 'C1syn' else ' <=30 bp'}, "
                                f"{walk_bases / 1e6:.1f} Mbases of walks) + " +
                                (f"{n_reads} reads of mean {n_bases / max(1, n_reads):.0f} bp per GPU (seed {rk['seed']}, {n_bases / 1e6:.2f} Mbases)" if args.scaling == "weak" else
                                 f"ONE set of {strong['total_reads']} reads ({args.strong_config}, {strong['total_bases'] / 1e6:.2f} Mbases) in {world} shard(s)"),
@@ -376,7 +402,7 @@ def main():
                      "note": "achieved/frac price the sketch kernel's time against ALL algorithmic bytes of a base (SURVEY 8d formula); kernel_own_frac prices it against "
                              "the bytes that kernel itself moves; step_frac = all algorithmic bytes / whole step time (every launch of the step)",
                      "kernel_gbases_per_s": launch_bases / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0},
-        "index_build_s": t_index, "graph_gbases_per_s": walk_bases / t_index / 1e9,
+        "index_build_s": t_index, "graph_gbases_per_s": walk_bases / t_index / 1e9, "index": index_info,
         "solve_s": t_solve, "end_to_end_s": (t_index + ms_per_step * 1e-3 + t_solve) if t_solve is not None else None,
         "synthetic_gen_s": t_gen,
     }
@@ -390,7 +416,7 @@ def main():
         ph = res["path_hap"]
         out["result"]["path_walks"] = [int(x) for x in ph[np.r_[True, ph[1:] != ph[:-1]]]] if len(ph) else []
 
-    if rank == 0 and world == 1 and not args.no_extra_legs:
+    if rank == 0 and world == 1 and not args.no_extra_legs and n_bases < 2e9:
         # PCIe-inclusive rate: the same read set handed over as HOST buffers (pinned) through phi_add_reads
         hb = np.ascontiguousarray(bases)
         ctx._chk(ctx._L.phi_host_register(ctx._h, hb.ctypes.data, hb.nbytes))
@@ -404,8 +430,9 @@ def main():
         torch.cuda.synchronize()
         out["h2d_inclusive_gbases_per_s"] = n_bases * reps / (time.perf_counter() - t0) / 1e9
         ctx._chk(ctx._L.phi_host_unregister(ctx._h, hb.ctypes.data))
-        out["file_to_fasta"] = file_to_fasta(g, bases, off, K, W)
-        out["file_to_fasta_s"] = (out["file_to_fasta"] or {}).get("seconds")
+        if walk_bases < 2e9:
+            out["file_to_fasta"] = file_to_fasta(g, bases, off, K, W)
+            out["file_to_fasta_s"] = (out["file_to_fasta"] or {}).get("seconds")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A, bases, off, K, W)
     elif rank == 0:

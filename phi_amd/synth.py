@@ -308,3 +308,92 @@ CONFIGS = {
     "tiny": (dict(backbone_len=60_000, n_walks=7, seed=11, max_sv=800), dict(coverage=2.0, seed=12)),
     "small": (dict(backbone_len=400_000, n_walks=16, seed=21, max_sv=2000), dict(coverage=1.0, seed=22)),
 }
+
+
+# ---------------------------------------------------------------------------------------------- native generator
+class NativeGraph(SynGraph):
+    """The same model made by libphi_synth.so (phi_amd/csrc/host/synth.cpp): counter-based generator, threads,
+    chunks -- what the chromosome-scale configuration (C5: 170 Mbp x 200 walks = 1.2 G walk entries, 34 M reads)
+    needs.  Its graphs are NOT those of make_graph for the same seed (another generator); the arrays are views
+    of the library's memory and live as long as this object."""
+
+    def __init__(self, backbone_len, n_walks, seed, site_spacing=250, chop=30, block_len=20_000, n_founders=6, max_sv=5000, threads=0):
+        import ctypes as C
+        import os
+        super().__init__()
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libphi_synth.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `python -m phi_amd.build`")
+        L = C.CDLL(path)
+        vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+        L.phi_syn_graph.argtypes = [i64, i32, u64, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
+        L.phi_syn_free.argtypes = [vp]
+        L.phi_syn_free.restype = None
+        for name, rt in (("n_vtx", i32), ("n_walks", i32), ("n_sites", i64)):
+            f = getattr(L, "phi_syn_" + name); f.argtypes = [vp]; f.restype = rt
+        for name in ("seq", "seq_off", "adj_off", "adj", "walk_off", "walk_vtx", "topo_rank"):
+            f = getattr(L, "phi_syn_" + name); f.argtypes = [vp]; f.restype = vp
+        L.phi_syn_sample.argtypes = [vp, u64, i32, vp, vp]
+        L.phi_syn_sample.restype = i64
+        L.phi_syn_reads.argtypes = [vp, u64, i64, i64, i32, C.c_double, vp, i32]
+        self._L, self._h = L, vp()
+        rc = L.phi_syn_graph(backbone_len, n_walks, seed, site_spacing, chop, block_len, n_founders, max_sv, threads, C.byref(self._h))
+        if rc:
+            raise RuntimeError(f"phi_syn_graph failed ({rc})")
+        self.n_vtx, self.n_walks = L.phi_syn_n_vtx(self._h), L.phi_syn_n_walks(self._h)
+
+        def view(name, ctype, n):
+            return np.ctypeslib.as_array(C.cast(getattr(L, "phi_syn_" + name)(self._h), C.POINTER(ctype)), shape=(n,))
+        self.seq_off = view("seq_off", C.c_int64, self.n_vtx + 1)
+        self.seq_concat = view("seq", C.c_uint8, int(self.seq_off[-1]))
+        self.adj_off = view("adj_off", C.c_int64, self.n_vtx + 1)
+        self.adj = view("adj", C.c_int32, int(self.adj_off[-1]))
+        self.walk_off = view("walk_off", C.c_int64, self.n_walks + 1)
+        self.walk_vtx = view("walk_vtx", C.c_int32, int(self.walk_off[-1]))
+        self.top_rank = view("topo_rank", C.c_int32, self.n_vtx)
+        self.hap_names = [f"syn{h:03d}.{h % 2}" for h in range(self.n_walks)]
+        self.hap_len = 0
+
+    def close(self):
+        if self._h:
+            self._L.phi_syn_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sample(self, seed, n_mosaic=3):
+        """Fix the sample the reads come from: a mosaic of n_mosaic walks.  Returns the truth dict of make_reads."""
+        import ctypes as C
+        walks = (C.c_int32 * n_mosaic)()
+        cuts = (C.c_double * max(1, n_mosaic - 1))()
+        self.hap_len = self._L.phi_syn_sample(self._h, seed, n_mosaic, walks, cuts)
+        if self.hap_len < 0:
+            raise RuntimeError("phi_syn_sample failed")
+        return dict(walks=list(walks), cuts=list(cuts)[:n_mosaic - 1], hap_len=self.hap_len)
+
+    def n_reads(self, coverage, read_len=150):
+        return max(1, (int(coverage * self.hap_len) + read_len - 1) // read_len)
+
+    def reads(self, seed, r_lo, r_hi, read_len=150, sub_err=0.005, out=None, threads=0):
+        """Reads r_lo .. r_hi-1 of read set `seed` as (uint8 bases, int64 offsets); any range gives the same bytes."""
+        n = r_hi - r_lo
+        if out is None:
+            out = np.empty(n * read_len, np.uint8)
+        if self._L.phi_syn_reads(self._h, seed, r_lo, r_hi, read_len, sub_err, out.ctypes.data, threads):
+            raise RuntimeError("phi_syn_reads failed")
+        return out, np.arange(n + 1, dtype=np.int64) * read_len
+
+
+# native configurations: (graph kwargs, sample seed, n_mosaic, read-set seed, coverage)
+NATIVE_CONFIGS = {
+    # BASELINE.json config 5 at its stated size: synCHR6-200, 170 Mbp backbone, 200 walks, 30x 150-bp reads (SURVEY.md 8d)
+    "C5": (dict(backbone_len=170_000_000, n_walks=200, seed=20001), 20002, 3, 20003, 30.0),
+    # the same generator at sizes the CPU checkers and quick GPU runs take
+    "C5n-mid": (dict(backbone_len=20_000_000, n_walks=200, seed=20001), 20002, 3, 20003, 30.0),
+    "C5n-small": (dict(backbone_len=400_000, n_walks=40, seed=31, max_sv=2000), 32, 3, 33, 4.0),
+    "C5n-tiny": (dict(backbone_len=30_000, n_walks=12, seed=41, max_sv=500, site_spacing=120, block_len=4000), 42, 2, 43, 6.0),
+}
