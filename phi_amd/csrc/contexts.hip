@@ -67,37 +67,65 @@ __global__ void __launch_bounds__(256) phi_walk_sum_kernel(const int32_t *__rest
                                                            const int32_t *__restrict__ cls_rec_off, const int64_t *__restrict__ walk_off,
                                                            int32_t n_walks, int64_t n_entries, unsigned long long *__restrict__ out)
 {
-    const int64_t n_round = (n_entries + 63) & ~(int64_t)63;
-    GRID_STRIDE(e, n_round) {
-        int32_t h = -1;
+    // every wave takes one contiguous slice of the entries (a walk is a contiguous range: a slice meets one
+    // or two of them), sums in registers and adds once per walk it met: thousands of atomics on a few dozen
+    // addresses would serialise at ~12 ns each
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t per = ((n_entries + n_waves - 1) / n_waves + 63) & ~(int64_t)63;
+    const int64_t lo = gw * per, hi = lo + per < n_entries ? lo + per : n_entries;
+    if (lo >= hi) return;
+    int32_t h = walk_of(walk_off, n_walks, lo);
+    int64_t h_end = walk_off[h + 1];
+    long long acc = 0;
+    for (int64_t e0 = lo; e0 < hi; e0 += 64) {
+        const int64_t e = e0 + lane;
         long long v = 0;
-        if (e < n_entries) {
-            h = walk_of(walk_off, n_walks, e);
+        if (e < hi) {
             const int32_t x = key[e];
             v = BY_CLASS ? (cls_rec_off[x + 1] - cls_rec_off[x]) : val_of[x];
         }
-        const int32_t h0 = __shfl(h, 0, 64);
-        if (__all(h == h0 || h < 0) && h0 >= 0) {
+        if (e0 + 64 <= h_end) acc += v;                      // the whole row lies in walk h
+        else {
+            // the row crosses into the next walk(s): flush walk by walk
+            int64_t row_lo = e0;
+            for (;;) {
+                const long long mine = (e >= row_lo && e < h_end) ? v : 0;
+                acc += mine;
+                if (h_end >= e0 + 64 || h_end >= hi) break;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&out[h0], (unsigned long long)v);
-        } else if (h >= 0 && v) {
-            atomicAdd(&out[h], (unsigned long long)v);
+                for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+                if (lane == 0 && acc) atomicAdd(&out[h], (unsigned long long)acc);
+                acc = 0;
+                row_lo = h_end;
+                h++;
+                h_end = walk_off[h + 1];
+            }
         }
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0 && acc) atomicAdd(&out[h], (unsigned long long)acc);
+}
+static inline unsigned walk_sum_grid(int64_t n_entries)
+{
+    int64_t nb = (n_entries + 256 * 64 - 1) / (256 * 64);       // >= 64 rows per wave
+    if (nb > 1024) nb = 1024;
+    return (unsigned)(nb < 1 ? 1 : nb);
 }
 void phi_launch_walk_bases(hipStream_t st, const int32_t *walk_vtx, const int32_t *vlen, const int64_t *walk_off, int32_t n_walks,
                            int64_t n_entries, unsigned long long *out)
 {
     if (n_entries > 0)
-        hipLaunchKernelGGL(phi_walk_sum_kernel<false>, dim3(grid_for(n_entries, 256)), dim3(256), 0, st, walk_vtx, vlen, nullptr,
+        hipLaunchKernelGGL(phi_walk_sum_kernel<false>, dim3(walk_sum_grid(n_entries)), dim3(256), 0, st, walk_vtx, vlen, nullptr,
                            walk_off, n_walks, n_entries, out);
 }
 void phi_launch_walk_rec_counts(hipStream_t st, const int32_t *ent_cls, const int32_t *cls_rec_off, const int64_t *walk_off,
                                 int32_t n_walks, int64_t n_entries, unsigned long long *out)
 {
     if (n_entries > 0)
-        hipLaunchKernelGGL(phi_walk_sum_kernel<true>, dim3(grid_for(n_entries, 256)), dim3(256), 0, st, ent_cls, nullptr, cls_rec_off,
+        hipLaunchKernelGGL(phi_walk_sum_kernel<true>, dim3(walk_sum_grid(n_entries)), dim3(256), 0, st, ent_cls, nullptr, cls_rec_off,
                            walk_off, n_walks, n_entries, out);
 }
 

@@ -72,19 +72,15 @@ int phi_scan_counts_wide(phi_ctx *c, const int32_t *cnt, int64_t n, int64_t *off
     return PHI_OK;
 }
 
-// phi_reset_reads only notes the reset; the next read batch folds it into its preparation launch.
-// Everything else that looks at the spectrum, the hit vector or the counters calls this first.
-int phi_flush_reset(phi_ctx *c)
+// (a reset leaves nothing pending: phi_reset_reads swaps the context's double buffers, see phi_ctx.h)
+int phi_flush_reset(phi_ctx *) { return PHI_OK; }
+
+static void swap_read_bufs(phi_ctx *c)
 {
-    if (!c->reset_pending) return PHI_OK;
-    c->reset_pending = false;
-    if (c->sp_cap == 0 && c->n_unique == 0) return PHI_OK;
-    phi_launch_reset_reads(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_hit.as<uint64_t>(),
-                           c->n_unique / 8 + 1, c->d_stripes.as<uint64_t>(), 2 * PHI_STRIPES * 8);
-    // a whole-set reset that starts generation sp_gen + 1: zero the flag of the generation after it
-    HIPCHK(hipMemsetAsync(scalar(c, S_SPDIRTY + (int)((c->sp_gen + 2) % 3)), 0, 8, c->stream));
-    c->sp_gen++; c->log_chunks = 0; c->sp_full = false;
-    return phi_hip_check(c, hipGetLastError(), "reset launch");
+    std::swap(c->d_sp_keys, c->alt.sp_keys); std::swap(c->sp_cap, c->alt.sp_cap);
+    std::swap(c->d_hit, c->alt.hit); std::swap(c->d_stripes, c->alt.stripes);
+    std::swap(c->d_splog, c->alt.splog); std::swap(c->d_splog_cnt, c->alt.splog_cnt);
+    std::swap(c->log_chunks, c->alt.log_chunks); std::swap(c->sp_full, c->alt.sp_full);
 }
 
 int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted)
@@ -178,7 +174,8 @@ int phi_ctx_create(int device_id, phi_ctx **out)
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PHI_ERR_DEVICE; }
     c->stream = c->own_stream;
     if (phi_dev_ensure(c, c->d_scalars, S_N * 8) || hipMemset(c->d_scalars.p, 0, S_N * 8) != hipSuccess ||
-        phi_dev_ensure(c, c->d_stripes, 2 * STRIPE_BYTES) || hipMemset(c->d_stripes.p, 0, 2 * STRIPE_BYTES) != hipSuccess) {
+        phi_dev_ensure(c, c->d_stripes, 2 * STRIPE_BYTES) || hipMemset(c->d_stripes.p, 0, 2 * STRIPE_BYTES) != hipSuccess ||
+        phi_dev_ensure(c, c->alt.stripes, 2 * STRIPE_BYTES) || hipMemset(c->alt.stripes.p, 0, 2 * STRIPE_BYTES) != hipSuccess) {
         (void)hipStreamDestroy(c->own_stream); delete c; return PHI_ERR_DEVICE;
     }
     // the first pageable host-to-device copy of a process sets up the runtime's staging buffers
@@ -206,11 +203,11 @@ void phi_ctx_destroy(phi_ctx *c)
     (void)phi_comm_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->alt.sp_keys, &c->alt.hit, &c->alt.stripes, &c->alt.splog, &c->alt.splog_cnt, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
-                     &c->d_wascii, &c->d_rbad, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
+                     &c->d_wascii, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
-                     &c->d_roff, &c->d_rwords, &c->d_rstarts, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
+                     &c->d_roff, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_bstart, &c->d_k_rec, &c->d_k_in, &c->d_cvtx, &c->d_ev_e, &c->d_ev_off, &c->d_ev,
@@ -451,7 +448,6 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     if (adj_off[n_vtx] > 0 && !adj) return phi_fail(c, PHI_ERR_INVALID, "phi_set_graph: adj is null");
     HIPCHK(hipSetDevice(c->device));
     c->have_graph = false;
-    c->reset_pending = false;
     c->solved = false;
 
     PhiStageTimer tm("set_graph");
@@ -657,6 +653,9 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         }
         PHICHK(phi_dev_ensure(c, c->d_hit, (size_t)(c->n_unique / 8 + 1) * 8));
         HIPCHK(hipMemsetAsync(c->d_hit.p, 0, (size_t)(c->n_unique / 8 + 1) * 8, c->stream));
+        PHICHK(phi_dev_ensure(c, c->alt.hit, (size_t)(c->n_unique / 8 + 1) * 8));
+        HIPCHK(hipMemsetAsync(c->alt.hit.p, 0, (size_t)(c->n_unique / 8 + 1) * 8, c->stream));
+        HIPCHK(hipMemsetAsync(c->alt.stripes.p, 0, 2 * STRIPE_BYTES, c->stream));
         HIPCHK(hipGetLastError());
         PHICHK(phi_sync_check(c));
         tg.lap("[gpu thread] walk sketch + table");
@@ -837,6 +836,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
 
     c->sp_cap = 0; c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
     c->log_chunks = 0; c->sp_full = true;
+    c->alt.sp_cap = 0; c->alt.log_chunks = 0; c->alt.sp_full = true; c->alt.needs_clean = false;
+    c->next_flag_zeroed = false;                               // (set_graph zeroed all scalars, the dirty flags among them)
     c->have_graph = true;
     return PHI_OK;
 }
@@ -891,50 +892,21 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     // w = 25); room for 1.5x that.  Denser input (at most one per base) is caught by the probe bound
     // and reported as PHI_ERR_OVERFLOW.
     PHICHK(sp_ensure(c, (int64_t)((double)n_bases * std::min(1.0, 3.0 / (c->w + 1))) + 16));
-    const int64_t n_words = (n_bases + 31) / 32;
-    PHICHK(phi_dev_ensure(c, c->d_rwords, (size_t)(n_words + 2) * 8));
-    const size_t n_sw = (size_t)(n_bases / 64 + 2);
-    PHICHK(phi_dev_ensure(c, c->d_rstarts, n_sw * 8));
-    PHICHK(phi_dev_ensure(c, c->d_rbad, (size_t)(n_words + 6) * 4));
-    // one preparation launch: [pending reset] + read-start bitmap + 2-bit pack
-    unsigned long long *batch_bad = (unsigned long long *)scalar(c, c->bad_parity ? S_BATCHBAD2 : S_BATCHBAD);
-    {
-        PhiPrepArgs P{};
-        P.sp_keys = c->d_sp_keys.as<uint64_t>(); P.sp_cap = (int64_t)c->sp_cap;
-        P.hit_words = c->d_hit.as<uint64_t>(); P.n_hit_words = c->n_unique / 8 + 1;
-        P.stripes = c->d_stripes.as<uint64_t>(); P.n_stripe_words = 2 * PHI_STRIPES * 8;
-        P.seq_off = (const int64_t *)d_read_off; P.n_seq = n_reads;
-        P.starts = c->d_rstarts.as<unsigned long long>(); P.n_sw = (int64_t)n_sw;
-        P.bases = (const uint8_t *)d_bases; P.n = n_bases; P.words = c->d_rwords.as<uint64_t>(); P.n_words = n_words;
-        P.badbits = c->d_rbad.as<uint32_t>();
-        P.batch_bad = batch_bad;
-        P.batch_bad_next = (unsigned long long *)scalar(c, c->bad_parity ? S_BATCHBAD : S_BATCHBAD2);
-        if (c->reset_pending) {
-            // this launch ends generation sp_gen: it empties the logged slots unless something was not logged
-            P.full = c->sp_full || !c->d_splog.p;
-            P.sp_log = c->d_splog.as<uint32_t>(); P.sp_log_cnt = c->d_splog_cnt.as<uint8_t>(); P.log_chunks = c->log_chunks;
-            P.sp_dirty = (const uint32_t *)scalar(c, S_SPDIRTY + (int)(c->sp_gen % 3));
-            P.sp_dirty_zero = (uint32_t *)scalar(c, S_SPDIRTY + (int)((c->sp_gen + 2) % 3));
-        }
-        phi_launch_prep_reads(c->stream, P, c->reset_pending);
-        if (c->reset_pending) { c->sp_gen++; c->log_chunks = 0; c->sp_full = false; }
-        c->reset_pending = false;
-        c->bad_parity ^= 1;
-    }
     // this batch's part of the insert log (a buffer that has to grow loses what it held)
     const int64_t n_log_chunks = phi_sketch_num_blocks(n_bases);
     if ((size_t)(c->log_chunks + n_log_chunks) * PHI_SPLOG * 4 > c->d_splog.cap || (size_t)(c->log_chunks + n_log_chunks) > c->d_splog_cnt.cap) {
         if (c->log_chunks > 0) c->sp_full = true;
-        HIPCHK(hipStreamSynchronize(c->stream));             // the preparation launch above may read the old buffers
+        HIPCHK(hipStreamSynchronize(c->stream));             // an earlier launch may still write the old buffers
         PHICHK(phi_dev_ensure(c, c->d_splog, (size_t)(c->log_chunks + n_log_chunks) * 2 * PHI_SPLOG * 4));
         PHICHK(phi_dev_ensure(c, c->d_splog_cnt, (size_t)(c->log_chunks + n_log_chunks) * 2));
     }
+    // ONE launch per batch: every wave stages its chunk straight from the ASCII bases (2-bit pack, bases outside
+    // ACGTacgt, read starts from the offsets), sketches, hashes and probes; windows touching a base outside ACGT
+    // take the exact byte-wise routine inside the same wave
     PhiSketchArgs A{};
-    A.badbits = c->d_rbad.as<unsigned long long>();      // windows touching such bases take the byte-wise path
     A.ascii = (const uint8_t *)d_bases;
+    A.read_off = (const int64_t *)d_read_off; A.n_reads = n_reads;
     A.allslow = 0;
-    A.words = c->d_rwords.as<uint64_t>();
-    A.starts = c->d_rstarts.as<unsigned long long>();
     A.n_bases = n_bases; A.k = c->k; A.w = c->w;
     A.sp_keys = c->d_sp_keys.as<uint64_t>(); A.sp_mask = c->sp_cap - 1;
     A.sp_count = sp_stripes(c);
@@ -942,11 +914,24 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     A.u_kv = c->d_u_kv.as<uint64_t>(); A.u_mask = c->u_cap - 1;
     A.hit = c->d_hit.as<uint8_t>();
     A.err = (uint32_t *)scalar(c, S_ERR);
-    A.batch_bad = batch_bad;                            // windows touching a base outside ACGT: byte-wise workgroups of the same launch
     A.sp_log = c->d_splog.as<uint32_t>(); A.sp_log_cnt = c->d_splog_cnt.as<uint8_t>(); A.log_base = c->log_chunks;
     A.sp_dirty = (uint32_t *)scalar(c, S_SPDIRTY + (int)(c->sp_gen % 3));
     if (c->sp_cap > 0xFFFFFFFFull) { A.sp_log = nullptr; c->sp_full = true; }   // the log holds 32-bit slots
     c->log_chunks += n_log_chunks;
+    if (c->alt.needs_clean) {
+        // the first launch since the reset: its waves empty what the ended generation filled (the other half of the
+        // double buffers) for the generation after this one, and zero that generation's dirty flag
+        A.q_clean = 1;
+        A.q_full = c->alt.sp_full || !c->alt.splog.p || c->alt.sp_cap > 0xFFFFFFFFull;
+        A.q_sp_keys = c->alt.sp_cap ? c->alt.sp_keys.as<uint64_t>() : nullptr; A.q_sp_cap = (int64_t)c->alt.sp_cap;
+        A.q_log = c->alt.splog.as<uint32_t>(); A.q_log_cnt = c->alt.splog_cnt.as<uint8_t>(); A.q_log_chunks = c->alt.log_chunks;
+        A.q_dirty = (const uint32_t *)scalar(c, S_SPDIRTY + (int)(c->alt.gen % 3));
+        A.dirty_zero = (uint32_t *)scalar(c, S_SPDIRTY + (int)((c->sp_gen + 1) % 3));
+        A.q_hit_words = c->alt.hit.as<uint64_t>(); A.q_n_hit_words = c->n_unique / 8 + 1;
+        A.q_stripes = c->alt.stripes.as<uint64_t>(); A.q_n_stripe_words = 2 * PHI_STRIPES * 8;
+        c->alt.needs_clean = false; c->alt.log_chunks = 0; c->alt.sp_full = false;
+        c->next_flag_zeroed = true;
+    }
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (c->prof && c->prof_period > 0 && (c->prof_seq++ % c->prof_period) == 0) {
         if (c->prof_used == c->prof_events.size()) {
@@ -1001,7 +986,22 @@ int phi_reset_reads(phi_ctx *c)
     if (!c) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reset_reads before phi_set_graph");
     HIPCHK(hipSetDevice(c->device));
-    c->reset_pending = true;
+    // The buffers this generation filled go to the back (the next read launch empties them), the other half
+    // comes to the front: no launch, no wait.
+    const bool front_dirty = c->alt.needs_clean;               // two resets with no read launch in between
+    swap_read_bufs(c);
+    c->alt.needs_clean = true; c->alt.gen = c->sp_gen;
+    if (front_dirty) {
+        // nothing emptied the half that comes to the front: do it now, the whole of it
+        if (c->sp_cap || c->n_unique)
+            phi_launch_reset_reads(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_hit.as<uint64_t>(),
+                                   c->n_unique / 8 + 1, c->d_stripes.as<uint64_t>(), 2 * PHI_STRIPES * 8);
+        c->log_chunks = 0; c->sp_full = false;
+        HIPCHK(hipGetLastError());
+    }
+    c->sp_gen++;
+    if (!c->next_flag_zeroed) HIPCHK(hipMemsetAsync(scalar(c, S_SPDIRTY + (int)(c->sp_gen % 3)), 0, 8, c->stream));   // the new generation's dirty flag
+    c->next_flag_zeroed = false;
     c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
     c->solved = false;
     return PHI_OK;

@@ -108,7 +108,7 @@ struct phi_ctx {
     int64_t sp_bound = 0;                             // host-side upper bound of the set size
     int64_t reads_bases = 0, reads_count = 0;
     int64_t spectrum_override = -1;
-    DevBuf d_rbases, d_roff, d_rwords, d_rstarts, d_rbad, d_export;
+    DevBuf d_rbases, d_roff, d_export;
     // device scalars: [0] err(u32 in low half) [1] n_bad [2] sp_count [3] n_emitted [4..] scratch
     DevBuf d_scalars;
     DevBuf d_stripes;                                 // [2][PHI_STRIPES][8] u64: distinct read hashes, emitted records
@@ -120,6 +120,18 @@ struct phi_ctx {
     int64_t log_chunks = 0;                           // chunks logged in this generation
     int64_t sp_gen = 0;
     bool sp_full = true;                              // the next reset must empty the whole set (import, regrow, log too small)
+    // Double buffers: everything a generation of reads writes (d_sp_keys / sp_cap, d_hit, d_stripes, d_splog*, log_chunks,
+    // sp_full) exists twice.  phi_reset_reads swaps the two sets on the host; the set the ended generation filled is emptied
+    // by the waves of the next read launch (sketch.hip clean_previous), ready for the generation after: no reset launch.
+    struct PhiReadBufs {
+        DevBuf sp_keys, hit, stripes, splog, splog_cnt;
+        uint64_t sp_cap = 0;
+        int64_t log_chunks = 0;
+        bool sp_full = true;
+        bool needs_clean = false;                     // filled by generation `gen`, not emptied yet
+        int64_t gen = 0;
+    } alt;
+    bool next_flag_zeroed = false;                    // a launch of this generation has zeroed the dirty flag of the next one
 
     // ---- scratch for sketch passes and compaction
     DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2, d_list3, d_walk_last;
@@ -147,8 +159,6 @@ struct phi_ctx {
     std::vector<int64_t> h_n_minimizers, h_n_anchors;
     phi_result result{};
     bool solved = false;
-    bool reset_pending = false;                       // phi_reset_reads noted, folded into the next batch's launch
-    int bad_parity = 0;                               // which of the two per-batch bad-base scalars is live
 
     // ---- profiling of the sketch kernel
     bool prof = false;

@@ -44,14 +44,19 @@ struct PhiSketchArgs {
     const uint64_t *u_kv; uint64_t u_mask; // walk-minimiser table as (key, dense id) pairs: one 16-byte load per probe
     uint8_t *hit;                          // per distinct walk minimiser (dense id)
     uint32_t *err;
-    // read batches: count of bases outside ACGTacgt of this batch (device scalar); when set, the PROBE
-    // launch carries byte-wise workgroups behind its fast_blocks 2-bit ones (set by the launcher)
-    const unsigned long long *batch_bad;
-    unsigned fast_blocks;
     // PHI_MODE_PROBE: log of the spectrum slots this batch fills (PHI_SPLOG entries per chunk, chunk
     // log_base + i of the reads since the last reset) so that the next reset empties those slots instead
     // of the whole table; *sp_dirty is raised when a chunk fills more, or the byte-wise path inserts
     uint32_t *sp_log; uint8_t *sp_log_cnt; int64_t log_base; uint32_t *sp_dirty;
+    // PHI_MODE_PROBE reads ASCII: the 2-bit pack, the bases outside ACGTacgt and the read-start bitmap of a chunk
+    // are made by the wave that sketches it (no preparation launch): `ascii` + read offsets
+    const int64_t *read_off; int64_t n_reads;
+    // ... and, in the first launch after a reset, every wave also empties its share of the buffers the PREVIOUS
+    // generation of reads filled (the other half of the context's double buffers), for the generation after this one
+    int32_t q_clean, q_full;
+    uint64_t *q_sp_keys; int64_t q_sp_cap; const uint32_t *q_log; const uint8_t *q_log_cnt; int64_t q_log_chunks;
+    const uint32_t *q_dirty; uint32_t *dirty_zero;
+    uint64_t *q_hit_words; int64_t q_n_hit_words; uint64_t *q_stripes; int64_t q_n_stripe_words;
 };
 
 // sketch.hip
@@ -59,18 +64,6 @@ void phi_launch_pack_ascii(hipStream_t st, const uint8_t *bases, int64_t n, uint
                            uint32_t *badbits, unsigned long long *n_bad);
 void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts);
 
-// one launch before the sketch of a read batch: [pending reset] + start bitmap + 2-bit pack
-struct PhiPrepArgs {
-    uint64_t *sp_keys; int64_t sp_cap; uint64_t *hit_words; int64_t n_hit_words;      // reset part
-    uint64_t *stripes; int64_t n_stripe_words;
-    // sparse reset: the logged slots of log_chunks chunks, unless *sp_dirty or full; *sp_dirty_zero is zeroed
-    const uint32_t *sp_log; const uint8_t *sp_log_cnt; int64_t log_chunks; const uint32_t *sp_dirty; uint32_t *sp_dirty_zero; int32_t full;
-    const int64_t *seq_off; int64_t n_seq; unsigned long long *starts; int64_t n_sw;   // bitmap part
-    const uint8_t *bases; int64_t n; uint64_t *words; int64_t n_words; uint32_t *badbits;   // pack part
-    unsigned long long *batch_bad, *batch_bad_next;
-    unsigned reset_blocks, bitmap_blocks;                                                // set by the launcher
-};
-void phi_launch_prep_reads(hipStream_t st, PhiPrepArgs P, bool with_reset);
 void phi_launch_sketch_bytes(hipStream_t st, int mode, const PhiSketchArgs &A, const unsigned long long *batch_bad);
 void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, uint64_t *hit_words, int64_t n_hit_words,
                             uint64_t *stripes, int64_t n_stripe_words);

@@ -170,33 +170,6 @@ __global__ void __launch_bounds__(256) phi_reset_reads_kernel(uint64_t *__restri
                      hit_words, n_hit_words, stripes, n_stripe_words);
 }
 
-// Everything a read batch needs before its sketch, in ONE launch (each tiny launch costs ~6 us on
-// the stream): blocks [0, reset_blocks) forget the previous reads when a reset is pending, the next
-// bitmap_blocks build the read-start bitmap, the rest pack the bases.  The three parts touch
-// disjoint buffers.  The per-batch count of bases outside ACGT ping-pongs between two scalars: this
-// launch counts into batch_bad (zeroed by the previous batch's launch) and zeroes batch_bad_next.
-__global__ void __launch_bounds__(256) phi_prep_reads_kernel(PhiPrepArgs P)
-{
-    unsigned b = blockIdx.x;
-    if (b == 0 && threadIdx.x == 0) {
-        *P.batch_bad_next = 0;
-        if (P.reset_blocks && P.sp_dirty_zero) *P.sp_dirty_zero = 0;     // the flag of the reads after the next reset
-    }
-    if (b < P.reset_blocks) {
-        const bool sparse = !P.full && P.sp_log && *P.sp_dirty == 0;
-        reset_reads_part((int64_t)b * 256 + threadIdx.x, (int64_t)P.reset_blocks * 256, P.sp_keys, P.sp_cap, P.hit_words,
-                         P.n_hit_words, P.stripes, P.n_stripe_words, P.sp_log, P.sp_log_cnt, P.log_chunks, sparse);
-        return;
-    }
-    b -= P.reset_blocks;
-    if (b < P.bitmap_blocks) {
-        start_bitmap_word((int64_t)b * 256 + threadIdx.x, P.seq_off, P.n_seq, P.starts, P.n_sw, P.n);
-        return;
-    }
-    b -= P.bitmap_blocks;
-    pack_ascii_word((int64_t)b * 256 + threadIdx.x, P.bases, P.n, P.words, P.n_words, P.badbits, P.batch_bad);
-}
-
 // ---------------------------------------------------------------------------------- helpers
 
 // Lanes of one wave exchange data through LDS without a workgroup barrier: LDS instructions of a
@@ -435,7 +408,7 @@ static __device__ __forceinline__ void bytes_role(const PhiSketchArgs &A, const 
                                                   int64_t blk, int64_t n_blk, unsigned long long *s_all)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (!A.allslow && *batch_bad == 0) return;
+    if (!A.allslow && batch_bad && *batch_bad == 0) return;
     const int64_t N = A.n_bases;
     const int64_t n_chunks = (N + WCH - 1) / WCH;
     const int64_t n_sw = N / 64 + 2;
@@ -473,33 +446,147 @@ static __device__ __forceinline__ void bytes_role(const PhiSketchArgs &A, const 
     }
 }
 
+
+// ---- read batches: what used to be a preparation launch, done by the waves of the sketch launch
+
+// This wave's share of emptying the buffers of the previous generation of reads (phi_reset_reads swaps the
+// context's double buffers; the generation after this one will fill them again): the spectrum slots that
+// generation logged -- or the whole set when something filled a slot without logging it --, its hit vector
+// and its striped counters.  The three loads it needs (dirty flag, the wave's log count, its logged slots)
+// are independent and are issued when the wave starts, beside the loads of its chunk; the stores come last.
+struct CleanLoad { uint32_t dirty; uint32_t cnt; uint32_t slot; };
+__device__ __forceinline__ CleanLoad clean_issue(const PhiSketchArgs &A, int64_t gw, int lane)
+{
+    CleanLoad c{1u, 0u, 0u};
+    if (A.q_sp_keys && !A.q_full && A.q_log) {
+        c.dirty = *A.q_dirty;
+        if (gw < A.q_log_chunks) {
+            c.cnt = A.q_log_cnt[gw];
+            if (lane < PHI_SPLOG) c.slot = A.q_log[gw * PHI_SPLOG + lane];
+        }
+    }
+    return c;
+}
+__device__ __forceinline__ void clean_finish(const PhiSketchArgs &A, int64_t gw, int64_t n_waves, int lane, const CleanLoad &c)
+{
+    if (gw == 0 && lane == 0 && A.dirty_zero) *A.dirty_zero = 0;        // the flag of the generation after this one
+    if (A.q_sp_keys) {
+        const bool sparse = !A.q_full && A.q_log && c.dirty == 0;
+        if (sparse) {
+            if (lane < PHI_SPLOG && lane < (int)c.cnt) A.q_sp_keys[c.slot] = PHI_EMPTY_KEY;
+            for (int64_t lc = gw + n_waves; lc < A.q_log_chunks; lc += n_waves)      // a smaller launch than the one that filled the log
+                if (lane < PHI_SPLOG && lane < (int)A.q_log_cnt[lc]) A.q_sp_keys[A.q_log[lc * PHI_SPLOG + lane]] = PHI_EMPTY_KEY;
+        } else {
+            for (int64_t i = gw * 64 + lane; i < A.q_sp_cap; i += n_waves * 64) A.q_sp_keys[i] = PHI_EMPTY_KEY;
+        }
+    }
+    for (int64_t i = gw * 64 + lane; i < A.q_n_hit_words; i += n_waves * 64) A.q_hit_words[i] = 0;
+    for (int64_t i = gw * 64 + lane; i < A.q_n_stripe_words; i += n_waves * 64) A.q_stripes[i] = 0;
+}
+
+// Read starts of a chunk from the read offsets.  The chunk's bitmap covers bases [c0-64, c0-64+64*SBW); the first
+// read starting at or after its first base is found by probing 64 consecutive offsets around position / mean
+// read length (one load when reads are of similar lengths), then 64-ary narrowing.
+struct StartProbe { int64_t base; int64_t v; int64_t nx; };
+__device__ __forceinline__ StartProbe start_probe_issue(const PhiSketchArgs &A, int64_t c0, int lane)
+{
+    const int64_t lo_b = c0 - 64 > 0 ? c0 - 64 : 0;
+    int64_t g = (int64_t)((double)lo_b / (double)A.n_bases * (double)A.n_reads) - 24;
+    g = g < 0 ? 0 : (g > A.n_reads - 63 ? (A.n_reads - 63 > 0 ? A.n_reads - 63 : 0) : g);
+    StartProbe p;
+    p.base = g;
+    const int64_t idx = g + lane;
+    p.v = idx <= A.n_reads ? A.read_off[idx] : INT64_MAX;              // read_off[n_reads] = n_bases closes the array
+    p.nx = idx + 1 <= A.n_reads ? A.read_off[idx + 1] : INT64_MAX;
+    return p;
+}
+__device__ __forceinline__ void set_start_bit(unsigned long long *s_bits, int64_t p, int64_t lo_b)
+{
+    const int bit = (int)(p - lo_b);
+    atomicOr(reinterpret_cast<unsigned int *>(s_bits) + (bit >> 5), 1u << (bit & 31));
+}
+__device__ __forceinline__ void start_bits_from_offsets(const PhiSketchArgs &A, int64_t c0, int lane, StartProbe pr,
+                                                        unsigned long long *s_bits)
+{
+    const int64_t lo_b = c0 - 64, hi_b = lo_b + 64 * SBW;
+    const unsigned long long ge = __ballot(pr.v >= lo_b), lt = __ballot(pr.v < hi_b);
+    if ((pr.base == 0 || !(ge & 1ull)) && !(lt >> 63)) {
+        // the 64 probed reads bracket the chunk (reads of similar lengths: nearly always): their offsets are all it takes
+        if (pr.base + lane < A.n_reads && pr.v >= lo_b && pr.v < hi_b && pr.nx > pr.v) set_start_bit(s_bits, pr.v, lo_b);
+        return;
+    }
+    {
+        // reads of uneven lengths (long reads): the guess by mean length was off; correct it by what the probe saw --
+        // the distance in bases from its middle offset, over the mean length -- and probe 64 reads there
+        int64_t vm = __shfl(pr.v, 32, 64);
+        if (vm == INT64_MAX) vm = A.n_bases;
+        const double mean = (double)A.n_bases / (double)A.n_reads;
+        int64_t g = pr.base + 32 + (int64_t)((double)(lo_b - vm) / mean) - 24;
+        g = g < 0 ? 0 : (g > A.n_reads - 63 ? (A.n_reads - 63 > 0 ? A.n_reads - 63 : 0) : g);
+        const int64_t idx = g + lane;
+        const int64_t v2 = idx <= A.n_reads ? A.read_off[idx] : INT64_MAX;
+        const int64_t nx2 = idx + 1 <= A.n_reads ? A.read_off[idx + 1] : INT64_MAX;
+        const unsigned long long ge2 = __ballot(v2 >= lo_b), lt2 = __ballot(v2 < hi_b);
+        if ((g == 0 || !(ge2 & 1ull)) && !(lt2 >> 63)) {
+            if (idx < A.n_reads && v2 >= lo_b && v2 < hi_b && nx2 > v2) set_start_bit(s_bits, v2, lo_b);
+            return;
+        }
+    }
+    // first index r0 in [0, n_reads] with read_off[r0] >= lo_b  (read_off[n_reads] = n_bases > lo_b): 64-ary narrowing
+    int64_t lo = 0, hi = A.n_reads;
+    int64_t base = pr.base, stride = 1, v = pr.v;
+    for (int round = 0; round < 64 && lo < hi; round++) {
+        if (round) {
+            stride = (hi - lo + 63) / 64;
+            base = lo;
+            const int64_t idx = base + lane * stride;
+            v = idx <= A.n_reads ? A.read_off[idx] : INT64_MAX;
+        }
+        const unsigned long long g2 = __ballot(v >= lo_b);
+        const int f = g2 ? __ffsll((long long)g2) - 1 : 64;              // the true lanes are a suffix
+        if (f == 0) { hi = base < hi ? base : hi; }
+        else {
+            const int64_t below = base + (int64_t)(f - 1) * stride;      // read_off[below] < lo_b
+            lo = below + 1 > lo ? below + 1 : lo;
+            if (f < 64) { const int64_t at = base + (int64_t)f * stride; hi = at < hi ? at : hi; }
+        }
+    }
+    // every read from r0 = lo on that starts below hi_b and owns a base sets its bit
+    for (int64_t r = lo + lane;; r += 64) {
+        int64_t p = INT64_MAX, nx = INT64_MAX;
+        if (r < A.n_reads) { p = A.read_off[r]; nx = A.read_off[r + 1]; }
+        if (p < hi_b && nx > p) set_start_bit(s_bits, p, lo_b);
+        if (__shfl(p, 63, 64) >= hi_b) break;                             // offsets are monotone: nothing further starts here
+    }
+}
+
 // WIDE: w > Q (windows of one lane overlap in a common core); otherwise brute force per window.
 // KT/WT: compile-time k and w of the specialised instance (0 = take them from the arguments).
 template <int MODE, bool WIDE, int KT, int WT>
 __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 {
+    constexpr bool FUSED = MODE == PHI_MODE_PROBE;      // read batches come as ASCII + read offsets (see phase 0)
     constexpr bool NEED_POS = MODE == PHI_MODE_WRITE;   // only the ordered write stores positions (ILP_index.cpp:423)
     constexpr bool FMIN = !NEED_POS && KT > 0 && KT <= 31;   // values < 2^62: minima by v_min_f64
     extern __shared__ uint64_t s_dyn[];
-
-    // read batches: the workgroups past the 2-bit ones take the byte-wise path (they leave at once
-    // when the batch holds no base outside ACGTacgt) -- one launch less per batch
-    if (MODE == PHI_MODE_PROBE && A.fast_blocks && blockIdx.x >= A.fast_blocks) {
-        bytes_role<MODE>(A, A.batch_bad, (int64_t)blockIdx.x - A.fast_blocks, (int64_t)gridDim.x - A.fast_blocks,
-                         (unsigned long long *)s_dyn);
-        return;
-    }
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k = KT ? KT : A.k, w = WT ? WT : A.w;
     const int64_t N = A.n_bases;
     const int64_t chunk = (int64_t)blockIdx.x * (TPB / 64) + wid;
     const int64_t c0 = chunk * WCH;                       // first window start of this chunk
-    if (c0 >= N) return;                                  // wave-uniform
+    // read batches, first launch after a reset: this wave's share of the buffers the previous generation of
+    // reads filled (stores into buffers nothing in this launch reads: no ordering needed)
+    CleanLoad cl{};
+    if (FUSED && A.q_clean) cl = clean_issue(A, chunk, lane);
+    if (c0 >= N) {                                        // wave-uniform
+        if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
+        return;
+    }
     const uint64_t kmask = phi_kmask(k);
     const int M = WCH + w;                                // canonical values m[l], l -> k-mer c0-1+l
     const int span = w + k - 1;                           // bases under one window
-    const bool have_bad = A.badbits != nullptr;
+    const bool have_bad = FUSED || A.badbits != nullptr;
 
     uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w, k);   // k-mers; later the window minima
     uint64_t *s_words = s_mp + phi_wave_mp_u64(w);
@@ -511,7 +598,38 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     // ---- phase 0: stage the chunk's packed words and bitmaps (the only global reads up to the
     //      output phase).  Local base lb <-> base c0-32+lb; local bit lp <-> base c0-64+lp.
     unsigned long long my_bad = 0;
-    {
+    StartProbe probe{};
+    if (FUSED) {
+        // straight from ASCII: lane -> 16 bases = one 32-bit half of a packed word + 16 flags of bases outside ACGTacgt
+        const int64_t b = c0 - 32 + 16 * (int64_t)lane;
+        uint32_t x[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};      // beyond the batch: 'A'
+        if (b >= 0 && b + 16 <= N && (((uintptr_t)A.ascii + (uintptr_t)b) & 15) == 0) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(A.ascii + b);
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        } else if (b + 16 > 0 && b < N) {
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (b + j >= 0 && b + j < N) x[j >> 2] = (x[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((uint32_t)A.ascii[b + j] << (8 * (j & 3)));
+        }
+        probe = start_probe_issue(A, c0, lane);           // the first probe of the read-start search travels with the bases
+        uint32_t code = 0, bad = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t t = ((x[q] >> 1) ^ (x[q] >> 2)) & 0x03030303u;      // 2-bit code of each byte
+            const uint32_t c8 = (t * 0x40100401u) >> 24;                        // the four codes, first base on top
+            code = (code << 8) | c8;
+            if (phi_ascii4(c8) != (x[q] & 0xDFDFDFDFu)) {                       // a byte outside ACGTacgt (rare)
+#pragma unroll
+                for (int j = 0; j < 4; j++) bad |= (uint32_t)(!phi_is_acgt((x[q] >> (8 * j)) & 0xFFu)) << (4 * q + j);
+            }
+        }
+        reinterpret_cast<uint32_t *>(s_words)[lane ^ 1] = code;                 // word = (even lane's half << 32) | odd lane's
+        uint16_t *s_bad16 = reinterpret_cast<uint16_t *>(s_bad);
+        if (lane < 62) s_bad16[lane + 2] = (uint16_t)bad;                       // bit of base b+j = 32 + 16 lane + j
+        else { s_bad16[lane - 62] = 0; bad = 0; }                               // bases before c0-32 / past c0+960 are never looked at
+        if (lane < SBW) s_bits[lane] = 0;
+        my_bad = bad;
+    } else {
         const int64_t n_words = (N + 31) / 32 + 2;        // the buffer carries two zero padding words
         const int64_t n_sw = N / 64 + 2;
         if (lane < SWW) {
@@ -648,6 +766,11 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
         }
     }
 
+    if (FUSED) {
+        // the read starts inside this chunk's base range, from the read offsets (answer of the probe issued in phase 0)
+        start_bits_from_offsets(A, c0, lane, probe, s_bits);
+        wave_sync();
+    }
     // ---- phase 3: candidate windows of this lane: outputs i = 1..Q, window start a = c0-1+lane*Q+i
     //      (local bit of base a = la + 63 with la = lane*Q + i)
     uint32_t cflag = 0, fflag = 0, pflag = 0;             // candidates; first windows; candidates that carry their predecessor
@@ -826,6 +949,14 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
         }
     }
 
+    if (FUSED && chunk_bad) {
+        // (rare) windows over a base outside ACGTacgt, or right after one: the exact byte-wise routine, by the wave
+        // that owns the chunk (its inserts are not logged: slow_windows raises the dirty flag)
+        int n_emit_slow = 0;
+        slow_windows<MODE>(A, c0, chunk, lane, k, w, s_bits, s_bad, false, 0, n_emit_slow, n_new);
+        n_emit += n_emit_slow;
+    }
+    if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
     if (MODE == PHI_MODE_COUNT) {
         if (lane == 0) A.block_cnt[chunk] = n_emit;
     } else if (MODE == PHI_MODE_PROBE) {
@@ -896,22 +1027,6 @@ void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_se
     hipLaunchKernelGGL(phi_mark_starts_kernel, dim3((unsigned)nb), dim3(256), 0, st, seq_off, n_seq, starts);
 }
 
-void phi_launch_prep_reads(hipStream_t st, PhiPrepArgs P, bool with_reset)
-{
-    int64_t rb = 0;
-    if (with_reset) {
-        int64_t n = P.sp_cap > P.n_hit_words ? P.sp_cap : P.n_hit_words;
-        if (n < P.n_stripe_words) n = P.n_stripe_words;
-        rb = (n + 255) / 256;
-        if (rb > 2048) rb = 2048;
-        if (rb < 1) rb = 1;
-    }
-    P.reset_blocks = (unsigned)rb;
-    P.bitmap_blocks = (unsigned)((P.n_sw + 255) / 256);
-    const int64_t pb = (P.n_words + 4 + 255) / 256;
-    hipLaunchKernelGGL(phi_prep_reads_kernel, dim3((unsigned)(rb + P.bitmap_blocks + pb)), dim3(256), 0, st, P);
-}
-
 void phi_launch_sketch_bytes(hipStream_t st, int mode, const PhiSketchArgs &A, const unsigned long long *batch_bad)
 {
     const int64_t nchunks = phi_sketch_num_blocks(A.n_bases);
@@ -962,14 +1077,8 @@ void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A0, hipEve
 {
     const int64_t nchunks = phi_sketch_num_blocks(A0.n_bases);
     if (nchunks <= 0) return;
-    PhiSketchArgs A = A0;
-    unsigned nb = (unsigned)((nchunks + TPB / 64 - 1) / (TPB / 64));
-    A.fast_blocks = 0;
-    if (mode == PHI_MODE_PROBE && A.batch_bad && !A.allslow) {
-        // byte-wise workgroups ride along (grid-stride over the chunks; usually they leave at once)
-        A.fast_blocks = nb;
-        nb += nb < 1024 ? nb : 1024;
-    }
+    const PhiSketchArgs &A = A0;
+    const unsigned nb = (unsigned)((nchunks + TPB / 64 - 1) / (TPB / 64));
     const size_t lds = (size_t)phi_wave_region_u64(A.w, A.k) * 8 * (TPB / 64);
     if (mode == PHI_MODE_COUNT) launch_sketch_mode<PHI_MODE_COUNT>(st, nb, lds, A, t0, t1);
     else if (mode == PHI_MODE_WRITE) launch_sketch_mode<PHI_MODE_WRITE>(st, nb, lds, A, t0, t1);

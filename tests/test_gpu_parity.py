@@ -714,8 +714,9 @@ def test_reset_is_deferred_but_never_visible(oracle, ctx_factory):
     torch.cuda.synchronize()
     assert int(hit.sum().item()) > 0
     c.reset_reads()
-    p2, n2 = c.hits_buffer()                        # by contract the pointer is fetched again after a reset
-    assert (p2, n2) == (p, n)
+    p2, n2 = c.hits_buffer()                        # by contract the pointer is fetched again after a reset (double buffers: it moves)
+    assert n2 == n
+    hit = torch.as_tensor(pdist.DevArray(p2, n2), device="cuda")
     torch.cuda.synchronize()
     assert int(hit.sum().item()) == 0
     # reset + other reads == a fresh context with the other reads (twice, to exercise both parities)
