@@ -21,7 +21,10 @@ int phi_fail(phi_ctx *c, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->last_error = buf;
+    if (c) {
+        std::lock_guard<std::mutex> g(c->err_mu);            // phi_set_graph runs a GPU thread beside the caller's: both may fail
+        c->last_error = buf;
+    }
     return code;
 }
 
@@ -880,18 +883,37 @@ static int sp_ensure(phi_ctx *c, int64_t est)
     return PHI_OK;
 }
 
+}  // extern "C"
+
+static int add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, bool replay);
+
+extern "C" {
+
 int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases)
+{
+    return add_reads_device_impl(c, d_bases, d_read_off, n_reads, n_bases, false);
+}
+
+}  // extern "C"
+
+// replay: the same batch again after the spectrum set was regrown (its first pass overflowed the set): everything a
+// batch does is idempotent (hit flags, set inserts) except the count of emitted minimisers, which is not repeated
+static int add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, bool replay)
 {
     if (!c) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads before phi_set_graph");
     if (n_reads < 0 || n_bases < 0 || (n_bases > 0 && (!d_bases || !d_read_off))) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads: bad arguments");
-    if (n_reads == 0 || n_bases == 0) { c->reads_count += n_reads; return PHI_OK; }
+    if (n_reads == 0 || n_bases == 0) { if (!replay) c->reads_count += n_reads; return PHI_OK; }
     HIPCHK(hipSetDevice(c->device));
     c->solved = false;
     // distinct minimisers of this batch: the emitted density of random sequence is 2/(w+1) (0.077 at
-    // w = 25); room for 1.5x that.  Denser input (at most one per base) is caught by the probe bound
-    // and reported as PHI_ERR_OVERFLOW.
-    PHICHK(sp_ensure(c, (int64_t)((double)n_bases * std::min(1.0, 3.0 / (c->w + 1))) + 16));
+    // w = 25); room for 1.5x that.  Denser input (low-complexity reads at large w: at most one per base) runs into
+    // the probe bound: phi_add_reads then regrows the set and replays the batch; a caller of phi_add_reads_device
+    // sees PHI_ERR_OVERFLOW at its next synchronising call.
+    int64_t est = replay ? (int64_t)(2 * c->sp_cap) : (int64_t)((double)n_bases * std::min(1.0, 3.0 / (c->w + 1))) + 16;
+    if (!replay && getenv("PHI_SP_EST_DIV")) est = est / std::max(1, atoi(getenv("PHI_SP_EST_DIV"))) + 16;   // tests: provoke the regrow
+    PHICHK(sp_ensure(c, est));
+    if (replay) c->sp_full = true;                            // what the replay inserts is in no log
     // this batch's part of the insert log (a buffer that has to grow loses what it held)
     const int64_t n_log_chunks = phi_sketch_num_blocks(n_bases);
     if ((size_t)(c->log_chunks + n_log_chunks) * PHI_SPLOG * 4 > c->d_splog.cap || (size_t)(c->log_chunks + n_log_chunks) > c->d_splog_cnt.cap) {
@@ -910,7 +932,7 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     A.n_bases = n_bases; A.k = c->k; A.w = c->w;
     A.sp_keys = c->d_sp_keys.as<uint64_t>(); A.sp_mask = c->sp_cap - 1;
     A.sp_count = sp_stripes(c);
-    A.n_emitted = emit_stripes(c);
+    A.n_emitted = replay ? nullptr : emit_stripes(c);
     A.u_kv = c->d_u_kv.as<uint64_t>(); A.u_mask = c->u_cap - 1;
     A.hit = c->d_hit.as<uint8_t>();
     A.err = (uint32_t *)scalar(c, S_ERR);
@@ -946,10 +968,11 @@ int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off
     }
     phi_launch_sketch(c->stream, PHI_MODE_PROBE, A, t0, t1);
     HIPCHK(hipGetLastError());
-    c->reads_bases += n_bases;
-    c->reads_count += n_reads;
+    if (!replay) { c->reads_bases += n_bases; c->reads_count += n_reads; }
     return PHI_OK;
 }
+
+extern "C" {
 
 int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_t n_reads)
 {
@@ -978,6 +1001,18 @@ int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_
     // host buffers are borrowed for the call only
     HIPCHK(hipStreamSynchronize(c->stream));
     tm.lap("sketch + probe");
+    // denser input than the read-spectrum set was sized for (the reference's std::map has no such limit,
+    // ILP_index.cpp:622-635): regrow the set and replay the batch
+    for (int attempt = 0; attempt < 6; attempt++) {
+        uint32_t err = 0;
+        HIPCHK(hipMemcpy(&err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
+        if (!(err & PHI_KERR_TABLE_FULL)) break;
+        err &= ~PHI_KERR_TABLE_FULL;
+        HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
+        PHICHK(add_reads_device_impl(c, c->d_rbases.p, c->d_roff.p, n_reads, n_bases, true));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        tm.lap("spectrum set regrown, batch replayed");
+    }
     return PHI_OK;
 }
 

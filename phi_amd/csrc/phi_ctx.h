@@ -66,6 +66,7 @@ struct phi_ctx {
     PhiComm *comm = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string last_error;
+    std::mutex err_mu;                                // guards last_error
 
     // params (main.cpp:118-131)
     int32_t k = 31, w = 25, recombination = 100;

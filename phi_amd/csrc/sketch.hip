@@ -440,7 +440,7 @@ static __device__ __forceinline__ void bytes_role(const PhiSketchArgs &A, const 
             if (lane == 0) {
                 const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
                 if (n_new) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new);
-                if (n_emit) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
+                if (n_emit && A.n_emitted) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
             }
         }
     }
@@ -970,7 +970,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
         if (lane == 0) {
             const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
             if (n_new) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new);
-            if (n_emit) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
+            if (n_emit && A.n_emitted) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
         }
     }
 }

@@ -1,20 +1,21 @@
 #!/bin/bash
 # Collect the profiles of a round on the MI355X box (run through gpurun from the repo root):
-#   gpurun --timeout 1200 -- 'bash profiles/collect.sh r01d'
+#   gpurun --timeout 1200 -- 'bash profiles/collect.sh r02a'
 # Writes under gpurun_out/<tag>/; copy the summaries into profiles/ afterwards (see README.md).
 set -u
 tag=${1:-rXX}
-out=gpurun_out/$tag
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-# 1. the bench line as the driver runs it (with the CPU baseline leg)
-timeout -k 10 400 python3 bench.py > $out/bench_line.json 2> $out/bench_line.err
+cd /tmp && export TMPDIR=/tmp
+B=$GRAFT_REPO_ROOT/bench.py
+# 1. the bench line as the driver runs it (with the CPU baseline and the extra legs)
+timeout -k 10 500 python3 $B > $out/bench_line.json 2> $out/bench_line.err
 # 2. per-kernel times of the same workload (kernel trace + stats only)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace -- python3 bench.py --no-cpu-baseline > $out/bench_line_under_rocprof.json 2> $out/ktrace.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ktrace -- python3 $B --no-cpu-baseline --no-extra-legs > $out/bench_line_under_rocprof.json 2> $out/ktrace.err
 cp $out/ktrace/*/*kernel_stats.csv $out/kernel_stats.csv
 # 3. HBM traffic of the sketch kernel: one counter per pass, no tracing
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $out/pmc_$ctr -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-solve > /dev/null 2> $out/pmc_$ctr.err
+  timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $out/pmc_$ctr -- python3 $B --steps 5 --warmup 1 --no-cpu-baseline --no-extra-legs --no-solve > /dev/null 2> $out/pmc_$ctr.err
 done
 python3 - "$out" <<'P'
 import csv, glob, json, sys, collections
@@ -29,8 +30,15 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     res[ctr] = {k: tot[k] / n[k] for k in tot}
 json.dump(res, open(f"{out}/pmc_hbm_counters.json", "w"), indent=1)
 for k in res.get("FETCH_SIZE", {}):
-    if "phi_sketch_kernel<2" in k or "MODE_PROBE" in k:
+    if "phi_sketch_kernel<2" in k:
         print(k[:60], "FETCH_SIZE kB", res["FETCH_SIZE"][k], "WRITE_SIZE kB", res["WRITE_SIZE"].get(k))
 P
+# 4. the other configurations (bench lines only)
+for cfg in C3 C4 C1syn; do
+  timeout -k 10 300 python3 $B --config $cfg --steps 100 --warmup 10 --no-cpu-baseline --no-extra-legs > $out/bench_line_$cfg.json 2> $out/bench_line_$cfg.err
+done
+timeout -k 10 300 python3 $B --config C5s --steps 5 --warmup 1 --no-cpu-baseline --no-extra-legs > $out/bench_line_C5s.json 2> $out/bench_line_C5s.err
+PHI_TIMING=1 timeout -k 10 600 python3 $B --config C5 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs > $out/bench_line_C5.json 2> $out/bench_line_C5.err
+timeout -k 10 600 python3 $B --config C5 --scaling strong --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs --no-solve > $out/bench_line_C5_strong.json 2> $out/bench_line_C5_strong.err
 head -8 $out/kernel_stats.csv | cut -c1-140
 cat $out/bench_line.json

@@ -1203,3 +1203,26 @@ def test_chromosome_scale_properties(ctx_factory, config):
     assert base[1] == truth["walks"]                                  # the mosaic is recovered
     if config != "C5":
         assert solve([2, 0, 1], False) == base
+
+
+def test_spectrum_set_regrows_on_dense_input(oracle, ctx_factory, monkeypatch):
+    """The read-spectrum set is sized for 1.5x the minimiser density of random sequence; denser input (low-complexity or
+    adversarial reads at large w) overflows it.  The reference's std::map has no limit (ILP_index.cpp:622-635):
+    phi_add_reads regrows the set and replays the batch.  PHI_SP_EST_DIV=1000 shrinks the estimate so that ordinary
+    random reads provoke it (65536 slots for ~10^5 distinct hashes)."""
+    rng = np.random.default_rng(606)
+    g = random_graph(rng, n_sites=10, n_walks=3, seg_len=(30, 60), alt_len=(2, 8))
+    k, w = 9, 10
+    reads = [bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(60, 140))).tolist()) for _ in range(9000)]
+    reads += mosaic_reads(rng, g, n_reads=40, read_len=60, n_seg=2)
+    monkeypatch.setenv("PHI_SP_EST_DIV", "1000")
+    ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=3)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads[:10])
+    ctx.add_reads(reads[10:])                                    # overflows the 65536-slot set: regrown, replayed
+    monkeypatch.delenv("PHI_SP_EST_DIV")
+    sk = [oracle.sketch(r, k, w)[0] for r in reads]
+    st = ctx.reads_stats()
+    assert st["n_distinct"] == len(np.unique(np.concatenate(sk))) > 65536
+    assert st["n_emitted"] == sum(len(x) for x in sk)            # the replay does not count twice
+    _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 3)
