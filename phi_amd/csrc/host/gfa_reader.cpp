@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include "gz_source.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -68,19 +69,21 @@ static bool slurp(const char *path, std::vector<char> &buf)
     } else {
         return false;
     }
-    gzFile fp = gzopen(path, "r");
-    if (!fp) return false;
-    gzbuffer(fp, 1 << 20);
+    // gzip: inflated by gz_source.h -- on many threads when the file is block gzip (BGZF), else by one thread
+    GzSource gz;
+    const char *e = getenv("PHI_HOST_THREADS");
+    int nt = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+    if (!gz.open(path, nt)) return false;
     size_t len = 0;
-    buf.resize((size_t)1 << 22);
-    for (;;) {
-        if (buf.size() - len < ((size_t)1 << 20)) buf.resize(buf.size() * 2);
-        const int n = gzread(fp, buf.data() + len, (unsigned)std::min<size_t>(buf.size() - len, (size_t)1 << 30));
-        if (n <= 0) break;
-        len += (size_t)n;
+    buf.clear();
+    std::vector<char> blk;
+    while (gz.next(blk)) {
+        if (buf.capacity() < len + blk.size()) buf.reserve(std::max(buf.capacity() * 2, len + blk.size()));
+        buf.insert(buf.end(), blk.begin(), blk.end());
+        len += blk.size();
     }
-    gzclose(fp);
-    buf.resize(len);
+    gz.close();
     return true;
 }
 

@@ -9,11 +9,13 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <zlib.h>
 #include <algorithm>
 #include <string>
 #include <vector>
 #include "../../../include/phi_host.h"
+#include "gz_source.h"
 
 struct phi_reads {
     std::vector<char> bases;
@@ -37,24 +39,29 @@ namespace {
 // A byte source with kstream's two primitives (kseq.h:100-150): one character, or the rest of the line.
 struct ByteSrc {
     FILE *fp = nullptr;                               // plain file ...
-    gzFile gz = nullptr;                              // ... or gzip
+    GzSource *gz = nullptr;                           // ... or gzip: inflated off this thread (gz_source.h), on many threads for BGZF
     std::vector<char> buf;
     size_t begin = 0, end = 0;
     bool is_eof = false;
 
+    static int inflate_threads()
+    {
+        const char *e = getenv("PHI_HOST_THREADS");
+        int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return n < 1 ? 1 : (n > 16 ? 16 : n);
+    }
     bool open(const char *path)
     {
         FILE *f = fopen(path, "rb");
         if (!f) return false;
         unsigned char magic[2] = {0, 0};
         const size_t got = fread(magic, 1, 2, f);
-        buf.resize((size_t)4 << 20);
         if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
             fclose(f);
-            gz = gzopen(path, "r");
-            if (!gz) return false;
-            gzbuffer(gz, 1 << 20);
+            gz = new GzSource();
+            if (!gz->open(path, inflate_threads())) { delete gz; gz = nullptr; return false; }
         } else {
+            buf.resize((size_t)4 << 20);
             rewind(f);
             fp = f;
         }
@@ -63,16 +70,21 @@ struct ByteSrc {
     void close()
     {
         if (fp) fclose(fp);
-        if (gz) gzclose(gz);
+        if (gz) { gz->close(); delete gz; }
         fp = nullptr; gz = nullptr;
     }
     bool refill()                                     // false: nothing more to read
     {
         if (is_eof) return false;
-        begin = 0;
-        long n;
-        if (gz) n = gzread(gz, buf.data(), (unsigned)buf.size());
-        else n = (long)fread(buf.data(), 1, buf.size(), fp);
+        begin = 0; end = 0;
+        if (gz) {
+            while (end == 0) {
+                if (!gz->next(buf)) { is_eof = true; return false; }      // (an inflate error ends the input, as gzread's -1 did)
+                end = buf.size();
+            }
+            return true;
+        }
+        const long n = (long)fread(buf.data(), 1, buf.size(), fp);
         end = n > 0 ? (size_t)n : 0;
         if (end < buf.size()) is_eof = true;
         return end > 0;
@@ -98,6 +110,17 @@ struct ByteSrc {
         }
         if (out.size() > 1 && out.back() == '\r') out.pop_back();
         return (long)out.size();
+    }
+    // the rest of the line, dropped: false when the source ended before a '\n'
+    bool skip_line()
+    {
+        for (;;) {
+            if (begin >= end && !refill()) return false;
+            const char *p = buf.data() + begin;
+            const char *nl = (const char *)memchr(p, '\n', end - begin);
+            if (nl) { begin += (size_t)(nl - p) + 1; return true; }
+            begin = end;
+        }
     }
     // the same for a string whose bytes are not kept: len / last byte stand for it
     long line_len(size_t &len, int &last)
@@ -139,6 +162,7 @@ struct ByteSrc {
 // sequence, -1 end of file, -2 quality string missing or of another length (the caller stops reading:
 // ILP_index.cpp:322).  Sequence lines are taken as they are (no filtering), empty lines skipped.
 struct KseqState {
+    bool want_names = true;                           // the streaming reader has no use for names: the header line is skipped whole
     int last_char = 0;
     std::string name, comment_sink;
     std::vector<char> seq, sink;
@@ -152,8 +176,15 @@ long kseq_next(ByteSrc &ks, KseqState &st)
         st.last_char = c;
     }
     st.seq.clear();
-    if (ks.word(st.name, &c) < 0) return -1;
-    if (c != '\n') { st.sink.clear(); ks.line(st.sink); }     // the comment
+    if (st.want_names) {
+        if (ks.word(st.name, &c) < 0) return -1;
+        if (c != '\n') { st.sink.clear(); ks.line(st.sink); }     // the comment
+    } else {
+        // name and comment together are the header line (a name that ends with the file ends the record list the
+        // same way: ks.word returns the name, the sequence loop below finds nothing)
+        if (ks.begin >= ks.end && ks.is_eof) return -1;
+        (void)ks.skip_line();
+    }
     while ((c = ks.getc()) != -1 && c != '>' && c != '+' && c != '@') {
         if (c == '\n') continue;                      // empty line
         st.seq.push_back((char)c);
@@ -161,8 +192,7 @@ long kseq_next(ByteSrc &ks, KseqState &st)
     }
     if (c == '>' || c == '@') st.last_char = c;
     if (c != '+') return (long)st.seq.size();         // FASTA
-    while ((c = ks.getc()) != -1 && c != '\n') {}     // the rest of the '+' line
-    if (c == -1) return -2;
+    if (!ks.skip_line()) return -2;                   // the rest of the '+' line
     size_t ql = 0;
     int qlast = 0;
     while (ks.line_len(ql, qlast) >= 0 && ql < st.seq.size()) {}
@@ -208,6 +238,7 @@ int phi_reads_stream_open(const char *path, phi_reads_stream **out, char *err, i
     if (!path || !out) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "null argument");
     *out = nullptr;
     phi_reads_stream *s = new phi_reads_stream();
+    s->st.want_names = false;
     if (!s->ks.open(path)) { delete s; return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to open the reads file %s", path); }
     *out = s;
     return PHI_HOST_OK;

@@ -314,3 +314,90 @@ def test_reads_readers_on_the_reference_kseq_vectors(built, oracle, tmp_path):
     assert hashlib.sha256(b"\0".join(bytes(bases[off[j]:off[j + 1]]) for j in range(len(names)))).hexdigest() == c["sha256_seqs"]
     if oracle.ref_available():                         # and, where it is built, the reference's reader itself
         assert oracle.ref_read_reads(os.path.join(DATA, "read.fa")) == oracle.read_reads(os.path.join(DATA, "read.fa"))
+
+
+def _bgzf(data, block=None, rng=None):
+    """Block gzip as bgzip / htslib write it: RFC 1952 members of <= 64 KB of input whose extra field 'BC' holds the
+    member's size minus one, closed by an empty member."""
+    import struct
+    import zlib
+    out = []
+    pos = 0
+    while True:
+        n = 0 if pos >= len(data) else (block if block else int(rng.integers(1, 65280)))
+        chunk = data[pos:pos + n]
+        pos += n
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 18 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<HBBHH", 6, 66, 67, 2, bsize - 1) + body +
+                   struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+        if not chunk:
+            break
+    return b"".join(out)
+
+
+def test_gzip_inputs_plain_block_and_concatenated(built, oracle, tmp_path, monkeypatch):
+    """gz_source.h: block gzip (BGZF) is inflated by a pool of threads, member boundaries cutting records, lines and
+    quality strings anywhere; plain gzip by one thread ahead of the parser; concatenated members, bytes after the
+    last member and a truncated file behave as they do under gzread (what the reference's kseq reads through).
+    Every variant must give the records of the uncompressed file, for the reads readers and the GFA reader."""
+    import gzip
+    import zlib
+    from phi_amd import ilp_index as H
+    rng = np.random.default_rng(77)
+    recs = []
+    for i in range(3000):
+        L = int(rng.integers(0, 500))
+        seq = bytes(rng.choice(list(b"ACGTN"), size=L).tolist())
+        if i % 2:
+            recs.append(b"@q%d c\n%s\n+\n%s\n" % (i, seq, bytes(rng.choice(list(b"@+>I"), size=L).tolist())))
+        else:
+            recs.append(b">r%d\n" % i + b"\n".join(seq[j:j + 70] for j in range(0, L, 70)) + b"\n")
+    text = b"".join(recs)
+    plain = tmp_path / "r.fq"
+    plain.write_bytes(text)
+    want_b, want_o, want_n = H.read_reads(str(plain))
+    variants = {
+        "gzip.gz": gzip.compress(text, 5),
+        "bgzf.gz": _bgzf(text, rng=rng),
+        "bgzf_tiny_blocks.gz": _bgzf(text[:200_000], block=137) ,
+        "members.gz": gzip.compress(text[:300_001]) + gzip.compress(text[300_001:700_000]) + gzip.compress(text[700_000:]),
+        "bgzf_then_plain_member.gz": _bgzf(text[:400_000], rng=rng)[:-28] + gzip.compress(text[400_000:]),
+        "trailing_garbage.gz": gzip.compress(text) + b"this is no gzip member",
+    }
+    for threads in ("1", "5"):
+        monkeypatch.setenv("PHI_HOST_THREADS", threads)
+        for name, blob in variants.items():
+            p = tmp_path / name
+            p.write_bytes(blob)
+            b, o, n = H.read_reads(str(p))
+            if name == "bgzf_tiny_blocks.gz":
+                pp = tmp_path / "part.fq"
+                pp.write_bytes(text[:200_000])
+                eb, eo, en = H.read_reads(str(pp))
+            else:
+                eb, eo, en = want_b, want_o, want_n
+            assert np.array_equal(o, eo) and np.array_equal(b, eb) and n == en, (name, threads)
+            got = np.concatenate([x for x, _ in H.stream_reads(str(p), bases_cap=100_000, reads_cap=300)])
+            assert np.array_equal(got, eb), (name, threads)
+    # a truncated gzip file gives the records that inflate, as gzread does (the last one possibly cut)
+    cut = tmp_path / "cut.gz"
+    cut.write_bytes(gzip.compress(text)[:200_000])
+    b, o, n = H.read_reads(str(cut))
+    assert 100 < len(n) < len(want_n) and n[:len(n) - 1] == want_n[:len(n) - 1]
+    assert np.array_equal(o[:len(n)], want_o[:len(n)])
+    # a corrupted BGZF member ends the input (no crash, no garbage past it)
+    bad = bytearray(_bgzf(text, block=60_000))
+    bad[len(bad) // 2] ^= 0xFF
+    (tmp_path / "bad.gz").write_bytes(bytes(bad))
+    b, o, n = H.read_reads(str(tmp_path / "bad.gz"))
+    assert len(n) < len(want_n)
+    # the GFA reader through the same source
+    g1 = H.Graph(os.path.join(DATA, "MHC_4.gfa.gz"))
+    raw = gzip.open(os.path.join(DATA, "MHC_4.gfa.gz"), "rb").read()
+    (tmp_path / "g.bgzf.gfa.gz").write_bytes(_bgzf(raw, rng=rng))
+    g2 = H.Graph(str(tmp_path / "g.bgzf.gfa.gz"))
+    for name in ("seq_off", "adj_off", "adj", "walk_off", "walk_vtx", "top_order_map"):
+        assert np.array_equal(getattr(g1, name), getattr(g2, name)), name
+    assert bytes(g1.seq_concat) == bytes(g2.seq_concat) and list(g1.hap_id2name) == list(g2.hap_id2name)

@@ -1212,7 +1212,7 @@ def test_spectrum_set_regrows_on_dense_input(oracle, ctx_factory, monkeypatch):
     random reads provoke it (65536 slots for ~10^5 distinct hashes)."""
     rng = np.random.default_rng(606)
     g = random_graph(rng, n_sites=10, n_walks=3, seg_len=(30, 60), alt_len=(2, 8))
-    k, w = 9, 10
+    k, w = 15, 10
     reads = [bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(60, 140))).tolist()) for _ in range(9000)]
     reads += mosaic_reads(rng, g, n_reads=40, read_len=60, n_seg=2)
     monkeypatch.setenv("PHI_SP_EST_DIV", "1000")
