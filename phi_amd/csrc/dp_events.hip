@@ -601,36 +601,69 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
 //   * refill the per-lane event ring from HBM and stage the step records, a period ahead;
 //   * write the (best score, run start) pairs of the events consumed in the previous period, the
 //     packed tops and the entry choices of its steps back to HBM.
-template <int NPW>
+//
+// BLOCKS OF STEPS IN PARALLEL.  The chain over the compact steps can be cut between steps k-1 and k when no
+// recombination edge crosses the cut and, on every walk, no anchor spans it (phi_solve.hip picks such "clean"
+// cuts): a run that crosses a clean cut scores its anchors left and right of it independently, so all that
+// crosses is ONE number per walk -- the best key  E_s - SB(s)  of its live runs -- and the steps of a block are a
+// max-plus linear map of that vector.  Three modes of the same kernel:
+//   DP_SEQ   one workgroup walks all steps (the only mode for graphs without usable cuts)
+//   DP_ROW   one workgroup per (block, entry walk j): the block's steps from the unit vector "key 0 on walk j"
+//            (walk starts inside the block only in the extra row j = n_walks) -> row j of the block's transfer
+//            matrix: the keys on all walks at the block's end, and the best value of a path ending inside
+//   DP_PATH  one workgroup per block, from the TRUE entry vector (the host chains the matrices): writes what
+//            DP_SEQ writes (best scores / run starts per event, tops, entries) plus, per walk, where the run
+//            that carries the best key out of the block began -- the backtrack follows runs across blocks
+enum { DP_SEQ = 0, DP_ROW = 1, DP_PATH = 2 };
+
+template <int NPW, int MODE, int P, int RINGT, int QD>
 __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpEventArgs A)
 {
-    constexpr int D = 16, P = 8;
+    constexpr int D = 2 * P;
     constexpr int PER_CHUNK = CHK / P;
-    static_assert(P % NPW == 0 && D == 2 * P && CHK % P == 0, "ring geometry");
-    __shared__ int4 s_rec[2 * CHK][2];              // step records: ring of two chunks, index = step mod 2*CHK
-    __shared__ int4 s_top[RING];                    // packed tops of recent steps
+    static_assert(P % NPW == 0 && CHK % P == 0, "ring geometry");
+    __shared__ int4 s_rec[2 * CHK][2];              // step records: ring of two chunks, index = (step - k0) mod 2*CHK
+    __shared__ int4 s_top[RINGT];                   // packed tops of recent steps
     __shared__ int2 s_ent[2 * P];                   // (source step, walk) of the entries of the last two periods
     __shared__ uint4 s_ev[D][3][64];
     __shared__ int4 s_res[D][64];                   // (best score, run start, entry) of consumed events
-    __shared__ int32_t s_qs[32][64], s_qE[32][64], s_qK[32][64];
+    __shared__ int32_t s_qs[QD][64], s_qE[QD][64], s_qK[QD][64];
     __shared__ int32_t s_vi[64];
 
     const int wave = threadIdx.x >> 6, h = threadIdx.x & 63;
     const bool has_walk = h < A.n_walks;
+    // the block of steps of this workgroup, and (DP_ROW) the walk the unit vector sits on
+    int32_t sb = 0, row_j = -1;
+    if (MODE == DP_ROW) { sb = (int32_t)(blockIdx.x / (unsigned)(A.n_walks + 1)); row_j = (int32_t)(blockIdx.x % (unsigned)(A.n_walks + 1)); }
+    if (MODE == DP_PATH) sb = (int32_t)blockIdx.x;
+    const int32_t k0 = MODE == DP_SEQ ? 0 : A.blk_lo[sb];
+    const int32_t k1 = MODE == DP_SEQ ? A.n_k : A.blk_lo[sb + 1];
+    const int32_t n_steps = k1 - k0;
     const int32_t eb = has_walk ? (int32_t)A.walk_off[h] : 0;
     const int32_t ee = has_walk ? (int32_t)A.walk_off[h + 1] : 0;
-    const int32_t vb = has_walk ? (int32_t)A.ev_off[h] : 0;     // events of this lane: [vb, ve)
+    const int32_t v0 = has_walk ? (int32_t)A.ev_off[h] : 0;     // events of this lane's walk: [v0, ve)
     const int32_t ve = has_walk ? (int32_t)A.ev_off[h + 1] : 0;
-    const int32_t n_k = A.n_k;
-    const int n_per = (n_k + P - 1) / P;
+    const int32_t vb = MODE == DP_SEQ ? v0 : (has_walk ? A.blk_ev[(int64_t)sb * 64 + h] : 0);   // first event inside the block
+    const int n_per = (n_steps + P - 1) / P;
+    if (MODE == DP_ROW && row_j < A.n_walks) {
+        // a walk that has not begun before the block, or has no event left, carries nothing in: the row is empty
+        const int32_t jb = A.blk_ev[(int64_t)sb * 64 + row_j];
+        if (jb <= (int32_t)A.ev_off[row_j] || jb >= (int32_t)A.ev_off[row_j + 1]) {            // uniform over the workgroup
+            if (wave == 0) {
+                A.row_out[(int64_t)blockIdx.x * 64 + h] = NEGK;
+                if (h == 0) A.rowend_out[blockIdx.x] = NEG;
+            }
+            return;
+        }
+    }
 
     if (wave > 0) {
         // ================================================================ producers
         const int pw = wave - 1;
         const uint4 *evg = reinterpret_cast<const uint4 *>(A.ev);
         auto stage = [&](int c) {
-            const int32_t s0 = c * CHK;
-            const int32_t ns = min(CHK, n_k - s0);
+            const int32_t s0 = k0 + c * CHK;
+            const int32_t ns = min(CHK, k1 - s0);
             const int4 *src = reinterpret_cast<const int4 *>(A.k_rec + (int64_t)s0 * 8);
             int4 *dst = &s_rec[(c & 1) * CHK][0];
             for (int i = pw * 64 + h; i < ns * 2; i += 64 * NPW) dst[i] = src[i];
@@ -649,23 +682,26 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
         __syncthreads();                             // B_0
         for (int p = 0;; p++) {
             const int32_t vi = has_walk ? s_vi[h] : 0;
-            // 1. results of the events consumed during the previous period
+            if (MODE != DP_ROW) {
+                // 1. results of the events consumed during the previous period
 #pragma unroll
-            for (int n = 0; n < P / NPW; n++) {
-                const int32_t x = vprev + pw + n * NPW;
-                if (x < vi) {
-                    const int4 r = s_res[x & (D - 1)][h];
-                    A.dmax[r.z] = r.x; A.bstart[r.z] = r.y;
+                for (int n = 0; n < P / NPW; n++) {
+                    const int32_t x = vprev + pw + n * NPW;
+                    if (x < vi) {
+                        const int4 r = s_res[x & (D - 1)][h];
+                        A.dmax[r.z] = r.x; A.bstart[r.z] = r.y;
+                    }
                 }
-            }
-            // 2. tops and entry choices of the previous period's steps (values of steps without
-            //    TOPS / ENTRY are never read back)
-            if (pw == 0 && p > 0 && h < P) {
-                const int32_t k = (p - 1) * P + h;
-                if (k < n_k) {
-                    reinterpret_cast<int4 *>(A.tops)[k] = s_top[k & (RING - 1)];
-                    const int2 en = s_ent[k & (2 * P - 1)];
-                    A.ent_src[k] = en.x; A.ent_h[k] = en.y;
+                // 2. tops and entry choices of the previous period's steps (values of steps without
+                //    TOPS / ENTRY are never read back)
+                if (pw == 0 && p > 0 && h < P) {
+                    const int32_t r = (p - 1) * P + h;
+                    if (r < n_steps) {
+                        const int32_t k = k0 + r;
+                        reinterpret_cast<int4 *>(A.tops)[k] = s_top[k & (RINGT - 1)];
+                        const int2 en = s_ent[r & (2 * P - 1)];
+                        A.ent_src[k] = en.x; A.ent_h[k] = en.y;
+                    }
                 }
             }
             if (p == n_per) break;                   // after the last barrier: only the write-backs
@@ -674,7 +710,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             uint4 t0[P / NPW], t1[P / NPW], t2[P / NPW];
 #pragma unroll
             for (int n = 0; n < P / NPW; n++) {
-                const int64_t xc = (ve > vb) ? min(wl + pw + n * NPW, ve - 1) : 0;
+                const int64_t xc = (ve > v0) ? min(wl + pw + n * NPW, ve - 1) : 0;
                 t0[n] = evg[xc * 3 + 0]; t1[n] = evg[xc * 3 + 1]; t2[n] = evg[xc * 3 + 2];
             }
 #pragma unroll
@@ -684,7 +720,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             }
             wl = max(wl, min(hi, wl + P));
             // 4. the step records of the next chunk
-            if (p % PER_CHUNK == 0 && (p / PER_CHUNK + 1) * CHK < n_k) stage(p / PER_CHUNK + 1);
+            if (p % PER_CHUNK == 0 && (p / PER_CHUNK + 1) * CHK < n_steps) stage(p / PER_CHUNK + 1);
             vprev = vi;
             __syncthreads();                         // B_{p+1}
         }
@@ -699,7 +735,11 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
     if (vi < ve) cA = s_ev[vi & (D - 1)][0][h];
     // live young runs: deque in LDS; the head (start, value) and the tail key also in registers
     int32_t qh = 0, qn = 0, hs = 0, hE = 0, tk = 0;
-    int32_t M = NEGK, sL = 0, Emax = NEG;            // best key of the old runs and its start; best value ever entered
+    int32_t M = NEGK, sL = MODE == DP_SEQ ? 0 : -1, Emax = NEG;   // best key of the old runs and its start (-1: began before this block); best value ever entered
+    if (MODE == DP_ROW && h == row_j) M = 0;
+    if (MODE == DP_PATH && has_walk) M = A.blk_S[(int64_t)sb * 64 + h];
+    const bool starts_on = MODE != DP_ROW || row_j == A.n_walks;   // walks may begin inside the block
+    int32_t endbest = NEG;                           // DP_ROW: best value at a walk's last entry inside the block
     int4 ra = s_rec[0][0], rb = s_rec[0][1];
     int4 lastq = make_int4(NEG, NEG, 0, 0);          // tops of the latest TOPS step, forwarded in registers
     int32_t lastk = -1;
@@ -717,17 +757,17 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             if (val > E || (val == E && (hh < Eh || (hh == Eh && src < Esrc)))) { E = val; Eh = hh; Esrc = src; }
         };
         const uint32_t b0 = (uint32_t)xa.z >> 8, b1 = (uint32_t)xa.w >> 8, b2 = (uint32_t)xb.x >> 8;
-        if (n_in == 1 && b0 < RING) {
+        if (n_in == 1 && b0 < RINGT) {
             const int32_t src = k - (int32_t)b0;
-            const int4 q = src == lastk ? lastq : s_top[src & (RING - 1)];
+            const int4 q = src == lastk ? lastq : s_top[src & (RINGT - 1)];
             const int32_t t1h = (q.z & 0x3FF) - 1, t1n = ((q.z >> 10) & 0x3FF) - 1, t2h = ((q.z >> 20) & 0x3FF) - 1;
             const bool cont = t1n == (xa.z & 0xFF);
             const int32_t hh = cont ? t2h : t1h;
             if (hh >= 0) { E = cont ? q.y : q.x; Eh = hh; Esrc = k - (int32_t)b0; }
-        } else if (n_in <= 3 && (b0 | b1 | b2) < RING) {
-            const int4 q0 = s_top[(k - b0) & (RING - 1)];
-            const int4 q1 = s_top[(k - b1) & (RING - 1)];
-            const int4 q2 = s_top[(k - b2) & (RING - 1)];
+        } else if (n_in <= 3 && (b0 | b1 | b2) < RINGT) {
+            const int4 q0 = s_top[(k - b0) & (RINGT - 1)];
+            const int4 q1 = s_top[(k - b1) & (RINGT - 1)];
+            const int4 q2 = s_top[(k - b2) & (RINGT - 1)];
             consider(q0, xa.z & 0xFF, k - (int32_t)b0);
             if (n_in > 1) consider(q1, xa.w & 0xFF, k - (int32_t)b1);
             if (n_in > 2) consider(q2, xb.x & 0xFF, k - (int32_t)b2);
@@ -736,23 +776,25 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                 const int32_t pk = j == 0 ? xa.z : j == 1 ? xa.w : j == 2 ? xb.x : A.k_in_packed[xa.y + j - 3];
                 const int32_t back = (int32_t)((uint32_t)pk >> 8);
                 const int32_t src = k - back;
-                // tops older than the ring come from HBM: the producers wrote them at least RING - 2P steps ago
-                const int4 q = back < RING ? s_top[src & (RING - 1)] : reinterpret_cast<const int4 *>(A.tops)[src];
+                // tops older than the ring come from HBM: the producers wrote them at least RINGT - 2P steps ago
+                // (a block of steps is never longer than its ring, and no edge enters it from before)
+                const int4 q = (back < RINGT || MODE == DP_ROW) ? s_top[src & (RINGT - 1)] : reinterpret_cast<const int4 *>(A.tops)[src];
                 consider(q, pk & 0xFF, src);
             }
         }
         if (Eh >= 0) E -= A.cost;
-        if (h == 0) s_ent[k & (2 * P - 1)] = make_int2(Esrc, Eh);
+        if (h == 0) s_ent[(k - k0) & (2 * P - 1)] = make_int2(Esrc, Eh);
     };
 
     for (int p = 0; p < n_per; p++) {
-        const int32_t k_end = min(n_k, (p + 1) * P);
-        for (int32_t k = p * P; k < k_end;) {
+        const int32_t r_end = min(n_steps, (p + 1) * P);
+        for (int32_t r = p * P; r < r_end;) {
+            const int32_t k = k0 + r;
             // records of the next two steps (past the last step: stale records, never used)
-            const int4 na = s_rec[(k + 1) & (2 * CHK - 1)][0], nb = s_rec[(k + 1) & (2 * CHK - 1)][1];
-            const int4 n2a = s_rec[(k + 2) & (2 * CHK - 1)][0], n2b = s_rec[(k + 2) & (2 * CHK - 1)][1];
+            const int4 na = s_rec[(r + 1) & (2 * CHK - 1)][0], nb = s_rec[(r + 1) & (2 * CHK - 1)][1];
+            const int4 n2a = s_rec[(r + 2) & (2 * CHK - 1)][0], n2b = s_rec[(r + 2) & (2 * CHK - 1)][1];
             // two alleles of one site (PHI_DP_PAIR: neither leaves states, no walk visits both): one iteration
-            const bool pair = (ra.x & PHI_DP_PAIR) && k + 1 < k_end;
+            const bool pair = (ra.x & PHI_DP_PAIR) && r + 1 < r_end;
             const int32_t stepk = (int32_t)cA.x;
             const bool second = pair && stepk == k + 1;
             const bool active = stepk == k || second;
@@ -779,23 +821,24 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                 oidx = gb[15 + 1024];
                 // runs older than 30 entries: one scalar
                 while (qn > 0 && t - hs >= 31) {
-                    const int32_t key = qn == 1 ? tk : s_qK[qh & 31][h];
+                    const int32_t key = qn == 1 ? tk : s_qK[qh & (QD - 1)][h];
                     if (key > M) { M = key; sL = hs; }
                     qh++; qn--;
-                    if (qn > 0) { hs = s_qs[qh & 31][h]; hE = s_qE[qh & 31][h]; }
+                    if (qn > 0) { hs = s_qs[qh & (QD - 1)][h]; hE = s_qE[qh & (QD - 1)][h]; }
                 }
                 // a run begins here: the walk start, or a recombination entry worth keeping
                 int32_t newE = NEG;
-                if (t == 0) { newE = 0; qn = 0; M = NEGK; Emax = NEG; }
+                if (t == 0) { newE = starts_on ? 0 : NEG; qn = 0; M = NEGK; Emax = NEG; }
                 else if ((flags & PHI_DP_NEED_ENTRY) && Eh >= 0) newE = E;
                 if (newE > Emax) {
                     Emax = newE;
                     const int32_t key = newE - SB;
                     while (qn > 0 && tk < key) {
                         qn--;
-                        if (qn > 0) tk = s_qK[(qh + qn - 1) & 31][h];
+                        if (qn > 0) tk = s_qK[(qh + qn - 1) & (QD - 1)][h];
                     }
-                    const int slq = (qh + qn) & 31;
+                    if (QD < 32 && qn == QD) { atomicOr(A.err, PHI_KERR_DP_QUEUE); qn--; }   // result void: the caller takes DP_SEQ
+                    const int slq = (qh + qn) & (QD - 1);
                     s_qs[slq][h] = t; s_qE[slq][h] = newE; s_qK[slq][h] = key;
                     if (qn == 0) { hs = t; hE = newE; }
                     tk = key;
@@ -807,14 +850,15 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                     int32_t best = M > NEGK / 2 ? M + End : NEG;
                     bs = sL;
                     for (int32_t j = 0; j < qn; j++) {
-                        const int32_t s = j == 0 ? hs : s_qs[(qh + j) & 31][h];
-                        const int32_t Es = j == 0 ? hE : s_qE[(qh + j) & 31][h];
+                        const int32_t s = j == 0 ? hs : s_qs[(qh + j) & (QD - 1)][h];
+                        const int32_t Es = j == 0 ? hE : s_qE[(qh + j) & (QD - 1)][h];
                         const int a = t - s;
                         const int32_t inside = !ovf ? (int32_t)gb[(a & 15) + (a >> 4) * 1024] : ev_count_inside(A, (int64_t)eb + s, e);
                         const int32_t val = Es + inside;
                         if (val > best) { best = val; bs = s; }
                     }
                     if (best > NEG / 2) dmax = best; else bs = 0;
+                    if (MODE == DP_ROW && e == ee - 1) endbest = max(endbest, dmax);
                 }
                 s_res[sl][h] = make_int4(dmax, bs, e, 0);
                 vi++;
@@ -852,19 +896,143 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                 }
                 lastq = ev_pack_tops(t1v, t1h, t1n, t2v, t2h);
                 lastk = k;
-                if (h == 0) s_top[k & (RING - 1)] = lastq;
+                if (h == 0) s_top[k & (RINGT - 1)] = lastq;
             }
-            if (pair) { ra = n2a; rb = n2b; k += 2; }
-            else { ra = na; rb = nb; k += 1; }
+            if (pair) { ra = n2a; rb = n2b; r += 2; }
+            else { ra = na; rb = nb; r += 1; }
         }
         s_vi[h] = vi;
         __syncthreads();                             // B_{p+1}
     }
+    if (MODE != DP_SEQ) {
+        // what crosses the cut at the block's end: the best key of this walk's live runs (oldest first, ties keep the
+        // older run) and where that run began
+        int32_t best = M > NEGK / 2 ? M : NEGK, bs = sL;
+        for (int32_t j = 0; j < qn; j++) {
+            const int32_t key = s_qK[(qh + j) & (QD - 1)][h];
+            if (key > best) { best = key; bs = s_qs[(qh + j) & (QD - 1)][h]; }
+        }
+        if (MODE == DP_ROW) {
+            A.row_out[(int64_t)blockIdx.x * 64 + h] = has_walk ? best : NEGK;
+            const int32_t eb_all = ev_wave_max_i32(endbest);
+            if (h == 0) A.rowend_out[blockIdx.x] = eb_all;
+        } else {
+            // (a walk with no event left when the block began carries nothing that is ever read: reported as "no run",
+            //  as the row pass does)
+            A.blk_keys_out[(int64_t)sb * 64 + h] = (has_walk && vb < ve) ? best : NEGK;
+            A.blk_carry[(int64_t)sb * 64 + h] = bs;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ where the chain may be cut (per solve)
+// diff[e0 + 1] += 1, diff[e1 + 1] -= 1 for every dp anchor (first / last entry e0 < e1): the prefix sum at entry e
+// is the number of anchors with e0 < e <= e1, i.e. that a cut right before e would split
+__global__ void __launch_bounds__(256) phi_cut_cov_kernel(const int32_t *__restrict__ a_e1, const uint8_t *__restrict__ a_span, int64_t n_a,
+                                                          int32_t *__restrict__ diff)
+{
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_a; g += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t e1 = a_e1[g], sp = a_span[g];
+        if (sp <= 0) continue;
+        atomicAdd(&diff[e1 - sp + 1], 1);
+        atomicAdd(&diff[e1 + 1], -1);
+    }
+}
+// clean[e] = 1 iff no anchor is split by a cut before entry e (cov_excl = exclusive prefix sums of diff)
+__global__ void __launch_bounds__(256) phi_cut_clean_kernel(const int32_t *__restrict__ cov_excl, int64_t n_entries, int32_t *__restrict__ clean)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= n_entries; e += (int64_t)gridDim.x * blockDim.x)
+        clean[e] = e < n_entries && cov_excl[e + 1] == 0;
+}
+// Between two consecutive events of a walk (entries l < p on compact steps a < b) the walk only runs along chain
+// vertices: a cut before any step in (a, b] is fine for this walk iff some entry in (l, p] is clean.  Where none is,
+// the steps a+1 .. b are closed: stepdiff[a + 1] += 1, stepdiff[b + 1] -= 1.
+__global__ void __launch_bounds__(256) phi_cut_events_kernel(const int32_t *__restrict__ ev_e, int64_t n_ev, const int64_t *__restrict__ ev_off,
+                                                             const int64_t *__restrict__ walk_off, int32_t n_walks,
+                                                             const int32_t *__restrict__ walk_vtx, const int32_t *__restrict__ cvtx,
+                                                             const int32_t *__restrict__ ncl_excl, int32_t *__restrict__ stepdiff)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ev; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t p = ev_e[i];
+        int lo = 0, hi = n_walks;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (walk_off[mid] <= p) lo = mid; else hi = mid;
+        }
+        if (i == ev_off[lo]) continue;                         // the walk's first event: nothing before it
+        const int32_t l = ev_e[i - 1];
+        if (ncl_excl[p + 1] - ncl_excl[l + 1] > 0) continue;   // a clean entry in (l, p]
+        const int32_t a = cvtx[walk_vtx[l]], b = cvtx[walk_vtx[p]];
+        atomicAdd(&stepdiff[a + 1], 1);
+        atomicAdd(&stepdiff[b + 1], -1);
+    }
+}
+// blk_ev[b][h] = first event of walk h on a compact step >= blk_lo[b]
+__global__ void __launch_bounds__(64) phi_blk_ev_kernel(const int32_t *__restrict__ blk_lo, int32_t n_blk, const int32_t *__restrict__ ev_e,
+                                                        const int64_t *__restrict__ ev_off, int32_t n_walks, const int32_t *__restrict__ walk_vtx,
+                                                        const int32_t *__restrict__ cvtx, int32_t *__restrict__ blk_ev)
+{
+    const int b = blockIdx.x, h = threadIdx.x;
+    if (b >= n_blk) return;
+    int32_t out = 0;
+    if (h < n_walks) {
+        const int32_t k0 = blk_lo[b];
+        int64_t lo = ev_off[h], hi = ev_off[h + 1];
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cvtx[walk_vtx[ev_e[mid]]] < k0) lo = mid + 1; else hi = mid;
+        }
+        out = (int32_t)lo;
+    }
+    blk_ev[(int64_t)b * 64 + h] = out;
+}
+void phi_launch_cut_cov(hipStream_t st, const int32_t *a_e1, const uint8_t *a_span, int64_t n_a, int32_t *diff)
+{
+    if (n_a <= 0) return;
+    int64_t nb = (n_a + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(phi_cut_cov_kernel, dim3((unsigned)nb), dim3(256), 0, st, a_e1, a_span, n_a, diff);
+}
+void phi_launch_cut_clean(hipStream_t st, const int32_t *cov_excl, int64_t n_entries, int32_t *clean)
+{
+    int64_t nb = (n_entries + 1 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(phi_cut_clean_kernel, dim3((unsigned)nb), dim3(256), 0, st, cov_excl, n_entries, clean);
+}
+void phi_launch_cut_events(hipStream_t st, const int32_t *ev_e, int64_t n_ev, const int64_t *ev_off, const int64_t *walk_off, int32_t n_walks,
+                           const int32_t *walk_vtx, const int32_t *cvtx, const int32_t *ncl_excl, int32_t *stepdiff)
+{
+    if (n_ev <= 0) return;
+    int64_t nb = (n_ev + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(phi_cut_events_kernel, dim3((unsigned)nb), dim3(256), 0, st, ev_e, n_ev, ev_off, walk_off, n_walks, walk_vtx, cvtx,
+                       ncl_excl, stepdiff);
+}
+void phi_launch_blk_ev(hipStream_t st, const int32_t *blk_lo, int32_t n_blk, const int32_t *ev_e, const int64_t *ev_off, int32_t n_walks,
+                       const int32_t *walk_vtx, const int32_t *cvtx, int32_t *blk_ev)
+{
+    if (n_blk > 0)
+        hipLaunchKernelGGL(phi_blk_ev_kernel, dim3((unsigned)n_blk), dim3(64), 0, st, blk_lo, n_blk, ev_e, ev_off, n_walks, walk_vtx, cvtx, blk_ev);
 }
 
 void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A)
 {
-    if (A.n_walks <= 64) hipLaunchKernelGGL(phi_dp_events_pc_kernel<2>, dim3(1), dim3(64 * 3), 0, st, A);
+    if (A.n_walks <= 64) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_SEQ, 8, RING, 32>), dim3(1), dim3(64 * 3), 0, st, A);
     else if (A.n_walks <= 128) hipLaunchKernelGGL(phi_dp_events_kernel<2>, dim3(1), dim3(128), 0, st, A);
     else hipLaunchKernelGGL(phi_dp_events_kernel<4>, dim3(1), dim3(256), 0, st, A);    // n_walks <= PHI_DP_EVENT_MAX_WALKS
+}
+
+// blocks of steps in parallel (<= 64 walks): the rows of the blocks' transfer matrices, then (the host has chained
+// them into the entry vector of every block) the blocks themselves.  A block is at most as long as its ring of tops
+// (A.blk_ring: 1024 steps, two workgroups per CU; 2048 for graphs whose longest stretch without a cut needs it).
+void phi_launch_dp_block_rows(hipStream_t st, const PhiDpEventArgs &A)
+{
+    const unsigned grid = (unsigned)A.n_blk * (unsigned)(A.n_walks + 1);
+    if (A.blk_ring <= 1024) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 1024, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
+    else hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 2048, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
+}
+void phi_launch_dp_block_paths(hipStream_t st, const PhiDpEventArgs &A)
+{
+    if (A.blk_ring <= 1024) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_PATH, 4, 1024, 16>), dim3((unsigned)A.n_blk), dim3(64 * 3), 0, st, A);
+    else hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_PATH, 4, 2048, 16>), dim3((unsigned)A.n_blk), dim3(64 * 3), 0, st, A);
 }

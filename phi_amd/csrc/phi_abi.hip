@@ -206,7 +206,7 @@ void phi_ctx_destroy(phi_ctx *c)
     (void)phi_comm_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->alt.sp_keys, &c->alt.hit, &c->alt.stripes, &c->alt.splog, &c->alt.splog_cnt, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.sp_keys, &c->alt.hit, &c->alt.stripes, &c->alt.splog, &c->alt.splog_cnt, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
@@ -805,6 +805,23 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         }
         for (int32_t v = 0; v < n_vtx; v++) cvtx[v] = c->h_cstep[topo_rank[v]];
         tm.lap("  compact records");
+        // where the chain of steps may be cut (dp_events.hip, blocks in parallel): not between the two steps of a pair,
+        // and only where no recombination edge of this or a later step comes from before the cut
+        {
+            c->h_k_cut_ok.assign((size_t)c->n_k + 1, 1);
+            int32_t min_src = INT32_MAX;                       // smallest source step of an in-edge of any step >= k
+            for (int32_t k = c->n_k - 1; k >= 0; k--) {
+                const int32_t *r = &k_rec[(size_t)k * 8];
+                const int n_in = (r[0] >> 8) & 0xFF;
+                for (int j = 0; j < n_in; j++) {
+                    const int32_t pk = j < 3 ? r[2 + j] : k_in[(size_t)r[1] + j - 3];
+                    min_src = std::min(min_src, k - (int32_t)((uint32_t)pk >> 8));
+                }
+                if (min_src < k) c->h_k_cut_ok[(size_t)k] = 0;
+                if (k > 0 && (k_rec[(size_t)(k - 1) * 8] & PHI_DP_PAIR)) c->h_k_cut_ok[(size_t)k] = 0;
+            }
+            c->h_k_cut_ok[0] = 0; c->h_k_cut_ok[(size_t)c->n_k] = 0;
+        }
         PHICHK(upload(c, c->d_k_rec, k_rec.data(), k_rec.size()));
         PHICHK(upload(c, c->d_k_in, k_in.data(), k_in.size()));
         PHICHK(upload(c, c->d_cvtx, cvtx.data(), cvtx.size()));

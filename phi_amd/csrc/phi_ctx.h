@@ -149,6 +149,13 @@ struct phi_ctx {
     int32_t n_k = 0;                                  // compact steps
     int64_t n_ev = 0;                                 // events
     std::vector<int32_t> h_cstep, h_kstep;            // topological step -> compact step (-1) and back
+    // blocks of compact steps solved in parallel (dp_events.hip DP_ROW / DP_PATH, <= 64 walks): per graph, the steps a cut
+    // may not sit before (a recombination edge would cross it / it would split a pair of allele steps); per solve, the cuts
+    std::vector<int32_t> h_k_cut_ok;                  // [n_k + 1]: 1 = structurally a cut may sit before step k
+    bool dp_blocks = false;
+    int32_t n_blk = 0, blk_ring = 1024;
+    std::vector<int32_t> h_blk_lo;
+    DevBuf d_blk_lo, d_blk_ev, d_blk_S, d_row_out, d_rowend, d_blk_keys, d_blk_carry, d_cov, d_cov2, d_stepdiff;
     DevBuf d_k_rec, d_k_in, d_cvtx, d_ev_e, d_ev_off, d_ev, d_cnt_end, d_cnt_start, d_off_end, d_off_start, d_scan_blk, d_scan_blk64, d_scan_blkoff;
     PhiAnchorSpan h_kept, h_dp;                       // kept anchors (in h_pin); dp anchors (span >= 1 edge: h_kept itself or h_dp_own)
     std::vector<PhiAnchorHost> h_dp_own;

@@ -236,8 +236,25 @@ struct PhiDpEventArgs {
     int32_t *ent_src, *ent_h;            // per compact step
     uint32_t *err;                       // PHI_KERR_DP_QUEUE
     int32_t q_limit;                     // 0 = the kernel's queue depth; tests lower it to provoke the fallback
+    // blocks of steps solved in parallel (<= 64 walks, dp_events.hip DP_ROW / DP_PATH): block b = steps [blk_lo[b], blk_lo[b+1])
+    int32_t n_blk, blk_ring;             // blk_ring: 1024 or 2048 = the longest block
+    const int32_t *blk_lo;               // [n_blk + 1]
+    const int32_t *blk_ev;               // [n_blk][64]: first event of each walk inside the block
+    const int32_t *blk_S;                // DP_PATH in: [n_blk][64] key of each walk entering the block (NEGK: none)
+    int32_t *row_out; int32_t *rowend_out;   // DP_ROW out: [n_blk * (n_walks + 1)][64] keys at the block's end; best value of a path ending inside
+    int32_t *blk_keys_out; int32_t *blk_carry;   // DP_PATH out: [n_blk][64] keys at the block's end; start of the run that carries them (-1: before the block)
 };
+#define PHI_DP_BLOCK_MAX 2048        // steps of a block at most (= the larger ring of tops)
+#define PHI_DP_NEGK (-(1 << 30))      // "no run" in key space
 void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A);
+void phi_launch_dp_block_rows(hipStream_t st, const PhiDpEventArgs &A);
+void phi_launch_dp_block_paths(hipStream_t st, const PhiDpEventArgs &A);
+void phi_launch_cut_cov(hipStream_t st, const int32_t *a_e1, const uint8_t *a_span, int64_t n_a, int32_t *diff);
+void phi_launch_cut_clean(hipStream_t st, const int32_t *cov_excl, int64_t n_entries, int32_t *clean);
+void phi_launch_cut_events(hipStream_t st, const int32_t *ev_e, int64_t n_ev, const int64_t *ev_off, const int64_t *walk_off, int32_t n_walks,
+                           const int32_t *walk_vtx, const int32_t *cvtx, const int32_t *ncl_excl, int32_t *stepdiff);
+void phi_launch_blk_ev(hipStream_t st, const int32_t *blk_lo, int32_t n_blk, const int32_t *ev_e, const int64_t *ev_off, int32_t n_walks,
+                       const int32_t *walk_vtx, const int32_t *cvtx, int32_t *blk_ev);
 void phi_launch_event_flags(hipStream_t st, const int32_t *walk_vtx, int64_t n_entries, const int32_t *cvtx, uint8_t *flags);
 void phi_launch_event_off(hipStream_t st, const int32_t *ev_e, int64_t n_ev, const int64_t *walk_off, int32_t n_walks,
                           int64_t *ev_off);

@@ -52,9 +52,98 @@ int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_
     return PHI_OK;
 }
 
+// ------------------------------------------------------------------------------------------ blocks of steps
+// Up to 64 walks: cut the chain of compact steps into blocks that the DP kernel solves in parallel (dp_events.hip
+// DP_ROW / DP_PATH).  A cut may sit before step k when the graph allows it (phi_set_graph: no recombination edge from
+// before the cut, not inside a pair of allele steps) and, on every walk, some entry between the walk's events around the
+// cut is split by no dp anchor -- found here, once per solve, from all dp anchors whatever their weights.
+static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
+{
+    c->dp_blocks = false;
+    c->n_blk = 0;
+    if (!c->dp_events || c->n_walks > 64 || getenv("PHI_DP_NOBLOCKS") || c->n_k < 4) return PHI_OK;
+    const int64_t ne = c->n_entries;
+    const int32_t nk = c->n_k;
+    PHICHK(phi_dev_ensure(c, c->d_cov, (size_t)(ne + 3) * 4));
+    PHICHK(phi_dev_ensure(c, c->d_cov2, (size_t)(ne + 3) * 4));
+    PHICHK(phi_dev_ensure(c, c->d_stepdiff, (size_t)(nk + 2) * 4));
+    {
+        const int64_t nb = phi_scan_i32_num_blocks(ne + 2);
+        PHICHK(phi_dev_ensure(c, c->d_scan_blk, (size_t)nb * 4));
+        PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
+    }
+    int32_t *d_a = c->d_cov.as<int32_t>(), *d_b = c->d_cov2.as<int32_t>();
+    HIPCHK(hipMemsetAsync(d_a, 0, (size_t)(ne + 3) * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_stepdiff.p, 0, (size_t)(nk + 2) * 4, c->stream));
+    phi_launch_cut_cov(c->stream, c->d_a_e1.as<int32_t>(), c->d_g_span.as<uint8_t>(), n_dp, d_a);
+    phi_launch_scan_i32(c->stream, d_a, ne + 1, d_b, c->d_scan_blk.as<int32_t>(), c->d_scan_blkoff.as<int64_t>());     // d_b[e + 1] = anchors a cut before e splits
+    phi_launch_cut_clean(c->stream, d_b, ne, d_a);                                                                       // d_a[e] = clean
+    phi_launch_scan_i32(c->stream, d_a, ne + 1, d_b, c->d_scan_blk.as<int32_t>(), c->d_scan_blkoff.as<int64_t>());     // d_b[e] = clean entries before e
+    phi_launch_cut_events(c->stream, c->d_ev_e.as<int32_t>(), c->n_ev, c->d_ev_off.as<int64_t>(), c->d_walk_off.as<int64_t>(), c->n_walks,
+                          c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(), d_b, c->d_stepdiff.as<int32_t>());
+    std::vector<int32_t> closed((size_t)nk + 2);
+    HIPCHK(hipMemcpyAsync(closed.data(), c->d_stepdiff.p, (size_t)(nk + 2) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int32_t k = 1; k <= nk + 1; k++) closed[(size_t)k] += closed[(size_t)k - 1];          // > 0: some walk forbids a cut before step k
+    auto cut_ok = [&](int32_t k) { return k > 0 && k < nk && c->h_k_cut_ok[(size_t)k] && closed[(size_t)k] == 0; };
+    if (getenv("PHI_TIMING")) {
+        int64_t n_struct = 0, n_both = 0, longest = 0, run = 0, longest_s = 0, run_s = 0;
+        for (int32_t k = 1; k < nk; k++) {
+            n_struct += c->h_k_cut_ok[(size_t)k] != 0;
+            if (cut_ok(k)) { n_both++; run = 0; } else longest = std::max(longest, ++run);
+            if (c->h_k_cut_ok[(size_t)k]) run_s = 0; else longest_s = std::max(longest_s, ++run_s);
+        }
+        fprintf(stderr, "[phi timing] solve: cuts: %lld of %d steps allowed by the graph (longest closed stretch %lld), %lld also clean of anchors (longest closed stretch %lld)\n",
+                (long long)n_struct, nk, (long long)longest_s, (long long)n_both, (long long)longest);
+    }
+    // block length: enough blocks to fill the machine with (walks + 1) tasks each, few enough to keep the chain short;
+    // a block is at most as long as its ring of tops: 1024 steps, or 2048 where the longest stretch without a cut needs it
+    bool placed = false;
+    for (int32_t ring = 1024; ring <= PHI_DP_BLOCK_MAX && !placed; ring *= 2) {
+        int64_t target = (int64_t)nk * (c->n_walks + 1) / 4096;
+        target = std::max<int64_t>(64, std::min<int64_t>(ring / 2, target));
+        if (const char *e = getenv("PHI_DP_BLOCK_STEPS")) target = std::max(1, std::min(ring, atoi(e)));   // tests: many small blocks
+        c->h_blk_lo.assign(1, 0);
+        bool ok = true;
+        for (int32_t start = 0; nk - start > target && ok;) {
+            int32_t cut = -1;
+            const int32_t hi = (int32_t)std::min<int64_t>((int64_t)start + ring, nk - 1);
+            for (int32_t k = (int32_t)(start + target); k <= hi && cut < 0; k++) if (cut_ok(k)) cut = k;
+            for (int32_t k = (int32_t)(start + target) - 1; k > start && cut < 0; k--) if (cut_ok(k)) cut = k;
+            if (cut < 0) {
+                if (nk - start > ring) ok = false;             // no usable cut within a ring's length
+                break;                                         // (else: the rest is one block)
+            }
+            c->h_blk_lo.push_back(cut);
+            start = cut;
+        }
+        if (ok && nk - c->h_blk_lo.back() <= ring) { placed = true; c->blk_ring = ring; }
+    }
+    if (!placed) return PHI_OK;                                // the chain stays whole
+    c->h_blk_lo.push_back(nk);
+    c->n_blk = (int32_t)c->h_blk_lo.size() - 1;
+    if (c->n_blk < 2) { c->n_blk = 0; return PHI_OK; }
+    const size_t nbk = (size_t)c->n_blk;
+    PHICHK(phi_dev_ensure(c, c->d_blk_lo, (nbk + 1) * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_ev, nbk * 64 * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_S, nbk * 64 * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_keys, nbk * 64 * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_carry, nbk * 64 * 4));
+    PHICHK(phi_dev_ensure(c, c->d_row_out, nbk * (size_t)(c->n_walks + 1) * 64 * 4));
+    PHICHK(phi_dev_ensure(c, c->d_rowend, nbk * (size_t)(c->n_walks + 1) * 4));
+    HIPCHK(hipMemcpyAsync(c->d_blk_lo.p, c->h_blk_lo.data(), (nbk + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    phi_launch_blk_ev(c->stream, c->d_blk_lo.as<int32_t>(), c->n_blk, c->d_ev_e.as<int32_t>(), c->d_ev_off.as<int64_t>(), c->n_walks,
+                      c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(), c->d_blk_ev.as<int32_t>());
+    HIPCHK(hipStreamSynchronize(c->stream));                   // h_blk_lo is a member, but the launch above must have its copy
+    c->dp_blocks = true;
+    if (getenv("PHI_TIMING")) fprintf(stderr, "[phi timing] solve: %d compact steps in %d blocks (rings of %d steps)\n", nk, c->n_blk, c->blk_ring);
+    return PHI_OK;
+}
+
 // ------------------------------------------------------------------------------------------ DP
 struct DpHost {
     std::vector<int32_t> ends, bstart, ent_u, ent_h;
+    std::vector<int32_t> rows, rowend, S, keys, carry;          // blocks in parallel: transfer rows, entry vectors, what the blocks report
 };
 
 // one DP launch with the given anchor weights; returns its value and the argmax path
@@ -95,7 +184,64 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
         phi_launch_dp_event_fill(c->stream, A, c->d_e_out.as<uint8_t>(), c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(),
                                  c->d_off_end.as<int32_t>(), c->d_off_start.as<int32_t>());
         if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("weights + per-run records"); }
-        phi_launch_dp_events(c->stream, A);
+        if (c->dp_blocks) {
+            // 1. every block from every entry walk (and from the walk starts inside it): rows of its transfer matrix
+            const int32_t nb = c->n_blk, nwk = c->n_walks, nrow = nwk + 1;
+            A.n_blk = nb; A.blk_ring = c->blk_ring; A.blk_lo = c->d_blk_lo.as<int32_t>(); A.blk_ev = c->d_blk_ev.as<int32_t>(); A.blk_S = c->d_blk_S.as<int32_t>();
+            A.row_out = c->d_row_out.as<int32_t>(); A.rowend_out = c->d_rowend.as<int32_t>();
+            A.blk_keys_out = c->d_blk_keys.as<int32_t>(); A.blk_carry = c->d_blk_carry.as<int32_t>();
+            phi_launch_dp_block_rows(c->stream, A);
+            H.rows.resize((size_t)nb * nrow * 64); H.rowend.resize((size_t)nb * nrow);
+            HIPCHK(hipMemcpyAsync(H.rows.data(), A.row_out, H.rows.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(H.rowend.data(), A.rowend_out, H.rowend.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            uint32_t kerr = 0;
+            HIPCHK(hipMemcpyAsync(&kerr, c->d_scalars.as<uint64_t>() + S_ERR, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (tr.on) tr.lap("block rows");
+            if (kerr & PHI_KERR_DP_QUEUE) {
+                // a walk had more live runs than a block task's queue holds: this graph keeps the whole chain
+                kerr &= ~PHI_KERR_DP_QUEUE;
+                HIPCHK(hipMemcpy(c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
+                c->dp_blocks = false;
+                return run_dp(c, wgt, H, value, segs);
+            }
+            // 2. chain: S_{b+1}[h'] = max(rows of walk starts, max_j S_b[j] + row_j[h'])  (max-plus, NEGK = no run)
+            H.S.assign((size_t)nb * 64, PHI_DP_NEGK);
+            std::vector<int64_t> cur(64, PHI_DP_NEGK), nxt(64);
+            int64_t end_best = INT64_MIN;
+            for (int32_t b = 0; b < nb; b++) {
+                for (int h = 0; h < 64; h++) H.S[(size_t)b * 64 + h] = cur[h] > PHI_DP_NEGK / 2 ? (int32_t)cur[h] : PHI_DP_NEGK;
+                std::fill(nxt.begin(), nxt.end(), (int64_t)PHI_DP_NEGK);
+                for (int32_t j = 0; j <= nwk; j++) {
+                    const int64_t base = j == nwk ? 0 : cur[j];
+                    if (j < nwk && base <= PHI_DP_NEGK / 2) continue;
+                    const int32_t *row = &H.rows[((size_t)b * nrow + j) * 64];
+                    for (int32_t h2 = 0; h2 < nwk; h2++)
+                        if (row[h2] > PHI_DP_NEGK / 2) nxt[h2] = std::max(nxt[h2], base + row[h2]);
+                    const int32_t re = H.rowend[(size_t)b * nrow + j];
+                    if (re > -(1 << 27)) end_best = std::max(end_best, base + re);
+                }
+                cur.swap(nxt);
+            }
+            // 3. the blocks again, in parallel, each from its true entry vector: everything the backtrack reads
+            HIPCHK(hipMemcpyAsync(c->d_blk_S.p, H.S.data(), H.S.size() * 4, hipMemcpyHostToDevice, c->stream));
+            phi_launch_dp_block_paths(c->stream, A);
+            H.keys.resize((size_t)nb * 64); H.carry.resize((size_t)nb * 64);
+            HIPCHK(hipMemcpyAsync(H.keys.data(), A.blk_keys_out, H.keys.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(H.carry.data(), A.blk_carry, H.carry.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            // the two passes must agree on what leaves every block (and so on the chain as a whole)
+            for (int32_t b = 0; b + 1 < nb; b++)
+                for (int32_t h = 0; h < nwk; h++) {
+                    const int32_t want = H.S[(size_t)(b + 1) * 64 + h], got = H.keys[(size_t)b * 64 + h];
+                    // a walk that begins inside block b+1 or ended before it carries nothing that is ever read
+                    if (want != got && !(want <= PHI_DP_NEGK / 2 && got <= PHI_DP_NEGK / 2))
+                        return phi_fail(c, PHI_ERR_DEVICE, "DP blocks: block %d leaves key %d on walk %d, the chained matrices say %d (internal error)", b, got, h, want);
+                }
+            (void)end_best;
+        } else {
+            phi_launch_dp_events(c->stream, A);
+        }
     } else {
         phi_launch_dp_words(c->stream, c->d_e_out.as<uint8_t>(), c->d_g_off.as<int64_t>(), c->d_g_span.as<uint8_t>(),
                             c->d_a_weight.as<uint8_t>(), ne, c->d_word.as<uint64_t>());
@@ -160,6 +306,14 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
         int32_t bs = 0;
         if (bulk) bs = H.bstart[e];
         else HIPCHK(hipMemcpy(&bs, d_bstart + e, 4, hipMemcpyDeviceToHost));
+        if (bs < 0 && c->dp_blocks && events) {
+            // the run crossed into its block: follow it back through the blocks it was carried over
+            const int32_t vq = c->h_walk_vtx[e];
+            const int32_t kq = c->h_cstep[c->h_topo_rank[vq]];
+            int32_t b = (int32_t)(std::upper_bound(c->h_blk_lo.begin(), c->h_blk_lo.end(), kq) - c->h_blk_lo.begin()) - 1;
+            while (bs < 0 && --b >= 0) bs = H.carry[(size_t)b * 64 + h];
+            if (bs < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack: a carried run has no beginning (internal error)");
+        }
         const int64_t es = c->h_walk_off[h] + bs;
         if (es < c->h_walk_off[h] || es > e) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack left the walk (internal error)");
         segs->push_back(Seg{h, (int32_t)es, (int32_t)e});
@@ -434,6 +588,7 @@ int phi_solve_impl(phi_ctx *c)
         PHICHK(phi_dev_ensure(c, c->d_word, (size_t)c->n_entries * 8));
     }
 
+    PHICHK(dp_prepare_blocks(c, n_dp));
     tm.lap("DP inputs");
     // ---- 4. exact solve
     const int64_t cost = 2 * (int64_t)(c->recombination / 2);

@@ -1226,3 +1226,49 @@ def test_spectrum_set_regrows_on_dense_input(oracle, ctx_factory, monkeypatch):
     assert st["n_distinct"] == len(np.unique(np.concatenate(sk))) > 65536
     assert st["n_emitted"] == sum(len(x) for x in sk)            # the replay does not count twice
     _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 3)
+
+
+@pytest.mark.parametrize("block_steps", ["1", "3", "16", None])
+def test_dp_blocks_in_parallel_equal_the_whole_chain(oracle, ctx_factory, monkeypatch, block_steps):
+    """Up to 64 walks the chain of compact steps is cut at clean cuts and the blocks are solved in parallel (transfer-matrix
+    rows, host chain, second pass from the true entry vectors).  PHI_DP_BLOCK_STEPS forces blocks of a few steps so that
+    small graphs have many cuts; PHI_DP_NOBLOCKS=1 keeps the chain whole.  Same objective, bound, proof and counters, a
+    feasible path of that value, over graphs with repeats, walks ending inside the graph, R = 0 .. 100."""
+    from oracle import solve_oracle as S
+    cases = []
+    for seed in range(10):
+        rng = np.random.default_rng(7700 + seed)
+        k, w = int(rng.integers(5, 12)), int(rng.integers(1, 7))
+        rep = bytes(rng.choice(list(b"ACGT"), size=k + 4).tolist()) if seed % 2 else None
+        g = random_graph(rng, n_sites=int(rng.integers(30, 120)), n_walks=int(rng.integers(2, 40)), seg_len=(3, 40),
+                         alt_len=(1, 10), p_del=0.25, repeat=rep)
+        if seed % 3 == 0:
+            g.paths[1] = g.paths[1][: len(g.paths[1]) - 3]               # ends on an interior vertex
+        reads = mosaic_reads(rng, g, n_reads=300, read_len=k + w + 30, n_seg=int(rng.integers(2, 6)), err=0.01)
+        R = int(rng.choice([0, 1, 3, 10, 100]))
+        cases.append((g, reads, k, w, R))
+    for g, reads, k, w, R in cases:
+        out = {}
+        for mode in ("blocks", "whole"):
+            if mode == "whole":
+                monkeypatch.setenv("PHI_DP_NOBLOCKS", "1")
+            elif block_steps is not None:
+                monkeypatch.setenv("PHI_DP_BLOCK_STEPS", block_steps)
+            ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=R)
+            ctx.set_solve_budget(64)
+            _set_graph(ctx, g)
+            ctx.add_reads(reads)
+            res = ctx.solve()
+            monkeypatch.delenv("PHI_DP_NOBLOCKS", raising=False)
+            monkeypatch.delenv("PHI_DP_BLOCK_STEPS", raising=False)
+            out[mode] = res
+        a, b = out["blocks"], out["whole"]
+        for key in ("spectrum_size", "filtered", "n_in_model"):
+            assert a[key] == b[key]
+        if a["optimal"] and b["optimal"]:
+            assert a["objective"] == b["objective"], (k, w, R, a["objective"], b["objective"])
+        st = oracle.run_stage12(g, reads, k, w, 1.0)
+        m = S.Model(g, st, R)
+        for res in (a, b):
+            obj, cov, nsw = m.objective(S.states_from_path(res["path_vtx"], res["path_hap"]))
+            assert obj == res["objective"] and obj <= res["upper_bound"]
