@@ -224,3 +224,26 @@ def test_cli_devices_list_and_run_budget(tmp_path, oracle):
         assert "after 3 DP run(s)" in r.stderr
     assert (tmp_path / "few0.fa").read_text() == (tmp_path / "few1.fa").read_text()      # reproducible
     assert (tmp_path / "few0.fa").read_text().startswith(">hard_hard LN:")
+
+
+def test_cli_through_the_vcf_route_and_the_log_scrape(tmp_path):
+    """README.md:25-30 of the reference runs the same sample through vcf2gfa.py: here phi_amd/vcf2gfa.py makes the graph
+    from test/MHC_4.vcf.gz + test/MHC-CHM13.0.fa.gz, PHI infers the haplotype of the CHM13 reads on it, and
+    phi_amd/eval_log.py scrapes the log as data/postprocessing_2_MIQP.py:55-79 does (the inferred sequence is the
+    reference walk: edit distance 0 to the CHM13 FASTA)."""
+    import sys
+    from phi_amd import eval_log
+    gfa = tmp_path / "MHC_4_vcf.gfa"
+    with open(gfa, "wb") as f:
+        subprocess.check_call([sys.executable, "-m", "phi_amd.vcf2gfa", "-v", os.path.join(DATA, "MHC_4.vcf.gz"),
+                               "-r", os.path.join(DATA, "MHC-CHM13.0.fa.gz")], stdout=f, cwd=ROOT)
+    out = tmp_path / "CHM13_vcf.fa"
+    r = _run_cli(["-t32", "-g", str(gfa), "-r", os.path.join(DATA, "CHM13_reads.fq.gz"), "-o", str(out)], tmp_path)
+    assert r.returncode == 0, r.stderr
+    got = eval_log.parse_log(r.stderr)
+    assert all(v is not None for v in got.values()), got
+    assert got["recombination_count"] == 0 and got["spectrum_size"] == 138834      # the reads' spectrum does not depend on the graph
+    assert abs(got["pct_filtered"] + got["pct_retained"] - 100.0) < 0.02
+    assert ">(REF.0,[0," in r.stderr
+    truth, query = eval_log.read_fasta(os.path.join(DATA, "MHC-CHM13.0.fa.gz")), eval_log.read_fasta(str(out))
+    assert query == truth and eval_log.edit_distance(truth[:20000], query[:20000]) == 0
