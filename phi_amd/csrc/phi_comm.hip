@@ -47,7 +47,7 @@ const RcclApi *rccl_api(std::string *why)
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *dl = nullptr;
     for (const char *n : names)
-        if ((dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if ((dl = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;   // (a host that already loaded RCCL -- torch -- shares that copy by its soname)
     if (!dl) { g_api.why = std::string("librccl not found: ") + dlerror(); if (why) *why = g_api.why; return nullptr; }
     RcclApi a;
     a.dl = dl;

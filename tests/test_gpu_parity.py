@@ -1272,3 +1272,56 @@ def test_dp_blocks_in_parallel_equal_the_whole_chain(oracle, ctx_factory, monkey
         for res in (a, b):
             obj, cov, nsw = m.objective(S.states_from_path(res["path_vtx"], res["path_hap"]))
             assert obj == res["objective"] and obj <= res["upper_bound"]
+
+
+def test_read_state_double_buffers_through_awkward_sequences(oracle, ctx_factory):
+    """phi_reset_reads swaps the context's two sets of read buffers; the next read launch empties the set left behind.
+    Sequences that stress the bookkeeping: resets with nothing in between (the half that comes to the front was never
+    emptied), a one-read batch after a large generation (a handful of waves empty a large log), a large batch after a
+    tiny one, batches of only empty / too-short reads, and a second phi_set_graph.  After every generation the spectrum,
+    the emitted count and the solve are those of a fresh context with the same reads."""
+    rng = np.random.default_rng(4242)
+    k, w = 13, 7
+    g = random_graph(rng, n_sites=30, n_walks=5, seg_len=(20, 60), alt_len=(1, 8))
+
+    def rseq(n):
+        return bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+    big = mosaic_reads(rng, g, n_reads=400, read_len=120, n_seg=3, err=0.01) + [rseq(4000) for _ in range(20)]
+    one = [mosaic_reads(rng, g, n_reads=1, read_len=90, n_seg=1)[0]]
+    mid = mosaic_reads(rng, g, n_reads=60, read_len=100, n_seg=2) + [rseq(300) + b"N" + rseq(200)]
+    plan = [("big", [big]), ("reset twice, then one read", "double"), ("one", [one]), ("big again", [big]), ("nothing but short reads", [[b"ACGT", b"", b"AC"]]),
+            ("mid in three batches", [mid[:20], mid[20:40], mid[40:]]), ("triple reset", "triple"), ("mid", [mid]), ("one", [one]), ("big", [big])]
+
+    def fresh(batches):
+        c = ctx_factory(k=k, w=w, threshold=1.0, recombination=5)
+        _set_graph(c, g)
+        for b in batches:
+            c.add_reads(b)
+        return c.reads_stats(), c.solve()
+
+    ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=5)
+    _set_graph(ctx, g)
+    for step, (name, batches) in enumerate(plan):
+        if batches == "double":
+            ctx.reset_reads(); ctx.reset_reads()
+            assert ctx.reads_stats()["n_distinct"] == 0
+            continue
+        if batches == "triple":
+            ctx.reset_reads(); ctx.reset_reads(); ctx.reset_reads()
+            assert ctx.solve()["spectrum_size"] == 0
+            continue
+        ctx.reset_reads()
+        for b in batches:
+            ctx.add_reads(b)
+        want_stats, want = fresh(batches)
+        assert ctx.reads_stats() == want_stats, name
+        got = ctx.solve()
+        for key in ("objective", "spectrum_size", "filtered", "n_in_model", "n_covered"):
+            assert got[key] == want[key], (name, key)
+        if step == 4:
+            _set_graph(ctx, g)                                   # the index again: the read state starts over
+            assert ctx.reads_stats()["n_reads"] == 0
+    reads = [r for b in [mid] for r in b]
+    ctx.reset_reads()
+    ctx.add_reads(reads)
+    _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 5)
