@@ -788,6 +788,10 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
 
     for (int p = 0; p < n_per; p++) {
         const int32_t r_end = min(n_steps, (p + 1) * P);
+        // The ring is guaranteed to hold this lane's next P events when a period begins, not one more: a lane that
+        // consumed an event on every step of the last period peeked at a record the producers were still loading
+        // (a stale slot: the lane then never saw its next event).  Peek again now that the barrier has passed.
+        if (vi < ve) cA = s_ev[vi & (D - 1)][0][h];
         for (int32_t r = p * P; r < r_end;) {
             const int32_t k = k0 + r;
             // records of the next two steps (past the last step: stale records, never used)

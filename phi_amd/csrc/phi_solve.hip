@@ -229,7 +229,14 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
             H.keys.resize((size_t)nb * 64); H.carry.resize((size_t)nb * 64);
             HIPCHK(hipMemcpyAsync(H.keys.data(), A.blk_keys_out, H.keys.size() * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipMemcpyAsync(H.carry.data(), A.blk_carry, H.carry.size() * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(&kerr, c->d_scalars.as<uint64_t>() + S_ERR, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
+            if (kerr & PHI_KERR_DP_QUEUE) {
+                kerr &= ~PHI_KERR_DP_QUEUE;
+                HIPCHK(hipMemcpy(c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
+                c->dp_blocks = false;
+                return run_dp(c, wgt, H, value, segs);
+            }
             // the two passes must agree on what leaves every block (and so on the chain as a whole)
             for (int32_t b = 0; b + 1 < nb; b++)
                 for (int32_t h = 0; h < nwk; h++) {
