@@ -452,7 +452,10 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
             const int inx = min(i + 1, CHK - 1);
             const int4 na = s_rec[b][inx][0], nb = s_rec[b][inx][1];
             if ((c | i) && (i & (P - 1)) == 0) issue();
-            if ((c | i) && (i & (P - 1)) == P / 2) land();
+            if ((c | i) && (i & (P - 1)) == P / 2) {
+                land();
+                if (vi < ve) cA = s_ev[vi & (D - 1)][0][h];     // (a peek made before its record landed saw a stale slot)
+            }
             const int32_t k = s0 + i;
             const int32_t flags = ra.x;
             const bool active = (int32_t)cA.x == k;
