@@ -61,6 +61,8 @@ def cpu_baseline(g_arrays, reads_concat, read_off, k, w, budget_s=6.0):
     sample, never part of the measured GPU path.  Reads sketch at -t1 and -t<threads>, then stages 1-2 of
     the whole configuration at -t<threads> (the reference parallelises the walk sketch over walks and the
     read sketch over reads, ILP_index.cpp:559,617; match and filter are timed as one-thread restatements)."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])    # the checker: built on demand, as tests/conftest.py does
     from oracle import oracle as O
     L = O.lib()
     raw = reads_concat.tobytes()
