@@ -208,6 +208,20 @@ typedef struct {
 } phi_index_info;
 int phi_index_stats(phi_ctx *ctx, phi_index_info *out);
 
+/*
+ * How the last phi_solve ran its DP (no reference counterpart: the reference hands the model to Gurobi).
+ * dp_mode: 0 = every vertex is a step (more than 256 walks, or the fallback of the event kernels), 1 = event
+ * driven, one chain over the compact steps, 2 = blocks of steps in parallel on walk lanes (<= 64 walks),
+ * 3 = blocks in parallel with their transfer rows on class lanes (65 .. 256 walks).  n_blocks = 0 unless 2 / 3;
+ * max_classes / mean_classes: class lanes per block of the last DP run (mode 3).
+ */
+typedef struct {
+    int64_t n_dp_anchors, n_events;
+    int32_t n_steps, n_blocks, dp_mode, max_classes;
+    double mean_classes;
+} phi_solve_info;
+int phi_solve_stats(phi_ctx *ctx, phi_solve_info *out);
+
 /* Minimisers of walk h found by phi_set_graph, sorted by position. */
 int phi_walk_minimizers(phi_ctx *ctx, int32_t walk, uint64_t *out_hash, int64_t *out_pos,
                         int64_t cap, int64_t *n_out);

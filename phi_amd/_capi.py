@@ -22,13 +22,18 @@ SYMBOLS = [
     "phi_spectrum_export", "phi_spectrum_import", "phi_spectrum_set_size", "phi_solve", "phi_path_sequence",
     "phi_sketch", "phi_walk_minimizers", "phi_walk_sharing", "phi_kept_anchors", "phi_prof_enable", "phi_prof_read",
     "phi_host_register", "phi_host_unregister", "phi_set_solve_budget",
-    "phi_index_stats", "phi_comm_unique_id", "phi_comm_init", "phi_comm_info", "phi_comm_allreduce_hits", "phi_comm_exchange", "phi_comm_destroy",
+    "phi_index_stats", "phi_solve_stats", "phi_comm_unique_id", "phi_comm_init", "phi_comm_info", "phi_comm_allreduce_hits", "phi_comm_exchange", "phi_comm_destroy",
 ]
 
 
 class PhiIndexInfo(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_entries", "walk_bases", "n_classes", "class_bases", "n_class_records",
                                          "n_walk_minimizers", "n_distinct_minimizers")] + [("sketch_gpu_ms", C.c_double)]
+
+
+class PhiSolveInfo(C.Structure):
+    _fields_ = [("n_dp_anchors", C.c_int64), ("n_events", C.c_int64), ("n_steps", C.c_int32), ("n_blocks", C.c_int32),
+                ("dp_mode", C.c_int32), ("max_classes", C.c_int32), ("mean_classes", C.c_double)]
 
 
 class PhiResult(C.Structure):
@@ -76,6 +81,7 @@ def load():
     L.phi_solve.argtypes = [vp, C.POINTER(PhiResult)]
     L.phi_set_solve_budget.argtypes = [vp, i64]
     L.phi_index_stats.argtypes = [vp, C.POINTER(PhiIndexInfo)]
+    L.phi_solve_stats.argtypes = [vp, C.POINTER(PhiSolveInfo)]
     L.phi_comm_unique_id.argtypes = [vp, C.c_size_t]
     L.phi_comm_init.argtypes = [vp, vp, i32, i32]
     L.phi_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]

@@ -74,6 +74,13 @@ class Context:
         self._chk(self._L.phi_index_stats(self._h, C.byref(r)))
         return {n: getattr(r, n) for n, _ in _capi.PhiIndexInfo._fields_}
 
+    def solve_stats(self):
+        """How the last solve ran its DP: mode (0 every vertex, 1 event chain, 2 blocks on walk lanes, 3 blocks with rows
+        on class lanes), blocks, class lanes per block."""
+        r = _capi.PhiSolveInfo()
+        self._chk(self._L.phi_solve_stats(self._h, C.byref(r)))
+        return {n: getattr(r, n) for n, _ in _capi.PhiSolveInfo._fields_}
+
     # ------------------------------------------------------------------ reads
     def add_reads(self, seqs):
         """seqs: list of bytes, or (concat bytes/uint8 array, int64 offsets)."""

@@ -25,12 +25,14 @@
 // Same transitions, same tie-breaks and the same outputs as dp.hip (which stays as the kernel for
 // more than 128 walks): tests/test_gpu_parity.py runs both on the same inputs.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "phi_kernels.h"
 
 #define NEG (-(1 << 28))
 #define NEGK (-(1 << 30))
 #define CHK PHI_DP_CHUNK
 #define RING PHI_DP_RING
+enum { DP_SEQ = 0, DP_ROW = 1, DP_PATH = 2 };   // modes of the event kernels (see phi_dp_events_pc_kernel)
 
 // ------------------------------------------------------------------ static: which entries are events
 __global__ void __launch_bounds__(256) phi_event_flags_kernel(const int32_t *__restrict__ walk_vtx, int64_t n_entries,
@@ -265,11 +267,14 @@ __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const int32_t *_
             carry = w[q] >> 56;
         }
         w[3] = (w[3] & 0x00FFFFFFFFFFFFFFull) | ((unsigned long long)e_out[e] << 56);
+        // End and SB count from the walk's first entry (anchors of earlier walks have both begun and ended there, so
+        // the two prefix sums agree at it): keys E - SB stay within the score range whatever the number of walks
+        const int32_t base = off_start[eb];
         uint4 A;
         A.x = (uint32_t)cvtx[walk_vtx[e]];
         A.y = (uint32_t)e | (ovf ? 0x80000000u : 0u);
-        A.z = (uint32_t)off_end[e + 1];
-        A.w = (uint32_t)off_start[e];
+        A.z = (uint32_t)(off_end[e + 1] - base);
+        A.w = (uint32_t)(off_start[e] - base);
         ev[i * 3 + 0] = A;
         ev[i * 3 + 1] = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
         ev[i * 3 + 2] = make_uint4((uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32));
@@ -370,7 +375,9 @@ __device__ int32_t ev_count_inside(const PhiDpEventArgs &A, int64_t es, int64_t 
     return n;
 }
 
-template <int NW>   // waves in the workgroup (1, 2 or 4)
+// MODE: DP_SEQ (one workgroup, all steps) or DP_PATH (one workgroup per block of steps, from the block's entry
+// vector A.blk_S; see the modes of phi_dp_events_pc_kernel below)
+template <int NW, int MODE>   // waves in the workgroup (1, 2 or 4)
 __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A)
 {
     constexpr int NT = NW * 64;
@@ -393,7 +400,10 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
     const bool has_walk = h < A.n_walks;
     const int64_t eb = has_walk ? A.walk_off[h] : 0;
     const int64_t ee = has_walk ? A.walk_off[h + 1] : 0;
-    const int64_t vb = has_walk ? A.ev_off[h] : 0;   // events of this lane: [vb, ve)
+    const int32_t sb = MODE == DP_PATH ? (int32_t)blockIdx.x : 0;
+    const int32_t kbeg = MODE == DP_PATH ? A.blk_lo[sb] : 0, kend = MODE == DP_PATH ? A.blk_lo[sb + 1] : A.n_k;
+    // events of this lane: [vb, ve) (DP_PATH: from the first one inside the block)
+    const int64_t vb = !has_walk ? 0 : MODE == DP_PATH ? (int64_t)A.blk_ev[(int64_t)sb * A.lane_stride + h] : A.ev_off[h];
     const int64_t ve = has_walk ? A.ev_off[h + 1] : 0;
     int64_t vi = vb;                                 // next event
     int64_t wl = vb;                                 // first event not yet in the ring
@@ -428,13 +438,14 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
 
     int32_t qh = 0, qt = 0;                          // deque [qh, qt) of young runs
     int32_t M = NEGK, sL = 0, Emax = NEG;            // best key of the old runs, its start; best value ever entered
+    if (MODE == DP_PATH) { sL = -1; if (has_walk) M = A.blk_S[(int64_t)sb * A.lane_stride + h]; }   // (-1: began before this block)
 
-    const int32_t n_steps = A.n_k;
+    const int32_t n_steps = kend - kbeg;
     const int n_chunks = (n_steps + CHK - 1) / CHK;
     auto stage = [&](int c) {
         const int b = c & 1;
-        const int32_t s0 = c * CHK;
-        const int32_t ns = min(CHK, n_steps - s0);
+        const int32_t s0 = kbeg + c * CHK;
+        const int32_t ns = min(CHK, kend - s0);
         const int4 *src = reinterpret_cast<const int4 *>(A.k_rec + (int64_t)s0 * 8);
         int4 *dst = &s_rec[b][0][0];
         for (int i = h; i < ns * 2; i += NT) dst[i] = src[i];
@@ -445,8 +456,8 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
     for (int c = 0; c < n_chunks; c++) {
         const int b = c & 1;
         if (c + 1 < n_chunks) stage(c + 1);
-        const int32_t s0 = c * CHK;
-        const int32_t ns = min(CHK, n_steps - s0);
+        const int32_t s0 = kbeg + c * CHK;
+        const int32_t ns = min(CHK, kend - s0);
         int4 ra = s_rec[b][0][0], rb = s_rec[b][0][1];
         for (int i = 0; i < ns; i++) {
             const int inx = min(i + 1, CHK - 1);
@@ -596,6 +607,17 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
         __threadfence_block();
         __syncthreads();
     }
+    if (MODE == DP_PATH) {
+        // what crosses the cut at the block's end: the best key of this walk's live runs (oldest first, ties keep the
+        // older run) and where that run began
+        int32_t best = M > NEGK / 2 ? M : NEGK, bs = sL;
+        for (int32_t j = qh; j != qt; j++) {
+            const int32_t key = s_qK[j & (QD - 1)][h];
+            if (key > best) { best = key; bs = s_qs[j & (QD - 1)][h]; }
+        }
+        A.blk_keys_out[(int64_t)sb * A.lane_stride + h] = (has_walk && vb < ve) ? best : NEGK;
+        A.blk_carry[(int64_t)sb * A.lane_stride + h] = bs;
+    }
 }
 
 // ------------------------------------------------------------------ up to 64 walks: consumer + producers
@@ -617,7 +639,6 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
 //   DP_PATH  one workgroup per block, from the TRUE entry vector (the host chains the matrices): writes what
 //            DP_SEQ writes (best scores / run starts per event, tops, entries) plus, per walk, where the run
 //            that carries the best key out of the block began -- the backtrack follows runs across blocks
-enum { DP_SEQ = 0, DP_ROW = 1, DP_PATH = 2 };
 
 template <int NPW, int MODE, int P, int RINGT, int QD>
 __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpEventArgs A)
@@ -634,27 +655,36 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
     __shared__ int32_t s_vi[64];
 
     const int wave = threadIdx.x >> 6, h = threadIdx.x & 63;
-    const bool has_walk = h < A.n_walks;
-    // the block of steps of this workgroup, and (DP_ROW) the walk the unit vector sits on
+    // the block of steps of this workgroup, and (DP_ROW) the lane the unit vector sits on.  DP_ROW may run on CLASS
+    // LANES (A.lane_walk, more than 64 walks): lane l stands for all walks that do the same inside the block and is
+    // played by the first of them; rows 0..63 are the class lanes, row 64 the walk starts.
+    const bool cls = MODE == DP_ROW && A.lane_walk != nullptr;
+    const unsigned n_rows = cls ? 65u : (unsigned)(A.n_walks + 1);
     int32_t sb = 0, row_j = -1;
-    if (MODE == DP_ROW) { sb = (int32_t)(blockIdx.x / (unsigned)(A.n_walks + 1)); row_j = (int32_t)(blockIdx.x % (unsigned)(A.n_walks + 1)); }
+    if (MODE == DP_ROW) { sb = (int32_t)(blockIdx.x / n_rows); row_j = (int32_t)(blockIdx.x % n_rows); }
     if (MODE == DP_PATH) sb = (int32_t)blockIdx.x;
+    const bool start_row = MODE == DP_ROW && row_j == (int32_t)n_rows - 1;
+    int32_t w = h;                                   // the walk behind this lane
+    bool has_walk = h < A.n_walks;
+    if (cls) { w = A.lane_walk[(int64_t)sb * 64 + h]; has_walk = w >= 0; if (!has_walk) w = 0; }
     const int32_t k0 = MODE == DP_SEQ ? 0 : A.blk_lo[sb];
     const int32_t k1 = MODE == DP_SEQ ? A.n_k : A.blk_lo[sb + 1];
     const int32_t n_steps = k1 - k0;
-    const int32_t eb = has_walk ? (int32_t)A.walk_off[h] : 0;
-    const int32_t ee = has_walk ? (int32_t)A.walk_off[h + 1] : 0;
-    const int32_t v0 = has_walk ? (int32_t)A.ev_off[h] : 0;     // events of this lane's walk: [v0, ve)
-    const int32_t ve = has_walk ? (int32_t)A.ev_off[h + 1] : 0;
-    const int32_t vb = MODE == DP_SEQ ? v0 : (has_walk ? A.blk_ev[(int64_t)sb * 64 + h] : 0);   // first event inside the block
+    const int32_t eb = has_walk ? (int32_t)A.walk_off[w] : 0;
+    const int32_t ee = has_walk ? (int32_t)A.walk_off[w + 1] : 0;
+    const int32_t v0 = has_walk ? (int32_t)A.ev_off[w] : 0;     // events of this lane's walk: [v0, ve)
+    const int32_t ve = has_walk ? (int32_t)A.ev_off[w + 1] : 0;
+    const int32_t vb = MODE == DP_SEQ ? v0 : (has_walk ? A.blk_ev[(int64_t)sb * A.lane_stride + w] : 0);   // first event inside the block
     const int n_per = (n_steps + P - 1) / P;
-    if (MODE == DP_ROW && row_j < A.n_walks) {
+    if (MODE == DP_ROW && !start_row) {
+        const int32_t wj = cls ? A.lane_walk[(int64_t)sb * 64 + row_j] : row_j;
+        if (wj < 0) return;                                      // no such class in this block (uniform)
         // a walk that has not begun before the block, or has no event left, carries nothing in: the row is empty
-        const int32_t jb = A.blk_ev[(int64_t)sb * 64 + row_j];
-        if (jb <= (int32_t)A.ev_off[row_j] || jb >= (int32_t)A.ev_off[row_j + 1]) {            // uniform over the workgroup
+        const int32_t jb = A.blk_ev[(int64_t)sb * A.lane_stride + wj];
+        if (jb <= (int32_t)A.ev_off[wj] || jb >= (int32_t)A.ev_off[wj + 1]) {            // uniform over the workgroup
             if (wave == 0) {
                 A.row_out[(int64_t)blockIdx.x * 64 + h] = NEGK;
-                if (h == 0) A.rowend_out[blockIdx.x] = NEG;
+                if (h == 0) { A.rowend_out[blockIdx.x] = NEG; if (A.rownew_out) A.rownew_out[blockIdx.x] = NEGK; }
             }
             return;
         }
@@ -740,9 +770,10 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
     int32_t qh = 0, qn = 0, hs = 0, hE = 0, tk = 0;
     int32_t M = NEGK, sL = MODE == DP_SEQ ? 0 : -1, Emax = NEG;   // best key of the old runs and its start (-1: began before this block); best value ever entered
     if (MODE == DP_ROW && h == row_j) M = 0;
-    if (MODE == DP_PATH && has_walk) M = A.blk_S[(int64_t)sb * 64 + h];
-    const bool starts_on = MODE != DP_ROW || row_j == A.n_walks;   // walks may begin inside the block
-    int32_t endbest = NEG;                           // DP_ROW: best value at a walk's last entry inside the block
+    if (MODE == DP_PATH && has_walk) M = A.blk_S[(int64_t)sb * A.lane_stride + h];
+    const bool starts_on = MODE != DP_ROW || start_row;   // walks may begin inside the block
+    int32_t endbest = NEG;
+    int32_t Kn = NEGK;                               // DP_ROW: best key of a run that began inside the block on this lane                           // DP_ROW: best value at a walk's last entry inside the block
     int4 ra = s_rec[0][0], rb = s_rec[0][1];
     int4 lastq = make_int4(NEG, NEG, 0, 0);          // tops of the latest TOPS step, forwarded in registers
     int32_t lastk = -1;
@@ -850,6 +881,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                     if (qn == 0) { hs = t; hE = newE; }
                     tk = key;
                     qn++;
+                    if (MODE == DP_ROW && key > Kn) Kn = key;
                 }
                 int32_t bs = 0;
                 if ((flags & PHI_DP_NEED_TOPS) || e == ee - 1) {
@@ -923,11 +955,14 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             A.row_out[(int64_t)blockIdx.x * 64 + h] = has_walk ? best : NEGK;
             const int32_t eb_all = ev_wave_max_i32(endbest);
             if (h == 0) A.rowend_out[blockIdx.x] = eb_all;
+            // what a walk of the unit lane's class other than the one that carries the key gets: the new runs of that lane
+            if (A.rownew_out && h == row_j) A.rownew_out[blockIdx.x] = Kn;
+            if (A.rownew_out && start_row && h == 0) A.rownew_out[blockIdx.x] = NEGK;
         } else {
             // (a walk with no event left when the block began carries nothing that is ever read: reported as "no run",
             //  as the row pass does)
-            A.blk_keys_out[(int64_t)sb * 64 + h] = (has_walk && vb < ve) ? best : NEGK;
-            A.blk_carry[(int64_t)sb * 64 + h] = bs;
+            A.blk_keys_out[(int64_t)sb * A.lane_stride + h] = (has_walk && vb < ve) ? best : NEGK;
+            A.blk_carry[(int64_t)sb * A.lane_stride + h] = bs;
         }
     }
 }
@@ -975,11 +1010,11 @@ __global__ void __launch_bounds__(256) phi_cut_events_kernel(const int32_t *__re
     }
 }
 // blk_ev[b][h] = first event of walk h on a compact step >= blk_lo[b]
-__global__ void __launch_bounds__(64) phi_blk_ev_kernel(const int32_t *__restrict__ blk_lo, int32_t n_blk, const int32_t *__restrict__ ev_e,
-                                                        const int64_t *__restrict__ ev_off, int32_t n_walks, const int32_t *__restrict__ walk_vtx,
-                                                        const int32_t *__restrict__ cvtx, int32_t *__restrict__ blk_ev)
+__global__ void __launch_bounds__(256) phi_blk_ev_kernel(const int32_t *__restrict__ blk_lo, int32_t n_blk, const int32_t *__restrict__ ev_e,
+                                                         const int64_t *__restrict__ ev_off, int32_t n_walks, const int32_t *__restrict__ walk_vtx,
+                                                         const int32_t *__restrict__ cvtx, int32_t *__restrict__ blk_ev)
 {
-    const int b = blockIdx.x, h = threadIdx.x;
+    const int b = blockIdx.x, h = threadIdx.x;             // blockDim.x = the lane stride: 64 or 256
     if (b >= n_blk) return;
     int32_t out = 0;
     if (h < n_walks) {
@@ -991,7 +1026,7 @@ __global__ void __launch_bounds__(64) phi_blk_ev_kernel(const int32_t *__restric
         }
         out = (int32_t)lo;
     }
-    blk_ev[(int64_t)b * 64 + h] = out;
+    blk_ev[(int64_t)b * blockDim.x + h] = out;
 }
 void phi_launch_cut_cov(hipStream_t st, const int32_t *a_e1, const uint8_t *a_span, int64_t n_a, int32_t *diff)
 {
@@ -1019,14 +1054,279 @@ void phi_launch_blk_ev(hipStream_t st, const int32_t *blk_lo, int32_t n_blk, con
                        const int32_t *walk_vtx, const int32_t *cvtx, int32_t *blk_ev)
 {
     if (n_blk > 0)
-        hipLaunchKernelGGL(phi_blk_ev_kernel, dim3((unsigned)n_blk), dim3(64), 0, st, blk_lo, n_blk, ev_e, ev_off, n_walks, walk_vtx, cvtx, blk_ev);
+        hipLaunchKernelGGL(phi_blk_ev_kernel, dim3((unsigned)n_blk), dim3(n_walks <= 64 ? 64 : 256), 0, st, blk_lo, n_blk, ev_e, ev_off, n_walks,
+                           walk_vtx, cvtx, blk_ev);
+}
+
+
+// ------------------------------------------------------------------ more than 64 walks: blocks on CLASS LANES
+// Inside a short block of steps most walks do the same thing: they run through the same vertices over the same
+// anchors (haplotypes that share the alleles of the block's few sites).  What a block does to a walk is a function of
+// the walk's event records inside it -- steps, entry distances, anchor counts relative to the walk's count at the
+// block's first event, out-edges -- so walks whose records agree form a CLASS, and the block's transfer matrix is
+// needed per class, not per walk: <= 64 class lanes run on the one-wave consumer kernel (DP_ROW), whatever the number
+// of walks.  A block with more than 64 classes raises PHI_KERR_DP_CLASSES (the caller keeps the whole chain).
+//
+// Per run and block: sig(walk) = 128-bit hash of (begun before the block, events left, and per event inside the
+// block: step - k0, entry - first entry, walk start / walk end, End - c, SB - c, the window counts G[a] for
+// a <= entry - first entry (older windows reach before the cut and are never read for a run that began inside),
+// the out-edge).  With c = SB at a walk's first event of the block, walks j, r of one class have
+// End_j - End_r = SB_j - SB_r = c_j - c_r throughout the block; d_j = c_j - c_r(class of j) is the walk's OFFSET
+// from the walk r that plays its class lane.
+__device__ __forceinline__ unsigned long long cls_mix(unsigned long long h, unsigned long long x, unsigned long long m)
+{
+    h = (h ^ x) * m;
+    return h ^ (h >> 29);
+}
+__global__ void __launch_bounds__(256) phi_blk_classes_kernel(PhiBlkClassArgs G)
+{
+    __shared__ unsigned long long s_a[256], s_b[256];
+    __shared__ int32_t s_idx[256], s_c0[256];
+    __shared__ int32_t s_wcnt[4];
+    const int b = blockIdx.x, h = threadIdx.x, lane = h & 63, wid = h >> 6;
+    const int32_t LS = G.lane_stride;
+    const bool has_walk = h < G.n_walks;
+    unsigned long long ha = 0x243F6A8885A308D3ull, hb = 0x13198A2E03707344ull;
+    int32_t c0 = 0;
+    if (has_walk) {
+        const uint4 *evg = reinterpret_cast<const uint4 *>(G.ev);
+        const int32_t k0 = G.blk_lo[b];
+        const int64_t v0 = G.ev_off[h], ve = G.ev_off[h + 1];
+        const int64_t vb = G.blk_ev[(int64_t)b * LS + h];
+        const int64_t vend = b + 1 < G.n_blk ? (int64_t)G.blk_ev[(int64_t)(b + 1) * LS + h] : ve;
+        const int64_t eb = G.walk_off[h], ee = G.walk_off[h + 1];
+        const unsigned long long head = (vb > v0 ? 1u : 0u) | (vb < ve ? 2u : 0u);
+        ha = cls_mix(ha, head, 0x9E3779B97F4A7C15ull); hb = cls_mix(hb, head, 0xC2B2AE3D27D4EB4Full);
+        int64_t e_first = 0;
+        for (int64_t i = vb; i < vend; i++) {
+            const uint4 A = evg[i * 3 + 0], B = evg[i * 3 + 1], C = evg[i * 3 + 2];
+            const int64_t e = (int64_t)(A.y & 0x7FFFFFFFu);
+            if (i == vb) { e_first = e; c0 = (int32_t)A.w; }
+            const int64_t rel = e - e_first;
+            unsigned long long w[4] = {(unsigned long long)B.x | ((unsigned long long)B.y << 32), (unsigned long long)B.z | ((unsigned long long)B.w << 32),
+                                       (unsigned long long)C.x | ((unsigned long long)C.y << 32), (unsigned long long)C.z | ((unsigned long long)C.w << 32)};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t keep = rel + 1 - 8 * q;              // bytes 8q .. 8q+7 hold the counts of ages 8q .. 8q+7
+                unsigned long long m = keep >= 8 ? ~0ull : keep <= 0 ? 0ull : ((1ull << (8 * keep)) - 1);
+                if (q == 3) m |= 0xFF00000000000000ull;            // byte 31: the out-edge
+                w[q] &= m;
+            }
+            const unsigned long long f0 = ((unsigned long long)(uint32_t)((int32_t)A.x - k0) << 32) | (unsigned long long)(uint32_t)rel;
+            const unsigned long long f1 = ((unsigned long long)(uint32_t)((int32_t)A.z - c0) << 32) | (unsigned long long)(uint32_t)((int32_t)A.w - c0);
+            unsigned long long f2 = (e == eb ? 1u : 0u) | (e == ee - 1 ? 2u : 0u);
+            if (A.y >> 31) f2 |= 4u | ((unsigned long long)(h + 1) << 8);   // counted from the walk's own anchors: a class of its own
+            const unsigned long long f[7] = {f0, f1, f2, w[0], w[1], w[2], w[3]};
+#pragma unroll
+            for (int q = 0; q < 7; q++) { ha = cls_mix(ha, f[q], 0x9E3779B97F4A7C15ull); hb = cls_mix(hb, f[q], 0xC2B2AE3D27D4EB4Full); }
+        }
+    }
+    s_a[h] = ha; s_b[h] = hb; s_c0[h] = c0;
+    if (h < 64) G.lane_walk[(int64_t)b * 64 + h] = -1;
+    __syncthreads();
+    // the class of a walk is led by the first walk with its signature
+    int32_t leader = h;
+    if (has_walk)
+        for (int j = 0; j < h; j++)
+            if (s_a[j] == ha && s_b[j] == hb) { leader = j; break; }
+    const bool is_leader = has_walk && leader == h;
+    const unsigned long long bal = __ballot(is_leader);
+    if (lane == 0) s_wcnt[wid] = __popcll(bal);
+    __syncthreads();
+    int32_t before = __popcll(bal & ((1ull << lane) - 1));
+    for (int x = 0; x < wid; x++) before += s_wcnt[x];
+    const int32_t total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    s_idx[h] = before;
+    __syncthreads();
+    if (h == 0) {
+        G.blk_ncls[b] = total < 64 ? total : 64;
+        if (total > 64) atomicOr(G.err, PHI_KERR_DP_CLASSES);
+    }
+    if (has_walk) {
+        const int32_t idx = s_idx[leader];
+        if (is_leader && idx < 64) G.lane_walk[(int64_t)b * 64 + idx] = h;
+        G.walk_lane[(int64_t)b * LS + h] = idx < 64 ? idx : 0;
+        G.coff[(int64_t)b * LS + h] = c0 - s_c0[leader];       // relative to the walk that plays the class lane
+
+    }
+}
+
+// The chain over the blocks, on class lanes: S_{b+1}[x] for every walk x from S_b and the block's class rows.
+// With l(x) the class lane of walk x in block b and d the offsets (keys of walk x are keys of its lane minus d[x]):
+//   own run, and runs begun on x's lane by it       S[x] + row[l(x)][l(x)]
+//   another walk j of x's class                     S[j] + d[j] + rownew[l(x)] - d[x]
+//   a walk j of another class C                     S[j] + d[j] + row[C][l(x)] - d[x]
+//   a walk that starts inside the block             row[64][l(x)] - d[x]
+// Only the best S[j] + d[j] of a class matters (and, for the walks that reach it, whether another walk does too or
+// else the second best).  One workgroup, one block per iteration, two barriers; thread (wave w, lane l) holds, in
+// registers, column l of the rows of classes C = w, w + 4, ..: the "another class" term is a function of the class
+// lane alone, so the four waves split the classes and leave four partial maxima per lane in LDS.  Rows and tables
+// of block b + DEPTH are on their way while block b is chained.  All sums stay far inside int32: keys and offsets are
+// bounded by the anchors of one walk (< 2^27, phi_solve.hip).
+__global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, const int32_t *__restrict__ rows, const int32_t *__restrict__ rownew,
+                                                            int32_t *__restrict__ blk_S)
+{
+    constexpr int NR = 65 * 64;
+    constexpr int DEPTH = 4;
+    constexpr int32_t NONE = INT32_MIN;
+    __shared__ int32_t s_b1[2][64], s_b2[2][64], s_n1[2][64];  // per class: best S + d, second best, walks that reach the best
+    __shared__ int32_t s_diag[2][64], s_start[2][64], s_new[2][64];
+    __shared__ int32_t s_part[2][4][64];
+    const int x = threadIdx.x, lane = x & 63, wid = __builtin_amdgcn_readfirstlane(x >> 6);
+    const int32_t LS = G.lane_stride, nb = G.n_blk;
+    const bool has_walk = x < G.n_walks;
+    int32_t S = NEGK;
+    int32_t st_row[DEPTH][16], st_x[DEPTH], st_lx[DEPTH], st_dx[DEPTH];
+    const int32_t *p_row = rows + wid * 64 + lane;   // + b * NR + 256 * i
+    const int32_t *p_x = wid == 0 ? rows + 64 * 64 + lane : rownew + lane;   // + b * (NR | 65): walk starts (wave 0), new-run keys (wave 1)
+    const int32_t x_stride = wid == 0 ? NR : 65;
+    const int32_t xs = has_walk ? x : 0;
+    auto issue = [&](auto J, int32_t b) {
+        constexpr int j = decltype(J)::value;
+        const int32_t *src = p_row + (int64_t)b * NR;
+#pragma unroll
+        for (int i = 0; i < 16; i++) st_row[j][i] = src[256 * i];
+        st_x[j] = wid < 2 ? p_x[(int64_t)b * x_stride] : NEGK;
+        st_lx[j] = G.walk_lane[(int64_t)b * LS + xs];
+        st_dx[j] = G.coff[(int64_t)b * LS + xs];
+    };
+    auto step = [&](auto J, int32_t b) {
+        constexpr int j = decltype(J)::value;
+        const int p = b & 1;
+        const int32_t lx = st_lx[j], dx = st_dx[j];
+        if (wid == 0) s_start[p][lane] = st_x[j];               // (lanes past the block's classes are never read)
+        if (wid == 1) s_new[p][lane] = st_x[j];
+        if (has_walk) blk_S[(int64_t)b * LS + x] = S;
+        const bool live = has_walk && S > NEGK / 2;
+        const int32_t v = S + dx;
+        if (live) atomicMax(&s_b1[p][lx], v);                   // (reset in the previous iteration, a barrier ago)
+        __syncthreads();
+        const int32_t b1 = s_b1[p][lx];
+        if (live) { if (v == b1) atomicAdd(&s_n1[p][lx], 1); else atomicMax(&s_b2[p][lx], v); }
+        if (x < 64) { s_b1[p ^ 1][x] = NONE; s_b2[p ^ 1][x] = NONE; s_n1[p ^ 1][x] = 0; }   // for the next iteration (last read before this iteration's first barrier)
+        // partial maxima over this wave's classes, for class lane `lane`
+        int32_t part = NONE, diag = NEGK;
+        // (branch-free: the sixteen LDS reads go out together.  Classes past the block's count have no live walk, so
+        //  their maximum is NONE and whatever lies in their rows is ignored)
+        int32_t o16[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) o16[i] = s_b1[p][wid + 4 * i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int32_t C = wid + 4 * i;
+            const int32_t r = st_row[j][i], o = o16[i];
+            diag = C == lane ? r : diag;
+            const bool ok = C != lane && o != NONE && r > NEGK / 2;
+            part = ok && o + r > part ? o + r : part;
+        }
+        s_part[p][wid][lane] = part;
+        if ((lane & 3) == wid) s_diag[p][lane] = diag;         // (row[l][l] is held by wave l mod 4)
+        issue(J, min(b + DEPTH, nb - 1));                      // (always: the compiler can then count the loads in flight instead of draining them)
+        __syncthreads();
+        int32_t best = NEGK;
+        if (has_walk) {
+            if (live) { const int32_t r = s_diag[p][lx]; if (r > NEGK / 2) best = S + r; }
+            {
+                // the best of the other walks of the class
+                const int32_t o = (live && v == b1 && s_n1[p][lx] == 1) ? s_b2[p][lx] : b1;
+                const int32_t kn = s_new[p][lx];
+                if (o != NONE && kn > NEGK / 2 && o + kn - dx > best) best = o + kn - dx;
+            }
+            const int32_t d = max(max(s_part[p][0][lx], s_part[p][1][lx]), max(s_part[p][2][lx], s_part[p][3][lx]));
+            if (d != NONE && d - dx > best) best = d - dx;
+            { const int32_t r = s_start[p][lx]; if (r > NEGK / 2 && r - dx > best) best = r - dx; }
+        }
+        S = best > NEGK / 2 ? best : NEGK;
+        // (no barrier here: the next iteration writes the other parity only, and what it reads of it was settled
+        //  before this iteration's second barrier)
+    };
+    if (x < 64) { s_b1[0][x] = NONE; s_b2[0][x] = NONE; s_n1[0][x] = 0; }
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    issue(I0{}, 0);
+    issue(I1{}, min(1, nb - 1));
+    issue(I2{}, min(2, nb - 1));
+    issue(I3{}, min(3, nb - 1));
+    __syncthreads();
+    int32_t b = 0;
+    for (; b + DEPTH <= nb; b += DEPTH) {
+        step(I0{}, b);
+        step(I1{}, b + 1);
+        step(I2{}, b + 2);
+        step(I3{}, b + 3);
+    }
+    if (b < nb) step(I0{}, b);
+    if (b + 1 < nb) step(I1{}, b + 1);
+    if (b + 2 < nb) step(I2{}, b + 2);
+}
+
+// the two passes must agree on what leaves every block: keys_out[b] (DP_PATH) against S[b + 1] (the chain)
+__global__ void __launch_bounds__(256) phi_blk_check_kernel(const int32_t *__restrict__ keys, const int32_t *__restrict__ S, int32_t n_blk,
+                                                            int32_t LS, int32_t n_walks, int32_t *__restrict__ bad)
+{
+    const int64_t n = (int64_t)(n_blk - 1) * LS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t h = (int32_t)(i % LS);
+        if (h >= n_walks) continue;
+        const int32_t got = keys[i], want = S[i + LS];
+        // (a walk that begins inside the next block or ended before it carries nothing that is ever read)
+        if (got != want && !(got <= NEGK / 2 && want <= NEGK / 2)) { atomicAdd(&bad[0], 1); atomicMin(&bad[1], (int32_t)(i / LS)); }
+    }
+}
+
+// backtrack across blocks: the last block before b_from in which the run carried on walk h began -> out = {block, start}
+__global__ void __launch_bounds__(256) phi_carry_resolve_kernel(const int32_t *__restrict__ carry, int32_t LS, int32_t b_from, int32_t h,
+                                                                int32_t *__restrict__ out)
+{
+    __shared__ int32_t s_best;
+    for (int32_t hi = b_from - 1; hi >= 0; hi -= 256) {
+        if (threadIdx.x == 0) s_best = -1;
+        __syncthreads();
+        const int32_t b = hi - (int32_t)threadIdx.x;
+        const int32_t v = b >= 0 ? carry[(int64_t)b * LS + h] : -1;
+        if (v >= 0) atomicMax(&s_best, b);
+        __syncthreads();
+        const int32_t bb = s_best;
+        if (bb >= 0) {
+            if (b == bb) { out[0] = bb; out[1] = v; }
+            return;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = -1; out[1] = -1; }
+}
+
+void phi_launch_blk_classes(hipStream_t st, const PhiBlkClassArgs &G)
+{
+    if (G.n_blk > 0) hipLaunchKernelGGL(phi_blk_classes_kernel, dim3((unsigned)G.n_blk), dim3(256), 0, st, G);
+}
+void phi_launch_blk_chain(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, int32_t *blk_S)
+{
+    hipLaunchKernelGGL(phi_blk_chain_kernel, dim3(1), dim3(256), 0, st, G, rows, rownew, blk_S);
+}
+void phi_launch_blk_check(hipStream_t st, const int32_t *keys, const int32_t *S, int32_t n_blk, int32_t LS, int32_t n_walks, int32_t *bad)
+{
+    int64_t nb = ((int64_t)(n_blk - 1) * LS + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(phi_blk_check_kernel, dim3((unsigned)nb), dim3(256), 0, st, keys, S, n_blk, LS, n_walks, bad);
+}
+void phi_launch_carry_resolve(hipStream_t st, const int32_t *carry, int32_t LS, int32_t b_from, int32_t h, int32_t *out)
+{
+    hipLaunchKernelGGL(phi_carry_resolve_kernel, dim3(1), dim3(256), 0, st, carry, LS, b_from, h, out);
+}
+// DP_PATH on walk lanes for more than 64 walks (blocks of at most 512 steps)
+void phi_launch_dp_block_paths_wide(hipStream_t st, const PhiDpEventArgs &A)
+{
+    if (A.n_walks <= 128) hipLaunchKernelGGL((phi_dp_events_kernel<2, DP_PATH>), dim3((unsigned)A.n_blk), dim3(128), 0, st, A);
+    else hipLaunchKernelGGL((phi_dp_events_kernel<4, DP_PATH>), dim3((unsigned)A.n_blk), dim3(256), 0, st, A);
 }
 
 void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A)
 {
     if (A.n_walks <= 64) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_SEQ, 8, RING, 32>), dim3(1), dim3(64 * 3), 0, st, A);
-    else if (A.n_walks <= 128) hipLaunchKernelGGL(phi_dp_events_kernel<2>, dim3(1), dim3(128), 0, st, A);
-    else hipLaunchKernelGGL(phi_dp_events_kernel<4>, dim3(1), dim3(256), 0, st, A);    // n_walks <= PHI_DP_EVENT_MAX_WALKS
+    else if (A.n_walks <= 128) hipLaunchKernelGGL((phi_dp_events_kernel<2, DP_SEQ>), dim3(1), dim3(128), 0, st, A);
+    else hipLaunchKernelGGL((phi_dp_events_kernel<4, DP_SEQ>), dim3(1), dim3(256), 0, st, A);    // n_walks <= PHI_DP_EVENT_MAX_WALKS
 }
 
 // blocks of steps in parallel (<= 64 walks): the rows of the blocks' transfer matrices, then (the host has chained
@@ -1034,7 +1334,7 @@ void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A)
 // (A.blk_ring: 1024 steps, two workgroups per CU; 2048 for graphs whose longest stretch without a cut needs it).
 void phi_launch_dp_block_rows(hipStream_t st, const PhiDpEventArgs &A)
 {
-    const unsigned grid = (unsigned)A.n_blk * (unsigned)(A.n_walks + 1);
+    const unsigned grid = (unsigned)A.n_blk * (A.lane_walk ? 65u : (unsigned)(A.n_walks + 1));
     if (A.blk_ring <= 1024) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 1024, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
     else hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 2048, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
 }

@@ -206,7 +206,7 @@ void phi_ctx_destroy(phi_ctx *c)
     (void)phi_comm_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.sp_keys, &c->alt.hit, &c->alt.stripes, &c->alt.splog, &c->alt.splog_cnt, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.sp_keys, &c->alt.hit, &c->alt.stripes, &c->alt.splog, &c->alt.splog_cnt, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
@@ -1279,6 +1279,27 @@ int phi_index_stats(phi_ctx *c, phi_index_info *out)
     for (int64_t m : c->h_n_minimizers) out->n_walk_minimizers += m;
     out->n_distinct_minimizers = c->n_unique;
     out->sketch_gpu_ms = c->index_gpu_ms;
+    return PHI_OK;
+}
+
+int phi_solve_stats(phi_ctx *c, phi_solve_info *out)
+{
+    if (!c || !out) return PHI_ERR_INVALID;
+    if (!c->solved) return phi_fail(c, PHI_ERR_STATE, "phi_solve_stats before phi_solve");
+    memset(out, 0, sizeof *out);
+    out->n_dp_anchors = (int64_t)c->h_dp.size();
+    out->n_events = c->dp_events ? c->n_ev : c->n_entries;
+    out->n_steps = c->dp_events ? c->n_k : c->n_vtx;
+    out->dp_mode = !c->dp_events ? 0 : !c->dp_blocks ? 1 : c->dp_cls ? 3 : 2;
+    out->n_blocks = c->dp_events && c->dp_blocks ? c->n_blk : 0;
+    if (out->dp_mode == 3 && c->n_blk > 0) {
+        HIPCHK(hipSetDevice(c->device));
+        std::vector<int32_t> n((size_t)c->n_blk);
+        HIPCHK(hipMemcpy(n.data(), c->d_blk_ncls.p, n.size() * 4, hipMemcpyDeviceToHost));
+        int64_t sum = 0;
+        for (int32_t v : n) { sum += v; out->max_classes = std::max(out->max_classes, v); }
+        out->mean_classes = (double)sum / (double)n.size();
+    }
     return PHI_OK;
 }
 

@@ -21,6 +21,7 @@ enum { PHI_MODE_COUNT = 0, PHI_MODE_WRITE = 1, PHI_MODE_PROBE = 2 };
 #define PHI_KERR_WALK_EDGE 4u   // consecutive walk vertices not joined by a graph edge
 #define PHI_KERR_CSR_ID 32u      // a minimiser id outside the table (internal error)
 #define PHI_KERR_DP_QUEUE 16u    // event DP: more live young runs on a lane than its queue holds
+#define PHI_KERR_DP_CLASSES 64u  // block DP on class lanes: a block holds more than 64 classes of walks
 
 struct PhiSketchArgs {
     const uint64_t *words;                 // packed bases (+2 padding words)
@@ -238,9 +239,12 @@ struct PhiDpEventArgs {
     int32_t q_limit;                     // 0 = the kernel's queue depth; tests lower it to provoke the fallback
     // blocks of steps solved in parallel (<= 64 walks, dp_events.hip DP_ROW / DP_PATH): block b = steps [blk_lo[b], blk_lo[b+1])
     int32_t n_blk, blk_ring;             // blk_ring: 1024 or 2048 = the longest block
+    int32_t lane_stride;                 // row length of the per-(block, walk) tables: 64 (<= 64 walks) or 256
+    const int32_t *lane_walk;            // DP_ROW on class lanes (> 64 walks): [n_blk][64] the walk that plays class lane l (-1: none)
+    int32_t *rownew_out;                 // DP_ROW on class lanes: [n_blk * 65] best key of a run begun inside the block on the unit lane
     const int32_t *blk_lo;               // [n_blk + 1]
-    const int32_t *blk_ev;               // [n_blk][64]: first event of each walk inside the block
-    const int32_t *blk_S;                // DP_PATH in: [n_blk][64] key of each walk entering the block (NEGK: none)
+    const int32_t *blk_ev;               // [n_blk][lane_stride]: first event of each walk inside the block
+    const int32_t *blk_S;                // DP_PATH in: [n_blk][lane_stride] key of each walk entering the block (NEGK: none)
     int32_t *row_out; int32_t *rowend_out;   // DP_ROW out: [n_blk * (n_walks + 1)][64] keys at the block's end; best value of a path ending inside
     int32_t *blk_keys_out; int32_t *blk_carry;   // DP_PATH out: [n_blk][64] keys at the block's end; start of the run that carries them (-1: before the block)
 };
@@ -249,6 +253,23 @@ struct PhiDpEventArgs {
 void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A);
 void phi_launch_dp_block_rows(hipStream_t st, const PhiDpEventArgs &A);
 void phi_launch_dp_block_paths(hipStream_t st, const PhiDpEventArgs &A);
+// more than 64 walks: the blocks' rows on class lanes (dp_events.hip)
+struct PhiBlkClassArgs {
+    int32_t n_blk, n_walks, lane_stride;
+    const int32_t *blk_lo, *blk_ev;      // [n_blk + 1], [n_blk][lane_stride]
+    const int64_t *ev_off, *walk_off;
+    const void *ev;                      // this run's event records
+    int32_t *lane_walk;                  // out [n_blk][64]: the walk that plays class lane l (-1: none)
+    int32_t *walk_lane;                  // out [n_blk][lane_stride]: the class lane of every walk
+    int32_t *coff;                       // out [n_blk][lane_stride]: the walk's offset from the walk that plays its class lane
+    int32_t *blk_ncls;                   // out [n_blk]
+    uint32_t *err;                       // PHI_KERR_DP_CLASSES
+};
+void phi_launch_blk_classes(hipStream_t st, const PhiBlkClassArgs &G);
+void phi_launch_blk_chain(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, int32_t *blk_S);
+void phi_launch_blk_check(hipStream_t st, const int32_t *keys, const int32_t *S, int32_t n_blk, int32_t LS, int32_t n_walks, int32_t *bad);
+void phi_launch_carry_resolve(hipStream_t st, const int32_t *carry, int32_t LS, int32_t b_from, int32_t h, int32_t *out);
+void phi_launch_dp_block_paths_wide(hipStream_t st, const PhiDpEventArgs &A);
 void phi_launch_cut_cov(hipStream_t st, const int32_t *a_e1, const uint8_t *a_span, int64_t n_a, int32_t *diff);
 void phi_launch_cut_clean(hipStream_t st, const int32_t *cov_excl, int64_t n_entries, int32_t *clean);
 void phi_launch_cut_events(hipStream_t st, const int32_t *ev_e, int64_t n_ev, const int64_t *ev_off, const int64_t *walk_off, int32_t n_walks,

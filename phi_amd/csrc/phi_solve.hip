@@ -61,7 +61,12 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
 {
     c->dp_blocks = false;
     c->n_blk = 0;
-    if (!c->dp_events || c->n_walks > 64 || getenv("PHI_DP_NOBLOCKS") || c->n_k < 4) return PHI_OK;
+    c->dp_cls = false;
+    if (!c->dp_events || c->n_walks > PHI_DP_EVENT_MAX_WALKS || getenv("PHI_DP_NOBLOCKS") || c->n_k < 4) return PHI_OK;
+    // more than 64 walks: short blocks, whose rows run on class lanes (dp_events.hip); few sites per block keep the
+    // walks of a block in at most 64 classes
+    const bool cls = c->n_walks > 64;
+    c->blk_ls = cls ? 256 : 64;
     const int64_t ne = c->n_entries;
     const int32_t nk = c->n_k;
     PHICHK(phi_dev_ensure(c, c->d_cov, (size_t)(ne + 3) * 4));
@@ -99,9 +104,10 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
     // block length: enough blocks to fill the machine with (walks + 1) tasks each, few enough to keep the chain short;
     // a block is at most as long as its ring of tops: 1024 steps, or 2048 where the longest stretch without a cut needs it
     bool placed = false;
-    for (int32_t ring = 1024; ring <= PHI_DP_BLOCK_MAX && !placed; ring *= 2) {
+    for (int32_t ring = cls ? 512 : 1024; ring <= (cls ? 512 : PHI_DP_BLOCK_MAX) && !placed; ring *= 2) {
         int64_t target = (int64_t)nk * (c->n_walks + 1) / 4096;
         target = std::max<int64_t>(64, std::min<int64_t>(ring / 2, target));
+        if (cls) target = 16;
         if (const char *e = getenv("PHI_DP_BLOCK_STEPS")) target = std::max(1, std::min(ring, atoi(e)));   // tests: many small blocks
         c->h_blk_lo.assign(1, 0);
         bool ok = true;
@@ -123,20 +129,29 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
     c->h_blk_lo.push_back(nk);
     c->n_blk = (int32_t)c->h_blk_lo.size() - 1;
     if (c->n_blk < 2) { c->n_blk = 0; return PHI_OK; }
-    const size_t nbk = (size_t)c->n_blk;
+    const size_t nbk = (size_t)c->n_blk, ls = (size_t)c->blk_ls, nrow = cls ? 65 : (size_t)(c->n_walks + 1);
     PHICHK(phi_dev_ensure(c, c->d_blk_lo, (nbk + 1) * 4));
-    PHICHK(phi_dev_ensure(c, c->d_blk_ev, nbk * 64 * 4));
-    PHICHK(phi_dev_ensure(c, c->d_blk_S, nbk * 64 * 4));
-    PHICHK(phi_dev_ensure(c, c->d_blk_keys, nbk * 64 * 4));
-    PHICHK(phi_dev_ensure(c, c->d_blk_carry, nbk * 64 * 4));
-    PHICHK(phi_dev_ensure(c, c->d_row_out, nbk * (size_t)(c->n_walks + 1) * 64 * 4));
-    PHICHK(phi_dev_ensure(c, c->d_rowend, nbk * (size_t)(c->n_walks + 1) * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_ev, nbk * ls * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_S, nbk * ls * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_keys, nbk * ls * 4));
+    PHICHK(phi_dev_ensure(c, c->d_blk_carry, nbk * ls * 4));
+    PHICHK(phi_dev_ensure(c, c->d_row_out, nbk * nrow * 64 * 4));
+    PHICHK(phi_dev_ensure(c, c->d_rowend, nbk * nrow * 4));
+    if (cls) {
+        PHICHK(phi_dev_ensure(c, c->d_lane_walk, nbk * 64 * 4));
+        PHICHK(phi_dev_ensure(c, c->d_walk_lane, nbk * ls * 4));
+        PHICHK(phi_dev_ensure(c, c->d_coff, nbk * ls * 4));
+        PHICHK(phi_dev_ensure(c, c->d_blk_ncls, nbk * 4));
+        PHICHK(phi_dev_ensure(c, c->d_rownew, nbk * nrow * 4));
+        PHICHK(phi_dev_ensure(c, c->d_blk_bad, 64));
+    }
     HIPCHK(hipMemcpyAsync(c->d_blk_lo.p, c->h_blk_lo.data(), (nbk + 1) * 4, hipMemcpyHostToDevice, c->stream));
     phi_launch_blk_ev(c->stream, c->d_blk_lo.as<int32_t>(), c->n_blk, c->d_ev_e.as<int32_t>(), c->d_ev_off.as<int64_t>(), c->n_walks,
                       c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(), c->d_blk_ev.as<int32_t>());
     HIPCHK(hipStreamSynchronize(c->stream));                   // h_blk_lo is a member, but the launch above must have its copy
     c->dp_blocks = true;
-    if (getenv("PHI_TIMING")) fprintf(stderr, "[phi timing] solve: %d compact steps in %d blocks (rings of %d steps)\n", nk, c->n_blk, c->blk_ring);
+    c->dp_cls = cls;
+    if (getenv("PHI_TIMING")) fprintf(stderr, "[phi timing] solve: %d compact steps in %d blocks (rings of %d steps)%s\n", nk, c->n_blk, c->blk_ring, cls ? ", rows on class lanes" : "");
     return PHI_OK;
 }
 
@@ -184,7 +199,55 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
         phi_launch_dp_event_fill(c->stream, A, c->d_e_out.as<uint8_t>(), c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(),
                                  c->d_off_end.as<int32_t>(), c->d_off_start.as<int32_t>());
         if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("weights + per-run records"); }
-        if (c->dp_blocks) {
+        A.lane_stride = c->blk_ls;
+        auto keep_whole_chain = [&](uint32_t kerr, uint32_t bit) -> int {
+            if (getenv("PHI_DP_STRICT")) return phi_fail(c, PHI_ERR_DEVICE, "DP blocks given up (kernel flag %u) under PHI_DP_STRICT", bit);   // tests
+            kerr &= ~bit;
+            HIPCHK(hipMemcpy(c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
+            c->dp_blocks = false;
+            c->dp_cls = false;
+            return run_dp(c, wgt, H, value, segs);
+        };
+        if (c->dp_blocks && c->dp_cls) {
+            // more than 64 walks.  1. the walks of every block in classes (this run's weights); 2. every block from
+            // every class lane: rows of its transfer matrix; 3. the chain over the blocks, on the device; 4. the blocks
+            // again, on walk lanes, from their true entry vectors; 5. the two passes must agree
+            const int32_t nb = c->n_blk;
+            A.n_blk = nb; A.blk_ring = c->blk_ring; A.blk_lo = c->d_blk_lo.as<int32_t>(); A.blk_ev = c->d_blk_ev.as<int32_t>(); A.blk_S = c->d_blk_S.as<int32_t>();
+            A.row_out = c->d_row_out.as<int32_t>(); A.rowend_out = c->d_rowend.as<int32_t>(); A.rownew_out = c->d_rownew.as<int32_t>();
+            A.blk_keys_out = c->d_blk_keys.as<int32_t>(); A.blk_carry = c->d_blk_carry.as<int32_t>();
+            A.lane_walk = c->d_lane_walk.as<int32_t>();
+            PhiBlkClassArgs G{};
+            G.n_blk = nb; G.n_walks = c->n_walks; G.lane_stride = c->blk_ls;
+            G.blk_lo = A.blk_lo; G.blk_ev = A.blk_ev; G.ev_off = A.ev_off; G.walk_off = A.walk_off; G.ev = A.ev;
+            G.lane_walk = c->d_lane_walk.as<int32_t>(); G.walk_lane = c->d_walk_lane.as<int32_t>(); G.coff = c->d_coff.as<int32_t>();
+            G.blk_ncls = c->d_blk_ncls.as<int32_t>(); G.err = A.err;
+            phi_launch_blk_classes(c->stream, G);
+            uint32_t kerr = 0;
+            if (tr.on) {
+                HIPCHK(hipMemcpyAsync(&kerr, c->d_scalars.as<uint64_t>() + S_ERR, 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                tr.lap("block classes");
+                if (kerr & PHI_KERR_DP_CLASSES) return keep_whole_chain(kerr, PHI_KERR_DP_CLASSES);
+            }
+            phi_launch_dp_block_rows(c->stream, A);
+            if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("block rows"); }
+            phi_launch_blk_chain(c->stream, G, A.row_out, A.rownew_out, c->d_blk_S.as<int32_t>());
+            if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("block chain"); }
+            A.lane_walk = nullptr;
+            phi_launch_dp_block_paths_wide(c->stream, A);
+            int32_t bad[2] = {0, INT32_MAX};
+            HIPCHK(hipMemcpyAsync(c->d_blk_bad.p, bad, 8, hipMemcpyHostToDevice, c->stream));
+            phi_launch_blk_check(c->stream, A.blk_keys_out, A.blk_S, nb, c->blk_ls, c->n_walks, c->d_blk_bad.as<int32_t>());
+            HIPCHK(hipMemcpyAsync(bad, c->d_blk_bad.p, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(&kerr, c->d_scalars.as<uint64_t>() + S_ERR, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (tr.on) tr.lap("block paths + check");
+            if (kerr & PHI_KERR_DP_CLASSES) return keep_whole_chain(kerr, PHI_KERR_DP_CLASSES);   // (rows and chain ran on clamped classes: void)
+            if (kerr & PHI_KERR_DP_QUEUE) return keep_whole_chain(kerr, PHI_KERR_DP_QUEUE);
+            if (bad[0])
+                return phi_fail(c, PHI_ERR_DEVICE, "DP blocks: %d keys leaving blocks (first in block %d) differ from the chained class rows (internal error)", bad[0], bad[1]);
+        } else if (c->dp_blocks) {
             // 1. every block from every entry walk (and from the walk starts inside it): rows of its transfer matrix
             const int32_t nb = c->n_blk, nwk = c->n_walks, nrow = nwk + 1;
             A.n_blk = nb; A.blk_ring = c->blk_ring; A.blk_lo = c->d_blk_lo.as<int32_t>(); A.blk_ev = c->d_blk_ev.as<int32_t>(); A.blk_S = c->d_blk_S.as<int32_t>();
@@ -318,7 +381,15 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_
             const int32_t vq = c->h_walk_vtx[e];
             const int32_t kq = c->h_cstep[c->h_topo_rank[vq]];
             int32_t b = (int32_t)(std::upper_bound(c->h_blk_lo.begin(), c->h_blk_lo.end(), kq) - c->h_blk_lo.begin()) - 1;
-            while (bs < 0 && --b >= 0) bs = H.carry[(size_t)b * 64 + h];
+            if (c->dp_cls) {
+                int32_t out[2] = {-1, -1};
+                phi_launch_carry_resolve(c->stream, c->d_blk_carry.as<int32_t>(), c->blk_ls, b, h, c->d_blk_bad.as<int32_t>() + 2);
+                HIPCHK(hipMemcpyAsync(out, c->d_blk_bad.as<int32_t>() + 2, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                bs = out[1];
+            } else {
+                while (bs < 0 && --b >= 0) bs = H.carry[(size_t)b * 64 + h];
+            }
             if (bs < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack: a carried run has no beginning (internal error)");
         }
         const int64_t es = c->h_walk_off[h] + bs;

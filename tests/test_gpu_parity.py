@@ -1274,6 +1274,63 @@ def test_dp_blocks_in_parallel_equal_the_whole_chain(oracle, ctx_factory, monkey
             assert obj == res["objective"] and obj <= res["upper_bound"]
 
 
+@pytest.mark.parametrize("block_steps", ["2", "5", None])
+def test_dp_blocks_on_class_lanes_equal_the_whole_chain(oracle, ctx_factory, monkeypatch, block_steps):
+    """More than 64 walks: the blocks' transfer rows run on CLASS lanes (walks that do the same inside a block share a
+    lane), the chain runs on the device, the second pass on walk lanes.  Against the whole chain (PHI_DP_NOBLOCKS=1) on
+    graphs of 65 .. 256 walks: same objective and bound, a feasible path of that value.  Graphs with few, short
+    minimisers (k ~ 5, w ~ 20) have many cuts that no anchor spans: with blocks of 2 steps their classes fit 64 lanes
+    (PHI_DP_STRICT turns a fallback into an error).  Dense graphs and longer blocks may exceed 64 classes and keep the
+    whole chain: the other path under test."""
+    from oracle import solve_oracle as S
+    for seed in range(10):
+        rng = np.random.default_rng(9100 + seed)
+        sparse = seed >= 4                                       # few, short minimisers: many cuts that no anchor spans
+        if sparse:
+            k, w = int(rng.integers(4, 7)), int(rng.integers(14, 26))
+        else:
+            k, w = int(rng.integers(5, 12)), int(rng.integers(1, 7))
+        n_walks = int(rng.choice([65, 70, 100, 128, 129, 200, 256]))
+        rep = bytes(rng.choice(list(b"ACGT"), size=k + 4).tolist()) if seed % 2 else None
+        g = random_graph(rng, n_sites=int(rng.integers(30, 90)), n_walks=n_walks, seg_len=(8, 40) if sparse else (3, 40), alt_len=(1, 10),
+                         p_del=0.25, repeat=rep)
+        if seed % 3 == 0:
+            g.paths[1] = g.paths[1][: len(g.paths[1]) - 3]               # ends on an interior vertex
+        reads = mosaic_reads(rng, g, n_reads=300, read_len=k + w + 30, n_seg=int(rng.integers(2, 6)), err=0.01)
+        R = int(rng.choice([0, 1, 3, 10, 100]))
+        out = {}
+        for mode in ("blocks", "whole"):
+            if mode == "whole":
+                monkeypatch.setenv("PHI_DP_NOBLOCKS", "1")
+            elif block_steps is not None:
+                monkeypatch.setenv("PHI_DP_BLOCK_STEPS", block_steps)
+                if block_steps == "2" and sparse:
+                    monkeypatch.setenv("PHI_DP_STRICT", "1")
+            ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=R)
+            ctx.set_solve_budget(32)
+            _set_graph(ctx, g)
+            ctx.add_reads(reads)
+            res = ctx.solve()
+            info = ctx.solve_stats()
+            if mode == "whole":
+                assert info["dp_mode"] == 1 and info["n_blocks"] == 0
+            elif block_steps == "2" and sparse:
+                assert info["dp_mode"] == 3 and info["n_blocks"] >= 4 and 1 <= info["max_classes"] <= 64, info
+            for name in ("PHI_DP_NOBLOCKS", "PHI_DP_BLOCK_STEPS", "PHI_DP_STRICT"):
+                monkeypatch.delenv(name, raising=False)
+            out[mode] = res
+        a, b = out["blocks"], out["whole"]
+        for key in ("spectrum_size", "filtered", "n_in_model"):
+            assert a[key] == b[key]
+        if a["optimal"] and b["optimal"]:
+            assert a["objective"] == b["objective"], (seed, n_walks, k, w, R, a["objective"], b["objective"])
+        st = oracle.run_stage12(g, reads, k, w, 1.0)
+        m = S.Model(g, st, R)
+        for res in (a, b):
+            obj, cov, nsw = m.objective(S.states_from_path(res["path_vtx"], res["path_hap"]))
+            assert obj == res["objective"] and obj <= res["upper_bound"]
+
+
 def test_read_state_double_buffers_through_awkward_sequences(oracle, ctx_factory):
     """phi_reset_reads swaps the context's two sets of read buffers; the next read launch empties the set left behind.
     Sequences that stress the bookkeeping: resets with nothing in between (the half that comes to the front was never
