@@ -122,7 +122,7 @@ int phi_pin_ensure(phi_ctx *c, size_t bytes)
     if (bytes <= c->h_pin_cap) return PHI_OK;
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     c->h_pin = nullptr; c->h_pin_cap = 0;
-    c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{};
+    c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{}; c->anchors_host = false;
     const size_t want = bytes + bytes / 4;
     if (hipHostMalloc(&c->h_pin, want, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; return phi_fail(c, PHI_ERR_NOMEM, "pinned host allocation of %zu bytes failed", want); }
     c->h_pin_cap = want;
@@ -206,7 +206,7 @@ void phi_ctx_destroy(phi_ctx *c)
     (void)phi_comm_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.sp_keys, &c->alt.hit, &c->alt.stripes, &c->alt.splog, &c->alt.splog_cnt, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->d_anchors, &c->d_cov_all, &c->d_cov_w, &c->d_slots, &c->d_slots2, &c->d_segs, &c->d_ctr, &c->d_vmax, &c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.sp_keys, &c->alt.hit, &c->alt.stripes, &c->alt.splog, &c->alt.splog_cnt, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
@@ -462,7 +462,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         ne = ne < 0 ? 0 : (ne > ((int64_t)1 << 31) ? ((int64_t)1 << 31) : ne);
         const size_t want = ((size_t)ne / 4 + 4096) * sizeof(PhiAnchorHost);
         if (want > c->h_pin_cap) {
-            c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{};
+            c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{}; c->anchors_host = false;
             c->pin_future = std::async(std::launch::async, [c, want]() {
                 (void)hipSetDevice(c->device);
                 if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -594,7 +594,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         HIPCHK(hipMemsetAsync(c->d_scalars.p, 0, S_N * 8, c->stream));
         HIPCHK(hipMemsetAsync(c->d_stripes.p, 0, 2 * STRIPE_BYTES, c->stream));
         PHICHK(build_classes(c, n_vtx, n_walks, n_entries));
-        c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{};
+        c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{}; c->anchors_host = false;
         if (tg.on) (void)hipStreamSynchronize(c->stream);
         tg.lap("[gpu thread] classes + class sketch");
         const int64_t nr = std::max<int64_t>(c->n_rec, 1);
@@ -1287,7 +1287,7 @@ int phi_solve_stats(phi_ctx *c, phi_solve_info *out)
     if (!c || !out) return PHI_ERR_INVALID;
     if (!c->solved) return phi_fail(c, PHI_ERR_STATE, "phi_solve_stats before phi_solve");
     memset(out, 0, sizeof *out);
-    out->n_dp_anchors = (int64_t)c->h_dp.size();
+    out->n_dp_anchors = c->n_dp;
     out->n_events = c->dp_events ? c->n_ev : c->n_entries;
     out->n_steps = c->dp_events ? c->n_k : c->n_vtx;
     out->dp_mode = !c->dp_events ? 0 : !c->dp_blocks ? 1 : c->dp_cls ? 3 : 2;
@@ -1339,7 +1339,8 @@ int phi_kept_anchors(phi_ctx *c, uint64_t *out_hash, int32_t *out_walk, int32_t 
 {
     if (!c || !n_out) return PHI_ERR_INVALID;
     if (!c->solved) return phi_fail(c, PHI_ERR_STATE, "phi_kept_anchors before phi_solve");
-    const int64_t n = (int64_t)c->h_kept.size();
+    const int64_t n = c->n_kept;
+    if (cap >= n) PHICHK(phi_host_anchors(c));                 // (a large model is solved on the device copy alone)
     *n_out = n;
     if (cap < n) return PHI_OK;
     if (out_hash && n && (int64_t)c->h_kept_hash.size() != n) {

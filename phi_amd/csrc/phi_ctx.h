@@ -161,6 +161,12 @@ struct phi_ctx {
     int32_t blk_ls = 64;                // row length of the per-(block, walk) tables
     DevBuf d_lane_walk, d_walk_lane, d_coff, d_blk_ncls, d_rownew, d_blk_bad;
     DevBuf d_k_rec, d_k_in, d_cvtx, d_ev_e, d_ev_off, d_ev, d_cnt_end, d_cnt_start, d_off_end, d_off_start, d_scan_blk, d_scan_blk64, d_scan_blkoff;
+    // The kept anchors as triples (minimiser id, first entry, last entry) in HBM, and whether the host has its copy:
+    // a large model whose anchors all span an edge is solved on the device copy (solve_dev.hip); h_kept / h_dp are then
+    // empty until something needs them (branch and bound, phi_kept_anchors: phi_host_anchors fetches them).
+    DevBuf d_anchors, d_cov_all, d_cov_w, d_slots, d_slots2, d_segs, d_ctr, d_vmax;
+    int64_t n_kept = 0, n_dp = 0;
+    bool anchors_host = false;
     PhiAnchorSpan h_kept, h_dp;                       // kept anchors (in h_pin); dp anchors (span >= 1 edge: h_kept itself or h_dp_own)
     std::vector<PhiAnchorHost> h_dp_own;
     void *h_pin = nullptr;                            // pinned host buffer the kept anchors are downloaded into
@@ -267,6 +273,7 @@ int phi_hip_check(phi_ctx *c, hipError_t e, const char *what);
 int phi_sync_check(phi_ctx *c);
 // pinned host buffer of at least `bytes` (contents are not kept)
 int phi_pin_ensure(phi_ctx *c, size_t bytes);
+int phi_host_anchors(phi_ctx *c);                      // the host copy of the kept anchors, fetched if it is not there
 // sums of the striped counters (waits for the stream)
 int phi_read_counts(phi_ctx *c, uint64_t *n_in_set, uint64_t *n_emitted);
 int phi_spectrum_count(phi_ctx *c, uint64_t *n_distinct);

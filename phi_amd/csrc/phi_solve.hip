@@ -52,6 +52,21 @@ int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_
     return PHI_OK;
 }
 
+// the host copy of the kept anchors (a large model is solved on the device copy: solve_dev.hip)
+int phi_host_anchors(phi_ctx *c)
+{
+    if (c->anchors_host) return PHI_OK;
+    const int64_t n = c->n_kept;
+    PHICHK(phi_pin_ensure(c, (size_t)std::max<int64_t>(n, 1) * sizeof(PhiAnchorHost)));
+    c->h_kept = PhiAnchorSpan{static_cast<PhiAnchorHost *>(c->h_pin), n};
+    if (n) HIPCHK(hipMemcpyAsync(c->h_kept.p, c->d_anchors.p, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->h_dp_own.clear();
+    c->h_dp = c->h_kept;                                       // (device mode only runs when every kept anchor spans an edge)
+    c->anchors_host = true;
+    return PHI_OK;
+}
+
 // ------------------------------------------------------------------------------------------ blocks of steps
 // Up to 64 walks: cut the chain of compact steps into blocks that the DP kernel solves in parallel (dp_events.hip
 // DP_ROW / DP_PATH).  A cut may sit before step k when the graph allows it (phi_set_graph: no recombination edge from
@@ -162,15 +177,16 @@ struct DpHost {
 };
 
 // one DP launch with the given anchor weights; returns its value and the argmax path
-static int run_dp(phi_ctx *c, const std::vector<uint8_t> &wgt, DpHost &H, int64_t *value, std::vector<Seg> *segs)
+// (wgt == nullptr: the weights are on the device already)
+static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_t *value, std::vector<Seg> *segs)
 {
-    const int64_t n_dp = (int64_t)c->h_dp.size();
+    const int64_t n_dp = c->n_dp;
     const int64_t ne = c->n_entries;
     const int32_t nv = c->n_vtx;
     const bool events = c->dp_events;
     const int32_t n_ent = events ? c->n_k : nv;                // length of the per-step outputs
     PhiStageTimer tr("dp run");
-    if (n_dp) HIPCHK(hipMemcpyAsync(c->d_a_weight.p, wgt.data(), (size_t)n_dp, hipMemcpyHostToDevice, c->stream));
+    if (n_dp && wgt) HIPCHK(hipMemcpyAsync(c->d_a_weight.p, wgt->data(), (size_t)n_dp, hipMemcpyHostToDevice, c->stream));
     int32_t *d_dmax = c->d_dmax.as<int32_t>(), *d_bstart = c->d_bstart.as<int32_t>();
     int32_t *d_ent_src = c->d_ent.as<int32_t>(), *d_ent_h = c->d_ent.as<int32_t>() + n_ent;
     if (events) {
@@ -537,30 +553,58 @@ int phi_solve_impl(phi_ctx *c)
         HIPCHK(hipMemcpyAsync(&n_kept, c->d_blk_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (n_kept >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 anchors in the model");
-        PHICHK(phi_pin_ensure(c, (size_t)std::max<int64_t>(n_kept, 1) * sizeof(PhiAnchorHost)));
-        c->h_kept = PhiAnchorSpan{static_cast<PhiAnchorHost *>(c->h_pin), n_kept};
-        c->h_dp = PhiAnchorSpan{};
+        c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{}; c->anchors_host = false;
+        c->n_kept = n_kept; c->n_dp = 0;
         c->h_kept_hash.clear();
+        PHICHK(phi_dev_ensure(c, c->d_anchors, (size_t)std::max<int64_t>(n_kept, 1) * 12));
+        static_assert(sizeof(PhiAnchorHost) == 12, "PhiAnchorHost is the device triple");
         if (n_kept) {
-            PHICHK(phi_dev_ensure(c, c->d_list2, (size_t)n_kept * 12));
-            X.out_tri = c->d_list2.as<int32_t>();
+            X.out_tri = c->d_anchors.as<int32_t>();
             phi_launch_expand_write(c->stream, X, 1);
-            static_assert(sizeof(PhiAnchorHost) == 12, "PhiAnchorHost is the device triple");
-            HIPCHK(hipMemcpyAsync(c->h_kept.p, c->d_list2.p, (size_t)n_kept * 12, hipMemcpyDeviceToHost, c->stream));
         }
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // The DP's per-anchor arrays (last entry, span), the anchors per walk and the checks on them, on the device.
+    // A large model whose anchors all span an edge (vertices shorter than k: every graph chopped to 30 bp) stays
+    // there: the host copy (6 GB at 5 * 10^8 anchors) is fetched only if the branch and bound proper needs it.
+    const int32_t *d_tri = c->d_anchors.as<int32_t>();
+    bool dev = false;
+    {
+        PHICHK(phi_dev_ensure(c, c->d_a_e1, (size_t)std::max<int64_t>(n_kept, 1) * 4));
+        PHICHK(phi_dev_ensure(c, c->d_g_span, (size_t)std::max<int64_t>(n_kept, 1)));
+        PHICHK(phi_dev_ensure(c, c->d_ctr, (size_t)(nw + 8) * 8));
+        HIPCHK(hipMemsetAsync(c->d_ctr.p, 0, (size_t)(nw + 8) * 8, c->stream));
+        unsigned long long *d_ctr = c->d_ctr.as<unsigned long long>();
+        phi_launch_anchor_prep(c->stream, d_tri, n_kept, c->d_walk_off.as<int64_t>(), nw, c->d_a_e1.as<int32_t>(), c->d_g_span.as<uint8_t>(), d_ctr + 8, d_ctr);
+        std::vector<unsigned long long> hc((size_t)nw + 8);
+        HIPCHK(hipMemcpyAsync(hc.data(), d_ctr, hc.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (hc[1] & 1) return phi_fail(c, PHI_ERR_DEVICE, "dp anchors not sorted by last entry (internal error)");
+        if (hc[1] & 2) return phi_fail(c, PHI_ERR_DEVICE, "an anchor spans %d edges or more (internal error)", PHI_RCAP);
+        c->h_n_anchors.assign(nw, 0);
+        for (int32_t h = 0; h < nw; h++) c->h_n_anchors[h] = (int64_t)hc[(size_t)h + 8];
+        int64_t dev_min = (int64_t)1 << 20;                    // below this the host loops are as fast as the extra launches
+        if (const char *e = getenv("PHI_SOLVE_DEVICE")) dev_min = atoi(e) ? 0 : INT64_MAX;     // tests: force either way
+        dev = hc[0] == 0 && n_kept >= dev_min && n_kept > 0;
+    }
     HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
     const int64_t filtered = (int64_t)sc[S_FILTERED], in_model = (int64_t)sc[S_INMODEL];
+    if (!dev) {
+        PHICHK(phi_pin_ensure(c, (size_t)std::max<int64_t>(n_kept, 1) * sizeof(PhiAnchorHost)));
+        c->h_kept = PhiAnchorSpan{static_cast<PhiAnchorHost *>(c->h_pin), n_kept};
+        if (n_kept) HIPCHK(hipMemcpyAsync(c->h_kept.p, d_tri, (size_t)n_kept * 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->anchors_host = true;
+    }
 
-    tm.lap("anchors D2H");
+    tm.lap(dev ? "anchor arrays (device)" : "anchors D2H");
     // dp anchors (span >= 1 edge; single-vertex anchors are ignored, :795/:846), anchors per walk and the
     // DP's per-anchor arrays: host threads over chunks of the kept list, order preserved
-    c->h_n_anchors.assign(nw, 0);
     std::vector<int32_t> a_e1;
     std::vector<uint8_t> a_span;
     std::vector<int16_t> dp_walk;                              // walk of every dp anchor
-    {
+    if (dev) c->n_dp = n_kept;
+    else {
+        c->h_n_anchors.assign(nw, 0);
         const int64_t chunk = (int64_t)1 << 16;
         const int64_t n_chunks = (n_kept + chunk - 1) / chunk;
         std::vector<int64_t> dp_cnt(n_chunks + 1, 0);
@@ -608,10 +652,11 @@ int phi_solve_impl(phi_ctx *c)
                 if (a_e1[i] < a_e1[i - 1]) { herr.set(PHI_ERR_DEVICE, "dp anchors not sorted by last entry (internal error)"); return; }
         });
         if (herr.failed()) return phi_fail(c, herr.code, "%s", herr.msg.c_str());
+        c->n_dp = (int64_t)c->h_dp.size();
     }
-    const int64_t n_dp = (int64_t)c->h_dp.size();
+    const int64_t n_dp = c->n_dp;
     // DP scores are int32 with -2^28 as "no state": a path scores at most one per anchor
-    if (n_dp >= ((int64_t)1 << 27)) {
+    if (n_dp >= ((int64_t)1 << 27) && !dev) {
         // a path is on one walk at every vertex, so it scores at most sum over vertices of the most anchors that
         // end there on one walk: that sum, not the number of anchors, has to stay inside the DP's score range
         std::vector<int32_t> vmax((size_t)c->n_vtx, 0);
@@ -631,15 +676,26 @@ int phi_solve_impl(phi_ctx *c)
     tm.lap("filter (GPU) + anchors D2H");
     // ---- 3. DP inputs
     {
-        PHICHK(phi_dev_ensure(c, c->d_a_e1, (size_t)std::max<int64_t>(n_dp, 1) * 4));
-        PHICHK(phi_dev_ensure(c, c->d_g_span, (size_t)std::max<int64_t>(n_dp, 1)));
         PHICHK(phi_dev_ensure(c, c->d_a_weight, (size_t)std::max<int64_t>(n_dp, 1)));
         PHICHK(phi_dev_ensure(c, c->d_g_off, (size_t)(c->n_entries + 1) * 8));
-        if (n_dp) {
+        if (n_dp && !dev) {
+            // (the dp list may be shorter than the kept list the device arrays were made from)
             HIPCHK(hipMemcpyAsync(c->d_a_e1.p, a_e1.data(), (size_t)n_dp * 4, hipMemcpyHostToDevice, c->stream));
             HIPCHK(hipMemcpyAsync(c->d_g_span.p, a_span.data(), (size_t)n_dp, hipMemcpyHostToDevice, c->stream));
         }
         phi_launch_entry_csr(c->stream, c->d_a_e1.as<int32_t>(), n_dp, c->n_entries, c->d_g_off.as<int64_t>());
+        if (dev && n_dp >= ((int64_t)1 << 27)) {
+            // the score range, as above: sum over vertices of the most anchors that end there on one walk
+            PHICHK(phi_dev_ensure(c, c->d_vmax, (size_t)c->n_vtx * 4));
+            HIPCHK(hipMemsetAsync(c->d_vmax.p, 0, (size_t)c->n_vtx * 4, c->stream));
+            HIPCHK(hipMemsetAsync(c->d_ctr.p, 0, 8, c->stream));
+            phi_launch_vertex_most(c->stream, c->d_g_off.as<int64_t>(), c->n_entries, c->d_walk_vtx.as<int32_t>(), c->d_vmax.as<int32_t>());
+            phi_launch_sum_i32(c->stream, c->d_vmax.as<int32_t>(), c->n_vtx, c->d_ctr.as<unsigned long long>());
+            unsigned long long bound = 0;
+            HIPCHK(hipMemcpyAsync(&bound, c->d_ctr.p, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (bound >= (1ull << 27)) return phi_fail(c, PHI_ERR_UNSUPPORTED, "a path could score %llu >= 2^27 anchors", bound);
+        }
         HIPCHK(hipStreamSynchronize(c->stream));
         {
             std::vector<int32_t> last(nw);
@@ -672,12 +728,13 @@ int phi_solve_impl(phi_ctx *c)
     const int64_t cost = 2 * (int64_t)(c->recombination / 2);
     // dp anchors of every minimiser (CSR over the dense minimiser ids), ascending anchor index
     const int64_t n_ids = c->n_unique;
-    std::vector<int32_t> sa_off(n_ids + 1, 0), sa_idx(std::max<int64_t>(n_dp, 1));
-    const bool dp_is_kept = c->h_dp.p == c->h_kept.p && c->h_dp.size() == c->h_kept.size();
+    std::vector<int32_t> sa_off, sa_idx;                       // (device mode: on the device only, until the host needs them)
+    if (!dev) { sa_off.assign((size_t)n_ids + 1, 0); sa_idx.resize((size_t)std::max<int64_t>(n_dp, 1)); }
+    const bool dp_is_kept = dev || (c->h_dp.p == c->h_kept.p && c->h_dp.size() == c->h_kept.size());
     if (dp_is_kept && n_dp > 0) {
-        // the dp list is the kept list, whose triples are still on the device: count / scan / scatter /
+        // the dp list is the kept list, whose triples are on the device: count / scan / scatter /
         // sort there (1-2 ms for 10^7 anchors; the host loop below takes 4 ms per million)
-        const int32_t *tri = c->d_list2.as<int32_t>();
+        const int32_t *tri = d_tri;
         PHICHK(phi_dev_ensure(c, c->d_sa_cnt, (size_t)(n_ids + 1) * 4));
         PHICHK(phi_dev_ensure(c, c->d_sa_cur, (size_t)(n_ids + 1) * 4));
         PHICHK(phi_dev_ensure(c, c->d_sa_off, (size_t)(n_ids + 2) * 4));
@@ -692,12 +749,16 @@ int phi_solve_impl(phi_ctx *c)
                             c->d_scan_blkoff.as<int64_t>());
         phi_launch_csr_scatter(c->stream, tri, n_dp, n_ids, c->d_sa_off.as<int32_t>(), c->d_sa_cur.as<int32_t>(), c->d_sa_idx.as<int32_t>());
         phi_launch_csr_sort(c->stream, c->d_sa_off.as<int32_t>(), n_ids, c->d_sa_idx.as<int32_t>());
-        HIPCHK(hipMemcpyAsync(sa_off.data(), c->d_sa_off.p, (size_t)(n_ids + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(sa_idx.data(), c->d_sa_idx.p, (size_t)n_dp * 4, hipMemcpyDeviceToHost, c->stream));
+        int32_t total = 0;
+        if (!dev) {
+            HIPCHK(hipMemcpyAsync(sa_off.data(), c->d_sa_off.p, (size_t)(n_ids + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(sa_idx.data(), c->d_sa_idx.p, (size_t)n_dp * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(hipMemcpyAsync(&total, c->d_sa_off.as<int32_t>() + n_ids, 4, hipMemcpyDeviceToHost, c->stream));
         uint32_t kerr = 0;
         HIPCHK(hipMemcpyAsync(&kerr, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if ((kerr & PHI_KERR_CSR_ID) || sa_off[n_ids] != (int32_t)n_dp)
+        if ((kerr & PHI_KERR_CSR_ID) || total != (int32_t)n_dp)
             return phi_fail(c, PHI_ERR_DEVICE, "minimiser id out of range (internal error)");
     } else {
         // (tried on host threads with atomic counters and per-list sorts: 7.5 ms against 4.3 ms for this loop)
@@ -754,7 +815,17 @@ int phi_solve_impl(phi_ctx *c)
     // Minimisers with two anchors on ONE walk (repeats along a haplotype) are what an additive DP counts
     // twice on sight: start the relaxation with them in S instead of discovering them by a first run.
     std::set<uint32_t> S0;
-    if (!getenv("PHI_NO_S0")) {
+    if (!getenv("PHI_NO_S0") && dev) {
+        PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)std::max<int64_t>(n_ids, 1)));
+        phi_launch_repeat_slots(c->stream, c->d_sa_off.as<int32_t>(), c->d_sa_idx.as<int32_t>(), d_tri, c->d_walk_off.as<int64_t>(), nw, n_ids,
+                                c->d_flags.as<uint8_t>());
+        int64_t n_rep = 0;
+        PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_ids, c->d_list, &n_rep));
+        std::vector<uint32_t> rep((size_t)n_rep);
+        if (n_rep) HIPCHK(hipMemcpy(rep.data(), c->d_list.p, (size_t)n_rep * 4, hipMemcpyDeviceToHost));
+        S0.insert(rep.begin(), rep.end());                     // (ascending: linear-time insertion)
+        if (tm.on) fprintf(stderr, "[phi timing] solve: %zu minimisers repeat along a walk\n", S0.size());
+    } else if (!getenv("PHI_NO_S0")) {
         std::vector<std::vector<uint32_t>> found(phi_host_threads());
         phi_parallel_chunks(n_ids, (int64_t)1 << 14, [&](int64_t lo, int64_t hi, int worker) {
             for (int64_t u = lo; u < hi; u++)
@@ -766,10 +837,35 @@ int phi_solve_impl(phi_ctx *c)
     }
     tm.lap("repeat set");
     DpHost H;
-    std::vector<uint8_t> wgt(n_dp, 1);
+    std::vector<uint8_t> wgt;                                  // host weights (host mode)
+    if (!dev) wgt.assign((size_t)n_dp, 1);
     std::vector<Seg> best_segs;
-    int64_t incumbent = INT64_MIN, global_ub = INT64_MIN;
+    int64_t incumbent = INT64_MIN, global_ub = INT64_MIN, best_cov = 0;
     int n_runs = 0;
+    std::vector<int32_t> cov_all, cov_w;                       // per minimiser: dp anchors traversed (all / weighted)
+    std::vector<uint32_t> touched;                             // minimisers with cov_all > 0
+    if (dev) {
+        PHICHK(phi_dev_ensure(c, c->d_cov_all, (size_t)std::max<int64_t>(n_ids, 1) * 4));
+        PHICHK(phi_dev_ensure(c, c->d_cov_w, (size_t)std::max<int64_t>(n_ids, 1) * 4));
+        HIPCHK(hipMemsetAsync(c->d_cov_all.p, 0, (size_t)std::max<int64_t>(n_ids, 1) * 4, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_cov_w.p, 0, (size_t)std::max<int64_t>(n_ids, 1) * 4, c->stream));
+    } else { cov_all.assign((size_t)n_ids, 0); cov_w.assign((size_t)n_ids, 0); }
+    // device mode ends where the branch and bound proper begins: the host copies arrive, the search goes on unchanged
+    auto to_host = [&]() -> int {
+        if (!dev) return PHI_OK;
+        PhiStageTimer th("solve");
+        PHICHK(phi_host_anchors(c));
+        sa_off.resize((size_t)n_ids + 1); sa_idx.resize((size_t)std::max<int64_t>(n_dp, 1));
+        HIPCHK(hipMemcpyAsync(sa_off.data(), c->d_sa_off.p, (size_t)(n_ids + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+        if (n_dp) HIPCHK(hipMemcpyAsync(sa_idx.data(), c->d_sa_idx.p, (size_t)n_dp * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        wgt.assign((size_t)n_dp, 1);
+        cov_all.assign((size_t)n_ids, 0); cov_w.assign((size_t)n_ids, 0);
+        touched.clear();
+        dev = false;
+        th.lap("  anchors and their map to the host (branch and bound)");
+        return PHI_OK;
+    };
     // branch and bound is finite and exact.  The reference's model.optimize() (ILP_index.cpp:1412-1418) has no
     // limit; this search has a budget counted in DP runs (phi_set_solve_budget, default 4096; <= 0 = none), never
     // in wall-clock time: the same input gives the same `optimal` flag on every run and every machine.
@@ -779,13 +875,12 @@ int phi_solve_impl(phi_ctx *c)
     std::vector<Node> stack;
     stack.push_back(Node{});
     std::vector<int64_t> open_ub;                              // bounds of nodes given up on
-    std::vector<int32_t> cov_all(n_ids, 0), cov_w(n_ids, 0);   // per minimiser: dp anchors traversed (all / weighted)
-    std::vector<uint32_t> touched;                             // minimisers with cov_all > 0
     while (!stack.empty()) {
         Node node = stack.back();
         stack.pop_back();
         std::map<uint32_t, int32_t> assign(node.assign.begin(), node.assign.end());
         std::map<uint32_t, std::vector<std::vector<int32_t>>> assign_clusters;
+        if (!assign.empty()) PHICHK(to_host());
         for (auto &kv : assign) assign_clusters[kv.first] = clusters_of(kv.first);
         std::set<uint32_t> S;
         if (node.assign.empty()) S = S0;
@@ -793,46 +888,88 @@ int phi_solve_impl(phi_ctx *c)
         bool closed = false;
         int64_t node_ub = node.ub;
         uint32_t branch_slot = 0;
-        bool have_branch = false;
+        bool have_branch = false, have_sets = false;
+        std::set<uint32_t> lastD, lastZ;
         for (int iter = 0; iter < 8 && !closed; iter++) {
             if (out_of_runs()) { exhausted = true; break; }
             // weights of this relaxation
-            std::fill(wgt.begin(), wgt.end(), 1);
-            for (uint32_t s : S) for (int32_t a : anchors_of(s)) wgt[a] = 0;
-            for (auto &kv : assign) {
-                if (S.count(kv.first)) continue;
-                const auto &cl = assign_clusters[kv.first];
-                for (size_t ci = 0; ci < cl.size(); ci++)
-                    if ((int32_t)ci != kv.second) for (int32_t a : cl[ci]) wgt[a] = 0;
+            std::vector<uint32_t> Sv;                          // S as a list (device mode)
+            if (dev) {
+                // (no assignments in device mode: to_host() runs before the first node that has one)
+                Sv.assign(S.begin(), S.end());
+                HIPCHK(hipMemsetAsync(c->d_a_weight.p, 1, (size_t)n_dp, c->stream));
+                PHICHK(phi_dev_ensure(c, c->d_slots, std::max<size_t>(Sv.size(), 1) * 4));
+                PHICHK(phi_dev_ensure(c, c->d_slots2, std::max<size_t>(Sv.size(), 1) * 4));
+                if (!Sv.empty()) HIPCHK(hipMemcpyAsync(c->d_slots.p, Sv.data(), Sv.size() * 4, hipMemcpyHostToDevice, c->stream));
+                phi_launch_zero_slots(c->stream, c->d_slots.as<uint32_t>(), (int64_t)Sv.size(), c->d_sa_off.as<int32_t>(), c->d_sa_idx.as<int32_t>(),
+                                      c->d_a_weight.as<uint8_t>());
+                HIPCHK(hipStreamSynchronize(c->stream));       // Sv is read by the copy
+            } else {
+                std::fill(wgt.begin(), wgt.end(), 1);
+                for (uint32_t s : S) for (int32_t a : anchors_of(s)) wgt[a] = 0;
+                for (auto &kv : assign) {
+                    if (S.count(kv.first)) continue;
+                    const auto &cl = assign_clusters[kv.first];
+                    for (size_t ci = 0; ci < cl.size(); ci++)
+                        if ((int32_t)ci != kv.second) for (int32_t a : cl[ci]) wgt[a] = 0;
+                }
             }
             int64_t val = 0;
             std::vector<Seg> segs;
             tm.lap("  weights of the relaxation");
-            PHICHK(run_dp(c, wgt, H, &val, &segs));
+            PHICHK(run_dp(c, dev ? nullptr : &wgt, H, &val, &segs));
             n_runs++;
             tm.lap("  DP run + backtrack");
             // exact value of this path and its additive value under wgt
-            for (uint32_t s : touched) { cov_all[s] = 0; cov_w[s] = 0; }
-            touched.clear();
-            int64_t add_w = 0;
-            for_covered(c, segs, [&](int64_t a) {
-                const uint32_t s = c->h_dp[a].slot;
-                if (!cov_all[s]++) touched.push_back(s);
-                if (wgt[a]) { cov_w[s]++; add_w++; }
-            });
             const int64_t n_sw = (int64_t)segs.size() - 1;
+            int64_t add_w = 0, n_touched = 0;
+            std::set<uint32_t> D, Z;
+            if (dev) {
+                // cover counts per minimiser on the device; back come the two sums and the two short lists
+                std::vector<int32_t> sg(segs.size() * 2);
+                for (size_t i = 0; i < segs.size(); i++) { sg[2 * i] = segs[i].es; sg[2 * i + 1] = segs[i].ee; }
+                const int64_t twice_cap = (int64_t)1 << 22;
+                PHICHK(phi_dev_ensure(c, c->d_segs, std::max<size_t>(sg.size(), 2) * 4));
+                PHICHK(phi_dev_ensure(c, c->d_list, (size_t)twice_cap * 4));
+                unsigned long long *d_ctr = c->d_ctr.as<unsigned long long>();
+                HIPCHK(hipMemcpyAsync(c->d_segs.p, sg.data(), sg.size() * 4, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(hipMemsetAsync(d_ctr, 0, 32, c->stream));
+                phi_launch_path_cover(c->stream, false, c->d_segs.as<int32_t>(), (int32_t)segs.size(), c->d_g_off.as<int64_t>(), d_tri, c->d_a_weight.as<uint8_t>(),
+                                      c->d_cov_all.as<int32_t>(), c->d_cov_w.as<int32_t>(), d_ctr, c->d_list.as<uint32_t>(), twice_cap);
+                phi_launch_uncovered_slots(c->stream, c->d_slots.as<uint32_t>(), (int64_t)Sv.size(), c->d_cov_all.as<int32_t>(), d_ctr, c->d_slots2.as<uint32_t>());
+                phi_launch_path_cover(c->stream, true, c->d_segs.as<int32_t>(), (int32_t)segs.size(), c->d_g_off.as<int64_t>(), d_tri, c->d_a_weight.as<uint8_t>(),
+                                      c->d_cov_all.as<int32_t>(), c->d_cov_w.as<int32_t>(), d_ctr, c->d_list.as<uint32_t>(), twice_cap);
+                unsigned long long hc[4];
+                HIPCHK(hipMemcpyAsync(hc, d_ctr, 32, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if ((int64_t)hc[2] > twice_cap) return phi_fail(c, PHI_ERR_OVERFLOW, "more than 2^22 minimisers counted twice by one path");
+                add_w = (int64_t)hc[0]; n_touched = (int64_t)hc[1];
+                std::vector<uint32_t> dl((size_t)hc[2]), zl((size_t)hc[3]);
+                if (hc[2]) HIPCHK(hipMemcpy(dl.data(), c->d_list.p, dl.size() * 4, hipMemcpyDeviceToHost));
+                if (hc[3]) HIPCHK(hipMemcpy(zl.data(), c->d_slots2.p, zl.size() * 4, hipMemcpyDeviceToHost));
+                D.insert(dl.begin(), dl.end());
+                Z.insert(zl.begin(), zl.end());
+            } else {
+                for (uint32_t s : touched) { cov_all[s] = 0; cov_w[s] = 0; }
+                touched.clear();
+                for_covered(c, segs, [&](int64_t a) {
+                    const uint32_t s = c->h_dp[a].slot;
+                    if (!cov_all[s]++) touched.push_back(s);
+                    if (wgt[a]) { cov_w[s]++; add_w++; }
+                });
+                n_touched = (int64_t)touched.size();
+            }
             add_w -= cost * n_sw;
             if (add_w != val) return phi_fail(c, PHI_ERR_DEVICE, "DP value %lld != value %lld of its own path (internal error)", (long long)val, (long long)add_w);
-            const int64_t true_val = (int64_t)touched.size() - cost * n_sw;
-            if (true_val > incumbent) { incumbent = true_val; best_segs = segs; }
+            const int64_t true_val = n_touched - cost * n_sw;
+            if (true_val > incumbent) { incumbent = true_val; best_segs = segs; best_cov = n_touched; }
             const int64_t ub = val + (int64_t)S.size();
             node_ub = std::min(node_ub, ub);
             if (n_runs == 1) global_ub = ub;
             if (node_ub <= incumbent) { closed = true; break; }
             // tighten: bound doubly-counted minimisers by the constant 1, release unused constants
-            std::set<uint32_t> D, Z;
-            for (uint32_t s : touched) if (cov_w[s] >= 2) D.insert(s);
-            for (uint32_t s : S) {
+            if (!dev) for (uint32_t s : touched) if (cov_w[s] >= 2) D.insert(s);
+            if (!dev) for (uint32_t s : S) {
                 // is any anchor this node still allows for s traversed?
                 bool covered = false;
                 if (cov_all[s]) {
@@ -851,13 +988,8 @@ int phi_solve_impl(phi_ctx *c)
                                n_runs, (long long)val, S.size(), (long long)ub, (long long)true_val, (long long)n_sw, D.size(), Z.size());
             tm.lap("  path value, tighten sets");
             if (D.empty() && Z.empty()) { closed = true; break; }   // bound attained by this path
-            // remember a branching candidate in canonical (first anchor) order
-            {
-                int32_t best_a = INT32_MAX;
-                for (uint32_t s : D) if (anchors_of(s)[0] < best_a) { best_a = anchors_of(s)[0]; branch_slot = s; }
-                if (D.empty()) for (uint32_t s : Z) if (!assign.count(s) && anchors_of(s)[0] < best_a) { best_a = anchors_of(s)[0]; branch_slot = s; }
-                have_branch = best_a != INT32_MAX;
-            }
+            // remember what a branching candidate is chosen from (below, in canonical = first anchor order)
+            lastD = D; lastZ = Z; have_sets = true;
             std::set<uint32_t> S2 = S;
             for (uint32_t s : D) S2.insert(s);
             for (uint32_t s : Z) S2.erase(s);
@@ -866,6 +998,13 @@ int phi_solve_impl(phi_ctx *c)
             S = S2;
         }
         if (closed) continue;
+        if (have_sets && !exhausted) {
+            PHICHK(to_host());                                 // (the minimiser -> anchors map)
+            int32_t best_a = INT32_MAX;
+            for (uint32_t s : lastD) if (anchors_of(s)[0] < best_a) { best_a = anchors_of(s)[0]; branch_slot = s; }
+            if (lastD.empty()) for (uint32_t s : lastZ) if (!assign.count(s) && anchors_of(s)[0] < best_a) { best_a = anchors_of(s)[0]; branch_slot = s; }
+            have_branch = best_a != INT32_MAX;
+        }
         if (exhausted || !have_branch) { open_ub.push_back(std::min(node_ub, global_ub)); if (exhausted) break; continue; }
         const auto cl = clusters_of(branch_slot);
         for (int32_t ci = (int32_t)cl.size() - 1; ci >= 0; ci--) {
@@ -893,9 +1032,7 @@ int phi_solve_impl(phi_ctx *c)
         }
     int32_t recomb = 0;
     for (size_t i = 1; i < c->h_path_hap.size(); i++) recomb += c->h_path_hap[i] != c->h_path_hap[i - 1];   // :1517-1519
-    for (uint32_t s : touched) cov_all[s] = 0;
-    int64_t n_cov = 0;
-    for_covered(c, best_segs, [&](int64_t a) { if (!cov_all[c->h_dp[a].slot]++) n_cov++; });
+    const int64_t n_cov = best_cov;                            // minimisers covered by the best path (counted when it was found)
 
     phi_result &R = c->result;
     R.objective = incumbent;

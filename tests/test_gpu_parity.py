@@ -1331,6 +1331,48 @@ def test_dp_blocks_on_class_lanes_equal_the_whole_chain(oracle, ctx_factory, mon
             assert obj == res["objective"] and obj <= res["upper_bound"]
 
 
+def test_solve_on_device_resident_anchors_equals_the_host_solve(oracle, ctx_factory, monkeypatch):
+    """A large model (>= 2^20 anchors that all span an edge) is solved with its anchors left in HBM: per-anchor DP arrays,
+    repeat set, relaxation weights and path cover counts by kernels (solve_dev.hip), the host copy fetched only when the
+    branch and bound proper starts.  PHI_SOLVE_DEVICE=1 / 0 forces either mode at any size: same result field by field
+    (objective, bound, proof, DP runs, path, counters, kept anchors) on instances that close at the root, that tighten
+    their constant sets, and that branch (R = 0 with repeats; a budget that runs out)."""
+    cases = []
+    for seed in range(12):
+        rng = np.random.default_rng(8800 + seed)
+        k, w = int(rng.integers(5, 12)), int(rng.integers(1, 7))
+        rep = bytes(rng.choice(list(b"ACGT"), size=k + 4).tolist()) if seed % 2 else None
+        n_walks = int(rng.choice([3, 8, 30, 70, 150]))
+        g = random_graph(rng, n_sites=int(rng.integers(25, 120)), n_walks=n_walks, seg_len=(3, 14), alt_len=(1, 8), p_del=0.25, repeat=rep)
+        reads = mosaic_reads(rng, g, n_reads=200, read_len=k + w + 25, n_seg=int(rng.integers(2, 5)), err=0.01)
+        cases.append((g, reads, k, w, int(rng.choice([0, 1, 2, 8, 100])), float(rng.choice([1.0, 0.6])), 200))
+    rng = np.random.default_rng(31)                              # the hard instance of the budget test, cut short
+    g = random_graph(rng, n_sites=400, n_walks=8, seg_len=(8, 16), alt_len=(3, 6), p_del=0.0)
+    cases.append((g, mosaic_reads(rng, g, n_reads=400, read_len=60, n_seg=4, err=0.01), 9, 3, 0, 1.0, 40))
+    n_branching = 0
+    for g, reads, k, w, R, T, budget in cases:
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PHI_SOLVE_DEVICE", mode)
+            ctx = ctx_factory(k=k, w=w, threshold=T, recombination=R)
+            ctx.set_solve_budget(budget)
+            _set_graph(ctx, g)
+            ctx.add_reads(reads)
+            res = ctx.solve()
+            out[mode] = (res, ctx.kept_anchors())
+            monkeypatch.delenv("PHI_SOLVE_DEVICE")
+        (a, ka), (b, kb) = out["1"], out["0"]
+        for key in a:
+            if isinstance(a[key], np.ndarray):
+                assert np.array_equal(a[key], b[key]), key
+            else:
+                assert a[key] == b[key], (key, a[key], b[key])
+        for x, y in zip(ka, kb):
+            assert np.array_equal(x, y)
+        n_branching += a["n_dp_runs"] > 8
+    assert n_branching >= 1                                      # some case went past the root node
+
+
 def test_read_state_double_buffers_through_awkward_sequences(oracle, ctx_factory):
     """phi_reset_reads swaps the context's two sets of read buffers; the next read launch empties the set left behind.
     Sequences that stress the bookkeeping: resets with nothing in between (the half that comes to the front was never
