@@ -343,6 +343,7 @@ def main():
     # ---- the rest of the job, once: spectrum merge (N > 1), filter + exact solve
     t_solve = None
     res = None
+    solve_info = None
     if not args.no_solve:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -353,6 +354,8 @@ def main():
         res = ctx.solve()
         torch.cuda.synchronize()
         t_solve = time.perf_counter() - t0
+        solve_info = ctx.solve_stats()
+        solve_info["dp_mode_name"] = ("every vertex a step", "event chain", "blocks in parallel, walk lanes", "blocks in parallel, rows on class lanes")[solve_info["dp_mode"]]
         if world > 1:
             o = torch.tensor([res["objective"], -res["objective"], res["spectrum_size"], -res["spectrum_size"]], dtype=torch.int64, device=ctl_dev)
             dist.all_reduce(o, op=dist.ReduceOp.MAX)
@@ -360,12 +363,12 @@ def main():
             assert int(o[2].item()) == -int(o[3].item()), "ranks disagree on the spectrum size"
         assert res["optimal"] == 1, "the quoted configuration must be solved to proven optimality"
 
-    # ---- roofline of the dominant kernel.  Algorithmic bytes per base, split by the kernel that
-    #      moves them: the preparation launch reads the ASCII base and writes the packed one (1.25 B); the sketch
-    #      kernel reads the packed base (0.25 B), and per emitted minimiser (density d) writes an 8-byte hash-sized
-    #      record's worth and probes 16 bytes (24 d).
-    b_prep, b_sketch = 1.25, 0.25 + 24.0 * density
-    b_alg = b_prep + b_sketch
+    # ---- roofline of the dominant kernel.  Algorithmic bytes per base by SURVEY.md 8d: 1 (ASCII) + 0.5 (packed 2-bit
+    #      write + read) + 24 d (an 8-byte record and a 16-byte probe per emitted minimiser, density d).  Since the
+    #      fusion of the preparation launch into the sketch kernel the packed form lives in LDS only: the kernel itself
+    #      moves 1 + 24 d; `frac` keeps the SURVEY formula, `kernel_own_frac` prices the kernel by what it moves.
+    b_packed, b_sketch = 0.5, 1.0 + 24.0 * density
+    b_alg = b_packed + b_sketch
     kern_avg_ms = kern_ms / max(1, n_launch)
     launch_bases = kern_bases / max(1, n_launch)
     achieved = launch_bases * b_alg / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0
@@ -398,14 +401,15 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "phi_sketch_kernel<PHI_MODE_PROBE>", "kernel_avg_ms": kern_avg_ms,
                      "kernel_launches": n_launch, "kernel_timed_every": args.prof_period, "bytes_per_base_algorithmic": b_alg, "minimiser_density": density,
-                     "bytes_per_base_by_kernel": {"phi_prep_reads_kernel": b_prep, "phi_sketch_kernel": b_sketch},
+                     "bytes_per_base_split": {"moved by phi_sketch_kernel (ASCII read, record, probe)": b_sketch,
+                                              "packed 2-bit write + read of the SURVEY formula (stays in LDS since the fusion: not moved)": b_packed},
                      "kernel_own_frac": (launch_bases * b_sketch / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if n_launch else 0.0,
                      "step_frac": step_frac,
-                     "note": "achieved/frac price the sketch kernel's time against ALL algorithmic bytes of a base (SURVEY 8d formula); kernel_own_frac prices it against "
-                             "the bytes that kernel itself moves; step_frac = all algorithmic bytes / whole step time (every launch of the step)",
+                     "note": "achieved/frac price the sketch kernel's time against the SURVEY 8d bytes of a base (1.5 + 24 d); kernel_own_frac prices it against "
+                             "the bytes the fused kernel itself moves (1 + 24 d); step_frac = SURVEY bytes / whole step time (the step is this one launch)",
                      "kernel_gbases_per_s": launch_bases / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0},
         "index_build_s": t_index, "graph_gbases_per_s": walk_bases / t_index / 1e9, "index": index_info,
-        "solve_s": t_solve, "end_to_end_s": (t_index + ms_per_step * 1e-3 + t_solve) if t_solve is not None else None,
+        "solve_s": t_solve, "solve": solve_info, "end_to_end_s": (t_index + ms_per_step * 1e-3 + t_solve) if t_solve is not None else None,
         "synthetic_gen_s": t_gen,
     }
     if other is not None:

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphi_amd.so")
+LIB_PATH = os.environ.get("PHI_AMD_LIB") or os.path.join(_HERE, "libphi_amd.so")   # (PHI_AMD_LIB: an experimental build)
 
 PHI_OK = 0
 PHI_ERR_INVALID, PHI_ERR_NOMEM, PHI_ERR_DEVICE, PHI_ERR_STATE = -1, -2, -3, -4

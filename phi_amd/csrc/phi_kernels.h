@@ -3,7 +3,9 @@
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
+#ifndef PHI_TPB
 #define PHI_TPB 256            // lanes per workgroup of the sketch kernel (4 waves)
+#endif
 #define PHI_WCH 512            // window positions per wave (each wave sketches its own chunk)
 #define PHI_MAX_W 256
 #define PHI_MAX_K 32

@@ -582,7 +582,7 @@ int phi_solve_impl(phi_ctx *c)
         if (hc[1] & 2) return phi_fail(c, PHI_ERR_DEVICE, "an anchor spans %d edges or more (internal error)", PHI_RCAP);
         c->h_n_anchors.assign(nw, 0);
         for (int32_t h = 0; h < nw; h++) c->h_n_anchors[h] = (int64_t)hc[(size_t)h + 8];
-        int64_t dev_min = (int64_t)1 << 20;                    // below this the host loops are as fast as the extra launches
+        int64_t dev_min = (int64_t)1 << 16;                    // below this the host loops are as fast as the extra launches
         if (const char *e = getenv("PHI_SOLVE_DEVICE")) dev_min = atoi(e) ? 0 : INT64_MAX;     // tests: force either way
         dev = hc[0] == 0 && n_kept >= dev_min && n_kept > 0;
     }

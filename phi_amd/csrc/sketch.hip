@@ -33,6 +33,9 @@
 #include "phi_dev.h"
 #include "phi_kernels.h"
 
+#ifndef PHI_ABL
+#define PHI_ABL 0
+#endif
 #define TPB PHI_TPB
 #define Q 8                     // windows per lane
 
@@ -672,6 +675,9 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
                     F = ((F << 2) | b) & kmask;
                     R = (R >> 2) | ((3 - b) << (2 * k - 2));
                 }
+#if PHI_ABL == 3
+                if (i == 0)
+#endif
                 s_p[i + ((lo7 + i) >> 3)] = FMIN ? min_u62(F, R) : (F < R ? F : R);
             }
         } else {
@@ -716,8 +722,10 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 #pragma unroll
             for (int i = Q - 2; i >= 0; i--) L[i] = min_u62(SQ(i), L[i + 1]);
             uint64_t core = SQ(Q);
+#if PHI_ABL != 1
 #pragma unroll
             for (int x = Q + 1; x < WT; x++) core = min_u62(core, SQ(x));
+#endif
             uint64_t Rr = 0;                      // min of m[base+w .. base+w+i)
 #pragma unroll
             for (int i = 0; i <= Q; i++) {
@@ -910,6 +918,9 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     // ---- phases 4 + 5: items on dense lanes, 64 per round: murmur3 of the item's minimum, the
     //      hash-change test against the item before it (the lane below; lane 0 takes the last lane of
     //      the round before), ordered compaction, output
+#if PHI_ABL == 2
+    ncand = 0;
+#endif
     if (ncand > 0) {
         uint64_t carry = PHI_EMPTY_KEY;
         for (int r0 = 0; r0 <= ncand; r0 += 64) {

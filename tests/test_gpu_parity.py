@@ -1332,7 +1332,7 @@ def test_dp_blocks_on_class_lanes_equal_the_whole_chain(oracle, ctx_factory, mon
 
 
 def test_solve_on_device_resident_anchors_equals_the_host_solve(oracle, ctx_factory, monkeypatch):
-    """A large model (>= 2^20 anchors that all span an edge) is solved with its anchors left in HBM: per-anchor DP arrays,
+    """A model of >= 2^16 anchors that all span an edge is solved with its anchors left in HBM: per-anchor DP arrays,
     repeat set, relaxation weights and path cover counts by kernels (solve_dev.hip), the host copy fetched only when the
     branch and bound proper starts.  PHI_SOLVE_DEVICE=1 / 0 forces either mode at any size: same result field by field
     (objective, bound, proof, DP runs, path, counters, kept anchors) on instances that close at the root, that tighten
