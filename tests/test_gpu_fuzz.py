@@ -19,6 +19,7 @@ SLICES = [
     ("fuzz_full_path.py", 7003, 14, [], "fuzz ok"),
     ("fuzz_vs_highs.py", 7004, 12, [], "ok"),
     ("fuzz_dp_kernels.py", 7005, 10, ["2", "257"], "ok"),
+    ("fuzz_dp_blocks.py", 7006, 12, ["2", "257"], "ok"),
 ]
 
 
