@@ -29,13 +29,14 @@
 // With `allslow` the byte-wise kernel handles every window (ordered write of walks that contain
 // such bases).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include "phi_dev.h"
 #include "phi_kernels.h"
-
 #ifndef PHI_ABL
-#define PHI_ABL 0
+#define PHI_ABL 0      // ablation / occupancy experiments: 0 = the product
 #endif
+
 #define TPB PHI_TPB
 #define Q 8                     // windows per lane
 
@@ -357,20 +358,30 @@ __device__ __forceinline__ void slow_windows(const PhiSketchArgs &A, int64_t c0,
 
 // k-mer slots of one wave: every lane rolls P = ceil((WCH + w) / 64) consecutive k-mers and stores all
 // of them (the lanes past WCH + w write k-mers nobody reads), so the roll needs no per-store check
+// (lanes whose first k-mer lies past WCH + w store nothing: the region ends with the last storing lane's P slots)
 __host__ __device__ static inline int phi_wave_mp_u64(int w)
 {
-    const int P = (WCH + w + 63) / 64;
-    return ((64 * P + 8) * 9) / 8 + 8;
+    const int M = WCH + w, P = (M + 63) / 64;
+    const int slots = ((M - 1) / P + 1) * P;
+    return ((slots + 8) * 9) / 8 + 8;
 }
 // items of one chunk: the window before its first candidate, its candidates, and one more per stretch of
 // windows the 2-bit path leaves to the byte-wise one (a stretch is longer than a window's span: the first
 // window after it carries its own predecessor, see phase 3); + 4 trash slots
 __host__ __device__ static inline int phi_wave_items(int w, int k) { return 1 + WCH + WCH / (w + k + 1) + 2; }
-__host__ __device__ static inline int phi_wave_region_u64(int w, int k)
+// An item is 32 bits when it carries the minimiser's position (ordered write of the walks), 16 bits otherwise
+// (slot 0 .. 512, "first window of its sequence", "only its hash is needed"): with the k-mer region above that is
+// 6.5 KB of LDS per wave for the read kernel -- six workgroups per CU instead of five, which is worth 10 % (the
+// kernel waits on its probes: DESIGN.md 4.1).
+__host__ __device__ static inline int phi_wave_region_u64(int w, int k, bool pos)
 {
-    return phi_wave_mp_u64(w) + SWW + 2 * SBW + (phi_wave_items(w, k) + 4 + 1) / 2;
+    const int item_bytes = pos ? 4 : 2;
+    return phi_wave_mp_u64(w) + SWW + 2 * SBW + ((phi_wave_items(w, k) + 4) * item_bytes + 7) / 8
+#if PHI_ABL == 4
+           + 256          // (occupancy experiment: fewer workgroups per CU)
+#endif
+        ;
 }
-#define PHI_ITEM_NOEMIT 0x40000000u   // item flag: only its hash is needed (the window before a candidate)
 
 // minimum of two k-mer values below 2^62 (k <= 31) in one instruction: bit patterns with the two top
 // bits clear are non-negative finite doubles (never NaN or infinity), and IEEE order of non-negative
@@ -566,7 +577,7 @@ __device__ __forceinline__ void start_bits_from_offsets(const PhiSketchArgs &A, 
 // WIDE: w > Q (windows of one lane overlap in a common core); otherwise brute force per window.
 // KT/WT: compile-time k and w of the specialised instance (0 = take them from the arguments).
 template <int MODE, bool WIDE, int KT, int WT>
-__global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
+__global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketch_kernel(PhiSketchArgs A)   // (reads: six waves per SIMD, at most 80 VGPRs)
 {
     constexpr bool FUSED = MODE == PHI_MODE_PROBE;      // read batches come as ASCII + read offsets (see phase 0)
     constexpr bool NEED_POS = MODE == PHI_MODE_WRITE;   // only the ordered write stores positions (ILP_index.cpp:423)
@@ -591,11 +602,14 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
     const int span = w + k - 1;                           // bases under one window
     const bool have_bad = FUSED || A.badbits != nullptr;
 
-    uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w, k);   // k-mers; later the window minima
+    using MetaT = typename std::conditional<NEED_POS, uint32_t, uint16_t>::type;
+    constexpr uint32_t ITEM_FIRST = NEED_POS ? 1u << 31 : 1u << 15;        // the first window of its sequence
+    constexpr uint32_t ITEM_NOEMIT = NEED_POS ? 1u << 30 : 1u << 14;       // only its hash is needed (the window before a candidate)
+    uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w, k, NEED_POS);   // k-mers; later the window minima
     uint64_t *s_words = s_mp + phi_wave_mp_u64(w);
     unsigned long long *s_bits = (unsigned long long *)(s_words + SWW);
     unsigned long long *s_bad = s_bits + SBW;
-    uint32_t *s_meta = (uint32_t *)(s_bad + SBW);         // WCH + 1 items + 8 trash slots
+    MetaT *s_meta = (MetaT *)(s_bad + SBW);               // WCH + 1 items + 8 trash slots
     uint64_t *s_q = s_mp + lane * (Q + 1);                // SM(lane * Q + x) == s_q[x + (x >> 3)]
 
     // ---- phase 0: stage the chunk's packed words and bitmaps (the only global reads up to the
@@ -667,6 +681,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             uint64_t nxt = lds_extract64(s_words, l0 + 31 + k);     // bases j+k .. j+k+31
             uint64_t *s_p = s_mp + l0 + (l0 >> 3);
             const int lo7 = l0 & 7;
+            const bool stores = l0 < M;                             // (the last lanes hold k-mers nobody reads)
 #pragma unroll
             for (int i = 0; i < P; i++) {
                 if (i) {
@@ -678,7 +693,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 #if PHI_ABL == 3
                 if (i == 0)
 #endif
-                s_p[i + ((lo7 + i) >> 3)] = FMIN ? min_u62(F, R) : (F < R ? F : R);
+                if (stores) s_p[i + ((lo7 + i) >> 3)] = FMIN ? min_u62(F, R) : (F < R ? F : R);
             }
         } else {
             const int l1 = min(l0 + P, M);
@@ -897,7 +912,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 #pragma unroll
             for (int i = 1; i <= Q; i++) {
                 const bool on = (cflag >> i) & 1u;
-                s_meta[on ? c : trash] = (uint32_t)(lane * Q + i) | ((uint32_t)wp[i] << 10) | ((fflag >> i) & 1u) << 31;
+                s_meta[on ? c : trash] = (MetaT)((uint32_t)(lane * Q + i) | (NEED_POS ? (uint32_t)wp[i] << 10 : 0u) | (((fflag >> i) & 1u) ? ITEM_FIRST : 0u));
                 c += on;
             }
         } else {
@@ -905,12 +920,12 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
 #pragma unroll
             for (int i = 1; i <= Q; i++) {
                 if ((cflag >> i) & 1u) {
-                    if ((pflag >> i) & 1u) s_meta[c++] = (uint32_t)(lane * Q + i - 1) | PHI_ITEM_NOEMIT;
-                    s_meta[c++] = (uint32_t)(lane * Q + i) | ((uint32_t)wp[i] << 10) | ((fflag >> i) & 1u) << 31;
+                    if ((pflag >> i) & 1u) s_meta[c++] = (MetaT)((uint32_t)(lane * Q + i - 1) | ITEM_NOEMIT);
+                    s_meta[c++] = (MetaT)((uint32_t)(lane * Q + i) | (NEED_POS ? (uint32_t)wp[i] << 10 : 0u) | (((fflag >> i) & 1u) ? ITEM_FIRST : 0u));
                 }
             }
         }
-        if (coff == 0 && cflag) s_meta[0] = (uint32_t)(lane * Q + __ffs((int)cflag) - 2) | PHI_ITEM_NOEMIT;
+        if (coff == 0 && cflag) s_meta[0] = (MetaT)((uint32_t)(lane * Q + __ffs((int)cflag) - 2) | ITEM_NOEMIT);
     }
     wave_sync();
 #undef SQ
@@ -935,7 +950,7 @@ __global__ void __launch_bounds__(TPB) phi_sketch_kernel(PhiSketchArgs A)
             const uint64_t hp = wave_prev_u64(h, carry, lane);
             carry = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), 63) << 32) |
                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, 63);
-            const bool emit = valid && !(meta & PHI_ITEM_NOEMIT) && ((meta >> 31) || h != hp);
+            const bool emit = valid && !(meta & ITEM_NOEMIT) && ((meta & ITEM_FIRST) || h != hp);
             const unsigned long long bal = __ballot(emit);
             uint32_t filled = PHI_NO_SLOT;
             if (emit) {
@@ -1090,7 +1105,7 @@ void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A0, hipEve
     if (nchunks <= 0) return;
     const PhiSketchArgs &A = A0;
     const unsigned nb = (unsigned)((nchunks + TPB / 64 - 1) / (TPB / 64));
-    const size_t lds = (size_t)phi_wave_region_u64(A.w, A.k) * 8 * (TPB / 64);
+    const size_t lds = (size_t)phi_wave_region_u64(A.w, A.k, mode == PHI_MODE_WRITE) * 8 * (TPB / 64);
     if (mode == PHI_MODE_COUNT) launch_sketch_mode<PHI_MODE_COUNT>(st, nb, lds, A, t0, t1);
     else if (mode == PHI_MODE_WRITE) launch_sketch_mode<PHI_MODE_WRITE>(st, nb, lds, A, t0, t1);
     else launch_sketch_mode<PHI_MODE_PROBE>(st, nb, lds, A, t0, t1);
