@@ -668,6 +668,9 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     int64_t out_base = 0;
     if (MODE == PHI_MODE_WRITE) out_base = A.block_off[chunk];
 
+#if PHI_ABL == 10
+    return;
+#endif
     // ---- phase 1: canonical k-mers, P consecutive per lane
     {
         const int P = KT ? (WCH + WT + 63) / 64 : (M + 63) / 64;
@@ -676,24 +679,26 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
             // interior chunk (all but the first and last of a batch): every k-mer a lane touches
             // exists, so the roll needs no per-position checks, and every lane stores all P of its
             // k-mers (the slots past M are spare).  Slot of l0+i: a0 + i + carry of (l0 & 7) + i.
-            uint64_t F = lds_extract64(s_words, l0 + 31) >> (64 - 2 * k);
-            uint64_t R = phi_revcomp(F, k);
-            uint64_t nxt = lds_extract64(s_words, l0 + 31 + k);     // bases j+k .. j+k+31
-            uint64_t *s_p = s_mp + l0 + (l0 >> 3);
-            const int lo7 = l0 & 7;
-            const bool stores = l0 < M;                             // (the last lanes hold k-mers nobody reads)
+            // (the last lanes, whose k-mers nobody reads, sit the roll out: one branch around all of it)
+            if (l0 < M) {
+                uint64_t F = lds_extract64(s_words, l0 + 31) >> (64 - 2 * k);
+                uint64_t R = phi_revcomp(F, k);
+                uint64_t nxt = lds_extract64(s_words, l0 + 31 + k);     // bases j+k .. j+k+31
+                uint64_t *s_p = s_mp + l0 + (l0 >> 3);
+                const int lo7 = l0 & 7;
 #pragma unroll
-            for (int i = 0; i < P; i++) {
-                if (i) {
-                    const uint64_t b = nxt >> 62;
-                    nxt <<= 2;
-                    F = ((F << 2) | b) & kmask;
-                    R = (R >> 2) | ((3 - b) << (2 * k - 2));
-                }
+                for (int i = 0; i < P; i++) {
+                    if (i) {
+                        const uint64_t b = nxt >> 62;
+                        nxt <<= 2;
+                        F = ((F << 2) | b) & kmask;
+                        R = (R >> 2) | ((3 - b) << (2 * k - 2));
+                    }
 #if PHI_ABL == 3
-                if (i == 0)
+                    if (i == 0)
 #endif
-                if (stores) s_p[i + ((lo7 + i) >> 3)] = FMIN ? min_u62(F, R) : (F < R ? F : R);
+                    s_p[i + ((lo7 + i) >> 3)] = FMIN ? min_u62(F, R) : (F < R ? F : R);
+                }
             }
         } else {
             const int l1 = min(l0 + P, M);
@@ -723,6 +728,9 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     }
     wave_sync();
 
+#if PHI_ABL == 11
+    return;
+#endif
     // ---- phase 2: minima of windows la = lane*Q .. lane*Q+Q  (window la = m[la .. la+w)); the
     //      k-mer of slot lane*Q + x is s_q[x + (x >> 3)]: constant offsets from one address
 #define SQ(x) s_q[(x) + ((x) >> 3)]
@@ -789,11 +797,23 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
         }
     }
 
+#if PHI_ABL == 12
+    { uint64_t acc = 0;
+#pragma unroll
+      for (int i = 0; i <= Q; i++) acc ^= wv[i] + (uint64_t)i;
+      asm volatile("" :: "v"(acc)); return; }
+#endif
     if (FUSED) {
         // the read starts inside this chunk's base range, from the read offsets (answer of the probe issued in phase 0)
         start_bits_from_offsets(A, c0, lane, probe, s_bits);
         wave_sync();
     }
+#if PHI_ABL == 13
+    { uint64_t acc = 0;
+#pragma unroll
+      for (int i = 0; i <= Q; i++) acc ^= wv[i] + (uint64_t)i;
+      asm volatile("" :: "v"(acc)); return; }
+#endif
     // ---- phase 3: candidate windows of this lane: outputs i = 1..Q, window start a = c0-1+lane*Q+i
     //      (local bit of base a = la + 63 with la = lane*Q + i)
     uint32_t cflag = 0, fflag = 0, pflag = 0;             // candidates; first windows; candidates that carry their predecessor
@@ -888,6 +908,12 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
             }
         }
     }
+#if PHI_ABL == 14
+    { uint64_t acc = cflag ^ (fflag << 9) ^ ((uint64_t)pflag << 20);
+#pragma unroll
+      for (int i = 0; i <= Q; i++) acc ^= wv[i] + (uint64_t)i;
+      asm volatile("" :: "v"(acc)); return; }
+#endif
     // wave prefix sum of the per-lane candidate counts
     int ncand, coff;
     {
@@ -908,7 +934,14 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
         // slots past the last item: no divergent branch per window
         int c = coff + 1;
         const int trash = phi_wave_items(w, k) + (lane & 3);
-        if (!chunk_bad) {
+        if (!chunk_bad && !NEED_POS) {
+            // a lane has 0.6 candidates on average, rarely more than three: a loop over the set bits issues fewer
+            // instructions than eight predicated stores
+            for (uint32_t f = cflag; f; f &= f - 1) {
+                const uint32_t i = (uint32_t)__ffs((int)f) - 1;
+                s_meta[c++] = (MetaT)((uint32_t)(lane * Q) + i + (((fflag >> i) & 1u) ? ITEM_FIRST : 0u));
+            }
+        } else if (!chunk_bad) {
 #pragma unroll
             for (int i = 1; i <= Q; i++) {
                 const bool on = (cflag >> i) & 1u;
@@ -930,6 +963,9 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     wave_sync();
 #undef SQ
 
+#if PHI_ABL == 15
+    { asm volatile("" :: "v"(ncand)); return; }
+#endif
     // ---- phases 4 + 5: items on dense lanes, 64 per round: murmur3 of the item's minimum, the
     //      hash-change test against the item before it (the lane below; lane 0 takes the last lane of
     //      the round before), ordered compaction, output
