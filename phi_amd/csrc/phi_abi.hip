@@ -945,6 +945,10 @@ static int add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_
     PhiSketchArgs A{};
     A.ascii = (const uint8_t *)d_bases;
     A.read_off = (const int64_t *)d_read_off; A.n_reads = n_reads;
+    {
+        const double q = (double)n_reads / (double)n_bases * 4294967296.0;      // (a guess: clamped, never wrong to round)
+        A.reads_per_base_q32 = q >= 2147483648.0 ? 0x80000000u : (uint32_t)q;
+    }
     A.allslow = 0;
     A.n_bases = n_bases; A.k = c->k; A.w = c->w;
     A.sp_keys = c->d_sp_keys.as<uint64_t>(); A.sp_mask = c->sp_cap - 1;

@@ -223,7 +223,10 @@ __device__ __forceinline__ uint32_t probe_tables(const PhiSketchArgs &A, uint64_
     if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return PHI_NO_SLOT; }
     uint64_t su = h & A.u_mask;
     const ulonglong2 *kv = reinterpret_cast<const ulonglong2 *>(A.u_kv);
-    const ulonglong2 e0 = kv[su];                      // key and dense id in one round trip
+    ulonglong2 e0 = kv[su];                            // key and dense id in one round trip
+    // (both halves made live here: left alone the compiler loads the key, and the id in a second, dependent load
+    //  inside the branch of a match -- 85 % of the probes)
+    asm volatile("" : "+v"(e0.x), "+v"(e0.y));
     // walk-minimiser table: lookup, mark the minimiser as hit
     if (e0.x == h) { A.hit[(uint32_t)e0.y] = 1; return PHI_NO_SLOT; }
     if (e0.x != PHI_EMPTY_KEY) {
@@ -494,8 +497,11 @@ __device__ __forceinline__ void clean_finish(const PhiSketchArgs &A, int64_t gw,
             for (int64_t i = gw * 64 + lane; i < A.q_sp_cap; i += n_waves * 64) A.q_sp_keys[i] = PHI_EMPTY_KEY;
         }
     }
-    for (int64_t i = gw * 64 + lane; i < A.q_n_hit_words; i += n_waves * 64) A.q_hit_words[i] = 0;
-    for (int64_t i = gw * 64 + lane; i < A.q_n_stripe_words; i += n_waves * 64) A.q_stripes[i] = 0;
+    // (wave-uniform guards: most waves of a large launch have nothing to empty and skip on scalar compares)
+    if (gw * 64 < A.q_n_hit_words)
+        for (int64_t i = gw * 64 + lane; i < A.q_n_hit_words; i += n_waves * 64) A.q_hit_words[i] = 0;
+    if (gw * 64 < A.q_n_stripe_words)
+        for (int64_t i = gw * 64 + lane; i < A.q_n_stripe_words; i += n_waves * 64) A.q_stripes[i] = 0;
 }
 
 // Read starts of a chunk from the read offsets.  The chunk's bitmap covers bases [c0-64, c0-64+64*SBW); the first
@@ -505,7 +511,9 @@ struct StartProbe { int64_t base; int64_t v; int64_t nx; };
 __device__ __forceinline__ StartProbe start_probe_issue(const PhiSketchArgs &A, int64_t c0, int lane)
 {
     const int64_t lo_b = c0 - 64 > 0 ? c0 - 64 : 0;
-    int64_t g = (int64_t)((double)lo_b / (double)A.n_bases * (double)A.n_reads) - 24;
+    // (a guess: any value is safe, the probe is checked for bracketing the chunk.  Position x reads per base in 0.32
+    //  fixed point: wave-uniform integer arithmetic instead of a double division per lane)
+    int64_t g = (int64_t)(((unsigned long long)lo_b * A.reads_per_base_q32) >> 32) - 24;
     g = g < 0 ? 0 : (g > A.n_reads - 63 ? (A.n_reads - 63 > 0 ? A.n_reads - 63 : 0) : g);
     StartProbe p;
     p.base = g;
@@ -664,7 +672,7 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     const bool chunk_bad = have_bad && __ballot(my_bad != 0) != 0ull;   // wave-uniform
     wave_sync();
 
-    int n_emit = 0, n_new = 0, n_log = 0;
+    int n_emit = 0, n_new = 0, n_log = 0, n_new_slow = 0;   // (n_new: per-lane count kept by probe_tables, unused here)
     int64_t out_base = 0;
     if (MODE == PHI_MODE_WRITE) out_base = A.block_off[chunk];
 
@@ -998,10 +1006,10 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
                     filled = probe_tables(A, h, n_new);
                 }
             }
-            if (MODE == PHI_MODE_PROBE && A.sp_log) {
-                // the slots this chunk fills, for the next reset
+            if (MODE == PHI_MODE_PROBE) {
+                // the slots this chunk fills (= its new spectrum entries, counted for the whole wave), for the next reset
                 const unsigned long long ib = __ballot(filled != PHI_NO_SLOT);
-                if (filled != PHI_NO_SLOT) {
+                if (A.sp_log && filled != PHI_NO_SLOT) {
                     const int pos = n_log + __popcll(ib & ((1ull << lane) - 1));
                     if (pos < PHI_SPLOG) A.sp_log[(A.log_base + chunk) * PHI_SPLOG + pos] = filled;
                 }
@@ -1014,9 +1022,12 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     if (FUSED && chunk_bad) {
         // (rare) windows over a base outside ACGTacgt, or right after one: the exact byte-wise routine, by the wave
         // that owns the chunk (its inserts are not logged: slow_windows raises the dirty flag)
-        int n_emit_slow = 0;
-        slow_windows<MODE>(A, c0, chunk, lane, k, w, s_bits, s_bad, false, 0, n_emit_slow, n_new);
+        int n_emit_slow = 0, n_new_lane = 0;
+        slow_windows<MODE>(A, c0, chunk, lane, k, w, s_bits, s_bad, false, 0, n_emit_slow, n_new_lane);
         n_emit += n_emit_slow;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n_new_lane += __shfl_xor(n_new_lane, d, 64);
+        n_new_slow = n_new_lane;
     }
     if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
     if (MODE == PHI_MODE_COUNT) {
@@ -1026,12 +1037,11 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
             A.sp_log_cnt[A.log_base + chunk] = (uint8_t)(n_log < PHI_SPLOG ? n_log : PHI_SPLOG);
             if (n_log > PHI_SPLOG) raise_sp_dirty(A.sp_dirty);
         }
-        // one atomic per wave for the number of new spectrum entries and emitted records
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) n_new += __shfl_xor(n_new, d, 64);
+        // one atomic per wave for the number of new spectrum entries (n_log counts them: wave-uniform) and emitted records
+        const int n_new_wave = n_log + n_new_slow;
         if (lane == 0) {
             const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
-            if (n_new) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new);
+            if (n_new_wave) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new_wave);
             if (n_emit && A.n_emitted) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
         }
     }
