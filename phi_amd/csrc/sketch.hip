@@ -592,6 +592,9 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     constexpr bool FMIN = !NEED_POS && KT > 0 && KT <= 31;   // values < 2^62: minima by v_min_f64
     extern __shared__ uint64_t s_dyn[];
 
+    // (wid stays a vector register: as a scalar -- readfirstlane -- the values derived from it overflow the SGPR file,
+    //  +9 % VALU instructions of v_writelane / v_readlane traffic; reading the output phase's arguments late, through
+    //  a laundered kernarg pointer, frees the SGPRs but pushes four VGPRs into scratch at the 80-register bound: -35 %)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k = KT ? KT : A.k, w = WT ? WT : A.w;
     const int64_t N = A.n_bases;
