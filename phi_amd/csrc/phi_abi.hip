@@ -201,6 +201,7 @@ int phi_ctx_create(int device_id, phi_ctx **out)
 void phi_ctx_destroy(phi_ctx *c)
 {
     if (c && c->pin_future.valid()) c->pin_future.wait();
+    if (c && c->dp_alloc_future.valid()) (void)c->dp_alloc_future.get();
     if (c && c->h_pin) { (void)hipSetDevice(c->device); (void)hipHostFree(c->h_pin); c->h_pin = nullptr; }
     if (!c) return;
     (void)phi_comm_destroy(c);
@@ -480,6 +481,24 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         if (walk_off[h + 1] <= walk_off[h]) return phi_fail(c, PHI_ERR_INVALID, "walk %d is empty", h);
     const int64_t n_edges = adj_off[n_vtx], n_entries = walk_off[n_walks];
     if (n_entries >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk entries");
+    // The DP's per-entry buffers of a chromosome-scale graph (7 x 4-8 bytes per walk entry: 37 GB at 1.3 G entries) are
+    // allocated now, on a thread of their own: the driver clears device memory as it hands it out (tens of GB/s), which
+    // otherwise shows up as half a second at the start of phi_solve.  Joined before this call returns.
+    if (c->dp_alloc_future.valid()) (void)c->dp_alloc_future.get();
+    if (n_entries >= ((int64_t)1 << 24) && n_walks <= PHI_DP_EVENT_MAX_WALKS) {
+        c->dp_alloc_future = std::async(std::launch::async, [c, n_entries]() -> int {
+            if (hipSetDevice(c->device) != hipSuccess) return PHI_ERR_DEVICE;
+            const size_t ne = (size_t)n_entries;
+            PHICHK(phi_dev_ensure(c, c->d_g_off, (ne + 1) * 8));
+            PHICHK(phi_dev_ensure(c, c->d_dmax, ne * 4));
+            PHICHK(phi_dev_ensure(c, c->d_bstart, ne * 4));
+            PHICHK(phi_dev_ensure(c, c->d_cnt_end, (ne + 1) * 4));
+            PHICHK(phi_dev_ensure(c, c->d_cnt_start, (ne + 1) * 4));
+            PHICHK(phi_dev_ensure(c, c->d_off_end, (ne + 3) * 4));
+            PHICHK(phi_dev_ensure(c, c->d_off_start, (ne + 3) * 4));
+            return PHI_OK;
+        });
+    }
     c->n_vtx = n_vtx; c->n_walks = n_walks; c->n_entries = n_entries;
 
     // topological order from the ranks; every edge must go forward (acyclic GFA, README.md:70-75)
@@ -858,6 +877,11 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     c->log_chunks = 0; c->sp_full = true;
     c->alt.sp_cap = 0; c->alt.log_chunks = 0; c->alt.sp_full = true; c->alt.needs_clean = false;
     c->next_flag_zeroed = false;                               // (set_graph zeroed all scalars, the dirty flags among them)
+    if (c->dp_alloc_future.valid()) {
+        const int rc = c->dp_alloc_future.get();
+        if (rc) return rc;
+        tm.lap("wait for the DP buffers");
+    }
     c->have_graph = true;
     return PHI_OK;
 }

@@ -172,6 +172,7 @@ struct phi_ctx {
     void *h_pin = nullptr;                            // pinned host buffer the kept anchors are downloaded into
     size_t h_pin_cap = 0;
     std::future<void> pin_future;                     // its allocation, started by phi_set_graph on a thread of its own
+    std::future<int> dp_alloc_future;                 // the DP's entry-sized buffers of a chromosome-scale graph, allocated beside phi_set_graph's host pass
     std::vector<uint64_t> h_kept_hash;
     std::vector<int32_t> h_path_vtx, h_path_hap;
     std::vector<int64_t> h_n_minimizers, h_n_anchors;

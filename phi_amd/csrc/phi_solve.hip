@@ -84,15 +84,17 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
     c->blk_ls = cls ? 256 : 64;
     const int64_t ne = c->n_entries;
     const int32_t nk = c->n_k;
-    PHICHK(phi_dev_ensure(c, c->d_cov, (size_t)(ne + 3) * 4));
-    PHICHK(phi_dev_ensure(c, c->d_cov2, (size_t)(ne + 3) * 4));
+    // (scratch of ne + 3 ints twice: the per-run prefix-sum buffers, which no run is using yet -- at chromosome scale
+    //  every buffer of this size is 5 GB that the driver clears on allocation)
+    PHICHK(phi_dev_ensure(c, c->d_off_end, (size_t)(ne + 3) * 4));
+    PHICHK(phi_dev_ensure(c, c->d_off_start, (size_t)(ne + 3) * 4));
     PHICHK(phi_dev_ensure(c, c->d_stepdiff, (size_t)(nk + 2) * 4));
     {
         const int64_t nb = phi_scan_i32_num_blocks(ne + 2);
         PHICHK(phi_dev_ensure(c, c->d_scan_blk, (size_t)nb * 4));
         PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
     }
-    int32_t *d_a = c->d_cov.as<int32_t>(), *d_b = c->d_cov2.as<int32_t>();
+    int32_t *d_a = c->d_off_end.as<int32_t>(), *d_b = c->d_off_start.as<int32_t>();
     HIPCHK(hipMemsetAsync(d_a, 0, (size_t)(ne + 3) * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->d_stepdiff.p, 0, (size_t)(nk + 2) * 4, c->stream));
     phi_launch_cut_cov(c->stream, c->d_a_e1.as<int32_t>(), c->d_g_span.as<uint8_t>(), n_dp, d_a);
@@ -329,6 +331,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
             phi_launch_dp_events(c->stream, A);
         }
     } else {
+        PHICHK(phi_dev_ensure(c, c->d_word, (size_t)c->n_entries * 8));          // (only the every-vertex kernel needs it)
         phi_launch_dp_words(c->stream, c->d_e_out.as<uint8_t>(), c->d_g_off.as<int64_t>(), c->d_g_span.as<uint8_t>(),
                             c->d_a_weight.as<uint8_t>(), ne, c->d_word.as<uint64_t>());
         PhiDpArgs A{};
@@ -462,6 +465,7 @@ struct Node {
 int phi_solve_impl(phi_ctx *c)
 {
     c->solved = false;
+    if (c->dp_alloc_future.valid()) PHICHK(c->dp_alloc_future.get());     // (a phi_set_graph that failed midway left it behind)
     PHICHK(phi_sync_check(c));
     PhiStageTimer tm("solve");
     uint64_t sc[S_N];
@@ -710,8 +714,8 @@ int phi_solve_impl(phi_ctx *c)
             const int64_t ne1 = c->n_entries + 1;
             PHICHK(phi_dev_ensure(c, c->d_cnt_end, (size_t)ne1 * 4));
             PHICHK(phi_dev_ensure(c, c->d_cnt_start, (size_t)ne1 * 4));
-            PHICHK(phi_dev_ensure(c, c->d_off_end, (size_t)ne1 * 4));
-            PHICHK(phi_dev_ensure(c, c->d_off_start, (size_t)ne1 * 4));
+            PHICHK(phi_dev_ensure(c, c->d_off_end, (size_t)(ne1 + 2) * 4));      // (+2: also the scratch of dp_prepare_blocks)
+            PHICHK(phi_dev_ensure(c, c->d_off_start, (size_t)(ne1 + 2) * 4));
             const int64_t nb = phi_scan_i32_num_blocks(c->n_entries);
             PHICHK(phi_dev_ensure(c, c->d_scan_blk, (size_t)nb * 4));
             PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
@@ -719,7 +723,6 @@ int phi_solve_impl(phi_ctx *c)
         }
         PHICHK(phi_dev_ensure(c, c->d_top, (size_t)c->n_vtx * 5 * 4));
         PHICHK(phi_dev_ensure(c, c->d_ent, (size_t)c->n_vtx * 2 * 4));
-        PHICHK(phi_dev_ensure(c, c->d_word, (size_t)c->n_entries * 8));
     }
 
     PHICHK(dp_prepare_blocks(c, n_dp));
