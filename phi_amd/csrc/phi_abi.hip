@@ -2,6 +2,8 @@
 // Host-side orchestration only; all per-base work runs in the kernels of sketch.hip, table.hip,
 // anchors.hip and dp.hip.  There is no CPU fallback: without a HIP device every entry point
 // that needs one returns PHI_ERR_DEVICE.
+#include <chrono>
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -43,7 +45,15 @@ int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes)
     if (bytes <= b.cap && b.p) return PHI_OK;
     if (b.p) { hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return phi_hip_check(c, e, "hipFree"); }
     size_t want = bytes < 256 ? 256 : bytes;
+    static const bool timing = getenv("PHI_TIMING_ALLOC") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&b.p, want);
+    if (timing) {
+        static std::atomic<long long> total_ns{0}, calls{0};
+        const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        total_ns += ns; calls++;
+        fprintf(stderr, "[phi alloc] %10zu bytes %8.1f us (total %lld calls, %.3f ms)\n", want, ns / 1e3, (long long)calls, total_ns / 1e6);
+    }
     if (e != hipSuccess) { b.p = nullptr; return phi_fail(c, PHI_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e)); }
     b.cap = want;
     return PHI_OK;
