@@ -79,7 +79,9 @@ PHI_HD uint64_t phi_revcomp(uint64_t f, int k)
 
 PHI_HD uint64_t phi_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
-// low 64 bits of a * c from three 32-bit multiplies (the quarter-rate instructions of the VALU):
+// low 64 bits of a * c from three 32-bit multiplies (measured on gfx950: v_mul_lo_u32 issues at the rate of
+// v_add_u32, v_mad_u64_u32 at 2/3 of it -- profiles/r02d_ubench_valu_rates.txt -- so the count of instructions,
+// not their kind, is what matters):
 // one full 32x32 -> 64 product and the low halves of the two cross products
 PHI_HD uint64_t phi_mul64(uint64_t a, uint64_t c)
 {
@@ -95,7 +97,7 @@ PHI_HD uint64_t phi_mul64(uint64_t a, uint64_t c)
 #endif
 }
 
-// h * 5 + c by shift and add (a 64-bit multiply-add would take the quarter-rate multiplier twice)
+// h * 5 + c by shift and add (a 64-bit multiply-add would be three multiply instructions)
 PHI_HD uint64_t phi_x5_plus(uint64_t h, uint64_t c)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
