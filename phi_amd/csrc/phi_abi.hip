@@ -510,6 +510,21 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         });
     }
     c->n_vtx = n_vtx; c->n_walks = n_walks; c->n_entries = n_entries;
+    // The graph arrays go to the device while this thread validates them (copies from the caller's pageable arrays:
+    // 52 MB and 3 ms at C2).  Only copies: no kernel indexes with them before the validation below has passed.
+    // (joined by the GPU thread, or by the future's destructor on an early return)
+    std::future<int> uploads = std::async(std::launch::async, [&]() -> int {
+        HIPCHK(hipSetDevice(c->device));
+        PHICHK(upload(c, c->d_seq, seq_concat, (size_t)seq_off[n_vtx]));
+        PHICHK(upload(c, c->d_seq_off, seq_off, (size_t)n_vtx + 1));
+        PHICHK(upload(c, c->d_walk_vtx, walk_vtx, (size_t)n_entries));
+        PHICHK(upload(c, c->d_walk_off, walk_off, (size_t)n_walks + 1));
+        PHICHK(upload(c, c->d_adj_off, adj_off, (size_t)n_vtx + 1));
+        if (n_edges == 0) PHICHK(phi_dev_ensure(c, c->d_adj, 4));
+        else PHICHK(upload(c, c->d_adj, adj, (size_t)n_edges));
+        PHICHK(upload(c, c->d_topo_rank, topo_rank, (size_t)n_vtx));
+        return PHI_OK;
+    });
 
     // topological order from the ranks; every edge must go forward (acyclic GFA, README.md:70-75)
     c->h_topo.assign(n_vtx, -1);
@@ -579,20 +594,12 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         struct PromiseGuard { std::promise<int> &p; bool done = false; ~PromiseGuard() { if (!done) p.set_value(PHI_ERR_DEVICE); } } pg{edges_promise};
         HIPCHK(hipSetDevice(c->device));
         PhiStageTimer tg("set_graph");
-        // (from the caller's arrays: the host copies are made by the main thread meanwhile)
-        PHICHK(upload(c, c->d_seq, seq_concat, (size_t)seq_off[n_vtx]));
-        PHICHK(upload(c, c->d_seq_off, seq_off, (size_t)n_vtx + 1));
-        PHICHK(upload(c, c->d_walk_vtx, walk_vtx, (size_t)n_entries));       // the caller's array: the host pass is still copying it
-        PHICHK(upload(c, c->d_walk_off, walk_off, (size_t)n_walks + 1));
+        PHICHK(uploads.get());                                 // (the graph arrays: on their way since before the validation)
         {
             // the walk-entry pass: walks follow edges of forward vertices (ILP_index.cpp:104-107 exits on reverse
             // strand; an edge-less step would leave an anchor's edge variables unconstrained, :799-815)
             int rc = PHI_OK;
             auto pass = [&]() -> int {
-                PHICHK(upload(c, c->d_adj_off, adj_off, (size_t)n_vtx + 1));
-                if (n_edges == 0) PHICHK(phi_dev_ensure(c, c->d_adj, 4));
-                else PHICHK(upload(c, c->d_adj, adj, (size_t)n_edges));
-                PHICHK(upload(c, c->d_topo_rank, topo_rank, (size_t)n_vtx));
                 PHICHK(phi_dev_ensure(c, c->d_e_out, (size_t)n_entries));
                 PHICHK(phi_dev_ensure(c, c->d_cnt_edge, cnt_edge.size() * 4));
                 PHICHK(phi_dev_ensure(c, c->d_walk_err, 16));
