@@ -1,0 +1,62 @@
+"""The read kernel's occupancy budget, checked where the code is built (no GPU needed: hipcc cross-compiles).
+
+`phi_sketch_kernel<PROBE, WIDE, 31, 25>` runs six waves per SIMD: at most 80 VGPRs (512 / 6, granule 8), no spill into
+scratch (a build that spilled four VGPRs ran 35 % slower; five waves instead of six, 9 %) and at most
+160 KB / 24 waves of LDS per wave.  A change that silently crosses one of these lines costs more than most
+optimisations gain: this test fails instead."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SRC = os.path.join(ROOT, "phi_amd", "csrc", "sketch.hip")
+
+
+@pytest.fixture(scope="module")
+def sketch_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not found")
+    out = tmp_path_factory.mktemp("asm") / "sketch.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), SRC],
+                          stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def _meta(asm, mangled_part):
+    """the amdhsa.kernels metadata entry of the kernel whose mangled name contains mangled_part"""
+    entries = asm.split("  - .agpr_count:")
+    hits = [e for e in entries[1:] if re.search(r"\.name:\s+\S*" + re.escape(mangled_part), e)]
+    assert len(hits) == 1, f"{len(hits)} metadata entries for {mangled_part}"
+    return {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|sgpr_count|sgpr_spill_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\d+)", hits[0])}
+
+
+def test_read_kernel_fits_six_waves_per_simd(sketch_asm):
+    m = _meta(sketch_asm, "phi_sketch_kernelILi2ELb1ELi31ELi25EE")          # MODE = PROBE, WIDE, k = 31, w = 25
+    assert m["vgpr_count"] <= 80, m
+    assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, m
+    # the generic read kernels (any k, w) must not use scratch either
+    for name in ("phi_sketch_kernelILi2ELb1ELi0ELi0EE", "phi_sketch_kernelILi2ELb0ELi0ELi0EE"):
+        g = _meta(sketch_asm, name)
+        assert g["vgpr_count"] <= 80 and g["vgpr_spill_count"] == 0 and g["private_segment_fixed_size"] == 0, (name, g)
+
+
+def test_read_kernel_lds_fits_twenty_four_waves_per_cu():
+    # phi_wave_region_u64(w, k, pos = false) of sketch.hip, restated: dynamic LDS per wave of the read kernel
+    WCH, SWW, SBW = 512, 32, 16
+    src = open(SRC).read()
+    assert re.search(r"#define SWW 32\b", src) and re.search(r"#define SBW 16\b", src) and "#define PHI_WCH 512" in open(os.path.join(ROOT, "phi_amd", "csrc", "phi_kernels.h")).read()
+
+    def region_bytes(w, k):
+        M = WCH + w
+        P = (M + 63) // 64
+        slots = ((M - 1) // P + 1) * P
+        mp = ((slots + 8) * 9) // 8 + 8
+        items = 1 + WCH + WCH // (w + k + 1) + 2
+        return (mp + SWW + 2 * SBW + ((items + 4) * 2 + 7) // 8) * 8
+
+    assert region_bytes(25, 31) * 24 <= 160 * 1024, region_bytes(25, 31)      # the default (k, w): six workgroups of four waves per CU
+    assert region_bytes(10, 15) * 24 <= 160 * 1024
