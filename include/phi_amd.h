@@ -15,7 +15,8 @@
  *   - one context per process per GPU, calls serialised by the caller (the reference is not
  *     re-entrant either: src/main.cpp:136-140).
  *
- * Limits (PHI_ERR_UNSUPPORTED / PHI_ERR_INVALID beyond them): k <= 32, w <= 256, at most 512 walks,
+ * Limits (PHI_ERR_UNSUPPORTED / PHI_ERR_INVALID beyond them): k <= 64 (k <= 32 on the fast 2-bit kernels; 33 .. 64 through
+ * the exact byte-wise routine, and only while no k-mer covers more than 32 vertices), w <= 256, at most 512 walks,
  * fewer than 2^31 walk entries, minimisers of the distinct walk contexts and anchors in the model, at most
  * 254 out-edges and 255 recombination in-edges per vertex, no walk through a segment without
  * sequence, no graph whose walks both start and end at interior vertices.

@@ -245,7 +245,7 @@ int phi_set_params(phi_ctx *c, int32_t k, int32_t w, float threshold, int32_t re
 {
     if (!c) return PHI_ERR_INVALID;
     if (c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_set_params must precede phi_set_graph");
-    if (k < 1 || k > PHI_MAX_K) return phi_fail(c, PHI_ERR_INVALID, "k=%d outside [1,%d] (2-bit k-mers are held in 64 bits)", k, PHI_MAX_K);
+    if (k < 1 || k > PHI_MAX_K) return phi_fail(c, PHI_ERR_INVALID, "k=%d outside [1,%d]", k, PHI_MAX_K);
     if (w < 1 || w > PHI_MAX_W) return phi_fail(c, PHI_ERR_INVALID, "w=%d outside [1,%d]", w, PHI_MAX_W);
     if (recombination < 0) return phi_fail(c, PHI_ERR_INVALID, "recombination penalty must be >= 0");
     c->k = k; c->w = w; c->threshold = threshold; c->recombination = recombination; c->flags = flags;
@@ -399,7 +399,7 @@ static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_e
         uint64_t n_bad = 0;
         HIPCHK(hipMemcpyAsync(&n_bad, scalar(c, S_NBAD), 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (n_bad) {
+        if (n_bad || c->k > PHI_MAX_K_PACKED) {                 // (k > 32: the byte-wise path for every window)
             PHICHK(phi_dev_ensure(c, c->d_wascii, (size_t)run + 64));
             HIPCHK(hipMemsetAsync(scalar(c, S_NBAD), 0, 8, c->stream));
             pack(c->d_wascii.as<uint8_t>());
@@ -990,7 +990,7 @@ static int add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_
         const double q = (double)n_reads / (double)n_bases * 4294967296.0;      // (a guess: clamped, never wrong to round)
         A.reads_per_base_q32 = q >= 2147483648.0 ? 0x80000000u : (uint32_t)q;
     }
-    A.allslow = 0;
+    A.allslow = c->k > PHI_MAX_K_PACKED;                       // longer k-mers: the byte-wise routine for every window
     A.n_bases = n_bases; A.k = c->k; A.w = c->w;
     A.sp_keys = c->d_sp_keys.as<uint64_t>(); A.sp_mask = c->sp_cap - 1;
     A.sp_count = sp_stripes(c);
@@ -1246,7 +1246,7 @@ int phi_sketch(phi_ctx *c, const char *bases, const int64_t *seq_off, int64_t n_
         if ((rc = phi_hip_check(c, hipMemcpy(&n_bad, scalar(c, S_NBAD), 8, hipMemcpyDeviceToHost), "D2H"))) break;
         int64_t total = 0;
         if ((rc = sketch_records(c, dW.as<uint64_t>(), dS.as<unsigned long long>(), n_bases, k, w,
-                                 n_bad ? dB.as<uint8_t>() : nullptr, dH, dP, &total))) break;
+                                 (n_bad || k > PHI_MAX_K_PACKED) ? dB.as<uint8_t>() : nullptr, dH, dP, &total))) break;
         if ((rc = phi_sync_check(c))) break;
         *n_out = total;
         if (cap >= total && total > 0) {

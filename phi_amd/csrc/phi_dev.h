@@ -179,6 +179,30 @@ PHI_HD uint64_t phi_murmur_lanes(uint64_t e0, uint64_t e1, uint64_t e2, uint64_t
     return h1 ^ h2;
 }
 
+// The same hash for k <= 64 bytes given as eight little-endian 8-byte lanes (bytes beyond k are zero): k-mers longer
+// than 32 bases, which only the exact byte-wise path handles (MurmurHash3.cpp:255-332: 16-byte blocks, then the tail).
+PHI_HD uint64_t phi_murmur_lanes8(const uint64_t *e, int k)
+{
+    const uint64_t c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
+    uint64_t h1 = 0, h2 = 0;
+    const int nblocks = k >> 4;
+    for (int b = 0; b < nblocks; b++) {
+        uint64_t k1 = e[2 * b], k2 = e[2 * b + 1];
+        k1 = phi_mul64(k1, c1); k1 = phi_rotl64(k1, 31); k1 = phi_mul64(k1, c2); h1 ^= k1;
+        h1 = phi_rotl64(h1, 27); h1 += h2; h1 = phi_x5_plus(h1, 0x52dce729);
+        k2 = phi_mul64(k2, c2); k2 = phi_rotl64(k2, 33); k2 = phi_mul64(k2, c1); h2 ^= k2;
+        h2 = phi_rotl64(h2, 31); h2 += h1; h2 = phi_x5_plus(h2, 0x38495ab5);
+    }
+    const int rem = k & 15;
+    if (rem > 8) { uint64_t k2 = e[2 * nblocks + 1]; k2 = phi_mul64(k2, c2); k2 = phi_rotl64(k2, 33); k2 = phi_mul64(k2, c1); h2 ^= k2; }
+    if (rem > 0) { uint64_t k1 = e[2 * nblocks]; k1 = phi_mul64(k1, c1); k1 = phi_rotl64(k1, 31); k1 = phi_mul64(k1, c2); h1 ^= k1; }
+    h1 ^= (uint64_t)k; h2 ^= (uint64_t)k;
+    h1 += h2; h2 += h1;
+    h1 = phi_fmix64(h1); h2 = phi_fmix64(h2);
+    h1 += h2; h2 += h1;
+    return h1 ^ h2;
+}
+
 // The same hash of the k ASCII bytes spelled by a right-aligned 2-bit k-mer value.  1 <= k <= 32.
 PHI_HD uint64_t phi_kmer_hash(uint64_t val, int k)
 {

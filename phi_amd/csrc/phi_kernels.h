@@ -8,7 +8,8 @@
 #endif
 #define PHI_WCH 512            // window positions per wave (each wave sketches its own chunk)
 #define PHI_MAX_W 256
-#define PHI_MAX_K 32
+#define PHI_MAX_K 64              // k-mers of up to 32 bases are 2-bit values in 64 bits (the fast kernels); 33 .. 64 take the
+#define PHI_MAX_K_PACKED 32       // exact byte-wise routine for every window (slow, exact: the reference is string based, any k)
 #define PHI_MAX_PROBE 4096     // linear-probe bound of the open-addressed tables
 #define PHI_SPLOG 32            // logged spectrum inserts per chunk of 512 windows (31 hashes are emitted per chunk of short reads)
 #define PHI_STRIPES 256          // counters are striped over 256 cache lines: one hot address

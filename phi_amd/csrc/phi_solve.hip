@@ -583,7 +583,9 @@ int phi_solve_impl(phi_ctx *c)
         HIPCHK(hipMemcpyAsync(hc.data(), d_ctr, hc.size() * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (hc[1] & 1) return phi_fail(c, PHI_ERR_DEVICE, "dp anchors not sorted by last entry (internal error)");
-        if (hc[1] & 2) return phi_fail(c, PHI_ERR_DEVICE, "an anchor spans %d edges or more (internal error)", PHI_RCAP);
+        if (hc[1] & 2)
+            return phi_fail(c, c->k > PHI_RCAP ? PHI_ERR_UNSUPPORTED : PHI_ERR_DEVICE, "an anchor spans %d edges or more%s", PHI_RCAP,
+                            c->k > PHI_RCAP ? ": with k > 32 the graph's vertices must be long enough for a k-mer to cover at most 32 of them" : " (internal error)");
         c->h_n_anchors.assign(nw, 0);
         for (int32_t h = 0; h < nw; h++) c->h_n_anchors[h] = (int64_t)hc[(size_t)h + 8];
         int64_t dev_min = (int64_t)1 << 16;                    // below this the host loops are as fast as the extra launches
@@ -643,7 +645,7 @@ int phi_solve_impl(phi_ctx *c)
                 while (k.e0 >= c->h_walk_off[hw + 1]) hw++;
                 if (k.e1 <= k.e0) continue;
                 dp_walk[o] = (int16_t)hw;
-                if (k.e1 - k.e0 >= PHI_RCAP) { herr.set(PHI_ERR_DEVICE, "anchor spans %d edges (internal error)", k.e1 - k.e0); return; }
+                if (k.e1 - k.e0 >= PHI_RCAP) { herr.set(c->k > PHI_RCAP ? PHI_ERR_UNSUPPORTED : PHI_ERR_DEVICE, "an anchor spans %d edges (at most %d are supported)", k.e1 - k.e0, PHI_RCAP - 1); return; }
                 if (!same) c->h_dp[o] = k;
                 a_e1[o] = k.e1;
                 a_span[o] = (uint8_t)(k.e1 - k.e0);

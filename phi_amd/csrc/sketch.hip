@@ -293,8 +293,18 @@ __device__ KRef window_best_bytes(const uint8_t *__restrict__ s, int64_t a, int 
     }
     return best;
 }
+template <bool LONGK>   // LONGK: k may exceed 32 (eight lanes; kept out of the kernels that never see such k)
 __device__ uint64_t khash_bytes(const uint8_t *__restrict__ s, KRef r, int k)
 {
+    if (LONGK && k > PHI_MAX_K_PACKED) {
+        uint64_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < 8; g++) {                               // (constant indices: the lanes stay in registers)
+            uint64_t v = 0;
+            for (int x = 8 * g; x < 8 * g + 8 && x < k; x++) v |= (uint64_t)kbyte(s, r, x, k) << (8 * (x & 7));
+            e[g] = v;
+        }
+        return phi_murmur_lanes8(e, k);
+    }
     uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
     for (int x = 0; x < k; x++) {
         const uint64_t b = (uint64_t)kbyte(s, r, x, k) << (8 * (x & 7));
@@ -309,7 +319,7 @@ __device__ __forceinline__ bool range_has_bit(const unsigned long long *s_bits, 
 }
 
 // Windows la = 1..WCH of this wave's chunk that need the byte-wise path, in position order.
-template <int MODE>
+template <int MODE, bool LONGK = false>
 __device__ __forceinline__ void slow_windows(const PhiSketchArgs &A, int64_t c0, int64_t chunk, int lane, int k, int w,
                                           const unsigned long long *s_bits, const unsigned long long *s_bad,
                                           bool allslow, int64_t out_base, int &n_emit, int &n_new)
@@ -328,12 +338,12 @@ __device__ __forceinline__ void slow_windows(const PhiSketchArgs &A, int64_t c0,
         if (todo) {
             const bool first = (s_bits[lp >> 6] >> (lp & 63)) & 1ull;
             const KRef best = window_best_bytes(A.ascii, a, k, w);
-            h = khash_bytes(A.ascii, best, k);
+            h = khash_bytes<LONGK>(A.ascii, best, k);
             pos = best.pos;
             if (first) emit = h != PHI_EMPTY_KEY;                   // prev_hash = UINT64_MAX (:383, :455)
             else {
                 const KRef prev = window_best_bytes(A.ascii, a - 1, k, w);
-                emit = !(prev.pos == best.pos && prev.rc == best.rc) && khash_bytes(A.ascii, prev, k) != h;
+                emit = !(prev.pos == best.pos && prev.rc == best.rc) && khash_bytes<LONGK>(A.ascii, prev, k) != h;
             }
         }
         const unsigned long long bal = __ballot(emit);
@@ -447,7 +457,8 @@ static __device__ __forceinline__ void bytes_role(const PhiSketchArgs &A, const 
         int n_emit = 0, n_new = 0;
         if (A.allslow || chunk_bad) {
             const int64_t out_base = (MODE == PHI_MODE_WRITE) ? A.block_off[chunk] : 0;
-            slow_windows<MODE>(A, c0, chunk, lane, A.k, A.w, s_bits, s_bad, A.allslow != 0, out_base, n_emit, n_new);
+            if (A.k > PHI_MAX_K_PACKED) slow_windows<MODE, true>(A, c0, chunk, lane, A.k, A.w, s_bits, s_bad, A.allslow != 0, out_base, n_emit, n_new);
+            else slow_windows<MODE>(A, c0, chunk, lane, A.k, A.w, s_bits, s_bad, A.allslow != 0, out_base, n_emit, n_new);
         }
         if (MODE == PHI_MODE_COUNT) {
             if (lane == 0) A.block_cnt[chunk] = n_emit;
@@ -596,7 +607,7 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     //  +9 % VALU instructions of v_writelane / v_readlane traffic; reading the output phase's arguments late, through
     //  a laundered kernarg pointer, frees the SGPRs but pushes four VGPRs into scratch at the 80-register bound: -35 %)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int k = KT ? KT : A.k, w = WT ? WT : A.w;
+    const int k = KT > 0 ? KT : A.k, w = WT ? WT : A.w;       // (KT = -1: the instantiation for k > 32, see below)
     const int64_t N = A.n_bases;
     const int64_t chunk = (int64_t)blockIdx.x * (TPB / 64) + wid;
     const int64_t c0 = chunk * WCH;                       // first window start of this chunk
@@ -682,9 +693,27 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
 #if PHI_ABL == 10
     return;
 #endif
+    if (FUSED && KT < 0) {
+        // k > 32 (an instantiation of its own: KT = -1): no 2-bit k-mers; every window of the chunk takes the exact byte-wise routine.  The
+        // slots it fills are not logged: slow_windows raises the dirty flag, the next reset empties the whole set.
+        start_bits_from_offsets(A, c0, lane, probe, s_bits);
+        wave_sync();
+        int n_emit_slow = 0, n_new_lane = 0;
+        slow_windows<MODE, true>(A, c0, chunk, lane, k, w, s_bits, s_bad, true, 0, n_emit_slow, n_new_lane);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n_new_lane += __shfl_xor(n_new_lane, d, 64);
+        if (A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
+        if (lane == 0) {
+            if (A.sp_log) A.sp_log_cnt[A.log_base + chunk] = 0;
+            const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
+            if (n_new_lane) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new_lane);
+            if (n_emit_slow && A.n_emitted) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit_slow);
+        }
+        return;
+    }
     // ---- phase 1: canonical k-mers, P consecutive per lane
     {
-        const int P = KT ? (WCH + WT + 63) / 64 : (M + 63) / 64;
+        const int P = KT > 0 ? (WCH + WT + 63) / 64 : (M + 63) / 64;
         const int l0 = lane * P;
         if (c0 >= 1 && c0 - 1 + (int64_t)P * 64 + k <= N) {
             // interior chunk (all but the first and last of a batch): every k-mer a lane touches
@@ -1141,6 +1170,12 @@ static void launch_sketch_mode(hipStream_t st, unsigned nb, size_t lds, const Ph
     if constexpr (MODE != PHI_MODE_WRITE) {
         if (A.k == 31 && A.w == 25) {
             hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, true, 31, 25>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
+            return;
+        }
+    }
+    if constexpr (MODE == PHI_MODE_PROBE) {
+        if (A.k > PHI_MAX_K_PACKED) {                      // reads with k > 32: staging, read starts and bookkeeping of the fused kernel, every window byte-wise
+            hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, true, -1, 0>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
             return;
         }
     }

@@ -15,7 +15,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 120
 n_ok = 0
 while time.time() < t_end:
-    k = int(rng.choice([31, 31, 31, int(rng.integers(1, 33))])); w = int(rng.choice([25, 25, int(rng.integers(1, 70))]))
+    k = int(rng.choice([31, 31, 31, int(rng.integers(1, 33)), int(rng.integers(33, 65))])); w = int(rng.choice([25, 25, int(rng.integers(1, 70))]))
     g = random_graph(rng, n_sites=int(rng.integers(3, 40)), n_walks=int(rng.integers(1, 9)), seg_len=(1, int(rng.integers(5, 120))), alt_len=(1, int(rng.integers(2, 40))))
     ctx = phi_amd.Context(0); ctx.set_params(k=k, w=w, threshold=1.0, recombination=5)
     _st = torch.cuda.Stream(); torch.cuda.set_stream(_st)

@@ -9,7 +9,7 @@ rng = np.random.default_rng(int(sys.argv[1])); t_end = time.time() + float(sys.a
 ctx = phi_amd.Context(0)
 n = 0
 while time.time() < t_end:
-    k = int(rng.choice([31, int(rng.integers(1, 33))])); w = int(rng.choice([25, int(rng.integers(1, 257))]))
+    k = int(rng.choice([31, int(rng.integers(1, 33)), int(rng.integers(1, 65))])); w = int(rng.choice([25, int(rng.integers(1, 257))]))   # (k > 32: the byte-wise routine for every window)
     seqs = []
     for _ in range(int(rng.integers(1, 12))):
         L = int(rng.choice([0, 1, k - 1, k, k + w - 2, k + w - 1, k + w, int(rng.integers(1, 6000))]))

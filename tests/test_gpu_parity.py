@@ -36,7 +36,8 @@ def _set_graph(ctx, g):
 
 # --------------------------------------------------------------------------- sketch kernel
 
-@pytest.mark.parametrize("k,w", [(31, 25), (3, 2), (15, 10), (32, 1), (1, 1), (21, 64), (31, 200), (5, 9), (32, 256), (2, 256), (31, 8), (31, 9)])
+@pytest.mark.parametrize("k,w", [(31, 25), (3, 2), (15, 10), (32, 1), (1, 1), (21, 64), (31, 200), (5, 9), (32, 256), (2, 256), (31, 8), (31, 9),
+                                 (33, 25), (40, 7), (47, 1), (48, 16), (63, 30), (64, 256)])
 def test_sketch_random_sequences(oracle, ctx_factory, k, w):
     rng = np.random.default_rng(1000 * k + w)
     ctx = ctx_factory()
@@ -80,7 +81,7 @@ def test_sketch_empty_and_errors(ctx_factory):
     h, p, s = ctx.sketch([b"", b""], 31, 25)
     assert len(h) == 0
     with pytest.raises(phi_amd.PhiError) as e:
-        ctx.sketch([b"ACGT"], 33, 25)
+        ctx.sketch([b"ACGT"], 65, 25)                      # (k <= 64: 33 .. 64 through the byte-wise routine)
     assert e.value.status == phi_amd.PHI_ERR_INVALID
     # the context stays usable after a failed call
     h, p, s = ctx.sketch([b"ACGTACGTAGCTAGCTAGCTAGCATCGATCGATCAGCTAGCTAGCATCGAT"], 5, 3)
@@ -221,6 +222,47 @@ def test_full_path_wide_windows(oracle, ctx_factory, k, w):
     ctx.add_reads(reads[100:])
     st, res, m = _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 6)
     assert res["spectrum_size"] > 50
+
+
+@pytest.mark.parametrize("k,w", [(33, 12), (45, 25), (64, 5)])
+def test_full_path_with_k_above_32(oracle, ctx_factory, k, w):
+    """The reference is string based and takes any k (ILP_index.cpp:388-394).  k-mers of 33 .. 64 bases do not fit the
+    2-bit kernels: graph side and read side take the exact byte-wise routine for every window (MurmurHash3 over up to
+    four 16-byte blocks), the rest of the path is unchanged -- as long as no k-mer covers 32 vertices or more
+    (PHI_ERR_UNSUPPORTED then: the DP's windows hold 31 run lengths).  Reads with lower case and N, batches that
+    start mid-set."""
+    rng = np.random.default_rng(500 * k + w)
+    g = random_graph(rng, n_sites=30, n_walks=5, seg_len=(25, 70), alt_len=(3, 12), p_del=0.1)
+    reads = mosaic_reads(rng, g, n_reads=220, read_len=k + w + 70, n_seg=3, err=0.004)
+    reads[3] = reads[3][:k + w - 2]                       # too short for a window
+    reads[4] = b""
+    reads[5] = reads[5][:40] + b"N" + reads[5][41:]
+    reads[6] = reads[6].lower()
+    ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=6)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads[:90])
+    ctx.add_reads(reads[90:])
+    st, res, m = _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 6)
+    assert res["spectrum_size"] > 50
+    # a second generation of reads on the same context: the slots of the first are emptied although they were never logged
+    ctx.reset_reads()
+    ctx.add_reads(reads[100:])
+    st2 = oracle.run_stage12(g, reads[100:], k, w, 1.0)
+    assert ctx.solve()["spectrum_size"] == len(st2.spectrum)
+
+
+def test_k_above_32_on_one_base_vertices_is_refused(oracle, ctx_factory):
+    """k = 40 on a graph chopped into 1-bp vertices: a k-mer covers 40 vertices, more than the DP's run-length window."""
+    import phi_amd
+    rng = np.random.default_rng(77)
+    g = random_graph(rng, n_sites=40, n_walks=3, seg_len=(1, 1), alt_len=(1, 1), p_del=0.0)
+    reads = mosaic_reads(rng, g, n_reads=60, read_len=70, n_seg=1, err=0.0)
+    ctx = ctx_factory(k=40, w=3, threshold=1.0, recombination=6)
+    _set_graph(ctx, g)
+    ctx.add_reads(reads)
+    with pytest.raises(phi_amd.PhiError) as e:
+        ctx.solve()
+    assert "spans" in str(e.value)
 
 
 def test_dense_spectrum_small_window(oracle, ctx_factory):
