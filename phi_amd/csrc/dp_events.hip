@@ -1335,11 +1335,15 @@ void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A)
 void phi_launch_dp_block_rows(hipStream_t st, const PhiDpEventArgs &A)
 {
     const unsigned grid = (unsigned)A.n_blk * (A.lane_walk ? 65u : (unsigned)(A.n_walks + 1));
-    if (A.blk_ring <= 1024) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 1024, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
+    // (blocks of at most 256 steps: a ring of 256 tops and queues of 8 runs make a task 51 KB of LDS, three per CU
+    //  instead of two -- the consumer wave is latency-bound, so throughput follows the number of resident tasks)
+    if (A.blk_ring <= 256) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 256, 8>), dim3(grid), dim3(64 * 3), 0, st, A);
+    else if (A.blk_ring <= 1024) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 1024, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
     else hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 2048, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
 }
 void phi_launch_dp_block_paths(hipStream_t st, const PhiDpEventArgs &A)
 {
-    if (A.blk_ring <= 1024) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_PATH, 4, 1024, 16>), dim3((unsigned)A.n_blk), dim3(64 * 3), 0, st, A);
+    if (A.blk_ring <= 256) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_PATH, 4, 256, 8>), dim3((unsigned)A.n_blk), dim3(64 * 3), 0, st, A);
+    else if (A.blk_ring <= 1024) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_PATH, 4, 1024, 16>), dim3((unsigned)A.n_blk), dim3(64 * 3), 0, st, A);
     else hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_PATH, 4, 2048, 16>), dim3((unsigned)A.n_blk), dim3(64 * 3), 0, st, A);
 }

@@ -120,8 +120,16 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
     }
     // block length: enough blocks to fill the machine with (walks + 1) tasks each, few enough to keep the chain short;
     // a block is at most as long as its ring of tops: 1024 steps, or 2048 where the longest stretch without a cut needs it
+    // (256-step blocks first: their tasks take 51 instead of 69 KB of LDS, three per CU; their queues hold 8 live runs
+    //  per lane, and a solve that meets more comes back here with blk_no_small set)
     bool placed = false;
-    for (int32_t ring = cls ? 512 : 1024; ring <= (cls ? 512 : PHI_DP_BLOCK_MAX) && !placed; ring *= 2) {
+    const int32_t rings_walk[] = {256, 1024, 2048}, rings_cls[] = {256, 512};
+    const int32_t *rings = cls ? rings_cls : rings_walk;
+    const int n_rings = cls ? 2 : 3;
+    static_assert(PHI_DP_BLOCK_MAX == 2048, "the largest ring of tops");
+    for (int ri = 0; ri < n_rings && !placed; ri++) {
+        const int32_t ring = rings[ri];
+        if (ring == 256 && c->blk_no_small) continue;
         int64_t target = (int64_t)nk * (c->n_walks + 1) / 4096;
         target = std::max<int64_t>(64, std::min<int64_t>(ring / 2, target));
         if (cls) target = 16;
@@ -219,9 +227,16 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("weights + per-run records"); }
         A.lane_stride = c->blk_ls;
         auto keep_whole_chain = [&](uint32_t kerr, uint32_t bit) -> int {
-            if (getenv("PHI_DP_STRICT")) return phi_fail(c, PHI_ERR_DEVICE, "DP blocks given up (kernel flag %u) under PHI_DP_STRICT", bit);   // tests
-            kerr &= ~bit;
+            // (both flags: block tasks that ran on clamped classes may have overflowed their queues as well)
+            kerr &= ~(bit | PHI_KERR_DP_QUEUE | PHI_KERR_DP_CLASSES);
             HIPCHK(hipMemcpy(c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
+            if (bit == PHI_KERR_DP_QUEUE && c->blk_ring <= 256 && !c->blk_no_small) {
+                // more than 8 live runs on a lane of a 256-step block task: the longer blocks have queues of 16
+                c->blk_no_small = true;
+                PHICHK(dp_prepare_blocks(c, n_dp));
+                return run_dp(c, wgt, H, value, segs);
+            }
+            if (getenv("PHI_DP_STRICT")) return phi_fail(c, PHI_ERR_DEVICE, "DP blocks given up (kernel flag %u) under PHI_DP_STRICT", bit);   // tests
             c->dp_blocks = false;
             c->dp_cls = false;
             return run_dp(c, wgt, H, value, segs);
@@ -279,13 +294,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
             HIPCHK(hipMemcpyAsync(&kerr, c->d_scalars.as<uint64_t>() + S_ERR, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             if (tr.on) tr.lap("block rows");
-            if (kerr & PHI_KERR_DP_QUEUE) {
-                // a walk had more live runs than a block task's queue holds: this graph keeps the whole chain
-                kerr &= ~PHI_KERR_DP_QUEUE;
-                HIPCHK(hipMemcpy(c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
-                c->dp_blocks = false;
-                return run_dp(c, wgt, H, value, segs);
-            }
+            if (kerr & PHI_KERR_DP_QUEUE) return keep_whole_chain(kerr, PHI_KERR_DP_QUEUE);   // (more live runs than a block task's queue holds)
             // 2. chain: S_{b+1}[h'] = max(rows of walk starts, max_j S_b[j] + row_j[h'])  (max-plus, NEGK = no run)
             H.S.assign((size_t)nb * 64, PHI_DP_NEGK);
             std::vector<int64_t> cur(64, PHI_DP_NEGK), nxt(64);
@@ -312,12 +321,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
             HIPCHK(hipMemcpyAsync(H.carry.data(), A.blk_carry, H.carry.size() * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipMemcpyAsync(&kerr, c->d_scalars.as<uint64_t>() + S_ERR, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            if (kerr & PHI_KERR_DP_QUEUE) {
-                kerr &= ~PHI_KERR_DP_QUEUE;
-                HIPCHK(hipMemcpy(c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
-                c->dp_blocks = false;
-                return run_dp(c, wgt, H, value, segs);
-            }
+            if (kerr & PHI_KERR_DP_QUEUE) return keep_whole_chain(kerr, PHI_KERR_DP_QUEUE);
             // the two passes must agree on what leaves every block (and so on the chain as a whole)
             for (int32_t b = 0; b + 1 < nb; b++)
                 for (int32_t h = 0; h < nwk; h++) {
@@ -727,6 +731,7 @@ int phi_solve_impl(phi_ctx *c)
         PHICHK(phi_dev_ensure(c, c->d_ent, (size_t)c->n_vtx * 2 * 4));
     }
 
+    c->blk_no_small = false;
     PHICHK(dp_prepare_blocks(c, n_dp));
     tm.lap("DP inputs");
     // ---- 4. exact solve
