@@ -358,3 +358,9 @@ void phi_launch_entry_csr(hipStream_t st, const int32_t *a_e1, int64_t n_a, int6
     hipLaunchKernelGGL(phi_entry_csr_kernel, dim3(grid_for(n_a + 1, 256)), dim3(256), 0, st, a_e1, n_a, n_entries,
                        g_off);
 }
+
+// One empty launch loads this translation unit's code object onto the device: the HIP runtime does that lazily, at the
+// first launch of any of its kernels (0.5-1.3 ms per unit, measured inside phi_set_graph / phi_solve before
+// phi_ctx_create did it up front).
+__global__ void phi_warm_anchors_kernel() {}
+void phi_warm_anchors(hipStream_t st) { hipLaunchKernelGGL(phi_warm_anchors_kernel, dim3(1), dim3(64), 0, st); }

@@ -544,3 +544,9 @@ void phi_launch_entry_len_range(hipStream_t st, const int32_t *walk_vtx, const i
 {
     if (n > 0) hipLaunchKernelGGL(phi_entry_len_range_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, walk_vtx, vlen, e_lo, n, lens);
 }
+
+// One empty launch loads this translation unit's code object onto the device: the HIP runtime does that lazily, at the
+// first launch of any of its kernels (0.5-1.3 ms per unit, measured inside phi_set_graph / phi_solve before
+// phi_ctx_create did it up front).
+__global__ void phi_warm_contexts_kernel() {}
+void phi_warm_contexts(hipStream_t st) { hipLaunchKernelGGL(phi_warm_contexts_kernel, dim3(1), dim3(64), 0, st); }

@@ -350,3 +350,9 @@ int phi_dp_num_waves(int n_walks)
     const int nw = (n_walks + 63) / 64;
     return nw <= 1 ? 1 : nw <= 2 ? 2 : nw <= 4 ? 4 : 8;
 }
+
+// One empty launch loads this translation unit's code object onto the device: the HIP runtime does that lazily, at the
+// first launch of any of its kernels (0.5-1.3 ms per unit, measured inside phi_set_graph / phi_solve before
+// phi_ctx_create did it up front).
+__global__ void phi_warm_dp_kernel() {}
+void phi_warm_dp(hipStream_t st) { hipLaunchKernelGGL(phi_warm_dp_kernel, dim3(1), dim3(64), 0, st); }

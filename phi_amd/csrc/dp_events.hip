@@ -1347,3 +1347,9 @@ void phi_launch_dp_block_paths(hipStream_t st, const PhiDpEventArgs &A)
     else if (A.blk_ring <= 1024) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_PATH, 4, 1024, 16>), dim3((unsigned)A.n_blk), dim3(64 * 3), 0, st, A);
     else hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_PATH, 4, 2048, 16>), dim3((unsigned)A.n_blk), dim3(64 * 3), 0, st, A);
 }
+
+// One empty launch loads this translation unit's code object onto the device: the HIP runtime does that lazily, at the
+// first launch of any of its kernels (0.5-1.3 ms per unit, measured inside phi_set_graph / phi_solve before
+// phi_ctx_create did it up front).
+__global__ void phi_warm_dp_events_kernel() {}
+void phi_warm_dp_events(hipStream_t st) { hipLaunchKernelGGL(phi_warm_dp_events_kernel, dim3(1), dim3(64), 0, st); }

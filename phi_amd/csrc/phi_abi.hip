@@ -61,10 +61,10 @@ int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes)
 
 static void dev_free(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
-template <class T> static int upload(phi_ctx *c, DevBuf &b, const T *src, size_t n)
+template <class T> static int upload(phi_ctx *c, DevBuf &b, const T *src, size_t n, hipStream_t st = nullptr)
 {
     PHICHK(phi_dev_ensure(c, b, (n ? n : 1) * sizeof(T)));
-    if (n) HIPCHK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    if (n) HIPCHK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, st ? st : c->stream));
     return PHI_OK;
 }
 
@@ -186,11 +186,16 @@ int phi_ctx_create(int device_id, phi_ctx **out)
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PHI_ERR_DEVICE; }
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return PHI_ERR_DEVICE; }
     if (phi_dev_ensure(c, c->d_scalars, S_N * 8) || hipMemset(c->d_scalars.p, 0, S_N * 8) != hipSuccess ||
         phi_dev_ensure(c, c->d_stripes, 2 * STRIPE_BYTES) || hipMemset(c->d_stripes.p, 0, 2 * STRIPE_BYTES) != hipSuccess ||
         phi_dev_ensure(c, c->alt.stripes, 2 * STRIPE_BYTES) || hipMemset(c->alt.stripes.p, 0, 2 * STRIPE_BYTES) != hipSuccess) {
-        (void)hipStreamDestroy(c->own_stream); delete c; return PHI_ERR_DEVICE;
+        (void)hipStreamDestroy(c->own_stream); (void)hipStreamDestroy(c->aux_stream); delete c; return PHI_ERR_DEVICE;
     }
+    // the kernels' code objects are loaded lazily, per translation unit, at their first launch: do that here, once
+    phi_warm_sketch(c->stream); phi_warm_table(c->stream); phi_warm_anchors(c->stream); phi_warm_contexts(c->stream);
+    phi_warm_dp(c->stream); phi_warm_dp_events(c->stream); phi_warm_solve_dev(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     // the first pageable host-to-device copy of a process sets up the runtime's staging buffers
     // (several ms): pay that here, once, not inside the first phi_set_graph
     {
@@ -230,6 +235,7 @@ void phi_ctx_destroy(phi_ctx *c)
     for (DevBuf *b : all) dev_free(*b);
     for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     (void)hipStreamDestroy(c->own_stream);
+    (void)hipStreamDestroy(c->aux_stream);
     delete c;
 }
 
@@ -311,6 +317,7 @@ static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_e
     c->h_walk_base.assign(n_walks + 1, 0);
     HIPCHK(hipMemcpyAsync(c->h_walk_base.data() + 1, c->d_list.p, (size_t)n_walks * 8, hipMemcpyDeviceToHost, c->stream));
 
+    tg.lap("[gpu thread]     events, vlen, walk bases");
     // ---- classes: table of context fingerprints, verified entry by entry
     PHICHK(phi_dev_ensure(c, c->d_ent_cls, (size_t)n_entries * 4));
     PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)n_entries));
@@ -325,6 +332,7 @@ static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_e
     // a pangenome has a few contexts per vertex; walks that share nothing have one per entry
     const uint64_t cap_max = pow2_at_least(std::max<uint64_t>(1024, 2 * (uint64_t)n_entries));
     uint64_t cap = std::min(cap_max, pow2_at_least(std::max<uint64_t>(1024, 4 * (uint64_t)n_vtx)));
+    tg.lap("[gpu thread]     entry buffers");
     for (int attempt = 0;; attempt++) {
         PHICHK(phi_dev_ensure(c, t_keys, cap * 8));
         PHICHK(phi_dev_ensure(c, t_rep, cap * 4));
@@ -354,11 +362,13 @@ static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_e
         err &= ~PHI_KERR_FP_COLLISION;
         HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
     }
+    tg.lap("[gpu thread]     table insert + verify");
     for (int32_t h = 0; h < n_walks; h++) c->h_walk_base[h + 1] += c->h_walk_base[h];
     c->walk_bases = c->h_walk_base[n_walks];
     // classes in the order of their representatives (smallest entry): the same on every rank
     PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_entries, c->d_cls_rep, &c->n_cls));
     const int64_t nc = c->n_cls;
+    tg.lap("[gpu thread]     compact representatives");
     PHICHK(phi_dev_ensure(c, c->d_cls_mult, (size_t)nc * 4));
     PHICHK(phi_dev_ensure(c, c->d_cls_left, (size_t)nc));
     PHICHK(phi_dev_ensure(c, c->d_cls_base, (size_t)(nc + 1) * 8));
@@ -472,7 +482,9 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         int64_t ne = walk_off[n_walks];                      // not validated yet: clamp
         ne = ne < 0 ? 0 : (ne > ((int64_t)1 << 31) ? ((int64_t)1 << 31) : ne);
         const size_t want = ((size_t)ne / 4 + 4096) * sizeof(PhiAnchorHost);
-        if (want > c->h_pin_cap) {
+        // (only for graphs whose solve is likely to take the host copy of the anchors: a model of 2^16 anchors or more
+        //  stays on the device, solve_dev.hip, and pinning tens of MB here holds up the other threads' HIP calls)
+        if (want > c->h_pin_cap && ne / 4 < ((int64_t)1 << 16) && !getenv("PHI_PREPIN")) {
             c->h_kept = PhiAnchorSpan{}; c->h_dp = PhiAnchorSpan{}; c->anchors_host = false;
             c->pin_future = std::async(std::launch::async, [c, want]() {
                 (void)hipSetDevice(c->device);
@@ -858,10 +870,12 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             }
             c->h_k_cut_ok[0] = 0; c->h_k_cut_ok[(size_t)c->n_k] = 0;
         }
-        PHICHK(upload(c, c->d_k_rec, k_rec.data(), k_rec.size()));
-        PHICHK(upload(c, c->d_k_in, k_in.data(), k_in.size()));
-        PHICHK(upload(c, c->d_cvtx, cvtx.data(), cvtx.size()));
-        HIPCHK(hipStreamSynchronize(c->stream));              // the vectors above go out of scope
+        // (on a stream of this thread's own: on the context's stream these copies queue behind the GPU thread's
+        //  kernels, and its small device-to-host reads behind them)
+        PHICHK(upload(c, c->d_k_rec, k_rec.data(), k_rec.size(), c->aux_stream));
+        PHICHK(upload(c, c->d_k_in, k_in.data(), k_in.size(), c->aux_stream));
+        PHICHK(upload(c, c->d_cvtx, cvtx.data(), cvtx.size(), c->aux_stream));
+        HIPCHK(hipStreamSynchronize(c->aux_stream));          // the vectors above go out of scope; nobody reads the copies before this
     }
     tm.lap("DP step stream");
     // ---- the GPU side has been running meanwhile

@@ -65,6 +65,7 @@ struct phi_ctx {
     int device = 0;
     PhiComm *comm = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t aux_stream = nullptr;    // the host thread's copies inside phi_set_graph, while the GPU thread works on `stream`
     std::string last_error;
     std::mutex err_mu;                                // guards last_error
 

@@ -5,6 +5,7 @@
 
 #ifndef PHI_TPB
 #define PHI_TPB 256            // lanes per workgroup of the sketch kernel (4 waves)
+
 #endif
 #define PHI_WCH 512            // window positions per wave (each wave sketches its own chunk)
 #define PHI_MAX_W 256
@@ -306,3 +307,12 @@ void phi_launch_dp_event_fill(hipStream_t st, const PhiDpEventArgs &A, const uin
 int phi_dp_num_waves(int n_walks);
 void phi_launch_dp_words(hipStream_t st, const uint8_t *e_out, const int64_t *g_off, const uint8_t *g_span,
                          const uint8_t *a_weight, int64_t n_entries, uint64_t *word);
+
+// code-object warm-up, one per translation unit (phi_ctx_create)
+void phi_warm_sketch(hipStream_t st);
+void phi_warm_table(hipStream_t st);
+void phi_warm_anchors(hipStream_t st);
+void phi_warm_contexts(hipStream_t st);
+void phi_warm_dp(hipStream_t st);
+void phi_warm_dp_events(hipStream_t st);
+void phi_warm_solve_dev(hipStream_t st);

@@ -1199,3 +1199,9 @@ void phi_launch_scan_counts(hipStream_t st, const int32_t *cnt, int64_t n, int64
 {
     hipLaunchKernelGGL(phi_scan_counts_kernel, dim3(1), dim3(1024), 0, st, cnt, n, off);
 }
+
+// One empty launch loads this translation unit's code object onto the device: the HIP runtime does that lazily, at the
+// first launch of any of its kernels (0.5-1.3 ms per unit, measured inside phi_set_graph / phi_solve before
+// phi_ctx_create did it up front).
+__global__ void phi_warm_sketch_kernel() {}
+void phi_warm_sketch(hipStream_t st) { hipLaunchKernelGGL(phi_warm_sketch_kernel, dim3(1), dim3(64), 0, st); }

@@ -188,3 +188,9 @@ void phi_launch_uncovered_slots(hipStream_t st, const uint32_t *slots, int64_t n
 {
     if (n > 0) hipLaunchKernelGGL(phi_uncovered_slots_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, slots, n, cov_all, ctr, out);
 }
+
+// One empty launch loads this translation unit's code object onto the device: the HIP runtime does that lazily, at the
+// first launch of any of its kernels (0.5-1.3 ms per unit, measured inside phi_set_graph / phi_solve before
+// phi_ctx_create did it up front).
+__global__ void phi_warm_solve_dev_kernel() {}
+void phi_warm_solve_dev(hipStream_t st) { hipLaunchKernelGGL(phi_warm_solve_dev_kernel, dim3(1), dim3(64), 0, st); }

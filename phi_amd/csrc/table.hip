@@ -275,3 +275,9 @@ void phi_launch_spectrum_export(hipStream_t st, const uint64_t *sp_keys, int64_t
         hipLaunchKernelGGL(phi_spectrum_export_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, st, sp_keys, cap, out,
                            n_out);
 }
+
+// One empty launch loads this translation unit's code object onto the device: the HIP runtime does that lazily, at the
+// first launch of any of its kernels (0.5-1.3 ms per unit, measured inside phi_set_graph / phi_solve before
+// phi_ctx_create did it up front).
+__global__ void phi_warm_table_kernel() {}
+void phi_warm_table(hipStream_t st) { hipLaunchKernelGGL(phi_warm_table_kernel, dim3(1), dim3(64), 0, st); }
