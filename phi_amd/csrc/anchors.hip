@@ -31,9 +31,9 @@ static inline unsigned grid_for(int64_t n, int tpb)
 // For every walk entry: the index of the graph edge the walk leaves its vertex by (255 = the walk ends
 // here), the number of walks crossing every edge, and (st_mask != null) the walks present on every
 // vertex -- what ILP_index::read_gfa keeps in `paths` / `haps` (ILP_index.cpp:85-113).  err[0] = first
-// failure: 1 empty segment, 2 step without a graph edge, 3 more than 254 out-edges; err[1..3] = walk, u, v.
+// failure: 1 empty segment, 2 step without a graph edge, 3 more than 254 out-edges, 4 vertex out of range; err[1..3] = walk, u, v.
 __global__ void __launch_bounds__(256) phi_walk_edges_kernel(const int32_t *__restrict__ walk_vtx, const int64_t *__restrict__ walk_off,
-                                                             int32_t n_walks, int64_t n_entries, const int64_t *__restrict__ adj_off,
+                                                             int32_t n_walks, int64_t n_entries, int32_t n_vtx, const int64_t *__restrict__ adj_off,
                                                              const int32_t *__restrict__ adj, const int64_t *__restrict__ seq_off,
                                                              const int32_t *__restrict__ topo_rank, uint8_t *__restrict__ e_out,
                                                              int32_t *__restrict__ cnt_edge, unsigned long long *__restrict__ st_mask,
@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256) phi_walk_edges_kernel(const int32_t *__re
         auto fail = [&](int32_t code, int32_t v) {
             if (atomicCAS(&err[0], 0, code) == 0) { err[1] = h; err[2] = u; err[3] = v; }
         };
+        if ((uint32_t)u >= (uint32_t)n_vtx) { fail(4, -1); e_out[e] = 255; continue; }        // (the range check of the walk entries: nothing indexed with u before this)
         if (seq_off[u + 1] == seq_off[u]) { fail(1, -1); e_out[e] = 255; continue; }
         if (st_mask) atomicOr(&st_mask[(size_t)topo_rank[u] * nw64 + (h >> 6)], 1ull << (h & 63));
         if (e + 1 < walk_off[h + 1]) {
@@ -67,13 +68,13 @@ __global__ void __launch_bounds__(256) phi_walk_edges_kernel(const int32_t *__re
     }
 }
 
-void phi_launch_walk_edges(hipStream_t st, const int32_t *walk_vtx, const int64_t *walk_off, int32_t n_walks, int64_t n_entries,
+void phi_launch_walk_edges(hipStream_t st, const int32_t *walk_vtx, const int64_t *walk_off, int32_t n_walks, int64_t n_entries, int32_t n_vtx,
                            const int64_t *adj_off, const int32_t *adj, const int64_t *seq_off, const int32_t *topo_rank,
                            uint8_t *e_out, int32_t *cnt_edge, unsigned long long *st_mask, int32_t nw64, int32_t *err)
 {
     if (n_entries > 0)
         hipLaunchKernelGGL(phi_walk_edges_kernel, dim3(grid_for(n_entries, 256)), dim3(256), 0, st, walk_vtx, walk_off, n_walks,
-                           n_entries, adj_off, adj, seq_off, topo_rank, e_out, cnt_edge, st_mask, nw64, err);
+                           n_entries, n_vtx, adj_off, adj, seq_off, topo_rank, e_out, cnt_edge, st_mask, nw64, err);
 }
 
 // ------------------------------------------------------------------------- minimiser -> anchors (CSR)

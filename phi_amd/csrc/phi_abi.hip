@@ -554,22 +554,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             indeg[v]++;
         }
 
-    // the kernels index with the walk entries: they must be in range before anything is launched
-    {
-        PhiHostError herr;
-        phi_parallel_chunks(n_entries, (int64_t)1 << 18, [&](int64_t lo, int64_t hi, int) {
-            uint32_t bad = 0;
-            for (int64_t e = lo; e < hi; e++) bad |= (uint32_t)walk_vtx[e] >= (uint32_t)n_vtx;
-            if (!bad) return;
-            for (int64_t e = lo; e < hi; e++)
-                if ((uint32_t)walk_vtx[e] >= (uint32_t)n_vtx) {
-                    const int32_t h = (int32_t)(std::upper_bound(walk_off, walk_off + n_walks + 1, e) - walk_off) - 1;
-                    herr.set(PHI_ERR_WALK, "walk %d holds vertex %d out of range", h, walk_vtx[e]);
-                    return;
-                }
-        });
-        if (herr.failed()) return phi_fail(c, herr.code, "%s", herr.msg.c_str());
-    }
+    // (the walk entries are range-checked by the first kernel that reads them: phi_walk_edges_kernel, code 4 below)
     tm.lap("validate graph, copies");
     // ---- the GPU side of the index (uploads, entry offsets, walk sketch, minimiser table) runs on its
     //      own host thread while this one makes the pass over the walk entries below: neither needs
@@ -621,7 +606,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                     PHICHK(phi_dev_ensure(c, c->d_st_mask, (size_t)n_vtx * nw64 * 8));
                     HIPCHK(hipMemsetAsync(c->d_st_mask.p, 0, (size_t)n_vtx * nw64 * 8, c->stream));
                 }
-                phi_launch_walk_edges(c->stream, c->d_walk_vtx.as<int32_t>(), c->d_walk_off.as<int64_t>(), n_walks, n_entries,
+                phi_launch_walk_edges(c->stream, c->d_walk_vtx.as<int32_t>(), c->d_walk_off.as<int64_t>(), n_walks, n_entries, n_vtx,
                                       c->d_adj_off.as<int64_t>(), c->d_adj.as<int32_t>(), c->d_seq_off.as<int64_t>(),
                                       c->d_topo_rank.as<int32_t>(), c->d_e_out.as<uint8_t>(), c->d_cnt_edge.as<int32_t>(),
                                       want_masks ? c->d_st_mask.as<unsigned long long>() : nullptr, nw64, c->d_walk_err.as<int32_t>());
@@ -740,6 +725,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     {
         const int erc = edges_future.get();
         if (erc) return erc;
+        if (walk_err[0] == 4) return phi_fail(c, PHI_ERR_WALK, "walk %d holds vertex %d out of range", walk_err[1], walk_err[2]);
         if (walk_err[0] == 1) return phi_fail(c, PHI_ERR_UNSUPPORTED, "walk %d passes through empty segment %d", walk_err[1], walk_err[2]);
         if (walk_err[0] == 2) return phi_fail(c, PHI_ERR_WALK, "walk %d steps %d->%d without a graph edge", walk_err[1], walk_err[2], walk_err[3]);
         if (walk_err[0] == 3) return phi_fail(c, PHI_ERR_UNSUPPORTED, "vertex %d has more than 254 out-edges", walk_err[2]);
@@ -799,6 +785,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     //      recombination can enter or leave, or a walk starts or ends; in-edges count compact steps back
     c->dp_events = n_walks <= PHI_DP_EVENT_MAX_WALKS && !getenv("PHI_DP_DENSE");
     c->n_k = 0; c->n_ev = 0;
+    std::vector<int32_t> k_rec, k_in, cvtx;                    // (alive until the end of this call: their uploads are not waited for here)
     if (c->dp_events) {
         std::vector<uint8_t> lane_only(n_vtx, 0);
         for (int32_t h = 0; h < n_walks; h++) {
@@ -813,7 +800,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                 c->h_kstep.push_back(s);
             }
         c->n_k = (int32_t)c->h_kstep.size();
-        std::vector<int32_t> k_rec((size_t)c->n_k * 8, 0), k_in, cvtx(n_vtx);
+        k_rec.assign((size_t)c->n_k * 8, 0); k_in.clear(); cvtx.assign(n_vtx, 0);
         for (int32_t k = 0; k < c->n_k; k++) {
             const int32_t s = c->h_kstep[k];
             const int32_t *ro = &st_rec[(size_t)s * 8];
@@ -870,12 +857,13 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             }
             c->h_k_cut_ok[0] = 0; c->h_k_cut_ok[(size_t)c->n_k] = 0;
         }
-        // (on a stream of this thread's own: on the context's stream these copies queue behind the GPU thread's
-        //  kernels, and its small device-to-host reads behind them)
-        PHICHK(upload(c, c->d_k_rec, k_rec.data(), k_rec.size(), c->aux_stream));
-        PHICHK(upload(c, c->d_k_in, k_in.data(), k_in.size(), c->aux_stream));
-        PHICHK(upload(c, c->d_cvtx, cvtx.data(), cvtx.size(), c->aux_stream));
-        HIPCHK(hipStreamSynchronize(c->aux_stream));          // the vectors above go out of scope; nobody reads the copies before this
+        // (tried on a stream of this thread's own, so that these copies do not queue behind the GPU thread's kernels:
+        //  0.8 ms slower -- the pageable copies of a second stream do not share the first one's staging)
+        PHICHK(upload(c, c->d_k_rec, k_rec.data(), k_rec.size()));
+        PHICHK(upload(c, c->d_k_in, k_in.data(), k_in.size()));
+        PHICHK(upload(c, c->d_cvtx, cvtx.data(), cvtx.size()));
+        // (no wait: a synchronisation here would also wait for whatever the GPU thread has queued on the stream; the
+        //  vectors live until phi_sync_check at the end of this call)
     }
     tm.lap("DP step stream");
     // ---- the GPU side has been running meanwhile

@@ -155,7 +155,7 @@ void phi_launch_entry_len_range(hipStream_t st, const int32_t *walk_vtx, const i
 // anchors.hip
 #define PHI_KERR_FP_COLLISION 8u   // two different vertex lists share a fingerprint: reseed
 // walk entries -> out-edge index per entry, walks per edge, walks per vertex (see anchors.hip)
-void phi_launch_walk_edges(hipStream_t st, const int32_t *walk_vtx, const int64_t *walk_off, int32_t n_walks, int64_t n_entries,
+void phi_launch_walk_edges(hipStream_t st, const int32_t *walk_vtx, const int64_t *walk_off, int32_t n_walks, int64_t n_entries, int32_t n_vtx,
                            const int64_t *adj_off, const int32_t *adj, const int64_t *seq_off, const int32_t *topo_rank,
                            uint8_t *e_out, int32_t *cnt_edge, unsigned long long *st_mask, int32_t nw64, int32_t *err);
 // CSR minimiser id -> anchor indices of a triple list (id, e0, e1): cnt / cur zeroed by the caller, off from a scan of cnt

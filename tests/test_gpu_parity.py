@@ -793,6 +793,13 @@ def test_bad_inputs(oracle, ctx_factory):
     with pytest.raises(phi_amd.PhiError) as e:
         ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], wv, A["top_rank"])
     assert e.value.status == phi_amd.PHI_ERR_WALK
+    # a walk entry that names no vertex (checked by the first kernel that reads the walks), at either end of the range
+    for bad in (len(A["seq_off"]) - 1, 10 ** 6, -1):
+        wv = A["walk_vtx"].copy()
+        wv[3] = bad
+        with pytest.raises(phi_amd.PhiError) as e:
+            ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], wv, A["top_rank"])
+        assert e.value.status == phi_amd.PHI_ERR_WALK and "out of range" in str(e.value)
     # a rank array that is not a topological order
     tr = A["top_rank"].copy()
     tr[[0, 7]] = tr[[7, 0]]
