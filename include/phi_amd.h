@@ -49,7 +49,9 @@ const char *phi_strerror(int status);
 /* Human-readable detail of the last failure on this context ("" if none). */
 const char *phi_last_error(const phi_ctx *ctx);
 
-/* ILP_index::ILP_index(gfa_t*) (ILP_index.cpp:4-6).  device_id = HIP device ordinal. */
+/* ILP_index::ILP_index(gfa_t*) (ILP_index.cpp:4-6).  device_id = HIP device ordinal.  Also pays the one-time costs of the
+ * HIP runtime on this device (code objects of the kernels, staging of the first host copy: ~10 ms) so that they do not
+ * fall into the first phi_set_graph / phi_solve: create the context while the graph file is being parsed. */
 int phi_ctx_create(int device_id, phi_ctx **out);
 void phi_ctx_destroy(phi_ctx *ctx);
 
@@ -65,7 +67,7 @@ int phi_set_stream(phi_ctx *ctx, void *hip_stream);
 #define PHI_FLAG_MIXED 2u      /* -m1 (main.cpp:62): accepted; integral optimum of equal value exists */
 
 /* main.cpp:118-131: k_mer, window, threshold, recombination, is_qclp/is_mixed.
- * k in [1,32], w in [1,256].  Must precede phi_set_graph. */
+ * k in [1,64] (33 .. 64: exact but slow, see the limits above), w in [1,256].  Must precede phi_set_graph. */
 int phi_set_params(phi_ctx *ctx, int32_t k, int32_t w, float threshold, int32_t recombination,
                    uint32_t flags);
 
