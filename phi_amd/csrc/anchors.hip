@@ -261,17 +261,17 @@ __global__ void __launch_bounds__(256) phi_group_max_kernel(PhiFilterArgs A, int
 {
     GRID_STRIDE(j, n_matched) {
         const int32_t r = A.m_rec[j];
-        const uint32_t slot = A.rec_slot[r];
-        atomicMax(&A.slot_maxcnt[slot], A.g_cnt[A.m_group[j]]);
-        if (A.rec_e1[r] > A.rec_e0[r]) A.slot_multi[slot] = 1;
+        const uint32_t id = A.u_uid[A.rec_slot[r]];          // (per dense id, not per slot of the 8x table: 30x smaller arrays)
+        atomicMax(&A.slot_maxcnt[id], A.g_cnt[A.m_group[j]]);
+        if (A.rec_e1[r] > A.rec_e0[r]) A.slot_multi[id] = 1;
     }
 }
 
-// pass 4: filtered / in-model counters over the table (ILP_index.cpp:698, :711, :822/:868)
-__global__ void __launch_bounds__(256) phi_slot_count_kernel(PhiFilterArgs A, int64_t u_cap)
+// pass 4: filtered / in-model counters over the distinct minimisers (ILP_index.cpp:698, :711, :822/:868)
+__global__ void __launch_bounds__(256) phi_slot_count_kernel(PhiFilterArgs A, int64_t n_ids)
 {
     int n_filtered = 0, n_model = 0;
-    GRID_STRIDE(s, u_cap) {
+    GRID_STRIDE(s, n_ids) {
         const uint32_t c = A.slot_maxcnt[s];
         if (c == 0) continue;                               // no anchor for this minimiser
         if ((float)c >= A.limit) n_filtered++;
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) phi_kept_flags_kernel(PhiFilterArgs A, in
 {
     GRID_STRIDE(j, n_matched) {
         const int32_t r = A.m_rec[j];
-        const bool keep = !((float)A.slot_maxcnt[A.rec_slot[r]] >= A.limit);
+        const bool keep = !((float)A.slot_maxcnt[A.u_uid[A.rec_slot[r]]] >= A.limit);
         kept[j] = keep;
         dp[j] = keep && A.rec_e1[r] > A.rec_e0[r];
     }

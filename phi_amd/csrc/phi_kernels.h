@@ -176,8 +176,9 @@ struct PhiFilterArgs {
     const int32_t *m_rec;                          // matched records (ascending)
     uint64_t *g_keys; int32_t *g_rep; uint32_t *g_cnt; uint64_t g_mask; uint64_t seed;   // group table
     int32_t *m_group;                              // group slot of each matched anchor
-    uint32_t *slot_maxcnt;                         // per minimiser-table slot: largest group
-    uint8_t *slot_multi;                           // per slot: has an anchor spanning >= 2 vertices
+    const uint32_t *u_uid;                         // minimiser-table slot -> dense minimiser id
+    uint32_t *slot_maxcnt;                         // per dense minimiser id: largest group
+    uint8_t *slot_multi;                           // per id: has an anchor spanning >= 2 vertices
     float limit;                                   // threshold * num_walks (ILP_index.cpp:698)
     unsigned long long *counters;                  // [0] filtered  [1] in model
     uint32_t *err;

@@ -508,11 +508,13 @@ int phi_solve_impl(phi_ctx *c)
     PHICHK(phi_dev_ensure(c, c->d_g_rep, g_cap * 4));
     PHICHK(phi_dev_ensure(c, c->d_g_cnt, g_cap * 4));
     PHICHK(phi_dev_ensure(c, c->d_m_group, (size_t)std::max<int64_t>(n_matched, 1) * 4));
-    PHICHK(phi_dev_ensure(c, c->d_slot_maxcnt, c->u_cap * 4));
-    PHICHK(phi_dev_ensure(c, c->d_slot_multi, c->u_cap));
+    const size_t n_slot_ids = (size_t)std::max<int64_t>(c->n_unique, 1);
+    PHICHK(phi_dev_ensure(c, c->d_slot_maxcnt, n_slot_ids * 4));
+    PHICHK(phi_dev_ensure(c, c->d_slot_multi, n_slot_ids));
     F.g_keys = c->d_g_keys.as<uint64_t>(); F.g_rep = c->d_g_rep.as<int32_t>(); F.g_cnt = c->d_g_cnt.as<uint32_t>();
     F.g_mask = g_cap - 1;
     F.m_group = c->d_m_group.as<int32_t>();
+    F.u_uid = c->d_u_uid.as<uint32_t>();
     F.slot_maxcnt = c->d_slot_maxcnt.as<uint32_t>(); F.slot_multi = c->d_slot_multi.as<uint8_t>();
     F.limit = c->threshold * (float)(uint32_t)nw;              // threshold * num_walks, float (:698)
     F.counters = (unsigned long long *)scalar(c, S_FILTERED);
@@ -532,11 +534,11 @@ int phi_solve_impl(phi_ctx *c)
         if (attempt == 7) return phi_fail(c, PHI_ERR_DEVICE, "anchor fingerprints collide under 8 seeds (internal error)");
         HIPCHK(hipMemset(scalar(c, S_ERR), 0, 4));
     }
-    HIPCHK(hipMemsetAsync(F.slot_maxcnt, 0, c->u_cap * 4, c->stream));
-    HIPCHK(hipMemsetAsync(F.slot_multi, 0, c->u_cap, c->stream));
+    HIPCHK(hipMemsetAsync(F.slot_maxcnt, 0, n_slot_ids * 4, c->stream));
+    HIPCHK(hipMemsetAsync(F.slot_multi, 0, n_slot_ids, c->stream));
     HIPCHK(hipMemsetAsync(scalar(c, S_FILTERED), 0, 16, c->stream));
     phi_launch_group_max(c->stream, F, n_matched);
-    phi_launch_slot_count(c->stream, F, (int64_t)c->u_cap);
+    phi_launch_slot_count(c->stream, F, c->n_unique);
     PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)std::max<int64_t>(std::max(n_matched, n_rec), 1)));
     PHICHK(phi_dev_ensure(c, c->d_flags2, (size_t)std::max<int64_t>(n_matched, 1)));
     phi_launch_kept_flags(c->stream, F, n_matched, c->d_flags.as<uint8_t>(), c->d_flags2.as<uint8_t>());
