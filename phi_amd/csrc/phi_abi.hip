@@ -700,23 +700,14 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     std::future<int> gpu_future = std::async(std::launch::async, gpu_part);
     // every early return below must first wait for that thread
     struct Joiner { std::future<int> &f; ~Joiner() { if (f.valid()) f.wait(); } } joiner{gpu_future};
-    // ---- host copies of the graph and its reverse adjacency, while the GPU thread uploads
+    // ---- host copies of the graph, while the GPU thread uploads
     c->h_seq.assign(seq_concat, seq_concat + seq_off[n_vtx]);
     c->h_seq_off.assign(seq_off, seq_off + n_vtx + 1);
     c->h_adj_off.assign(adj_off, adj_off + n_vtx + 1);
     c->h_adj.assign(adj, adj + n_edges);
     c->h_walk_off.assign(walk_off, walk_off + n_walks + 1);
     c->h_topo_rank.assign(topo_rank, topo_rank + n_vtx);
-    // reverse adjacency
-    c->h_in_off.assign(n_vtx + 1, 0);
-    for (int32_t v = 0; v < n_vtx; v++) c->h_in_off[v + 1] = c->h_in_off[v] + indeg[v];
-    c->h_in_src.resize(n_edges);
-    {
-        std::vector<int64_t> cur(c->h_in_off.begin(), c->h_in_off.end() - 1);
-        for (int32_t u = 0; u < n_vtx; u++)
-            for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) c->h_in_src[cur[adj[x]]++] = u;
-    }
-    tm.lap("host copies, reverse adjacency");
+    tm.lap("host copies");
     // ---- one parallel pass over the walk entries (host threads over fixed chunks of entries):
     //   * walks follow edges of forward vertices (ILP_index.cpp:104-107 exits on reverse strand; an
     //     edge-less step would make the anchor's edge variables unconstrained, :799-815)

@@ -79,8 +79,8 @@ struct phi_ctx {
     bool have_graph = false;
     int32_t n_vtx = 0, n_walks = 0;
     std::vector<char> h_seq;
-    std::vector<int64_t> h_seq_off, h_adj_off, h_walk_off, h_walk_base, h_in_off;   // h_walk_base: flat base offset of each walk
-    std::vector<int32_t> h_adj, h_topo_rank, h_topo, h_in_src;
+    std::vector<int64_t> h_seq_off, h_adj_off, h_walk_off, h_walk_base;   // h_walk_base: flat base offset of each walk
+    std::vector<int32_t> h_adj, h_topo_rank, h_topo;
     PhiRawBuf<int32_t> h_walk_vtx;                    // host copy of the walk entries
     int64_t n_entries = 0, walk_bases = 0;
 
