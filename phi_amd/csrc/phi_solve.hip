@@ -1039,18 +1039,23 @@ int phi_solve_impl(phi_ctx *c)
 
     tm.lap("DP runs + certificate");
     // ---- 5. decode (:1431-1525)
-    c->h_path_vtx.clear();
-    c->h_path_hap.clear();
+    int64_t n_path_vtx = 0;
+    for (const Seg &s : best_segs) n_path_vtx += (int64_t)s.ee - s.es + 1;
+    c->h_path_vtx.resize((size_t)n_path_vtx);
+    c->h_path_hap.resize((size_t)n_path_vtx);
     int64_t hap_len = 0;
-    for (const Seg &s : best_segs)
-        for (int32_t e = s.es; e <= s.ee; e++) {
-            const int32_t v = c->h_walk_vtx[e];
-            c->h_path_vtx.push_back(v);
-            c->h_path_hap.push_back(s.h);
-            hap_len += c->h_seq_off[v + 1] - c->h_seq_off[v];
+    {
+        int64_t o = 0;
+        for (const Seg &s : best_segs) {
+            memcpy(c->h_path_vtx.data() + o, c->h_walk_vtx.data() + s.es, (size_t)(s.ee - s.es + 1) * 4);
+            std::fill(c->h_path_hap.begin() + o, c->h_path_hap.begin() + o + (s.ee - s.es + 1), s.h);
+            for (int32_t e = s.es; e <= s.ee; e++) { const int32_t v = c->h_walk_vtx[e]; hap_len += c->h_seq_off[v + 1] - c->h_seq_off[v]; }
+            o += (int64_t)s.ee - s.es + 1;
         }
+    }
+    // adjacent label changes (:1517-1519): the labels change exactly between the path's stretches
     int32_t recomb = 0;
-    for (size_t i = 1; i < c->h_path_hap.size(); i++) recomb += c->h_path_hap[i] != c->h_path_hap[i - 1];   // :1517-1519
+    for (size_t i = 1; i < best_segs.size(); i++) recomb += best_segs[i].h != best_segs[i - 1].h;
     const int64_t n_cov = best_cov;                            // minimisers covered by the best path (counted when it was found)
 
     phi_result &R = c->result;
