@@ -39,21 +39,14 @@ int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_
     *n_out = 0;
     const int64_t nb = phi_compact_num_blocks(n);
     if (nb == 0) return PHI_OK;
-    static const bool trace = getenv("PHI_TIMING_COMPACT") != nullptr;
-    PhiStageTimer tc("compact");
-    tc.on = trace;
     PHICHK(phi_dev_ensure(c, c->d_blk_cnt, (size_t)nb * 4));
     PHICHK(phi_dev_ensure(c, c->d_blk_off, (size_t)(nb + 1) * 8));
-    if (trace) tc.lap("ensure");
     phi_launch_flag_count(c->stream, flags, n, c->d_blk_cnt.as<int32_t>());
     PHICHK(phi_scan_counts_wide(c, c->d_blk_cnt.as<int32_t>(), nb, c->d_blk_off.as<int64_t>()));
-    if (trace) tc.lap("launches");
     int64_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, c->d_blk_off.as<int64_t>() + nb, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (trace) tc.lap("D2H + sync");
     PHICHK(phi_dev_ensure(c, out, (size_t)std::max<int64_t>(total, 1) * 4));
-    if (trace) tc.lap("ensure out");
     phi_launch_flag_write(c->stream, flags, n, c->d_blk_off.as<int64_t>(), out.as<int32_t>());
     *n_out = total;
     return PHI_OK;
