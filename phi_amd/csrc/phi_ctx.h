@@ -159,6 +159,7 @@ struct phi_ctx {
     DevBuf d_blk_lo, d_blk_ev, d_blk_S, d_row_out, d_rowend, d_blk_keys, d_blk_carry, d_cov, d_cov2, d_stepdiff;
     // more than 64 walks: the blocks' rows run on class lanes (dp_events.hip), regrouped per DP run
     bool dp_cls = false;
+    int32_t blk_cls_target = 16;        // class-lane blocks: steps per block aimed at (halved when a block holds more than 64 classes)
     bool blk_no_small = false;          // this solve met a block task with more than 8 live runs on a lane: no 256-step blocks
     int32_t blk_ls = 64;                // row length of the per-(block, walk) tables
     DevBuf d_lane_walk, d_walk_lane, d_coff, d_blk_ncls, d_rownew, d_blk_bad;

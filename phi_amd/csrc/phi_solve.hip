@@ -132,7 +132,7 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
         if (ring == 256 && c->blk_no_small) continue;
         int64_t target = (int64_t)nk * (c->n_walks + 1) / 4096;
         target = std::max<int64_t>(64, std::min<int64_t>(ring / 2, target));
-        if (cls) target = 16;
+        if (cls) target = c->blk_cls_target;
         if (const char *e = getenv("PHI_DP_BLOCK_STEPS")) target = std::max(1, std::min(ring, atoi(e)));   // tests: many small blocks
         c->h_blk_lo.assign(1, 0);
         bool ok = true;
@@ -230,6 +230,13 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
             // (both flags: block tasks that ran on clamped classes may have overflowed their queues as well)
             kerr &= ~(bit | PHI_KERR_DP_QUEUE | PHI_KERR_DP_CLASSES);
             HIPCHK(hipMemcpy(c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
+            if (bit == PHI_KERR_DP_CLASSES && c->blk_cls_target > 2 && !getenv("PHI_DP_BLOCK_STEPS")) {
+                // a block with more than 64 classes of walks (denser variation than the block length was chosen for):
+                // shorter blocks hold fewer sites; only below two steps per block does the whole chain take over
+                c->blk_cls_target /= 2;
+                PHICHK(dp_prepare_blocks(c, n_dp));
+                return run_dp(c, wgt, H, value, segs);
+            }
             if (bit == PHI_KERR_DP_QUEUE && c->blk_ring <= 256 && !c->blk_no_small) {
                 // more than 8 live runs on a lane of a 256-step block task: the longer blocks have queues of 16
                 c->blk_no_small = true;
@@ -734,6 +741,7 @@ int phi_solve_impl(phi_ctx *c)
     }
 
     c->blk_no_small = false;
+    c->blk_cls_target = 16;
     PHICHK(dp_prepare_blocks(c, n_dp));
     tm.lap("DP inputs");
     // ---- 4. exact solve
