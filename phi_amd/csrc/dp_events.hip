@@ -102,8 +102,9 @@ __global__ void __launch_bounds__(256) phi_scan_blocksum_kernel(const int32_t *_
     if (threadIdx.x == 0) blk[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-__global__ void __launch_bounds__(256) phi_scan_apply_kernel(const int32_t *__restrict__ cnt, int64_t n,
-                                                             const int64_t *__restrict__ blk_off, int32_t *__restrict__ off)
+// (off may be cnt itself: a thread reads its four counts before it writes its four sums, and nobody else's)
+__global__ void __launch_bounds__(256) phi_scan_apply_kernel(const int32_t *cnt, int64_t n,
+                                                             const int64_t *__restrict__ blk_off, int32_t *off)
 {
     __shared__ int s_w[4];
     const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;

@@ -230,7 +230,7 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_bstart, &c->d_k_rec, &c->d_k_in, &c->d_cvtx, &c->d_ev_e, &c->d_ev_off, &c->d_ev,
-                     &c->d_cnt_end, &c->d_cnt_start, &c->d_off_end, &c->d_off_start, &c->d_scan_blk, &c->d_scan_blk64, &c->d_scan_blkoff, &c->d_top,
+                     &c->d_off_end, &c->d_off_start, &c->d_scan_blk, &c->d_scan_blk64, &c->d_scan_blkoff, &c->d_top,
                      &c->d_ent};
     for (DevBuf *b : all) dev_free(*b);
     for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -503,7 +503,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         if (walk_off[h + 1] <= walk_off[h]) return phi_fail(c, PHI_ERR_INVALID, "walk %d is empty", h);
     const int64_t n_edges = adj_off[n_vtx], n_entries = walk_off[n_walks];
     if (n_entries >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk entries");
-    // The DP's per-entry buffers of a chromosome-scale graph (7 x 4-8 bytes per walk entry: 37 GB at 1.3 G entries) are
+    // The DP's per-entry buffers of a chromosome-scale graph (5 x 4-8 bytes per walk entry: 26 GB at 1.3 G entries) are
     // allocated now, on a thread of their own: the driver clears device memory as it hands it out (tens of GB/s), which
     // otherwise shows up as half a second at the start of phi_solve.  Joined before this call returns.
     if (c->dp_alloc_future.valid()) (void)c->dp_alloc_future.get();
@@ -514,8 +514,6 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             PHICHK(phi_dev_ensure(c, c->d_g_off, (ne + 1) * 8));
             PHICHK(phi_dev_ensure(c, c->d_dmax, ne * 4));
             PHICHK(phi_dev_ensure(c, c->d_bstart, ne * 4));
-            PHICHK(phi_dev_ensure(c, c->d_cnt_end, (ne + 1) * 4));
-            PHICHK(phi_dev_ensure(c, c->d_cnt_start, (ne + 1) * 4));
             PHICHK(phi_dev_ensure(c, c->d_off_end, (ne + 3) * 4));
             PHICHK(phi_dev_ensure(c, c->d_off_start, (ne + 3) * 4));
             return PHI_OK;

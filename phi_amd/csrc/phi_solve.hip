@@ -201,13 +201,15 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
     int32_t *d_ent_src = c->d_ent.as<int32_t>(), *d_ent_h = c->d_ent.as<int32_t>() + n_ent;
     if (events) {
         // per run: anchors ending / starting per entry -> prefix sums -> one record per event
-        HIPCHK(hipMemsetAsync(c->d_cnt_end.p, 0, (size_t)ne * 4, c->stream));
-        HIPCHK(hipMemsetAsync(c->d_cnt_start.p, 0, (size_t)ne * 4, c->stream));
+        // (counted into the buffers that then hold the prefix sums: the scan works in place, and at chromosome scale every
+        //  array of this size is 5 GB)
+        HIPCHK(hipMemsetAsync(c->d_off_end.p, 0, (size_t)(ne + 1) * 4, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_off_start.p, 0, (size_t)(ne + 1) * 4, c->stream));
         phi_launch_dp_counts(c->stream, c->d_a_e1.as<int32_t>(), c->d_g_span.as<uint8_t>(), c->d_a_weight.as<uint8_t>(), n_dp,
-                             c->d_cnt_end.as<int32_t>(), c->d_cnt_start.as<int32_t>());
-        phi_launch_scan_i32(c->stream, c->d_cnt_end.as<int32_t>(), ne, c->d_off_end.as<int32_t>(), c->d_scan_blk.as<int32_t>(),
+                             c->d_off_end.as<int32_t>(), c->d_off_start.as<int32_t>());
+        phi_launch_scan_i32(c->stream, c->d_off_end.as<int32_t>(), ne, c->d_off_end.as<int32_t>(), c->d_scan_blk.as<int32_t>(),
                             c->d_scan_blkoff.as<int64_t>());
-        phi_launch_scan_i32(c->stream, c->d_cnt_start.as<int32_t>(), ne, c->d_off_start.as<int32_t>(), c->d_scan_blk.as<int32_t>(),
+        phi_launch_scan_i32(c->stream, c->d_off_start.as<int32_t>(), ne, c->d_off_start.as<int32_t>(), c->d_scan_blk.as<int32_t>(),
                             c->d_scan_blkoff.as<int64_t>());
         PhiDpEventArgs A{};
         A.n_k = c->n_k; A.n_walks = c->n_walks; A.n_ev = c->n_ev;
@@ -727,8 +729,6 @@ int phi_solve_impl(phi_ctx *c)
         PHICHK(phi_dev_ensure(c, c->d_bstart, (size_t)c->n_entries * 4));
         if (c->dp_events) {
             const int64_t ne1 = c->n_entries + 1;
-            PHICHK(phi_dev_ensure(c, c->d_cnt_end, (size_t)ne1 * 4));
-            PHICHK(phi_dev_ensure(c, c->d_cnt_start, (size_t)ne1 * 4));
             PHICHK(phi_dev_ensure(c, c->d_off_end, (size_t)(ne1 + 2) * 4));      // (+2: also the scratch of dp_prepare_blocks)
             PHICHK(phi_dev_ensure(c, c->d_off_start, (size_t)(ne1 + 2) * 4));
             const int64_t nb = phi_scan_i32_num_blocks(c->n_entries);
