@@ -1337,8 +1337,11 @@ void phi_launch_dp_block_rows(hipStream_t st, const PhiDpEventArgs &A)
 {
     const unsigned grid = (unsigned)A.n_blk * (A.lane_walk ? 65u : (unsigned)(A.n_walks + 1));
     // (blocks of at most 256 steps: a ring of 256 tops and queues of 8 runs make a task 51 KB of LDS, three per CU
-    //  instead of two -- the consumer wave is latency-bound, so throughput follows the number of resident tasks)
-    if (A.blk_ring <= 256) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 256, 8>), dim3(grid), dim3(64 * 3), 0, st, A);
+    //  instead of two -- the consumer wave is latency-bound, so throughput follows the number of resident tasks;
+    //  the second pass keeps this layout, the rows go one step further:)
+    // (a period of two steps instead of four halves the event ring and the result ring: 35 KB, FOUR tasks per CU; the extra
+    //  barriers cost the consumer less than the fourth task gains -- C2 rows 2.8 -> 2.3 ms with their copy to the host)
+    if (A.blk_ring <= 256) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 2, 256, 8>), dim3(grid), dim3(64 * 3), 0, st, A);
     else if (A.blk_ring <= 1024) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 1024, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
     else hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 2048, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
 }
