@@ -93,6 +93,35 @@ int phi_add_reads(phi_ctx *ctx, const char *bases, const int64_t *read_off, int6
 /* Same, with both arrays already resident in this GPU's HBM (n_bases = read_off[n_reads]). */
 int phi_add_reads_device(phi_ctx *ctx, const void *d_bases, const void *d_read_off, int64_t n_reads,
                          int64_t n_bases);
+/*
+ * The same stage fed with the reads file's TEXT (FASTA or FASTQ, already inflated), in pieces of any size in file order:
+ * the records are found on the device (kseq's rules, src/kseq.h:192-233, ILP_index.cpp:313-328, for the two regular
+ * layouts: FASTQ with four lines per record; FASTA, wrapped or not) instead of by a byte-at-a-time state machine on one
+ * host core, and piece i + 1 crosses the link while piece i is sketched.
+ *   phi_reads_text_begin   start a stream; max_chunk_bytes sizes the device buffers (a longer piece is cut)
+ *   phi_add_reads_text     the next bytes of the stream.  The device takes the whole records it finds and keeps the
+ *                          unfinished rest for the next call.  *irregular = 1: the text is not laid out in one of the
+ *                          two regular ways (carriage returns, a wrapped FASTQ record, text before the first header,
+ *                          a record longer than the buffers ...): nothing more is taken, further calls fail with
+ *                          PHI_ERR_STATE, and the caller finishes the stream on the exact host reader (phi_host.h)
+ *   phi_reads_text_end     ends the stream and hands back the bytes handed over but NOT taken (valid until the next
+ *                          phi_reads_text_begin) -- after an irregular piece: everything from the first byte not taken
+ *                          to the end of that call's bytes; at the end of a regular file: the last record, whose end
+ *                          only the end of the file shows -- to be parsed by the host reader and added with
+ *                          phi_add_reads; *n_taken = bytes of the stream taken as whole records.
+ * Together the device-side records and the host-parsed rest are exactly kseq's records of the file.
+ */
+int phi_reads_text_begin(phi_ctx *ctx, int64_t max_chunk_bytes);
+int phi_add_reads_text(phi_ctx *ctx, const char *text, int64_t n_bytes, int32_t *irregular);
+int phi_reads_text_end(phi_ctx *ctx, const char **pending, int64_t *n_pending, int64_t *n_taken);
+/* Introspection for the parity tests: the records the device took from the LAST piece handed to phi_add_reads_text (their
+ * bases back to back and their offsets, off[0] = 0), copied to the host.  Sizes only when the buffers are too small. */
+int phi_reads_text_last_batch(phi_ctx *ctx, char *bases, int64_t cap_bases, int64_t *off, int64_t cap_reads, int64_t *n_reads,
+                              int64_t *n_bases);
+/* For a stream whose chunks go to SEVERAL contexts in turn (one per GPU): hands out the bytes this context holds
+ * unfinished (valid until its next phi_add_reads_text) and forgets them, so that the caller can put them in front of the
+ * next chunk on whichever context takes it.  Does not wait for the sketch of the records already taken. */
+int phi_reads_text_detach_carry(phi_ctx *ctx, const char **bytes, int64_t *n);
 /* Forget all reads seen so far (graph index is kept).  The clearing itself may be folded into the
  * next batch's first launch; every call on this context that observes the spectrum, the counters
  * or the hit vector sees the reads forgotten.  A hit-vector pointer obtained earlier from

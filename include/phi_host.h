@@ -68,6 +68,21 @@ int64_t phi_reads_stream_reads(const phi_reads_stream *s);  /* records / bases r
 int64_t phi_reads_stream_bases(const phi_reads_stream *s);
 void phi_reads_stream_close(phi_reads_stream *s);
 
+/* The same records from text that is already in memory followed by blocks a callback hands over: the way to finish, on
+ * this exact state machine, a stream whose beginning the device has taken (phi_add_reads_text, phi_amd.h).  next returns
+ * the length of the next block and its address (valid until the next call), 0 at the end, negative on error; it may be NULL. */
+typedef int64_t (*phi_text_block_fn)(void *user, const char **block);
+int phi_reads_stream_open_blocks(const char *prefix, int64_t n_prefix, phi_text_block_fn next, void *user, phi_reads_stream **out,
+                                 char *err, int err_cap);
+
+/* The (inflated) text of a reads file as it is -- no parsing on the host: the bytes go to phi_add_reads_text, which finds the
+ * records on the device.  phi_text_stream_read fills buf with the next bytes (plain files: several preads at once, so that
+ * a pinned buffer fills at more than one core's copy rate) and returns their number: 0 at the end, negative on error. */
+typedef struct phi_text_stream phi_text_stream;
+int phi_text_stream_open(const char *path, phi_text_stream **out, char *err, int err_cap);
+int64_t phi_text_stream_read(phi_text_stream *s, char *buf, int64_t cap, char *err, int err_cap);
+void phi_text_stream_close(phi_text_stream *s);
+
 /* Record id of the output: basename(gfa) minus extension + "_" + basename(reads), minus the last
  * extension of the whole string.  Returns the length or -1 if cap is too small. */
 int phi_hap_name(const char *gfa_path, const char *reads_path, char *out, int cap);

@@ -23,6 +23,7 @@ SYMBOLS = [
     "phi_sketch", "phi_walk_minimizers", "phi_walk_sharing", "phi_kept_anchors", "phi_prof_enable", "phi_prof_read",
     "phi_host_register", "phi_host_unregister", "phi_set_solve_budget",
     "phi_index_stats", "phi_solve_stats", "phi_comm_unique_id", "phi_comm_init", "phi_comm_info", "phi_comm_allreduce_hits", "phi_comm_exchange", "phi_comm_destroy",
+    "phi_reads_text_begin", "phi_add_reads_text", "phi_reads_text_end", "phi_reads_text_detach_carry", "phi_reads_text_last_batch",
 ]
 
 
@@ -73,6 +74,11 @@ def load():
     L.phi_add_reads.argtypes = [vp, vp, vp, i64]
     L.phi_add_reads_device.argtypes = [vp, vp, vp, i64, i64]
     L.phi_reset_reads.argtypes = [vp]
+    L.phi_reads_text_begin.argtypes = [vp, i64]
+    L.phi_add_reads_text.argtypes = [vp, vp, i64, C.POINTER(i32)]
+    L.phi_reads_text_end.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
+    L.phi_reads_text_detach_carry.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.phi_reads_text_last_batch.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.phi_reads_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.phi_hits_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.phi_spectrum_export.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]

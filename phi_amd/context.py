@@ -94,6 +94,37 @@ class Context:
             concat = np.frombuffer(b"".join(seqs), np.uint8)
         self._chk(self._L.phi_add_reads(self._h, _ptr(concat), _ptr(off), len(off) - 1))
 
+    def reads_text_begin(self, max_chunk_bytes=64 << 20):
+        self._chk(self._L.phi_reads_text_begin(self._h, max_chunk_bytes))
+
+    def add_reads_text(self, text):
+        """The next bytes of a FASTA / FASTQ text; the records are found on the device.  True when the text is irregular
+        (nothing more is taken: finish on the host reader with what reads_text_end hands back + the rest of the stream)."""
+        buf = np.frombuffer(text, np.uint8) if not isinstance(text, np.ndarray) else text
+        irr = C.c_int32()
+        self._chk(self._L.phi_add_reads_text(self._h, _ptr(buf), len(buf), C.byref(irr)))
+        return bool(irr.value)
+
+    def reads_text_end(self):
+        """(bytes handed over but not taken, stream bytes taken as whole records)."""
+        p, n, t = C.c_void_p(), C.c_int64(), C.c_int64()
+        self._chk(self._L.phi_reads_text_end(self._h, C.byref(p), C.byref(n), C.byref(t)))
+        return (C.string_at(p.value, n.value) if n.value else b""), t.value
+
+    def reads_text_last_batch(self):
+        """(uint8 bases, int64 offsets) of the records the device took from the last piece of text."""
+        nr, nb = C.c_int64(), C.c_int64()
+        self._chk(self._L.phi_reads_text_last_batch(self._h, None, 0, None, 0, C.byref(nr), C.byref(nb)))
+        bases, off = np.zeros(nb.value, np.uint8), np.zeros(nr.value + 1, np.int64)
+        if nr.value:
+            self._chk(self._L.phi_reads_text_last_batch(self._h, _ptr(bases), nb.value, _ptr(off), nr.value, C.byref(nr), C.byref(nb)))
+        return bases, off
+
+    def reads_text_detach_carry(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self._L.phi_reads_text_detach_carry(self._h, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value) if n.value else b""
+
     def add_reads_device(self, d_bases, d_read_off, n_reads, n_bases):
         self._chk(self._L.phi_add_reads_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_read_off), n_reads, n_bases))
 

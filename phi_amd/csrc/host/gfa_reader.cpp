@@ -14,26 +14,47 @@
 //   Kahn topological order with a FIFO queue                       src/ILP_index.cpp:115-154
 // Differences, by design: duplicate L-lines are merged; adjacency lists are sorted by target id
 // (the reference's order depends on an unstable radix sort); a cyclic graph is an error.
+//
+// How the work is laid out (a chromosome-scale GFA is >= 10 GB of text, 99 % of it W-lines):
+//   * a plain file is MAPPED, never copied: lines and fields are slices of the mapping, the pages of a walk
+//     are given back (MADV_DONTNEED) as soon as its vertices are resolved, so the anonymous memory of the
+//     reader is the output arrays only.  A gzip file is inflated first (gz_source.h: on many threads when it
+//     is block gzip) and then parsed the same way;
+//   * lines are found and split into fields by all host threads over slices of the text cut at line ends;
+//   * segment ids are first-seen order, so names are entered by ONE thread, over the S/L records the slices
+//     found -- into a table that maps names of the form <prefix><decimal number> (the names of every chopped
+//     pangenome graph: "17", "s17") by direct indexing and any other name by open addressing;
+//   * the walks are resolved by all threads over PIECES of the W-lines (a 170-Mbp walk is one line of 60 MB):
+//     a counting pass fixes where every piece writes, the second pass looks the names up and writes the
+//     vertices straight into the final array.
+#include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #include "gz_source.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
-#include <queue>
 #include <string>
 #include <thread>
 #include <vector>
 #include "../../../include/phi_host.h"
 
 struct phi_graph {
-    std::vector<std::string> seg_names, hap_names;
-    std::string seq_concat;
+    std::vector<char> name_arena;                      // segment names, NUL-terminated, back to back
+    std::vector<int64_t> name_off;
+    std::vector<std::string> hap_names;
+    char *seq_concat = nullptr;                        // malloc'd (not zero-filled: every byte is written)
+    int32_t *walk_vtx = nullptr;
     std::vector<int64_t> seq_off, adj_off, walk_off;
-    std::vector<int32_t> adj, walk_vtx, topo_rank;
+    std::vector<int32_t> adj, topo_rank;
+    int32_t n_seg = 0;
+    ~phi_graph() { free(seq_concat); free(walk_vtx); }
 };
 
 static int fail(char *err, int cap, int code, const char *fmt, ...)
@@ -47,45 +68,81 @@ static int fail(char *err, int cap, int code, const char *fmt, ...)
     return code;
 }
 
-// the whole (possibly gzip-compressed) file in memory; lines and fields are slices of it
-static bool slurp(const char *path, std::vector<char> &buf)
+static int host_threads()
 {
-    // plain files: one read of the whole file; gzip (magic 1f 8b): inflate through zlib
-    if (FILE *fp = fopen(path, "rb")) {
-        unsigned char magic[2] = {0, 0};
-        const size_t got = fread(magic, 1, 2, fp);
-        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(fp, 0, SEEK_END) == 0) {
-            const long sz = ftell(fp);
-            if (sz >= 0) {
-                rewind(fp);
-                buf.resize((size_t)sz);
-                const size_t n = sz ? fread(buf.data(), 1, (size_t)sz, fp) : 0;
-                fclose(fp);
-                buf.resize(n);
-                return true;
-            }
-        }
-        fclose(fp);
-    } else {
-        return false;
-    }
-    // gzip: inflated by gz_source.h -- on many threads when the file is block gzip (BGZF), else by one thread
-    GzSource gz;
-    const char *e = getenv("PHI_HOST_THREADS");
-    int nt = e ? atoi(e) : (int)std::thread::hardware_concurrency();
-    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
-    if (!gz.open(path, nt)) return false;
-    size_t len = 0;
-    buf.clear();
-    std::vector<char> blk;
-    while (gz.next(blk)) {
-        if (buf.capacity() < len + blk.size()) buf.reserve(std::max(buf.capacity() * 2, len + blk.size()));
-        buf.insert(buf.end(), blk.begin(), blk.end());
-        len += blk.size();
-    }
-    gz.close();
-    return true;
+    int nt = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("PHI_HOST_THREADS")) nt = atoi(e);
+    return std::max(1, std::min(nt, 16));
 }
+
+template <class F> static void parallel_for(int64_t n, F fn)
+{
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n));
+    if (nt == 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
+    std::atomic<int64_t> next{0};
+    auto work = [&]() { for (int64_t i; (i = next.fetch_add(1)) < n;) fn(i); };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
+// The text of the file: a read-only mapping (plain file) or the inflated bytes (gzip).
+struct Text {
+    const char *p = nullptr;
+    size_t n = 0;
+    void *map = nullptr;
+    size_t map_n = 0;
+    std::vector<char> own;
+    ~Text() { if (map) munmap(map, map_n); }
+    // 0 ok, -1 cannot open / read, -2 gzip stream corrupt
+    int load(const char *path)
+    {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return -1;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); return -1; }
+        unsigned char magic[2] = {0, 0};
+        const ssize_t got = pread(fd, magic, 2, 0);
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            ::close(fd);
+            GzSource gz;
+            if (!gz.open(path, host_threads())) return -1;
+            std::vector<char> blk;
+            while (gz.next(blk)) {
+                if (own.capacity() < own.size() + blk.size()) own.reserve(std::max(own.capacity() * 2, own.size() + blk.size()));
+                own.insert(own.end(), blk.begin(), blk.end());
+            }
+            const bool ok = gz.ok();
+            gz.close();
+            if (!ok) return -2;
+            p = own.data(); n = own.size();
+            return 0;
+        }
+        if (!S_ISREG(st.st_mode) || st.st_size == 0) {
+            // a pipe / character device / empty file: read what there is
+            char tmp[1 << 16];
+            for (ssize_t r; (r = read(fd, tmp, sizeof tmp)) > 0;) own.insert(own.end(), tmp, tmp + r);
+            ::close(fd);
+            p = own.data(); n = own.size();
+            return 0;
+        }
+        map_n = (size_t)st.st_size;
+        map = mmap(nullptr, map_n, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (map == MAP_FAILED) { map = nullptr; return -1; }
+        (void)madvise(map, map_n, MADV_WILLNEED);
+        p = (const char *)map; n = map_n;
+        return 0;
+    }
+    // the pages wholly inside [lo, hi) are not needed again
+    void done_with(const char *lo, const char *hi) const
+    {
+        if (!map) return;
+        const uintptr_t pg = 4096, a = ((uintptr_t)lo + pg - 1) & ~(pg - 1), b = (uintptr_t)hi & ~(pg - 1);
+        if (b > a) (void)madvise((void *)a, b - a, MADV_DONTNEED);
+    }
+};
 
 struct Slice { const char *p; size_t n; };
 
@@ -102,10 +159,72 @@ struct StageTimer {
     }
 };
 
-// segment name -> id: open addressing over slices of the file buffer
+// segment name -> id.  Names <prefix><canonical decimal number below a bound that grows with the table> are indexed
+// directly (the prefix is that of the first name entered); every other name goes through open addressing over slices
+// of the text, with a 32-bit tag of the hash beside the id so that a probe touches the text only to confirm.
 class NameTable {
 public:
-    NameTable() { grow(1 << 16); }
+    NameTable() { grow(1 << 12); }
+    int32_t size() const { return (int32_t)keys_.size(); }
+    const std::vector<Slice> &keys() const { return keys_; }
+
+    int32_t find(const char *p, size_t n) const
+    {
+        const int64_t num = number(p, n);
+        if (num >= 0 && (size_t)num < direct_.size() && direct_[(size_t)num] >= 0) return direct_[(size_t)num];
+        if (n_hashed_ == 0) return -1;
+        const uint64_t h = hash(p, n);
+        const uint32_t tag = (uint32_t)(h >> 32) | 1u;
+        for (size_t i = h & mask_;; i = (i + 1) & mask_) {
+            const Slot s = slot_[i];
+            if (s.tag == 0) return -1;
+            if (s.tag == tag) {
+                const Slice &k = keys_[(size_t)s.id];
+                if (k.n == n && memcmp(k.p, p, n) == 0) return s.id;
+            }
+        }
+    }
+    int32_t add(const char *p, size_t n)            // id of an existing or new name
+    {
+        const int32_t f = find(p, n);
+        if (f >= 0) return f;
+        const int32_t id = (int32_t)keys_.size();
+        if (id == 0) {                               // the prefix of the direct index: the leading non-digits of the first name
+            size_t l = 0;
+            while (l < n && !(p[l] >= '0' && p[l] <= '9')) l++;
+            if (l <= sizeof prefix_) { memcpy(prefix_, p, l); prefix_n_ = l; }
+        }
+        keys_.push_back(Slice{p, n});
+        const int64_t num = number(p, n);
+        const int64_t bound = std::max<int64_t>(1 << 20, 16 * (int64_t)keys_.size());
+        if (num >= 0 && num < bound) {
+            if ((size_t)num >= direct_.size()) direct_.resize((size_t)std::min<int64_t>(bound, std::max<int64_t>(num + 1, 2 * (int64_t)direct_.size())), -1);
+            direct_[(size_t)num] = id;
+            return id;
+        }
+        if ((n_hashed_ + 1) * 2 > slot_.size()) grow(slot_.size() * 2);
+        insert(id);
+        n_hashed_++;
+        return id;
+    }
+private:
+    struct Slot { int32_t id; uint32_t tag; };       // tag 0 = empty
+    // the number behind the prefix when the name is <prefix><decimal without leading zeros, at most 9 digits>, else -1
+    int64_t number(const char *p, size_t n) const
+    {
+        if (n <= prefix_n_ || n - prefix_n_ > 9) return -1;
+        if (prefix_n_ && memcmp(p, prefix_, prefix_n_) != 0) return -1;
+        const char *d = p + prefix_n_;
+        const size_t nd = n - prefix_n_;
+        if (d[0] == '0' && nd > 1) return -1;
+        int64_t v = 0;
+        for (size_t i = 0; i < nd; i++) {
+            const unsigned c = (unsigned)(d[i] - '0');
+            if (c > 9) return -1;
+            v = v * 10 + c;
+        }
+        return v;
+    }
     static uint64_t hash(const char *p, size_t n)
     {
         uint64_t h = 0xcbf29ce484222325ull ^ (n * 0x9E3779B97F4A7C15ull);
@@ -116,42 +235,27 @@ public:
         h ^= h >> 32; h *= 0xd6e8feb86659fd93ull; h ^= h >> 32;
         return h;
     }
-    int32_t find(const char *p, size_t n) const
-    {
-        for (size_t i = hash(p, n) & mask_;; i = (i + 1) & mask_) {
-            const int32_t id = slot_[i];
-            if (id < 0) return -1;
-            const Slice &k = keys_[id];
-            if (k.n == n && memcmp(k.p, p, n) == 0) return id;
-        }
-    }
-    int32_t add(const char *p, size_t n)            // id of an existing or new name
-    {
-        const int32_t f = find(p, n);
-        if (f >= 0) return f;
-        if ((keys_.size() + 1) * 2 > slot_.size()) grow(slot_.size() * 2);
-        const int32_t id = (int32_t)keys_.size();
-        keys_.push_back(Slice{p, n});
-        insert(id);
-        return id;
-    }
-    const std::vector<Slice> &keys() const { return keys_; }
-private:
     void insert(int32_t id)
     {
-        size_t i = hash(keys_[id].p, keys_[id].n) & mask_;
-        while (slot_[i] >= 0) i = (i + 1) & mask_;
-        slot_[i] = id;
+        const uint64_t h = hash(keys_[(size_t)id].p, keys_[(size_t)id].n);
+        size_t i = h & mask_;
+        while (slot_[i].tag != 0) i = (i + 1) & mask_;
+        slot_[i] = Slot{id, (uint32_t)(h >> 32) | 1u};
     }
     void grow(size_t cap)
     {
-        slot_.assign(cap, -1);
+        std::vector<Slot> old;
+        old.swap(slot_);
+        slot_.assign(cap, Slot{-1, 0});
         mask_ = cap - 1;
-        for (int32_t id = 0; id < (int32_t)keys_.size(); id++) insert(id);
+        for (const Slot &s : old) if (s.tag) insert(s.id);
     }
-    std::vector<int32_t> slot_;
+    std::vector<Slot> slot_;
     std::vector<Slice> keys_;
-    size_t mask_ = 0;
+    std::vector<int32_t> direct_;
+    size_t mask_ = 0, n_hashed_ = 0;
+    char prefix_[16];
+    size_t prefix_n_ = 0;
 };
 
 // fields of a line: up to cap tab-separated slices
@@ -167,44 +271,22 @@ static int split_tabs(const char *p, const char *e, Slice *f, int cap)
     return n;
 }
 
-template <class F> static void parallel_for(int n, F fn)
+namespace {
+struct Rec {                                          // an S-line (a = name, b = sequence or null) or an L-line (a, b = names)
+    const char *a, *b;
+    uint32_t an, bn;
+    char type, ov, ow;
+};
+struct WRec {
+    Slice sample, text;
+    int hap;
+    size_t before;                                    // index of the next S/L record of its slice: what the line can name
+    int32_t n_known = 0;
+};
+struct SliceOut { std::vector<Rec> recs; std::vector<WRec> walks; };
+
+void scan_slice(const char *p, const char *end, SliceOut &o)
 {
-    int nt = (int)std::thread::hardware_concurrency();
-    if (const char *e = getenv("PHI_HOST_THREADS")) nt = atoi(e);
-    nt = std::max(1, std::min(std::min(nt, 16), n));
-    if (nt == 1) { for (int i = 0; i < n; i++) fn(i); return; }
-    std::atomic<int> next{0};
-    auto work = [&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
-}
-
-extern "C" {
-
-int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
-{
-    if (!path || !out) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "null argument");
-    *out = nullptr;
-    StageTimer tm;
-    std::vector<char> buf;
-    if (!slurp(path, buf)) return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to load the GFA file %s", path);
-    tm.lap("read / inflate");
-
-    NameTable table;
-    std::vector<Slice> seqs;                                         // per segment; n = 0: no sequence
-    std::vector<char> has_seq;
-    std::vector<std::pair<uint32_t, uint32_t>> arcs;                 // oriented vertices v = seg<<1 | strand
-    struct Walk { std::string sample; int hap; std::vector<uint32_t> v; Slice text; int32_t n_known; bool any_rev = false; };
-    std::vector<Walk> walks;
-    auto add_seg = [&](const Slice &f) {
-        const int32_t id = table.add(f.p, f.n);
-        if ((size_t)id == seqs.size()) { seqs.push_back(Slice{nullptr, 0}); has_seq.push_back(0); }
-        return id;
-    };
-
-    const char *p = buf.data(), *const end = buf.data() + buf.size();
     Slice f[8];
     while (p < end) {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
@@ -215,164 +297,279 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
             const char t = p[0];
             const int nf = split_tabs(p, le, f, t == 'W' ? 8 : 6);
             if (t == 'S' && nf >= 3) {
-                const int32_t id = add_seg(f[1]);
-                if (f[2].n > 0 && f[2].p[0] != '*') { seqs[id] = f[2]; has_seq[id] = 1; }
-                else { seqs[id] = Slice{nullptr, 0}; has_seq[id] = 0; }
+                const bool has = f[2].n > 0 && f[2].p[0] != '*';
+                o.recs.push_back(Rec{f[1].p, has ? f[2].p : nullptr, (uint32_t)f[1].n, has ? (uint32_t)f[2].n : 0u, 'S', 0, 0});
             } else if (t == 'L' && nf >= 5) {
                 if (f[2].n == 1 && f[4].n == 1) {
                     const char ov = f[2].p[0], ow = f[4].p[0];
-                    if ((ov == '+' || ov == '-') && (ow == '+' || ow == '-')) {
-                        const uint32_t v = (uint32_t)add_seg(f[1]) << 1 | (ov != '+');
-                        const uint32_t w = (uint32_t)add_seg(f[3]) << 1 | (ow != '+');
-                        arcs.emplace_back(v, w);
-                    }
+                    if ((ov == '+' || ov == '-') && (ow == '+' || ow == '-'))
+                        o.recs.push_back(Rec{f[1].p, f[3].p, (uint32_t)f[1].n, (uint32_t)f[3].n, 'L', ov, ow});
                 }
             } else if (t == 'W' && nf >= 7) {
-                Walk wk;
-                wk.sample.assign(f[1].p, f[1].n);
-                wk.hap = atoi(std::string(f[2].p, f[2].n).c_str());
-                wk.text = f[6];
-                wk.n_known = (int32_t)seqs.size();           // names are resolved against the segments seen so far
-                walks.push_back(std::move(wk));
+                WRec w;
+                w.sample = f[1];
+                w.hap = atoi(std::string(f[2].p, f[2].n).c_str());
+                w.text = f[6];
+                if (const char *tab = (const char *)memchr(w.text.p, '\t', w.text.n)) w.text.n = (size_t)(tab - w.text.p);   // optional tags follow
+                w.before = o.recs.size();
+                o.walks.push_back(w);
             }
         }
         p = next;
     }
-    tm.lap("S / L lines");
-    // the walks' vertex lists: one host thread per W-line
-    parallel_for((int)walks.size(), [&](int wi) {
-        Walk &wk = walks[wi];
-        const char *s = wk.text.p;
-        const size_t n = wk.text.n;
-        wk.v.reserve(n / 4 + 4);
-        size_t i = 0;
-        while (i < n) {
-            if (s[i] == '>' || s[i] == '<') {
-                size_t j = i + 1;
-                while (j < n && s[j] != '>' && s[j] != '<' && s[j] != '\t') j++;
-                const int32_t id = table.find(s + i + 1, j - i - 1);
-                if (id >= 0 && id < wk.n_known) {
-                    wk.v.push_back((uint32_t)id << 1 | (s[i] == '<'));
-                    wk.any_rev |= s[i] == '<';
-                }
-                i = j;
-            } else if (s[i] == '\t') break;                // optional tags after the walk
-            else i++;
+}
+
+inline bool is_step(char c) { return c == '>' || c == '<'; }
+
+struct Piece { int32_t walk; const char *lo, *hi; int64_t n = 0, out = 0, dropped = 0; bool any_rev = false; };
+}  // namespace
+
+extern "C" {
+
+int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
+{
+    if (!path || !out) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "null argument");
+    *out = nullptr;
+    StageTimer tm;
+    Text text;
+    if (const int lr = text.load(path))
+        return fail(err, err_cap, PHI_HOST_ERR_IO, lr == -2 ? "gzip stream corrupt in the GFA file %s" : "failed to load the GFA file %s", path);
+    tm.lap(text.map ? "map" : "read / inflate");
+
+    // ---- lines and fields, on all threads over slices of the text cut at line ends
+    const char *const t0 = text.p, *const tend = text.p + text.n;
+    const int n_slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads() * 4, text.n / ((size_t)1 << 20) + 1));
+    std::vector<const char *> cut((size_t)n_slices + 1, tend);
+    cut[0] = t0;
+    for (int i = 1; i < n_slices; i++) {
+        const char *q = t0 + text.n / (size_t)n_slices * (size_t)i;
+        if (q < cut[(size_t)i - 1]) q = cut[(size_t)i - 1];
+        const char *nl = q < tend ? (const char *)memchr(q, '\n', (size_t)(tend - q)) : nullptr;
+        cut[(size_t)i] = nl ? nl + 1 : tend;
+    }
+    std::vector<SliceOut> so((size_t)n_slices);
+    parallel_for(n_slices, [&](int64_t i) { scan_slice(cut[(size_t)i], cut[(size_t)i + 1], so[(size_t)i]); });
+    tm.lap("lines + fields (threads)");
+
+    // ---- segment ids in first-seen order: one thread, over the records in file order
+    NameTable table;
+    std::vector<Slice> seqs;                                         // per segment; n = 0: no sequence
+    std::vector<std::pair<uint32_t, uint32_t>> arcs;                 // oriented vertices v = seg<<1 | strand
+    {
+        size_t n_rec = 0;
+        for (const SliceOut &s : so) n_rec += s.recs.size();
+        seqs.reserve(n_rec);
+        arcs.reserve(n_rec);
+    }
+    auto add_seg = [&](const char *p, uint32_t n) {
+        const int32_t id = table.add(p, n);
+        if ((size_t)id == seqs.size()) seqs.push_back(Slice{nullptr, 0});
+        return id;
+    };
+    std::vector<WRec *> walks;
+    for (SliceOut &s : so) {
+        size_t wi = 0;
+        for (size_t i = 0; i <= s.recs.size(); i++) {
+            while (wi < s.walks.size() && s.walks[wi].before == i) {
+                s.walks[wi].n_known = table.size();                  // names are resolved against the segments seen so far
+                walks.push_back(&s.walks[wi++]);
+            }
+            if (i == s.recs.size()) break;
+            const Rec &r = s.recs[i];
+            if (r.type == 'S') {
+                const int32_t id = add_seg(r.a, r.an);
+                seqs[(size_t)id] = Slice{r.b, r.bn};                  // a later S-line of the same name replaces the sequence
+            } else {
+                const uint32_t v = (uint32_t)add_seg(r.a, r.an) << 1 | (r.ov != '+');
+                const uint32_t w = (uint32_t)add_seg(r.b, r.bn) << 1 | (r.ow != '+');
+                arcs.emplace_back(v, w);
+            }
         }
+        std::vector<Rec>().swap(s.recs);
+    }
+    const int32_t n_seg = table.size();
+    const int64_t n_walks = (int64_t)walks.size();
+    tm.lap("segment ids (one thread)");
+
+    // ---- the walks' vertices: pieces of the W-lines, cut at steps, on all threads
+    std::vector<Piece> pieces;
+    {
+        const size_t PIECE = getenv("PHI_GFA_PIECE") ? std::max<size_t>(16, (size_t)atoll(getenv("PHI_GFA_PIECE"))) : ((size_t)1 << 20);
+        for (int64_t wi = 0; wi < n_walks; wi++) {
+            const char *s = walks[(size_t)wi]->text.p, *const e = s + walks[(size_t)wi]->text.n;
+            const char *lo = s;
+            while (lo < e) {
+                const char *hi = (size_t)(e - lo) > PIECE + PIECE / 2 ? lo + PIECE : e;
+                while (hi < e && !is_step(*hi)) hi++;                // a name never straddles two pieces
+                pieces.push_back(Piece{(int32_t)wi, lo, hi});
+                lo = hi;
+            }
+            if (s == e) pieces.push_back(Piece{(int32_t)wi, s, e});
+        }
+    }
+    parallel_for((int64_t)pieces.size(), [&](int64_t i) {
+        Piece &pc = pieces[(size_t)i];
+        int64_t n = 0;
+        for (const char *q = pc.lo; q < pc.hi; q++) n += is_step(*q);
+        pc.n = n;
     });
-    const std::vector<Slice> &names = table.keys();
+    phi_graph *g = new phi_graph();
+    g->walk_off.assign((size_t)n_walks + 1, 0);
+    {
+        int64_t o = 0;
+        size_t pi = 0;
+        for (int64_t wi = 0; wi < n_walks; wi++) {
+            g->walk_off[(size_t)wi] = o;
+            for (; pi < pieces.size() && pieces[pi].walk == wi; pi++) { pieces[pi].out = o; o += pieces[pi].n; }
+        }
+        g->walk_off[(size_t)n_walks] = o;
+    }
+    const int64_t n_entries = g->walk_off[(size_t)n_walks];
+    uint32_t *wv = (uint32_t *)malloc(std::max<size_t>(1, (size_t)n_entries) * 4);
+    if (!wv) { delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory for %lld walk entries", (long long)n_entries); }
+    g->walk_vtx = (int32_t *)wv;
+    const uint32_t DROP = 0xFFFFFFFFu;
+    parallel_for((int64_t)pieces.size(), [&](int64_t i) {
+        Piece &pc = pieces[(size_t)i];
+        const int32_t n_known = walks[(size_t)pc.walk]->n_known;
+        const char *const e = walks[(size_t)pc.walk]->text.p + walks[(size_t)pc.walk]->text.n;
+        uint32_t *dst = wv + pc.out;
+        const char *q = pc.lo;
+        while (q < pc.hi && !is_step(*q)) q++;                       // (bytes before the first step of a walk)
+        while (q < pc.hi) {
+            const char *nm = q + 1, *r = nm;
+            while (r < e && !is_step(*r)) r++;
+            const int32_t id = table.find(nm, (size_t)(r - nm));
+            if (id >= 0 && id < n_known) { *dst++ = (uint32_t)id << 1 | (*q == '<'); pc.any_rev |= *q == '<'; }
+            else { *dst++ = DROP; pc.dropped++; }
+            q = r;
+        }
+        text.done_with(pc.lo, pc.hi);
+    });
+    bool any_rev = false;
+    int64_t dropped = 0;
+    for (const Piece &pc : pieces) { any_rev |= pc.any_rev; dropped += pc.dropped; }
+    if (dropped) {                                                   // steps naming no known segment are left out
+        int64_t o = 0;
+        for (int64_t wi = 0; wi < n_walks; wi++) {
+            const int64_t lo = g->walk_off[(size_t)wi], hi = g->walk_off[(size_t)wi + 1];
+            g->walk_off[(size_t)wi] = o;
+            for (int64_t x = lo; x < hi; x++) if (wv[x] != DROP) wv[o++] = wv[x];
+        }
+        g->walk_off[(size_t)n_walks] = o;
+    }
     tm.lap("W lines (threads)");
 
-    const int32_t n_seg = (int32_t)names.size();
     // gfa_walk_flip: the first walk to touch a segment fixes its strand; a walk that disagrees
     // with the majority of its vertices is reverse-complemented
-    bool any_rev = false;
-    for (const Walk &w : walks) any_rev |= w.any_rev;
     if (any_rev) {                                     // all-forward walks agree with every first touch: nothing to flip
-        std::vector<int8_t> strand(n_seg, 0);
-        for (const Walk &w : walks)
-            for (uint32_t v : w.v)
-                if (strand[v >> 1] == 0) strand[v >> 1] = (v & 1) ? -1 : 1;
-        parallel_for((int)walks.size(), [&](int wi) {
-            Walk &w = walks[wi];
+        std::vector<int8_t> strand((size_t)n_seg, 0);
+        for (int64_t x = 0, n = g->walk_off[(size_t)n_walks]; x < n; x++)
+            if (strand[wv[x] >> 1] == 0) strand[wv[x] >> 1] = (wv[x] & 1) ? -1 : 1;
+        parallel_for(n_walks, [&](int64_t wi) {
+            uint32_t *b = wv + g->walk_off[(size_t)wi], *e = wv + g->walk_off[(size_t)wi + 1];
             int64_t agree = 0;
-            for (uint32_t v : w.v) agree += (((v & 1) ? -1 : 1) == strand[v >> 1]);
-            if (agree >= (int64_t)w.v.size() - agree) return;
-            std::reverse(w.v.begin(), w.v.end());
-            for (uint32_t &v : w.v) v ^= 1;
+            for (uint32_t *v = b; v < e; v++) agree += (((*v & 1) ? -1 : 1) == strand[*v >> 1]);
+            if (agree >= (e - b) - agree) return;
+            std::reverse(b, e);
+            for (uint32_t *v = b; v < e; v++) *v ^= 1;
         });
     }
-    // arcs: drop those touching a sequence-less segment, add complements, merge duplicates
+    // oriented vertices -> segment ids; a reverse-strand vertex left in a walk is an error (ILP_index.cpp:104-107)
     {
-        std::vector<std::pair<uint32_t, uint32_t>> all;
-        all.reserve(arcs.size() * 2);
-        for (auto &a : arcs) {
-            if (!has_seq[a.first >> 1] || seqs[a.first >> 1].n == 0) continue;
-            if (!has_seq[a.second >> 1] || seqs[a.second >> 1].n == 0) continue;
-            all.push_back(a);
-            all.emplace_back(a.second ^ 1, a.first ^ 1);
-        }
-        std::sort(all.begin(), all.end());
-        all.erase(std::unique(all.begin(), all.end()), all.end());
-        arcs.swap(all);
-    }
-
-    tm.lap("walk flips, arcs");
-    phi_graph *g = new phi_graph();
-    g->seg_names.reserve(n_seg);
-    for (int32_t i = 0; i < n_seg; i++) g->seg_names.emplace_back(names[i].p, names[i].n);
-    g->seq_off.assign(n_seg + 1, 0);
-    for (int32_t i = 0; i < n_seg; i++) g->seq_off[i + 1] = g->seq_off[i] + (int64_t)seqs[i].n;
-    g->seq_concat.resize((size_t)g->seq_off[n_seg]);
-    for (int32_t i = 0; i < n_seg; i++) if (seqs[i].n) memcpy(&g->seq_concat[(size_t)g->seq_off[i]], seqs[i].p, seqs[i].n);
-    g->adj_off.assign(n_seg + 1, 0);
-    for (auto &a : arcs) if (!(a.first & 1)) g->adj_off[(a.first >> 1) + 1]++;
-    for (int32_t i = 0; i < n_seg; i++) g->adj_off[i + 1] += g->adj_off[i];
-    g->adj.resize((size_t)g->adj_off[n_seg]);
-    {
-        std::vector<int64_t> cur(g->adj_off.begin(), g->adj_off.end() - 1);
-        for (auto &a : arcs) if (!(a.first & 1)) g->adj[cur[a.first >> 1]++] = (int32_t)(a.second >> 1);
-        // two oriented targets can collapse onto one segment once orientation is dropped
-        std::vector<int64_t> off2(n_seg + 1, 0);
-        std::vector<int32_t> adj2;
-        for (int32_t u = 0; u < n_seg; u++) {
-            auto b = g->adj.begin() + g->adj_off[u], e = g->adj.begin() + g->adj_off[u + 1];
-            std::sort(b, e);
-            e = std::unique(b, e);
-            adj2.insert(adj2.end(), b, e);
-            off2[u + 1] = (int64_t)adj2.size();
-        }
-        g->adj.swap(adj2);
-        g->adj_off.swap(off2);
-    }
-    g->walk_off.assign(walks.size() + 1, 0);
-    for (size_t w = 0; w < walks.size(); w++) {
-        g->walk_off[w + 1] = g->walk_off[w] + (int64_t)walks[w].v.size();
-        g->hap_names.push_back(walks[w].sample + "." + std::to_string(walks[w].hap));
-    }
-    g->walk_vtx.resize((size_t)g->walk_off[walks.size()]);
-    {
-        std::atomic<int64_t> bad{-1};                  // (walk << 32 | vertex) of the first reverse-strand vertex
-        parallel_for((int)walks.size(), [&](int wi) {
-            int32_t *dst = g->walk_vtx.data() + g->walk_off[wi];
-            const std::vector<uint32_t> &v = walks[wi].v;
-            for (size_t i = 0; i < v.size(); i++) {
-                if (v[i] & 1) {
-                    int64_t expect = -1;
-                    bad.compare_exchange_strong(expect, (int64_t)wi << 32 | v[i]);
+        const int64_t n = g->walk_off[(size_t)n_walks], CH = (int64_t)1 << 20, n_ch = (n + CH - 1) / CH;
+        std::atomic<int64_t> first_bad{INT64_MAX};
+        parallel_for(n_ch, [&](int64_t c) {
+            const int64_t lo = c * CH, hi = std::min(n, lo + CH);
+            for (int64_t x = lo; x < hi; x++) {
+                if (wv[x] & 1) {
+                    int64_t cur = first_bad.load();
+                    while (x < cur && !first_bad.compare_exchange_weak(cur, x)) {}
                     return;
                 }
-                dst[i] = (int32_t)(v[i] >> 1);
+                wv[x] >>= 1;
             }
         });
-        int64_t first = -1;                            // report the lowest walk, as the sequential loop did
-        if (bad.load() >= 0)
-            for (size_t w = 0; w < walks.size() && first < 0; w++)
-                for (uint32_t v : walks[w].v) if (v & 1) { first = (int64_t)w << 32 | v; break; }
-        if (first >= 0) {
-            const int code = fail(err, err_cap, PHI_HOST_ERR_WALK, "Error: Walk %d has reverse strand vertices %u", (int)(first >> 32), (uint32_t)first);
+        if (first_bad.load() != INT64_MAX) {
+            const int64_t x = first_bad.load();
+            const int64_t w = (int64_t)(std::upper_bound(g->walk_off.begin(), g->walk_off.end(), x) - g->walk_off.begin()) - 1;
+            // (entries before x in other chunks may already be converted; x itself is not)
+            const int code = fail(err, err_cap, PHI_HOST_ERR_WALK, "Error: Walk %d has reverse strand vertices %u", (int)w, wv[x]);
             delete g;
             return code;
         }
     }
+    tm.lap("walk flips, vertex ids");
+
+    // ---- arrays
+    g->n_seg = n_seg;
+    const std::vector<Slice> &names = table.keys();
+    g->name_off.assign((size_t)n_seg + 1, 0);
+    for (int32_t i = 0; i < n_seg; i++) g->name_off[(size_t)i + 1] = g->name_off[(size_t)i] + (int64_t)names[(size_t)i].n + 1;
+    g->name_arena.resize((size_t)g->name_off[(size_t)n_seg]);
+    g->seq_off.assign((size_t)n_seg + 1, 0);
+    for (int32_t i = 0; i < n_seg; i++) g->seq_off[(size_t)i + 1] = g->seq_off[(size_t)i] + (int64_t)seqs[(size_t)i].n;
+    g->seq_concat = (char *)malloc(std::max<size_t>(1, (size_t)g->seq_off[(size_t)n_seg]));
+    if (!g->seq_concat) { delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory"); }
+    {
+        const int64_t CH = 1 << 16, n_ch = ((int64_t)n_seg + CH - 1) / CH;
+        parallel_for(n_ch, [&](int64_t c) {
+            for (int64_t i = c * CH, hi = std::min<int64_t>(n_seg, (c + 1) * CH); i < hi; i++) {
+                if (seqs[(size_t)i].n) memcpy(g->seq_concat + g->seq_off[(size_t)i], seqs[(size_t)i].p, seqs[(size_t)i].n);
+                char *d = g->name_arena.data() + g->name_off[(size_t)i];
+                memcpy(d, names[(size_t)i].p, names[(size_t)i].n);
+                d[names[(size_t)i].n] = '\0';
+            }
+        });
+    }
+    for (int64_t w = 0; w < n_walks; w++)
+        g->hap_names.push_back(std::string(walks[(size_t)w]->sample.p, walks[(size_t)w]->sample.n) + "." + std::to_string(walks[(size_t)w]->hap));
+    // arcs: those touching a segment without sequence are dropped; an arc v -> w and its complement w' -> v' give the
+    // forward-strand adjacency (target orientation dropped): u -> w when v = u+, and w -> v when w is a reverse strand
+    {
+        std::vector<int64_t> cnt((size_t)n_seg + 1, 0);
+        auto each = [&](auto fn) {
+            for (const auto &a : arcs) {
+                const uint32_t v = a.first, w = a.second;
+                if (seqs[v >> 1].n == 0 || seqs[w >> 1].n == 0) continue;
+                if (!(v & 1)) fn(v >> 1, w >> 1);
+                if (w & 1) fn(w >> 1, v >> 1);
+            }
+        };
+        each([&](uint32_t u, uint32_t) { cnt[(size_t)u + 1]++; });
+        for (int32_t i = 0; i < n_seg; i++) cnt[(size_t)i + 1] += cnt[(size_t)i];
+        std::vector<int32_t> tgt((size_t)cnt[(size_t)n_seg]);
+        std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+        each([&](uint32_t u, uint32_t x) { tgt[(size_t)cur[u]++] = (int32_t)x; });
+        // duplicate links, and oriented targets that collapse onto one segment, are merged
+        g->adj_off.assign((size_t)n_seg + 1, 0);
+        int64_t o = 0;
+        for (int32_t u = 0; u < n_seg; u++) {
+            int32_t *b = tgt.data() + cnt[(size_t)u], *e = tgt.data() + cnt[(size_t)u + 1];
+            if (e - b > 1) { std::sort(b, e); e = std::unique(b, e); }
+            g->adj_off[(size_t)u] = o;
+            for (; b < e; b++) tgt[(size_t)o++] = *b;             // (o never passes the read position)
+        }
+        g->adj_off[(size_t)n_seg] = o;
+        tgt.resize((size_t)o);
+        g->adj.swap(tgt);
+    }
     tm.lap("arrays");
     // Kahn's algorithm, FIFO
     {
-        std::vector<int32_t> indeg(n_seg, 0);
-        for (int32_t v : g->adj) indeg[v]++;
-        std::queue<int32_t> q;
-        for (int32_t i = 0; i < n_seg; i++) if (indeg[i] == 0) q.push(i);
-        g->topo_rank.assign(n_seg, 0);
-        int32_t n_done = 0;
-        while (!q.empty()) {
-            const int32_t u = q.front();
-            q.pop();
-            g->topo_rank[u] = n_done++;
-            for (int64_t x = g->adj_off[u]; x < g->adj_off[u + 1]; x++)
-                if (--indeg[g->adj[x]] == 0) q.push(g->adj[x]);
+        std::vector<int32_t> indeg((size_t)n_seg, 0), q((size_t)n_seg);
+        for (int32_t v : g->adj) indeg[(size_t)v]++;
+        int32_t head = 0, tail = 0;
+        for (int32_t i = 0; i < n_seg; i++) if (indeg[(size_t)i] == 0) q[(size_t)tail++] = i;
+        g->topo_rank.assign((size_t)n_seg, 0);
+        while (head < tail) {
+            const int32_t u = q[(size_t)head];
+            g->topo_rank[(size_t)u] = head++;
+            for (int64_t x = g->adj_off[(size_t)u]; x < g->adj_off[(size_t)u + 1]; x++)
+                if (--indeg[(size_t)g->adj[(size_t)x]] == 0) q[(size_t)tail++] = g->adj[(size_t)x];
         }
-        if (n_done != n_seg) {
-            const int code = fail(err, err_cap, PHI_HOST_ERR_CYCLE, "graph is not acyclic: %d of %d vertices sorted", n_done, n_seg);
+        if (head != n_seg) {
+            const int code = fail(err, err_cap, PHI_HOST_ERR_CYCLE, "graph is not acyclic: %d of %d vertices sorted", head, n_seg);
             delete g;
             return code;
         }
@@ -383,23 +580,23 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
 }
 
 void phi_graph_free(phi_graph *g) { delete g; }
-int32_t phi_graph_n_vtx(const phi_graph *g) { return (int32_t)g->seg_names.size(); }
+int32_t phi_graph_n_vtx(const phi_graph *g) { return g->n_seg; }
 int32_t phi_graph_n_walks(const phi_graph *g) { return (int32_t)g->hap_names.size(); }
 int64_t phi_graph_n_edges(const phi_graph *g) { return (int64_t)g->adj.size(); }
-const char *phi_graph_seq_concat(const phi_graph *g) { return g->seq_concat.data(); }
+const char *phi_graph_seq_concat(const phi_graph *g) { return g->seq_concat; }
 const int64_t *phi_graph_seq_off(const phi_graph *g) { return g->seq_off.data(); }
 const int64_t *phi_graph_adj_off(const phi_graph *g) { return g->adj_off.data(); }
 const int32_t *phi_graph_adj(const phi_graph *g) { return g->adj.data(); }
 const int64_t *phi_graph_walk_off(const phi_graph *g) { return g->walk_off.data(); }
-const int32_t *phi_graph_walk_vtx(const phi_graph *g) { return g->walk_vtx.data(); }
+const int32_t *phi_graph_walk_vtx(const phi_graph *g) { return g->walk_vtx; }
 const int32_t *phi_graph_topo_rank(const phi_graph *g) { return g->topo_rank.data(); }
 const char *phi_graph_hap_name(const phi_graph *g, int32_t w)
 {
-    return (w >= 0 && w < (int32_t)g->hap_names.size()) ? g->hap_names[w].c_str() : "";
+    return (w >= 0 && w < (int32_t)g->hap_names.size()) ? g->hap_names[(size_t)w].c_str() : "";
 }
 const char *phi_graph_seg_name(const phi_graph *g, int32_t v)
 {
-    return (v >= 0 && v < (int32_t)g->seg_names.size()) ? g->seg_names[v].c_str() : "";
+    return (v >= 0 && v < g->n_seg) ? g->name_arena.data() + g->name_off[(size_t)v] : "";
 }
 
 }  // extern "C"

@@ -145,8 +145,14 @@ private:
         }
     done:
         if (tail_at_ != (size_t)-1 && !stop_ && !failed_) {
-            // a trailing part that is not BGZF (rare: a plain member appended): serial, after everything before it
-            inflate_from(tail_at_, seq);
+            // a trailing part that is not BGZF (rare: a plain member appended, or bytes that are no gzip at all): serial,
+            // once every batch before it is inflated -- if the tail turns out to be no gzip member it is the end of the
+            // input, as under gzread, and must not cost the batches still queued
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_out_.wait(lk, [&] { return stop_ || failed_ || pending_ == 0; });
+            }
+            if (!stop_ && !failed_) inflate_from(tail_at_, seq, seq > 0);
         }
         { std::lock_guard<std::mutex> lk(mu_); producers_done_ = true; }
         cv_work_.notify_all(); cv_out_.notify_all();
@@ -215,7 +221,8 @@ private:
         cv_out_.notify_all();
     }
 
-    void inflate_from(size_t at, int64_t seq)
+    // after_members: whole members came before `at` -- bytes there that are no gzip member are then ignored, as gzread does
+    void inflate_from(size_t at, int64_t seq, bool after_members = false)
     {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
@@ -223,7 +230,7 @@ private:
         zs.next_in = const_cast<unsigned char *>(map_ + at);
         size_t left = size_ - at;
         const size_t BLK = (size_t)4 << 20;
-        int members = 0;                                                  // members inflated to their end
+        int members = after_members ? 1 : 0;                              // members inflated to their end
         bool fresh = true;                                                // no byte of the current member's output yet
         for (bool end = false; !end;) {
             std::vector<char> out(BLK);

@@ -5,21 +5,35 @@
 //   ./PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta> [-k -w -R -q -m -T -t -d -N -c]
 //         [--device N | --devices 0,1,..] [--dp-budget RUNS]
 //
-// --devices: one context and one host thread per GPU; every GPU builds the full index, the read chunks are
-// handed out through a work queue (the shards balance themselves), the library's RCCL exchange (phi_comm_*)
-// merges hit vectors and spectra once, and the first GPU solves and reports.
+// --devices: one context and one host thread per GPU; every GPU builds the full index, the chunks of the reads file are
+// handed out in turn, the library's RCCL exchange (phi_comm_*) merges hit vectors and spectra once, and the first
+// GPU solves and reports.  A read set smaller than --shard-min-bases per GPU uses fewer GPUs.
 //
 // Flag semantics (main.cpp:38-95): -q (IQP/ILP), -m (mixed/integer), -N (naive expanded graph)
 // choose between formulations with the same optimum; they are accepted and mapped onto the one
 // exact solver.  -t only sized OpenMP/Gurobi thread pools and is accepted and ignored.  The log
 // lines scraped by the reference's evaluation scripts (data/postprocessing_2_MIQP.py:55-79) keep
 // their exact formats.
+//
+// From process start to the closed FASTA what a small input pays is the HIP runtime, not the
+// path: ~60-180 ms to start it, ~20 ms per hardware queue, and ~100 ms for the driver to take the process's GPU state
+// down again when it ends.  So: the device context is made by a thread of its own while the graph is parsed; the reads
+// file goes to the device as raw text (the records are found there: phi_add_reads_text); and the process that does
+// the work is a CHILD -- the parent returns the child's status the moment the FASTA is closed and the log written, the
+// child's teardown (free of the arrays, the driver's cleanup) goes on behind it.  PHI_DETACH=0 keeps one process.
+// Exit status: 0; 1 on any error; 3 when --dp-budget was given and ran out before the path was proven optimal.
+#include <errno.h>
 #include <getopt.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/prctl.h>
 #include <sys/resource.h>
+#include <sys/stat.h>
 #include <sys/time.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <functional>
@@ -61,6 +75,33 @@ static void stamp(const char *func)
     fprintf(stderr, "[M::%s::%.3f*%.2f] ", func, w, cputime() / (w > 0 ? w : 1e-9));
 }
 
+// PHI_TIMING=1: the stages of the run, each with its begin and end on the process's clock (seconds since main was entered)
+struct StageMarks {
+    bool on = getenv("PHI_TIMING") != nullptr;
+    std::mutex mu;
+    struct M { std::string name; double b, e; };
+    std::vector<M> marks;
+    void add(const char *name, double b, double e)
+    {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(mu);
+        marks.push_back(M{name, b - t0_real, e - t0_real});
+    }
+    void print()
+    {
+        if (!on) return;
+        std::sort(marks.begin(), marks.end(), [](const M &a, const M &b) { return a.b < b.b; });
+        fprintf(stderr, "[phi timing] main: entered at epoch %.6f\n", t0_real);
+        for (const M &m : marks) fprintf(stderr, "[phi timing] main: stage %-34s %8.3f -> %8.3f s  (%9.3f ms)\n", m.name.c_str(), m.b, m.e, (m.e - m.b) * 1e3);
+    }
+};
+static StageMarks g_marks;
+struct Stage {
+    const char *name; double b;
+    explicit Stage(const char *n) : name(n), b(realtime()) {}
+    ~Stage() { g_marks.add(name, b, realtime()); }
+};
+
 static void usage(FILE *fp, int k, int w, int R, int q, int m, float T, int t, const char *g, const char *r, const char *o, int d)
 {
     fprintf(fp, "Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta> \n");
@@ -78,146 +119,176 @@ static void usage(FILE *fp, int k, int w, int R, int q, int m, float T, int t, c
     fprintf(fp, "    -d bool      Debug mode [%d]\n", d);
 }
 
-int main(int argc, char *argv[])
-{
-    int k = 31, w = 25, n_threads = 4, recombination = 100, is_qclp = 1, is_naive = 0, is_mixed = 1, debug = 0, help = 0;
+struct Options {
+    int k = 31, w = 25, n_threads = 4, recombination = 100, is_qclp = 1, is_naive = 0, is_mixed = 1, debug = 0;
     int device = 0, max_occ = 5000;
     std::vector<int> devices;                                 // --devices: one context (and host thread) per GPU
-    long long dp_budget = -1;                                 // --dp-budget: DP runs of the exact search (default: the library's)
+    long long dp_budget = -1;                                 // --dp-budget: DP runs of the exact search; not given: no limit, as model.optimize()
+    long long shard_min_bases = 50000000;                     // --shard-min-bases: text bytes of reads a further GPU must be worth
     float threshold = 1.0f;
     std::string gfa_file, reads_file, hap_file;
-    static struct option long_options[] = {{"version", no_argument, 0, 300}, {"device", required_argument, 0, 301}, {"dp-budget", required_argument, 0, 302}, {"devices", required_argument, 0, 303}, {0, 0, 0, 0}};
-    int c;
-    // main.cpp:38 declares -h with an argument; a bare -h falls into the usage branch either way
-    while ((c = getopt_long(argc, argv, "x:d:c:l:s:m:R:q:T:N:h:k:w:t:g:r:o:DS", long_options, nullptr)) >= 0) {
-        if (c == 'w') w = atoi(optarg);
-        else if (c == 'k') k = atoi(optarg);
-        else if (c == 't') n_threads = atoi(optarg);
-        else if (c == 'm') is_mixed = atoi(optarg);
-        else if (c == 'g') gfa_file = optarg;
-        else if (c == 'R') recombination = atoi(optarg);
-        else if (c == 'q') is_qclp = atoi(optarg);
-        else if (c == 'N') is_naive = atoi(optarg);
-        else if (c == 'T') threshold = (float)atof(optarg);
-        else if (c == 'r') reads_file = optarg;
-        else if (c == 'o') hap_file = optarg;
-        else if (c == 'c') max_occ = atoi(optarg);
-        else if (c == 'd') debug = atoi(optarg);
-        else if (c == 'h' || c == '?') help = 1;
-        else if (c == 300) { fprintf(stderr, "PHI version: %s\n", PHI_VERSION); return 0; }
-        else if (c == 301) device = atoi(optarg);
-        else if (c == 302) dp_budget = atoll(optarg);
-        else if (c == 303) {                                   // --devices 0,1,2,...: shard the reads over these GPUs
-            devices.clear();
-            for (const char *p = optarg; *p;) {
-                char *end = nullptr;
-                const long d = strtol(p, &end, 10);
-                if (end == p || d < 0) { fprintf(stderr, "[E::main] --devices takes a comma-separated list of GPU ordinals\n"); return 1; }
-                devices.push_back((int)d);
-                p = *end == ',' ? end + 1 : end;
-                if (*end && *end != ',') { fprintf(stderr, "[E::main] --devices takes a comma-separated list of GPU ordinals\n"); return 1; }
-            }
-        }
+    int argc = 0;
+    char **argv = nullptr;
+};
+
+// ---- the queue of raw text chunks between the reader thread and the device thread(s)
+struct Chunk { char *text = nullptr; int64_t n = 0; };
+struct ChunkQueue {
+    std::vector<Chunk> buf;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> q_free, q_full;                           // buffer indices; a full entry with n == 0 ends the stream
+    bool stop = false;
+    int take_full()                                           // blocks; the end marker stays in the queue for the other takers
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !q_full.empty(); });
+        const int s = q_full.front();
+        if (buf[(size_t)s].n > 0) q_full.pop_front();
+        return s;
     }
-    (void)max_occ; (void)is_naive; (void)n_threads;
-    if (argc < 2 || gfa_file.empty() || reads_file.empty() || hap_file.empty() || help) {
-        usage(stderr, k, w, recombination, is_qclp, is_mixed, threshold, n_threads, gfa_file.c_str(), reads_file.c_str(), hap_file.c_str(), debug);
-        return 1;
+    void give_free(int s)
+    {
+        { std::lock_guard<std::mutex> lk(mu); q_free.push_back(s); }
+        cv.notify_all();
     }
-    t0_real = realtime();
+};
+
+// the rest of the stream for the host reader: blocks straight from the queue (phi_reads_stream_open_blocks)
+struct QueueBlocks { ChunkQueue *q; int held = -1; };
+static int64_t next_block_from_queue(void *user, const char **block)
+{
+    QueueBlocks *qb = (QueueBlocks *)user;
+    if (qb->held >= 0) { qb->q->give_free(qb->held); qb->held = -1; }
+    const int s = qb->q->take_full();
+    const Chunk &c = qb->q->buf[(size_t)s];
+    if (c.n <= 0) return c.n;                                 // 0: the end; negative: the reader thread failed
+    qb->held = s;
+    *block = c.text;
+    return c.n;
+}
+
+static int run(const Options &o)
+{
+    const int k = o.k, w = o.w, recombination = o.recombination, is_qclp = o.is_qclp, is_mixed = o.is_mixed, debug = o.debug;
+    const std::string &gfa_file = o.gfa_file, &reads_file = o.reads_file, &hap_file = o.hap_file;
     char err[512] = "";
 
     // The device context (HIP initialisation) and the reads file are prepared by two host threads
     // while this one parses the graph: the three are independent.
-    if (devices.empty()) devices.push_back(device);
-    const int n_dev = (int)devices.size();
-    for (int i = 0; i < n_dev; i++)
-        for (int j = 0; j < i; j++)
+    std::vector<int> devices = o.devices;
+    if (devices.empty()) devices.push_back(o.device);
+    for (size_t i = 0; i < devices.size(); i++)
+        for (size_t j = 0; j < i; j++)
             if (devices[i] == devices[j]) { fprintf(stderr, "[E::main] --devices names GPU %d twice\n", devices[i]); return 1; }
+    // a read set is sharded only over as many GPUs as it can keep busy: every further GPU costs an exchange (~tens of
+    // microseconds) and an index build, and one GPU scores 50 Mbases in a fifth of a millisecond
+    if (devices.size() > 1) {
+        struct stat st;
+        long long bytes = (stat(reads_file.c_str(), &st) == 0 && S_ISREG(st.st_mode)) ? (long long)st.st_size : -1;
+        if (bytes >= 0) {
+            const size_t want = (size_t)std::max<long long>(1, (bytes + o.shard_min_bases - 1) / std::max<long long>(1, o.shard_min_bases));
+            if (want < devices.size()) {
+                fprintf(stderr, "[M::main] reads file of %lld bytes: using %zu of the %zu GPUs given (--shard-min-bases %lld per GPU)\n", bytes, want, devices.size(), o.shard_min_bases);
+                devices.resize(want);
+            }
+        }
+    }
+    const int n_dev = (int)devices.size();
     std::vector<phi_ctx *> ctxs((size_t)n_dev, nullptr);
-    const bool timing = getenv("PHI_TIMING") != nullptr;
+    const bool timing = g_marks.on;
     std::future<int> f_ctx = std::async(std::launch::async, [&]() {
+        Stage st("device context(s) [thread]");
         // one host thread per GPU (each context initialises its own device)
         std::vector<std::future<int>> fs;
         for (int i = 0; i < n_dev; i++)
             fs.push_back(std::async(std::launch::async, [&, i]() { return phi_ctx_create(devices[(size_t)i], &ctxs[(size_t)i]); }));
         int r = 0;
         for (auto &f : fs) { const int ri = f.get(); if (ri && !r) r = ri; }
-        if (timing) fprintf(stderr, "[phi timing] main: %d device context(s) ready at %.3f s\n", n_dev, realtime() - t0_real);
         return r;
     });
-    // Reads are streamed: a host thread parses the file chunk by chunk into three
-    // buffers (pinned once the device context exists) while this thread parses the graph, builds the
-    // index and then hands every finished chunk to phi_add_reads -- parse / inflate of chunk i+1
-    // overlaps the device copy and the kernels of chunk i, and host memory stays bounded.
-    struct Chunk { char *bases; int64_t *off; int64_t n_reads; };
-    const int64_t chunk_bases = getenv("PHI_READ_CHUNK") ? std::max<int64_t>(1024, atoll(getenv("PHI_READ_CHUNK"))) : ((int64_t)64 << 20);
-    const int64_t chunk_reads = chunk_bases / 64 + 1024;
-    const int N_CHUNK_BUF = 2 + n_dev;                       // one in flight per GPU, two with the parser
-    std::vector<Chunk> chunk_buf(N_CHUNK_BUF);
-    for (auto &cb : chunk_buf) {
-        cb.bases = (char *)malloc((size_t)chunk_bases);
-        cb.off = (int64_t *)malloc((size_t)(chunk_reads + 1) * sizeof(int64_t));
-        cb.n_reads = 0;
-        if (!cb.bases || !cb.off) { fprintf(stderr, "[E::%s] out of memory\n", __func__); return 1; }
+
+    // The reads file is streamed as TEXT: a host thread fills chunk buffers with the file's (inflated)
+    // bytes while this thread parses the graph and builds the index; every chunk then goes to phi_add_reads_text, which
+    // finds the records on the device -- chunk i + 1 crosses the link while chunk i is sketched, and no byte of a
+    // regular file is looked at by a host core.  Host memory stays bounded: 2 + GPUs buffers.
+    int64_t chunk_bytes = getenv("PHI_READ_CHUNK") ? std::max<int64_t>(256, atoll(getenv("PHI_READ_CHUNK"))) : ((int64_t)64 << 20);
+    {
+        struct stat st;
+        if (stat(reads_file.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && !getenv("PHI_READ_CHUNK")) {
+            FILE *fp = fopen(reads_file.c_str(), "rb");
+            unsigned char m2[2] = {0, 0};
+            const bool gz = fp && fread(m2, 1, 2, fp) == 2 && m2[0] == 0x1f && m2[1] == 0x8b;
+            if (fp) fclose(fp);
+            if (!gz) chunk_bytes = std::min<int64_t>(chunk_bytes, ((int64_t)st.st_size + 4095) & ~(int64_t)4095);   // a small file: one chunk of its size
+        }
     }
-    std::mutex q_mu;
-    std::condition_variable q_cv;
-    std::deque<int> q_free, q_full;                          // buffer indices; a full entry with n_reads == 0 ends the stream
-    for (int i = 0; i < N_CHUNK_BUF; i++) q_free.push_back(i);
+    ChunkQueue Q;
+    const int N_CHUNK_BUF = 2 + n_dev;                        // one in flight per GPU, two with the reader
+    Q.buf.resize((size_t)N_CHUNK_BUF);
+    for (int i = 0; i < N_CHUNK_BUF; i++) {
+        Q.buf[(size_t)i].text = (char *)malloc((size_t)chunk_bytes);
+        if (!Q.buf[(size_t)i].text) { fprintf(stderr, "[E::%s] out of memory\n", __func__); return 1; }
+        Q.q_free.push_back(i);
+    }
     char rerr[512] = "";
-    int64_t total_reads = 0;
-    bool stop_reader = false;
     std::future<int> f_reads = std::async(std::launch::async, [&]() {
-        phi_reads_stream *rs = nullptr;
-        int r = phi_reads_stream_open(reads_file.c_str(), &rs, rerr, sizeof rerr);
+        Stage st("reads file -> text chunks [thread]");
+        phi_text_stream *ts = nullptr;
+        int r = phi_text_stream_open(reads_file.c_str(), &ts, rerr, sizeof rerr);
         for (;;) {
             int slot;
             {
-                std::unique_lock<std::mutex> lk(q_mu);
-                q_cv.wait(lk, [&] { return !q_free.empty() || stop_reader; });
-                if (stop_reader) break;
-                slot = q_free.front(); q_free.pop_front();
+                std::unique_lock<std::mutex> lk(Q.mu);
+                Q.cv.wait(lk, [&] { return !Q.q_free.empty() || Q.stop; });
+                if (Q.stop) break;
+                slot = Q.q_free.front(); Q.q_free.pop_front();
             }
             int64_t n = 0;
             if (r == PHI_HOST_OK) {
-                n = phi_reads_stream_next(rs, chunk_buf[slot].bases, chunk_bases, chunk_buf[slot].off, chunk_reads, rerr, sizeof rerr);
-                if (n < 0) { r = (int)n; n = 0; }
-            }
-            chunk_buf[slot].n_reads = n;
+                n = phi_text_stream_read(ts, Q.buf[(size_t)slot].text, chunk_bytes, rerr, sizeof rerr);
+                if (n < 0) { r = (int)n; }
+            } else n = r;
+            Q.buf[(size_t)slot].n = n;                        // 0 ends the stream, a negative value ends it as failed
             {
-                std::lock_guard<std::mutex> lk(q_mu);
-                q_full.push_back(slot);
+                std::lock_guard<std::mutex> lk(Q.mu);
+                Q.q_full.push_back(slot);
             }
-            q_cv.notify_all();
-            if (n == 0) break;
+            Q.cv.notify_all();
+            if (n <= 0) break;
         }
-        if (rs) { total_reads = phi_reads_stream_reads(rs); phi_reads_stream_close(rs); }
-        if (timing) fprintf(stderr, "[phi timing] main: reads parsed at %.3f s\n", realtime() - t0_real);
+        if (ts) phi_text_stream_close(ts);
         return r;
     });
     auto stop_reads = [&]() {
-        { std::lock_guard<std::mutex> lk(q_mu); stop_reader = true; }
-        q_cv.notify_all();
+        { std::lock_guard<std::mutex> lk(Q.mu); Q.stop = true; }
+        Q.cv.notify_all();
         if (f_reads.valid()) f_reads.wait();
     };
 
     // ---- graph (main.cpp:101-115)
     phi_graph *g = nullptr;
-    if (phi_gfa_read(gfa_file.c_str(), &g, err, sizeof err) != PHI_HOST_OK) {
-        if (err[0] == 'E') fprintf(stderr, "%s\n", err);            // walk error text of ILP_index.cpp:105
-        else fprintf(stderr, "[E::%s] failed to load the GFA file\n", __func__);
-        if (err[0] && err[0] != 'E') fprintf(stderr, "[E::%s] %s\n", __func__, err);
-        f_ctx.wait(); stop_reads();
-        return 1;
+    {
+        Stage st("GFA read + parse");
+        if (phi_gfa_read(gfa_file.c_str(), &g, err, sizeof err) != PHI_HOST_OK) {
+            if (err[0] == 'E') fprintf(stderr, "%s\n", err);            // walk error text of ILP_index.cpp:105
+            else fprintf(stderr, "[E::%s] failed to load the GFA file\n", "main");
+            if (err[0] && err[0] != 'E') fprintf(stderr, "[E::%s] %s\n", "main", err);
+            f_ctx.wait(); stop_reads();
+            return 1;
+        }
     }
-    stamp(__func__);
+    stamp("main");
     fprintf(stderr, "Loaded graph from: %s\n", gfa_file.c_str());
     char hap_name[4096];
-    if (phi_hap_name(gfa_file.c_str(), reads_file.c_str(), hap_name, sizeof hap_name) < 0) { fprintf(stderr, "[E::%s] output name too long\n", __func__); f_ctx.wait(); stop_reads(); return 1; }
+    if (phi_hap_name(gfa_file.c_str(), reads_file.c_str(), hap_name, sizeof hap_name) < 0) { fprintf(stderr, "[E::%s] output name too long\n", "main"); f_ctx.wait(); stop_reads(); return 1; }
 
-    int rc = f_ctx.get();
-    if (rc) { fprintf(stderr, "[E::%s] no usable MI355X (HIP) device %d: %s\n", __func__, devices[0], phi_strerror(rc)); stop_reads(); return 1; }
+    int rc;
+    {
+        Stage st("wait for the device context");
+        rc = f_ctx.get();
+    }
+    if (rc) { fprintf(stderr, "[E::%s] no usable MI355X (HIP) device %d: %s\n", "main", devices[0], phi_strerror(rc)); stop_reads(); return 1; }
     phi_ctx *ctx = ctxs[0];                                   // the context that solves and reports
     auto die_on = [&](phi_ctx *cx, const char *what, int code) {
         fprintf(stderr, "[E::%s] %s: %s: %s\n", "main", what, phi_strerror(code), phi_last_error(cx));
@@ -225,11 +296,14 @@ int main(int argc, char *argv[])
         return 1;
     };
     auto die = [&](const char *what, int code) { return die_on(ctx, what, code); };
-    // rc of the first device thread that failed, with its context
+    // One phase of the job on every GPU, each on its own host thread.  All threads of a phase are joined before the next
+    // begins, and a collective (RCCL) is a phase of its own that is entered only when the phase before returned 0 on every
+    // GPU: a rank that failed can then never leave the others waiting inside ncclCommInitRank / ncclAllReduce.
+    std::atomic<bool> failed{false};
     auto run_on_all = [&](const char *what, const std::function<int(int, phi_ctx *)> &fn) -> int {
-        if (n_dev == 1) { const int r = fn(0, ctx); return r ? die(what, r) : 0; }
+        if (n_dev == 1) { const int r = fn(0, ctx); if (r) failed = true; return r ? die(what, r) : 0; }
         std::vector<std::future<int>> fs;
-        for (int i = 0; i < n_dev; i++) fs.push_back(std::async(std::launch::async, [&, i]() { return fn(i, ctxs[(size_t)i]); }));
+        for (int i = 0; i < n_dev; i++) fs.push_back(std::async(std::launch::async, [&, i]() { const int r = fn(i, ctxs[(size_t)i]); if (r) failed = true; return r; }));
         int bad = -1, brc = 0;
         for (int i = 0; i < n_dev; i++) { const int r = fs[(size_t)i].get(); if (r && bad < 0) { bad = i; brc = r; } }
         if (bad >= 0) {
@@ -244,56 +318,141 @@ int main(int argc, char *argv[])
     unsigned char comm_id[PHI_COMM_ID_BYTES];
     if (n_dev > 1 && (rc = phi_comm_unique_id(comm_id, sizeof comm_id))) { fprintf(stderr, "[E::main] RCCL is not available: %s\n", phi_strerror(rc)); stop_reads(); return 1; }
 
-    // ---- stage 1a: walks (ILP_index.cpp:556-611) on every GPU, while the reads are still being parsed
+    // ---- stage 1a: walks (ILP_index.cpp:556-611) on every GPU, while the reads are still being read
     const int32_t n_walks = phi_graph_n_walks(g);
-    if (run_on_all("graph", [&](int i, phi_ctx *cx) -> int {
-            int r = phi_set_params(cx, k, w, threshold, recombination, flags);
-            if (!r && dp_budget >= 0) r = phi_set_solve_budget(cx, dp_budget);
-            if (!r) r = phi_set_graph(cx, phi_graph_n_vtx(g), phi_graph_seq_concat(g), phi_graph_seq_off(g), phi_graph_adj_off(g),
-                                      phi_graph_adj(g), n_walks, phi_graph_walk_off(g), phi_graph_walk_vtx(g), phi_graph_topo_rank(g));
-            if (r == PHI_ERR_WALK && n_dev == 1) fprintf(stderr, "Error: %s\n", phi_last_error(cx));
-            if (!r && n_dev > 1) r = phi_comm_init(cx, comm_id, i, n_dev);
-            return r;
-        })) return 1;
+    {
+        Stage st("phi_set_graph (index build)");
+        if (run_on_all("graph", [&](int, phi_ctx *cx) -> int {
+                int r = phi_set_params(cx, k, w, o.threshold, recombination, flags);
+                // the reference's model.optimize() has no limit (ILP_index.cpp:1412-1418): none here unless --dp-budget asks for one
+                if (!r) r = phi_set_solve_budget(cx, o.dp_budget >= 0 ? o.dp_budget : 0);
+                if (!r) r = phi_set_graph(cx, phi_graph_n_vtx(g), phi_graph_seq_concat(g), phi_graph_seq_off(g), phi_graph_adj_off(g),
+                                          phi_graph_adj(g), n_walks, phi_graph_walk_off(g), phi_graph_walk_vtx(g), phi_graph_topo_rank(g));
+                if (r == PHI_ERR_WALK && n_dev == 1) fprintf(stderr, "Error: %s\n", phi_last_error(cx));
+                return r;
+            })) return 1;
+    }
+    if (n_dev > 1) {
+        Stage st("RCCL communicator");
+        if (run_on_all("communicator", [&](int i, phi_ctx *cx) -> int { return phi_comm_init(cx, comm_id, i, n_dev); })) return 1;
+    }
 
-    // ---- reads (main.cpp:136-137) and stage 1b/2a (:615-655), chunk by chunk: every GPU takes the next
-    //      finished chunk (a work queue: the shards balance themselves), then the one exchange of the job
+    // ---- reads (main.cpp:136-137) and stage 1b/2a (:615-655), chunk by chunk.  The chunks are taken in stream order,
+    //      one GPU at a time (a chunk needs the unfinished rest of the one before); the sketch of a chunk runs on
+    //      behind the turn.  Text that is not laid out regularly goes through the host reader from that byte on.
     std::atomic<int> n_chunks{0};
     std::atomic<bool> pinned{true};
     std::once_flag pin_once;
-    if (run_on_all("reads", [&](int, phi_ctx *cx) -> int {
-            for (;;) {
-                int slot;
-                {
-                    std::unique_lock<std::mutex> lk(q_mu);
-                    q_cv.wait(lk, [&] { return !q_full.empty(); });
-                    slot = q_full.front();
-                    if (chunk_buf[(size_t)slot].n_reads == 0) break;          // end of the stream: left in the queue for the other GPUs
-                    q_full.pop_front();
+    std::mutex turn_mu;
+    std::vector<char> carry;                                  // several GPUs: the bytes the last turn left unfinished
+    bool stream_done = false;                                 // under turn_mu
+    int64_t host_parsed_bases = 0;
+    // the host reader over `prefix` + the rest of the queue -> phi_add_reads on this GPU (under turn_mu)
+    auto finish_on_host = [&](phi_ctx *cx, const char *prefix, int64_t n_prefix, bool rest_of_queue) -> int {
+        Stage st("host reader (kseq state machine)");
+        QueueBlocks qb{&Q, -1};
+        phi_reads_stream *rs = nullptr;
+        if (phi_reads_stream_open_blocks(prefix, n_prefix, rest_of_queue ? next_block_from_queue : nullptr, &qb, &rs, rerr, sizeof rerr) != PHI_HOST_OK) return PHI_ERR_INVALID;
+        const int64_t cap_b = std::max<int64_t>((int64_t)1 << 20, std::min<int64_t>(chunk_bytes, (int64_t)64 << 20)), cap_r = cap_b / 32 + 1024;
+        std::vector<char> hb((size_t)cap_b);
+        std::vector<int64_t> ho((size_t)cap_r + 1);
+        int r = PHI_OK;
+        for (;;) {
+            const int64_t n = phi_reads_stream_next(rs, hb.data(), cap_b, ho.data(), cap_r, rerr, sizeof rerr);
+            if (n < 0) { r = PHI_ERR_INVALID; break; }
+            if (n == 0) break;
+            host_parsed_bases += ho[(size_t)n];
+            if ((r = phi_add_reads(cx, hb.data(), ho.data(), n))) break;
+        }
+        phi_reads_stream_close(rs);
+        if (qb.held >= 0) Q.give_free(qb.held);
+        if (r == PHI_ERR_INVALID && rerr[0]) fprintf(stderr, "[E::main] %s\n", rerr);
+        return r;
+    };
+    {
+        Stage st("reads: text -> device, records, sketch");
+        if (run_on_all("reads", [&](int, phi_ctx *cx) -> int {
+                int r = phi_reads_text_begin(cx, chunk_bytes);
+                bool open = r == PHI_OK;
+                while (!r) {
+                    std::unique_lock<std::mutex> turn(turn_mu);
+                    if (stream_done || failed) break;
+                    const int slot = Q.take_full();
+                    Chunk &cb = Q.buf[(size_t)slot];
+                    if (cb.n <= 0) {
+                        // the end of the stream (left in the queue for the other GPUs): what is still unfinished is the file's
+                        // last record, whose end only the end of the file shows -- the host reader's
+                        stream_done = true;
+                        if (cb.n < 0) { r = PHI_ERR_INVALID; fprintf(stderr, "[E::main] %s\n", rerr); break; }
+                        const char *pend = nullptr;
+                        int64_t n_pend = 0;
+                        r = phi_reads_text_end(cx, &pend, &n_pend, nullptr);
+                        open = false;
+                        if (!r && n_dev > 1) { pend = carry.data(); n_pend = (int64_t)carry.size(); }
+                        if (!r && n_pend) r = finish_on_host(cx, pend, n_pend, false);
+                        break;
+                    }
+                    if (++n_chunks >= 2)
+                        // a file of more than one chunk: pin the buffers, so that the device copy of every further
+                        // chunk is a direct DMA (pinning takes milliseconds: not worth it for a single chunk)
+                        std::call_once(pin_once, [&]() {
+                            for (auto &b : Q.buf) if (phi_host_register(cx, b.text, (size_t)chunk_bytes) != PHI_OK) pinned = false;
+                        });
+                    int32_t irr_carry = 0, irr = 0;
+                    if (n_dev > 1 && !carry.empty()) r = phi_add_reads_text(cx, carry.data(), (int64_t)carry.size(), &irr_carry);
+                    if (!r && !irr_carry) r = phi_add_reads_text(cx, cb.text, cb.n, &irr);
+                    if (!r && (irr_carry || irr)) {
+                        // not one of the two regular layouts: the exact state machine takes the stream from the first byte not taken
+                        stream_done = true;
+                        const char *pend = nullptr;
+                        int64_t n_pend = 0;
+                        r = phi_reads_text_end(cx, &pend, &n_pend, nullptr);
+                        open = false;
+                        std::vector<char> all;
+                        if (!r && irr_carry) {                 // (the carry, fed as a piece of its own, was what did not fit: this chunk follows it)
+                            all.assign(pend, pend + n_pend);
+                            all.insert(all.end(), cb.text, cb.text + cb.n);
+                            pend = all.data(); n_pend = (int64_t)all.size();
+                        }
+                        Q.give_free(slot);
+                        if (!r) {
+                            if (timing) fprintf(stderr, "[phi timing] main: the reads text is not regular FASTA / 4-line FASTQ: host reader from the first byte not taken\n");
+                            r = finish_on_host(cx, pend, n_pend, true);
+                        }
+                        break;
+                    }
+                    if (!r && n_dev > 1) {
+                        const char *p = nullptr;
+                        int64_t n = 0;
+                        r = phi_reads_text_detach_carry(cx, &p, &n);
+                        if (!r) carry.assign(p, p + n);
+                    }
+                    Q.give_free(slot);
                 }
-                const Chunk &cb = chunk_buf[(size_t)slot];
-                if (++n_chunks >= 2)
-                    // a file of more than one chunk: pin the buffers, so that the device copy of every further
-                    // chunk is a direct DMA (pinning takes milliseconds: not worth it for a single chunk)
-                    std::call_once(pin_once, [&]() {
-                        for (auto &b : chunk_buf) if (phi_host_register(cx, b.bases, (size_t)chunk_bases) != PHI_OK) pinned = false;
-                    });
-                const int r = phi_add_reads(cx, cb.bases, cb.off, cb.n_reads);
-                if (r) return r;
-                {
-                    std::lock_guard<std::mutex> lk(q_mu);
-                    q_free.push_back(slot);
-                }
-                q_cv.notify_all();
-            }
-            return n_dev > 1 ? phi_comm_exchange(cx) : PHI_OK;
-        })) return 1;
-    if (f_reads.get() != PHI_HOST_OK) { fprintf(stderr, "[E::%s] %s\n", __func__, rerr); return 1; }
+                if (open) { const int r2 = phi_reads_text_end(cx, nullptr, nullptr, nullptr); if (!r) r = r2; }
+                return r;
+            })) return 1;
+    }
+    if (f_reads.get() != PHI_HOST_OK) { fprintf(stderr, "[E::%s] %s\n", "main", rerr); return 1; }
+    if (n_dev > 1) {
+        Stage st("RCCL exchange");
+        if (run_on_all("exchange", [&](int, phi_ctx *cx) -> int { return phi_comm_exchange(cx); })) return 1;
+    }
+    int64_t total_reads = 0;
+    for (phi_ctx *cx : ctxs) {
+        int64_t nr = 0;
+        if ((rc = phi_reads_stats(cx, &nr, nullptr, nullptr, nullptr))) return die_on(cx, "reads", rc);
+        total_reads += nr;
+    }
     stamp("ILP_function");
     fprintf(stderr, "Graph has %d vertices, %d walks and read has %d reads\n", phi_graph_n_vtx(g), n_walks, (int)total_reads);
     // ---- stages 2b-3 (:670-1525)
     phi_result res;
-    if ((rc = phi_solve(ctx, &res))) return die("solve", rc);
+    {
+        Stage st("phi_solve (filter, exact solve, decode)");
+        if ((rc = phi_solve(ctx, &res))) return die("solve", rc);
+    }
+    const double t_report = realtime();
 
     fprintf(stderr, "Number of Minimizers\n");
     for (int32_t h = 0; h < n_walks; h++) fprintf(stderr, "%s : %d\n", phi_graph_hap_name(g, h), (int)res.n_minimizers[h]);
@@ -353,36 +512,135 @@ int main(int argc, char *argv[])
         if (res.n_path) fprintf(stderr, ">(%s,[%lld,%lld])", phi_graph_hap_name(g, prev_hap), (long long)prev_str_id, (long long)(str_id - 1));
         fprintf(stderr, "\n");
     }
+    g_marks.add("report (log lines)", t_report, realtime());
 
     // ---- FASTA (:1577-1598)
-    std::vector<char> seq((size_t)(res.hap_len > 0 ? res.hap_len : 1));
-    if ((rc = phi_path_sequence(ctx, seq.data(), res.hap_len))) return die("sequence", rc);
-    if (phi_write_fasta(hap_file.c_str(), hap_name, seq.data(), res.hap_len) != PHI_HOST_OK) {
-        fprintf(stderr, "[E::%s] cannot write %s\n", __func__, hap_file.c_str());
-        return 1;
+    {
+        Stage st("FASTA write");
+        std::vector<char> seq((size_t)(res.hap_len > 0 ? res.hap_len : 1));
+        if ((rc = phi_path_sequence(ctx, seq.data(), res.hap_len))) return die("sequence", rc);
+        if (phi_write_fasta(hap_file.c_str(), hap_name, seq.data(), res.hap_len) != PHI_HOST_OK) {
+            fprintf(stderr, "[E::%s] cannot write %s\n", "main", hap_file.c_str());
+            return 1;
+        }
     }
     stamp("ILP_function");
     fprintf(stderr, "Haplotype of size: %d written to: %s\n", (int)res.hap_len, hap_file.c_str());
 
-    fprintf(stderr, "[M::%s] PHI Version: %s\n", __func__, PHI_VERSION);
-    fprintf(stderr, "[M::%s] CMD:", __func__);
-    for (int i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
-    fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", __func__, realtime() - t0_real, cputime(),
+    fprintf(stderr, "[M::%s] PHI Version: %s\n", "main", PHI_VERSION);
+    fprintf(stderr, "[M::%s] CMD:", "main");
+    for (int i = 0; i < o.argc; ++i) fprintf(stderr, " %s", o.argv[i]);
+    fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", "main", realtime() - t0_real, cputime(),
             peakrss() / 1024.0 / 1024.0 / 1024.0);
-    if (timing) fprintf(stderr, "[phi timing] main: %d read chunk(s) of up to %lld bases%s on %d GPU(s)\n", n_chunks.load(), (long long)chunk_bases, n_chunks >= 2 && pinned ? ", pinned" : "", n_dev);
-    for (auto &cb : chunk_buf) {
-        if (n_chunks >= 2) (void)phi_host_unregister(ctx, cb.bases);
-        free(cb.bases); free(cb.off);
+    if (timing) {
+        fprintf(stderr, "[phi timing] main: %d text chunk(s) of up to %lld bytes%s on %d GPU(s); %lld bases through the host reader; FASTA closed at epoch %.6f\n",
+                n_chunks.load(), (long long)chunk_bytes, n_chunks >= 2 && pinned ? ", pinned" : "", n_dev, (long long)host_parsed_bases, realtime());
+        g_marks.print();
     }
-    phi_graph_free(g);
-    for (phi_ctx *cx : ctxs) phi_ctx_destroy(cx);
+    int status = 0;
     if (!res.optimal) {
-        // the reference returns only what model.optimize() proved (ILP_index.cpp:1418): an unproven path is
-        // written (it is feasible and within the printed bound) but the exit status says so
+        // the reference returns only what model.optimize() proved (ILP_index.cpp:1418); here that can only fall short when
+        // --dp-budget set a limit: the path written is feasible and within the printed bound, the exit status says so
         fprintf(stderr, "[W::main] the path written is NOT proven optimal: the exact search used its budget of %d DP runs "
-                        "(objective %lld, proven upper bound %lld); raise it with --dp-budget N (0 = no limit)\n",
+                        "(objective %lld, proven upper bound %lld); raise it with --dp-budget N (0 = no limit, the default)\n",
                 res.n_dp_runs, (long long)res.objective, (long long)res.upper_bound);
-        return 3;
+        status = 3;
     }
-    return 0;
+    if (getenv("PHI_FULL_TEARDOWN")) {                        // (leak checks: give everything back in order)
+        stop_reads();
+        for (auto &cb : Q.buf) {
+            if (n_chunks >= 2) (void)phi_host_unregister(ctx, cb.text);
+            free(cb.text);
+        }
+        phi_graph_free(g);
+        for (phi_ctx *cx : ctxs) phi_ctx_destroy(cx);
+    }
+    return status;
+}
+
+int main(int argc, char *argv[])
+{
+    Options o;
+    int help = 0;
+    static struct option long_options[] = {{"version", no_argument, 0, 300}, {"device", required_argument, 0, 301}, {"dp-budget", required_argument, 0, 302},
+                                           {"devices", required_argument, 0, 303}, {"shard-min-bases", required_argument, 0, 304}, {0, 0, 0, 0}};
+    int c;
+    // main.cpp:38 declares -h with an argument; a bare -h falls into the usage branch either way
+    while ((c = getopt_long(argc, argv, "x:d:c:l:s:m:R:q:T:N:h:k:w:t:g:r:o:DS", long_options, nullptr)) >= 0) {
+        if (c == 'w') o.w = atoi(optarg);
+        else if (c == 'k') o.k = atoi(optarg);
+        else if (c == 't') o.n_threads = atoi(optarg);
+        else if (c == 'm') o.is_mixed = atoi(optarg);
+        else if (c == 'g') o.gfa_file = optarg;
+        else if (c == 'R') o.recombination = atoi(optarg);
+        else if (c == 'q') o.is_qclp = atoi(optarg);
+        else if (c == 'N') o.is_naive = atoi(optarg);
+        else if (c == 'T') o.threshold = (float)atof(optarg);
+        else if (c == 'r') o.reads_file = optarg;
+        else if (c == 'o') o.hap_file = optarg;
+        else if (c == 'c') o.max_occ = atoi(optarg);
+        else if (c == 'd') o.debug = atoi(optarg);
+        else if (c == 'h' || c == '?') help = 1;
+        else if (c == 300) { fprintf(stderr, "PHI version: %s\n", PHI_VERSION); return 0; }
+        else if (c == 301) o.device = atoi(optarg);
+        else if (c == 302) o.dp_budget = atoll(optarg);
+        else if (c == 304) o.shard_min_bases = std::max<long long>(1, atoll(optarg));
+        else if (c == 303) {                                   // --devices 0,1,2,...: shard the reads over these GPUs
+            o.devices.clear();
+            for (const char *p = optarg; *p;) {
+                char *end = nullptr;
+                const long d = strtol(p, &end, 10);
+                if (end == p || d < 0) { fprintf(stderr, "[E::main] --devices takes a comma-separated list of GPU ordinals\n"); return 1; }
+                o.devices.push_back((int)d);
+                p = *end == ',' ? end + 1 : end;
+                if (*end && *end != ',') { fprintf(stderr, "[E::main] --devices takes a comma-separated list of GPU ordinals\n"); return 1; }
+            }
+        }
+    }
+    if (argc < 2 || o.gfa_file.empty() || o.reads_file.empty() || o.hap_file.empty() || help) {
+        usage(stderr, o.k, o.w, o.recombination, o.is_qclp, o.is_mixed, o.threshold, o.n_threads, o.gfa_file.c_str(), o.reads_file.c_str(), o.hap_file.c_str(), o.debug);
+        return 1;
+    }
+    o.argc = argc; o.argv = argv;
+    t0_real = realtime();
+
+    // The work is done by a child; this process returns the child's status as soon as the child reports it -- after the
+    // FASTA is closed and the log written, before the teardown.  Not under a profiler or any other preloaded library that
+    // may have started the GPU runtime in this process already (a runtime does not survive a fork), and not when asked.
+    bool detach = true;
+    if (const char *e = getenv("PHI_DETACH")) detach = atoi(e) != 0;
+    if (getenv("LD_PRELOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("HSA_TOOLS_LIB")) detach = false;
+    int report_fd = -1;
+    if (detach) {
+        int pfd[2];
+        if (pipe(pfd) == 0) {
+            fflush(nullptr);
+            const pid_t pid = fork();
+            if (pid > 0) {
+                close(pfd[1]);
+                unsigned char st = 0;
+                ssize_t r;
+                do r = read(pfd[0], &st, 1); while (r < 0 && errno == EINTR);
+                if (r == 1) _exit(st);
+                int ws = 0;                                   // the pipe closed without a status: the child died
+                while (waitpid(pid, &ws, 0) < 0 && errno == EINTR) {}
+                _exit(WIFEXITED(ws) ? WEXITSTATUS(ws) : 128 + (WIFSIGNALED(ws) ? WTERMSIG(ws) : 0));
+            } else if (pid == 0) {
+                close(pfd[0]);
+                report_fd = pfd[1];
+                (void)prctl(PR_SET_PDEATHSIG, SIGTERM);        // a killed parent takes the child with it
+            } else { close(pfd[0]); close(pfd[1]); }           // no fork: one process
+        }
+    }
+    const int status = run(o);
+    fflush(nullptr);
+    if (report_fd >= 0) {
+        const unsigned char st = (unsigned char)status;
+        ssize_t r;
+        do r = write(report_fd, &st, 1); while (r < 0 && errno == EINTR);
+        // nothing more is written: let a pipe that captures the log see its end now, not when the teardown is over
+        close(report_fd); close(0); close(1); close(2);
+    }
+    // the arrays, the contexts and the runtime are given back by the exit itself (PHI_FULL_TEARDOWN=1 frees them one by one first)
+    _exit(status);
 }

@@ -11,8 +11,13 @@
 #include <string.h>
 #include <stdlib.h>
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../../include/phi_host.h"
 #include "gz_source.h"
@@ -40,6 +45,14 @@ namespace {
 struct ByteSrc {
     FILE *fp = nullptr;                               // plain file ...
     GzSource *gz = nullptr;                           // ... or gzip: inflated off this thread (gz_source.h), on many threads for BGZF
+    // ... or text that is already in memory, followed by blocks a callback hands over (the rest of a stream whose
+    // beginning the device has taken: phi_reads_stream_open_blocks)
+    const char *mem = nullptr;
+    size_t mem_n = 0, mem_at = 0;
+    phi_text_block_fn next_block = nullptr;
+    void *next_user = nullptr;
+    bool from_blocks = false;
+    bool failed = false;                              // the source broke (corrupt gzip stream, callback error): not a clean end
     std::vector<char> buf;
     size_t begin = 0, end = 0;
     bool is_eof = false;
@@ -73,13 +86,33 @@ struct ByteSrc {
         if (gz) { gz->close(); delete gz; }
         fp = nullptr; gz = nullptr;
     }
+    void open_blocks(const char *prefix, size_t n_prefix, phi_text_block_fn fn, void *user)
+    {
+        mem = prefix; mem_n = n_prefix; mem_at = 0; next_block = fn; next_user = user; from_blocks = true;
+    }
     bool refill()                                     // false: nothing more to read
     {
         if (is_eof) return false;
         begin = 0; end = 0;
+        if (from_blocks) {
+            while (end == 0) {
+                if (mem_at < mem_n) {
+                    const size_t n = std::min(mem_n - mem_at, (size_t)4 << 20);
+                    buf.assign(mem + mem_at, mem + mem_at + n);
+                    mem_at += n;
+                } else {
+                    const char *p = nullptr;
+                    const int64_t n = next_block ? next_block(next_user, &p) : 0;
+                    if (n <= 0) { is_eof = true; failed = n < 0; return false; }
+                    buf.assign(p, p + n);
+                }
+                end = buf.size();
+            }
+            return true;
+        }
         if (gz) {
             while (end == 0) {
-                if (!gz->next(buf)) { is_eof = true; return false; }      // (an inflate error ends the input, as gzread's -1 did)
+                if (!gz->next(buf)) { is_eof = true; failed = !gz->ok(); return false; }   // a corrupt stream is an error, not the end of the file
                 end = buf.size();
             }
             return true;
@@ -219,7 +252,9 @@ int phi_reads_read(const char *path, phi_reads **out, char *err, int err_cap)
         r->bases.insert(r->bases.end(), st.seq.begin(), st.seq.end());
         r->off.push_back((int64_t)r->bases.size());
     }
+    const bool broke = ks.failed;
     ks.close();
+    if (broke) { delete r; return fail(err, err_cap, PHI_HOST_ERR_IO, "gzip stream corrupt in the reads file %s", path); }
     *out = r;
     return PHI_HOST_OK;
 }
@@ -244,6 +279,17 @@ int phi_reads_stream_open(const char *path, phi_reads_stream **out, char *err, i
     return PHI_HOST_OK;
 }
 
+int phi_reads_stream_open_blocks(const char *prefix, int64_t n_prefix, phi_text_block_fn next, void *user, phi_reads_stream **out,
+                                 char *err, int err_cap)
+{
+    if (!out || n_prefix < 0 || (n_prefix > 0 && !prefix)) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "bad arguments");
+    phi_reads_stream *s = new phi_reads_stream();
+    s->st.want_names = false;
+    s->ks.open_blocks(prefix, (size_t)n_prefix, next, user);
+    *out = s;
+    return PHI_HOST_OK;
+}
+
 int64_t phi_reads_stream_next(phi_reads_stream *s, char *bases, int64_t bases_cap, int64_t *off, int64_t reads_cap,
                               char *err, int err_cap)
 {
@@ -252,7 +298,11 @@ int64_t phi_reads_stream_next(phi_reads_stream *s, char *bases, int64_t bases_ca
     off[0] = 0;
     while (n < reads_cap && !s->done) {
         if (!s->pending) {
-            if (kseq_next(s->ks, s->st) < 0) { s->done = true; break; }
+            if (kseq_next(s->ks, s->st) < 0) {
+                s->done = true;
+                if (s->ks.failed) return fail(err, err_cap, PHI_HOST_ERR_IO, "the reads text broke off: gzip stream corrupt, or the source failed");
+                break;
+            }
             s->pending = true;
         }
         const int64_t len = (int64_t)s->st.seq.size();
@@ -276,6 +326,104 @@ void phi_reads_stream_close(phi_reads_stream *s)
 {
     if (!s) return;
     s->ks.close();
+    delete s;
+}
+
+// ---- the (inflated) text of a reads file as it is, for the device-side record splitter (phi_add_reads_text): no parsing
+//      here at all.  Plain files are read with several preads at once straight into the caller's (pinned) buffer.
+struct phi_text_stream {
+    int fd = -1;
+    int64_t size = 0, pos = 0;
+    GzSource *gz = nullptr;
+    std::vector<char> blk;
+    size_t blk_at = 0;
+    bool eof = false;
+};
+
+int phi_text_stream_open(const char *path, phi_text_stream **out, char *err, int err_cap)
+{
+    if (!path || !out) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to open the reads file %s", path);
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = pread(fd, magic, 2, 0);
+    phi_text_stream *s = new phi_text_stream();
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        ::close(fd);
+        s->gz = new GzSource();
+        if (!s->gz->open(path, ByteSrc::inflate_threads())) { delete s->gz; delete s; return fail(err, err_cap, PHI_HOST_ERR_IO, "failed to open the reads file %s", path); }
+    } else {
+        struct stat st;
+        s->fd = fd;
+        s->size = (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) ? (int64_t)st.st_size : -1;   // -1: a pipe, read sequentially
+    }
+    *out = s;
+    return PHI_HOST_OK;
+}
+
+int64_t phi_text_stream_read(phi_text_stream *s, char *buf, int64_t cap, char *err, int err_cap)
+{
+    if (!s || !buf || cap <= 0) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "bad arguments");
+    if (s->eof) return 0;
+    int64_t n = 0;
+    if (s->gz) {
+        while (n < cap) {
+            if (s->blk_at == s->blk.size()) {
+                s->blk_at = 0;
+                if (!s->gz->next(s->blk)) {
+                    s->blk.clear();
+                    s->eof = true;
+                    if (!s->gz->ok()) return fail(err, err_cap, PHI_HOST_ERR_IO, "gzip stream corrupt in the reads file");
+                    break;
+                }
+            }
+            const size_t take = std::min<size_t>((size_t)(cap - n), s->blk.size() - s->blk_at);
+            memcpy(buf + n, s->blk.data() + s->blk_at, take);
+            s->blk_at += take; n += (int64_t)take;
+        }
+        return n;
+    }
+    if (s->size < 0) {                                  // not a regular file
+        while (n < cap) {
+            const ssize_t r = ::read(s->fd, buf + n, (size_t)(cap - n));
+            if (r < 0) return fail(err, err_cap, PHI_HOST_ERR_IO, "read error on the reads file");
+            if (r == 0) { s->eof = true; break; }
+            n += r;
+        }
+        return n;
+    }
+    const int64_t want = std::min<int64_t>(cap, s->size - s->pos);
+    if (want <= 0) { s->eof = true; return 0; }
+    // a page-cache read is a memcpy in the kernel, ~3 GB/s on one thread: several at once
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ByteSrc::inflate_threads(), 8), want / ((int64_t)4 << 20)));
+    std::atomic<int> bad{0};
+    auto part = [&](int t) {
+        int64_t lo = want * t / nt, hi = want * (t + 1) / nt;
+        while (lo < hi) {
+            const ssize_t r = pread(s->fd, buf + lo, (size_t)(hi - lo), (off_t)(s->pos + lo));
+            if (r <= 0) { bad.store(1); return; }          // (a file that shrank under us)
+            lo += r;
+        }
+    };
+    if (nt == 1) part(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(part, t);
+        part(0);
+        for (auto &t : th) t.join();
+    }
+    if (bad.load()) return fail(err, err_cap, PHI_HOST_ERR_IO, "read error on the reads file");
+    s->pos += want;
+    if (s->pos >= s->size) s->eof = true;
+    return want;
+}
+
+void phi_text_stream_close(phi_text_stream *s)
+{
+    if (!s) return;
+    if (s->fd >= 0) ::close(s->fd);
+    if (s->gz) { s->gz->close(); delete s->gz; }
     delete s;
 }
 

@@ -102,7 +102,7 @@ int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted)
     if (frc) return frc;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return phi_fail(c, PHI_ERR_DEVICE, "stream synchronize failed");
     std::vector<uint64_t> h(2 * PHI_STRIPES * 8);
-    int rc = phi_hip_check(c, hipMemcpy(h.data(), c->d_stripes.p, 2 * STRIPE_BYTES, hipMemcpyDeviceToHost), "D2H counters");
+    int rc = phi_hip_check(c, phi_copy_sync(c, h.data(), c->d_stripes.p, 2 * STRIPE_BYTES, hipMemcpyDeviceToHost), "D2H counters");
     if (rc) return rc;
     uint64_t a = 0, b = 0;
     for (int i = 0; i < PHI_STRIPES; i++) { a += h[(size_t)i * 8]; b += h[(size_t)(PHI_STRIPES + i) * 8]; }
@@ -145,7 +145,7 @@ int phi_sync_check(phi_ctx *c)
     PHICHK(phi_flush_reset(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     uint64_t s[S_N];
-    HIPCHK(hipMemcpy(s, c->d_scalars.p, sizeof s, hipMemcpyDeviceToHost));
+    HIPCHK(phi_copy_sync(c, s, c->d_scalars.p, sizeof s, hipMemcpyDeviceToHost));
     const uint32_t err = (uint32_t)s[S_ERR];
     if (err & PHI_KERR_TABLE_FULL) return phi_fail(c, PHI_ERR_OVERFLOW, "open-addressed table overflow (probe bound %d)", PHI_MAX_PROBE);
     if (err & PHI_KERR_SENTINEL) return phi_fail(c, PHI_ERR_UNSUPPORTED, "a minimiser hashes to UINT64_MAX (table sentinel)");
@@ -177,30 +177,47 @@ int phi_ctx_create(int device_id, phi_ctx **out)
 {
     if (!out) return PHI_ERR_INVALID;
     *out = nullptr;
+    PhiStageTimer tm("ctx_create");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return PHI_ERR_DEVICE;
+    tm.lap("runtime start (hipInit)");
     if (device_id < 0 || device_id >= n_dev) return PHI_ERR_INVALID;
     if (hipSetDevice(device_id) != hipSuccess) return PHI_ERR_DEVICE;
     phi_ctx *c = new (std::nothrow) phi_ctx();
     if (!c) return PHI_ERR_NOMEM;
     c->device = device_id;
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PHI_ERR_DEVICE; }
+    // A stream is a hardware queue: ~20 ms each to create.  The second one (the host thread's copies inside
+    // phi_set_graph) is made by a thread of its own while this one warms the first up; nothing here touches the null
+    // stream, whose queue would cost as much again (phi_copy_sync / phi_memset_sync in phi_ctx.h).
+    std::future<hipError_t> aux = std::async(std::launch::async, [c, device_id]() {
+        hipError_t e = hipSetDevice(device_id);
+        return e != hipSuccess ? e : hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    });
+    auto bail = [&](int code) {
+        if (aux.valid()) (void)aux.get();
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+        dev_free(c->d_scalars); dev_free(c->d_stripes); dev_free(c->alt.stripes);
+        delete c;
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(PHI_ERR_DEVICE);
     c->stream = c->own_stream;
-    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return PHI_ERR_DEVICE; }
-    if (phi_dev_ensure(c, c->d_scalars, S_N * 8) || hipMemset(c->d_scalars.p, 0, S_N * 8) != hipSuccess ||
-        phi_dev_ensure(c, c->d_stripes, 2 * STRIPE_BYTES) || hipMemset(c->d_stripes.p, 0, 2 * STRIPE_BYTES) != hipSuccess ||
-        phi_dev_ensure(c, c->alt.stripes, 2 * STRIPE_BYTES) || hipMemset(c->alt.stripes.p, 0, 2 * STRIPE_BYTES) != hipSuccess) {
-        (void)hipStreamDestroy(c->own_stream); (void)hipStreamDestroy(c->aux_stream); delete c; return PHI_ERR_DEVICE;
-    }
+    tm.lap("stream");
+    if (phi_dev_ensure(c, c->d_scalars, S_N * 8) || hipMemsetAsync(c->d_scalars.p, 0, S_N * 8, c->stream) != hipSuccess ||
+        phi_dev_ensure(c, c->d_stripes, 2 * STRIPE_BYTES) || hipMemsetAsync(c->d_stripes.p, 0, 2 * STRIPE_BYTES, c->stream) != hipSuccess ||
+        phi_dev_ensure(c, c->alt.stripes, 2 * STRIPE_BYTES) || hipMemsetAsync(c->alt.stripes.p, 0, 2 * STRIPE_BYTES, c->stream) != hipSuccess)
+        return bail(PHI_ERR_DEVICE);
     // the kernels' code objects are loaded lazily, per translation unit, at their first launch: do that here, once
     phi_warm_sketch(c->stream); phi_warm_table(c->stream); phi_warm_anchors(c->stream); phi_warm_contexts(c->stream);
-    phi_warm_dp(c->stream); phi_warm_dp_events(c->stream); phi_warm_solve_dev(c->stream);
-    (void)hipStreamSynchronize(c->stream);
+    phi_warm_dp(c->stream); phi_warm_dp_events(c->stream); phi_warm_solve_dev(c->stream); phi_warm_reads_text(c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(PHI_ERR_DEVICE);
+    tm.lap("scalars + code objects");
     // the first pageable host-to-device copy of a process sets up the runtime's staging buffers
     // (several ms): pay that here, once, not inside the first phi_set_graph
     {
         DevBuf warm;
-        std::vector<char> h((size_t)4 << 20, 0);
+        std::vector<char> h((size_t)1 << 20, 0);
         if (phi_dev_ensure(c, warm, h.size()) == PHI_OK) {
             (void)hipMemcpyAsync(warm.p, h.data(), h.size(), hipMemcpyHostToDevice, c->stream);
             (void)hipMemcpyAsync(h.data(), warm.p, h.size(), hipMemcpyDeviceToHost, c->stream);
@@ -209,6 +226,9 @@ int phi_ctx_create(int device_id, phi_ctx **out)
         }
         c->last_error.clear();
     }
+    tm.lap("first host copies");
+    if (aux.get() != hipSuccess) { c->aux_stream = nullptr; return bail(PHI_ERR_DEVICE); }
+    tm.lap("wait for the second stream");
     *out = c;
     return PHI_OK;
 }
@@ -234,6 +254,15 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_ent};
     for (DevBuf *b : all) dev_free(*b);
     for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t e : c->piece_events) (void)hipEventDestroy(e);
+    if (c->h_err) (void)hipHostFree(c->h_err);
+    {
+        auto &T = c->text;
+        for (int i = 0; i < 2; i++) { dev_free(T.text[i]); dev_free(T.bases[i]); dev_free(T.roff[i]); }
+        dev_free(T.tile_cnt); dev_free(T.ls); dev_free(T.pre); dev_free(T.blk); dev_free(T.sum);
+        if (T.h_sum) (void)hipHostFree(T.h_sum);
+        if (T.ev_copy) (void)hipEventDestroy(T.ev_copy);
+    }
     (void)hipStreamDestroy(c->own_stream);
     (void)hipStreamDestroy(c->aux_stream);
     delete c;
@@ -350,7 +379,7 @@ static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_e
             if (cap == cap_max) return phi_fail(c, PHI_ERR_OVERFLOW, "walk-context table overflow (internal error)");
             cap = std::min(cap_max, cap * 8);
             err &= ~PHI_KERR_TABLE_FULL;
-            HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
+            HIPCHK(phi_copy_sync(c, scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
             attempt--;
             continue;
         }
@@ -360,7 +389,7 @@ static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_e
         if (!(err & PHI_KERR_FP_COLLISION)) break;
         if (attempt >= 7) return phi_fail(c, PHI_ERR_DEVICE, "walk-context fingerprints collide under 8 seeds (internal error)");
         err &= ~PHI_KERR_FP_COLLISION;
-        HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
+        HIPCHK(phi_copy_sync(c, scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
     }
     tg.lap("[gpu thread]     table insert + verify");
     for (int32_t h = 0; h < n_walks; h++) c->h_walk_base[h + 1] += c->h_walk_base[h];
@@ -934,20 +963,18 @@ static int sp_ensure(phi_ctx *c, int64_t est)
 
 }  // extern "C"
 
-static int add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, bool replay);
-
 extern "C" {
 
 int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases)
 {
-    return add_reads_device_impl(c, d_bases, d_read_off, n_reads, n_bases, false);
+    return phi_add_reads_device_impl(c, d_bases, d_read_off, n_reads, n_bases, 0, false);
 }
 
 }  // extern "C"
 
 // replay: the same batch again after the spectrum set was regrown (its first pass overflowed the set): everything a
 // batch does is idempotent (hit flags, set inserts) except the count of emitted minimisers, which is not repeated
-static int add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, bool replay)
+int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, int64_t off_bias, bool replay)
 {
     if (!c) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads before phi_set_graph");
@@ -976,7 +1003,7 @@ static int add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_
     // take the exact byte-wise routine inside the same wave
     PhiSketchArgs A{};
     A.ascii = (const uint8_t *)d_bases;
-    A.read_off = (const int64_t *)d_read_off; A.n_reads = n_reads;
+    A.read_off = (const int64_t *)d_read_off; A.n_reads = n_reads; A.off_bias = off_bias;
     {
         const double q = (double)n_reads / (double)n_bases * 4294967296.0;      // (a guess: clamped, never wrong to round)
         A.reads_per_base_q32 = q >= 2147483648.0 ? 0x80000000u : (uint32_t)q;
@@ -1025,6 +1052,31 @@ static int add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_
     return PHI_OK;
 }
 
+
+// After the stream has been waited for: if the spectrum set overflowed under the batch whose data still sits at
+// (d_bases, d_off) -- denser input than the set was sized for; the reference's std::map has no such limit,
+// ILP_index.cpp:622-635 -- regrow the set and replay that batch.  err = the device error word as read behind the batch.
+static int replay_if_full(phi_ctx *c, uint32_t err, const void *d_bases, const void *d_off, int64_t n_reads, int64_t n_bases, int64_t off_bias)
+{
+    for (int attempt = 0; attempt < 6 && (err & PHI_KERR_TABLE_FULL); attempt++) {
+        err &= ~PHI_KERR_TABLE_FULL;
+        HIPCHK(phi_copy_sync(c, scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
+        PHICHK(phi_add_reads_device_impl(c, d_bases, d_off, n_reads, n_bases, off_bias, true));
+        HIPCHK(phi_copy_sync(c, &err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
+    }
+    return PHI_OK;
+}
+
+static bool offsets_monotone(const int64_t *off, int64_t n)
+{
+    // branch-free, so that the compiler vectorises it: 33 000 offsets in a few microseconds
+    auto span = [off](int64_t lo, int64_t hi) { int bad = 0; for (int64_t r = lo; r < hi; r++) bad |= off[r + 1] < off[r]; return bad; };
+    if (n < (1 << 20)) return !span(0, n);
+    std::atomic<int> bad{0};
+    phi_parallel_chunks(n, (int64_t)1 << 20, [&](int64_t lo, int64_t hi, int) { if (span(lo, hi)) bad.store(1); });
+    return !bad.load();
+}
+
 extern "C" {
 
 int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_t n_reads)
@@ -1034,38 +1086,223 @@ int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_
     if (n_reads < 0 || (n_reads > 0 && !read_off)) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads: bad arguments");
     if (n_reads == 0) return PHI_OK;
     if (read_off[0] != 0) return phi_fail(c, PHI_ERR_INVALID, "read_off must start at 0");
-    for (int64_t r = 0; r < n_reads; r++)
-        if (read_off[r + 1] < read_off[r]) return phi_fail(c, PHI_ERR_INVALID, "read_off not monotone at read %lld", (long long)r);
+    if (!offsets_monotone(read_off, n_reads)) {
+        for (int64_t r = 0; r < n_reads; r++)
+            if (read_off[r + 1] < read_off[r]) return phi_fail(c, PHI_ERR_INVALID, "read_off not monotone at read %lld", (long long)r);
+    }
     const int64_t n_bases = read_off[n_reads];
     if (n_bases > 0 && !bases) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads: bases is null");
     HIPCHK(hipSetDevice(c->device));
     PhiStageTimer tm("add_reads");
-    // the previous batch may still be reading the staging buffers
-    HIPCHK(hipStreamSynchronize(c->stream));
-    tm.lap("wait for the stream");
+    // (every call ends with a wait for the stream: nothing of an earlier batch still reads the staging buffers)
     PHICHK(phi_dev_ensure(c, c->d_rbases, (size_t)std::max<int64_t>(n_bases, 1)));
     PHICHK(phi_dev_ensure(c, c->d_roff, (size_t)(n_reads + 1) * 8));
+    if (!c->h_err) HIPCHK(hipHostMalloc((void **)&c->h_err, 64, hipHostMallocDefault));
     tm.lap("buffers");
-    if (n_bases) HIPCHK(hipMemcpyAsync(c->d_rbases.p, bases, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_roff.p, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    if (tm.on) (void)hipStreamSynchronize(c->stream);
-    tm.lap("H2D");
-    PHICHK(phi_add_reads_device(c, c->d_rbases.p, c->d_roff.p, n_reads, n_bases));
-    // host buffers are borrowed for the call only
+    // The batch goes over in PIECES cut at read ends: piece j + 1 is copied (aux_stream) while piece j is sketched
+    // (stream), so that a batch costs its copy time plus one short kernel, not copy + kernel.  The offsets go first,
+    // whole; a piece's kernel reads its slice of them (off_bias).  PCIe moves ~55 GB/s: a 1-MB piece is 19 us of copy
+    // against ~7 us of kernel.
+    static const int64_t piece_bytes = getenv("PHI_H2D_PIECE") ? std::max<int64_t>(1 << 12, atoll(getenv("PHI_H2D_PIECE"))) : ((int64_t)1 << 20);
+    HIPCHK(hipMemcpyAsync(c->d_roff.p, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->aux_stream));
+    int64_t r0 = 0;
+    size_t n_piece = 0;
+    while (r0 < n_reads) {
+        // the piece ends at the last read that starts before its byte budget runs out (a longer read is a piece of its own)
+        int64_t r1 = (int64_t)(std::upper_bound(read_off + r0, read_off + n_reads + 1, read_off[r0] + piece_bytes) - read_off) - 1;
+        if (r1 <= r0) r1 = r0 + 1;
+        if (n_reads - r1 < (r1 - r0) / 4) r1 = n_reads;        // no short last piece
+        const int64_t b0 = read_off[r0], nb = read_off[r1] - b0;
+        if (nb) HIPCHK(hipMemcpyAsync((char *)c->d_rbases.p + b0, bases + b0, (size_t)nb, hipMemcpyHostToDevice, c->aux_stream));
+        if (n_piece == c->piece_events.size()) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->piece_events.push_back(e);
+        }
+        HIPCHK(hipEventRecord(c->piece_events[n_piece], c->aux_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->piece_events[n_piece], 0));
+        n_piece++;
+        PHICHK(phi_add_reads_device_impl(c, (const char *)c->d_rbases.p + b0, c->d_roff.as<int64_t>() + r0, r1 - r0, nb, b0, false));
+        r0 = r1;
+    }
+    // the error word behind the last kernel; host buffers are borrowed for the call only: one wait for everything
+    HIPCHK(hipMemcpyAsync(c->h_err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    tm.lap("sketch + probe");
-    // denser input than the read-spectrum set was sized for (the reference's std::map has no such limit,
-    // ILP_index.cpp:622-635): regrow the set and replay the batch
-    for (int attempt = 0; attempt < 6; attempt++) {
-        uint32_t err = 0;
-        HIPCHK(hipMemcpy(&err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
-        if (!(err & PHI_KERR_TABLE_FULL)) break;
-        err &= ~PHI_KERR_TABLE_FULL;
-        HIPCHK(hipMemcpy(scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
-        PHICHK(add_reads_device_impl(c, c->d_rbases.p, c->d_roff.p, n_reads, n_bases, true));
-        HIPCHK(hipStreamSynchronize(c->stream));
+    tm.lap("H2D + sketch + probe (pieces)");
+    if (*c->h_err & PHI_KERR_TABLE_FULL) {
+        PHICHK(replay_if_full(c, *c->h_err, c->d_rbases.p, c->d_roff.p, n_reads, n_bases, 0));
         tm.lap("spectrum set regrown, batch replayed");
     }
+    return PHI_OK;
+}
+
+// ---- reads as raw text: the records are found on the device (reads_text.hip)
+
+int phi_reads_text_begin(phi_ctx *c, int64_t max_chunk_bytes)
+{
+    if (!c) return PHI_ERR_INVALID;
+    if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reads_text_begin before phi_set_graph");
+    if (max_chunk_bytes <= 0) return phi_fail(c, PHI_ERR_INVALID, "phi_reads_text_begin: bad chunk size");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    auto &T = c->text;
+    const uint32_t chunk = (uint32_t)std::min<int64_t>(std::max<int64_t>(max_chunk_bytes, 64), (int64_t)1 << 28);
+    // the carry holds what a chunk leaves unfinished: a record at most (the longest reads are a few Mbases, twice that as FASTQ)
+    const uint32_t carry = getenv("PHI_TEXT_CARRY") ? (uint32_t)std::max<long long>(64, atoll(getenv("PHI_TEXT_CARRY"))) & ~15u : std::max<uint32_t>(chunk / 2, 1u << 24);
+    const uint32_t line_cap = (carry + chunk) / 16 + 1024;    // a line of a read file is 75 bytes on average, never 16 (then: irregular)
+    for (int i = 0; i < 2; i++) {
+        PHICHK(phi_dev_ensure(c, T.text[i], (size_t)carry + chunk + 64));
+        PHICHK(phi_dev_ensure(c, T.bases[i], (size_t)carry + chunk + 64));
+        PHICHK(phi_dev_ensure(c, T.roff[i], ((size_t)line_cap + 2) * 8));
+    }
+    PHICHK(phi_dev_ensure(c, T.tile_cnt, ((size_t)phi_text_num_tiles(0, carry + chunk + 64) + 2) * 4));
+    PHICHK(phi_dev_ensure(c, T.ls, ((size_t)line_cap + 2) * 4));
+    PHICHK(phi_dev_ensure(c, T.pre, ((size_t)line_cap + 2) * 8));
+    PHICHK(phi_dev_ensure(c, T.blk, ((size_t)phi_text_scan_blocks(line_cap) + 1) * 8));
+    PHICHK(phi_dev_ensure(c, T.sum, sizeof(PhiTextSummary)));
+    if (!T.h_sum) HIPCHK(hipHostMalloc((void **)&T.h_sum, 64 + sizeof(PhiTextSummary), hipHostMallocDefault));
+    if (!T.ev_copy) HIPCHK(hipEventCreateWithFlags(&T.ev_copy, hipEventDisableTiming));
+    T.carry_cap = carry; T.chunk_cap = chunk; T.line_cap = line_cap;
+    T.active = true; T.irregular = false; T.started = false; T.mode = 0;
+    T.fed = 0; T.taken = 0; T.slot = 0; T.carry_len = 0; T.carry_at = carry; T.h_carry.clear();
+    T.last_slot = -1; T.why = 0; T.first_bad = 0; T.detached = false;
+    return PHI_OK;
+}
+
+}  // extern "C"
+
+// the sketch of the chunk before may have overflowed the spectrum set: its bases and offsets are still in their slot
+static int text_replay_last(phi_ctx *c, uint32_t err)
+{
+    auto &T = c->text;
+    if (T.last_slot < 0 || !(err & PHI_KERR_TABLE_FULL)) return PHI_OK;
+    return replay_if_full(c, err, T.bases[T.last_slot].p, T.roff[T.last_slot].p, T.last_reads, T.last_bases, 0);
+}
+
+static int text_piece(phi_ctx *c, const char *p, uint32_t m, int32_t *irregular)
+{
+    auto &T = c->text;
+    T.dbg_reads = 0; T.dbg_bases = 0;
+    if (!T.started) {
+        T.started = true;
+        // the layout is decided by the first byte of the stream; text before the first header is the host reader's business
+        if (p[0] == '@') T.mode = 1;
+        else if (p[0] == '>') T.mode = 0;
+        else { T.irregular = true; T.why = PHI_TEXT_IRREGULAR_LAYOUT; T.first_bad = 0; *irregular = 1; return PHI_OK; }
+    }
+    if (T.detached) { T.h_carry.clear(); T.detached = false; }
+    const int slot = T.slot ^ 1;
+    const uint32_t C = T.carry_cap, start = C - T.carry_len, end = C + m;
+    uint8_t *buf = T.text[slot].as<uint8_t>();
+    // chunk i + 1 crosses the link while chunk i is sketched: the copy runs on aux_stream, everything else on `stream`
+    HIPCHK(hipMemcpyAsync(buf + C, p, m, hipMemcpyHostToDevice, c->aux_stream));
+    HIPCHK(hipEventRecord(T.ev_copy, c->aux_stream));
+    if (T.carry_len)
+        HIPCHK(hipMemcpyAsync(buf + start, T.text[T.slot].as<uint8_t>() + T.carry_at, T.carry_len, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, T.ev_copy, 0));
+    HIPCHK(hipMemsetAsync(T.sum.p, 0, sizeof(PhiTextSummary), c->stream));
+    HIPCHK(hipMemsetAsync(&T.sum.as<PhiTextSummary>()->first_bad, 0xFF, 4, c->stream));
+    PhiTextArgs A{};
+    A.buf = buf; A.start = start; A.end = end; A.mode = T.mode; A.line_cap = T.line_cap;
+    A.tile_cnt = T.tile_cnt.as<uint32_t>(); A.ls = T.ls.as<uint32_t>(); A.pre = T.pre.as<uint64_t>(); A.blk = T.blk.as<uint64_t>();
+    A.read_off = T.roff[slot].as<int64_t>(); A.bases = T.bases[slot].as<uint8_t>(); A.sum = T.sum.as<PhiTextSummary>();
+    phi_launch_reads_text(c->stream, A);
+    HIPCHK(hipGetLastError());
+    uint32_t *h_err = (uint32_t *)((char *)T.h_sum + sizeof(PhiTextSummary));
+    HIPCHK(hipMemcpyAsync(T.h_sum, T.sum.p, sizeof(PhiTextSummary), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                 // also ends the sketch of the chunk before, and the copy of this one
+    PHICHK(text_replay_last(c, *h_err));
+    T.last_slot = -1;
+    T.dbg_reads = 0; T.dbg_bases = 0;
+    const PhiTextSummary S = *T.h_sum;
+    const uint32_t tail = end - S.cons_end;
+    if (S.err || tail > C) {
+        // nothing of this chunk is taken: the caller parses the pending bytes (phi_reads_text_end) and this chunk on the host
+        T.irregular = true; T.why = S.err ? S.err : PHI_TEXT_IRREGULAR_LINES; T.first_bad = S.first_bad; *irregular = 1;
+        return PHI_OK;
+    }
+    if (S.n_rec) {
+        PHICHK(phi_add_reads_device_impl(c, T.bases[slot].p, T.roff[slot].p, (int64_t)S.n_rec, (int64_t)S.n_bases, 0, false));
+        T.last_slot = slot; T.last_reads = (int64_t)S.n_rec; T.last_bases = (int64_t)S.n_bases;
+        T.dbg_slot = slot; T.dbg_reads = (int64_t)S.n_rec; T.dbg_bases = (int64_t)S.n_bases;
+    }
+    // the bytes not taken, on the host as well: the last `tail` bytes of (carry before + this chunk)
+    if (tail <= m) T.h_carry.assign(p + m - tail, p + m);
+    else {
+        const size_t keep = tail - m;                        // of the carry before
+        T.h_carry.erase(T.h_carry.begin(), T.h_carry.end() - (ptrdiff_t)keep);
+        T.h_carry.insert(T.h_carry.end(), p, p + m);
+    }
+    T.taken += (int64_t)(S.cons_end - start);
+    T.fed += m;
+    T.carry_len = tail; T.carry_at = S.cons_end; T.slot = slot;
+    return PHI_OK;
+}
+
+extern "C" {
+
+int phi_add_reads_text(phi_ctx *c, const char *text, int64_t n_bytes, int32_t *irregular)
+{
+    if (!c || !irregular || n_bytes < 0 || (n_bytes > 0 && !text)) return PHI_ERR_INVALID;
+    *irregular = 0;
+    auto &T = c->text;
+    if (!T.active) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads_text before phi_reads_text_begin");
+    if (T.irregular) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads_text after an irregular chunk: finish the stream on the host reader");
+    HIPCHK(hipSetDevice(c->device));
+    for (int64_t at = 0; at < n_bytes; ) {
+        const uint32_t m = (uint32_t)std::min<int64_t>(n_bytes - at, T.chunk_cap);
+        PHICHK(text_piece(c, text + at, m, irregular));
+        if (*irregular) {
+            // what the device has not taken = the carry + the rest of this call's bytes: all of it is handed back by
+            // phi_reads_text_end, the caller goes on with the bytes of the stream AFTER this call's
+            T.h_carry.insert(T.h_carry.end(), text + at, text + n_bytes);
+            break;
+        }
+        at += m;
+    }
+    return PHI_OK;
+}
+
+int phi_reads_text_last_batch(phi_ctx *c, char *bases, int64_t cap_bases, int64_t *off, int64_t cap_reads, int64_t *n_reads, int64_t *n_bases)
+{
+    if (!c || !n_reads || !n_bases) return PHI_ERR_INVALID;
+    auto &T = c->text;
+    *n_reads = T.dbg_reads; *n_bases = T.dbg_bases;
+    if (T.dbg_reads == 0 || cap_reads < T.dbg_reads || cap_bases < T.dbg_bases || !off) return PHI_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (T.dbg_bases && bases) HIPCHK(phi_copy_sync(c, bases, T.bases[T.dbg_slot].p, (size_t)T.dbg_bases, hipMemcpyDeviceToHost));
+    HIPCHK(phi_copy_sync(c, off, T.roff[T.dbg_slot].p, (size_t)(T.dbg_reads + 1) * 8, hipMemcpyDeviceToHost));
+    return PHI_OK;
+}
+
+int phi_reads_text_detach_carry(phi_ctx *c, const char **bytes, int64_t *n)
+{
+    if (!c || !bytes || !n) return PHI_ERR_INVALID;
+    auto &T = c->text;
+    if (!T.active || T.irregular) return phi_fail(c, PHI_ERR_STATE, "phi_reads_text_detach_carry: no regular text stream is open");
+    *bytes = T.h_carry.data(); *n = (int64_t)T.h_carry.size();
+    T.carry_len = 0; T.detached = true;                       // (the host copy is dropped by the next piece: the pointer stays valid until then)
+    return PHI_OK;
+}
+
+int phi_reads_text_end(phi_ctx *c, const char **pending, int64_t *n_pending, int64_t *n_taken)
+{
+    if (!c) return PHI_ERR_INVALID;
+    auto &T = c->text;
+    if (!T.active) return phi_fail(c, PHI_ERR_STATE, "phi_reads_text_end before phi_reads_text_begin");
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t err = 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(phi_copy_sync(c, &err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
+    PHICHK(text_replay_last(c, err));
+    T.last_slot = -1;
+    T.active = false;
+    if (T.detached) { T.h_carry.clear(); T.detached = false; }      // (handed out already)
+    if (pending) *pending = T.h_carry.data();
+    if (n_pending) *n_pending = (int64_t)T.h_carry.size();
+    if (n_taken) *n_taken = T.taken;
     return PHI_OK;
 }
 
@@ -1234,7 +1471,7 @@ int phi_sketch(phi_ctx *c, const char *bases, const int64_t *seq_off, int64_t n_
                               (unsigned long long *)scalar(c, S_NBAD));
         if ((rc = phi_hip_check(c, hipStreamSynchronize(c->stream), "sync"))) break;
         uint64_t n_bad = 0;
-        if ((rc = phi_hip_check(c, hipMemcpy(&n_bad, scalar(c, S_NBAD), 8, hipMemcpyDeviceToHost), "D2H"))) break;
+        if ((rc = phi_hip_check(c, phi_copy_sync(c, &n_bad, scalar(c, S_NBAD), 8, hipMemcpyDeviceToHost), "D2H"))) break;
         int64_t total = 0;
         if ((rc = sketch_records(c, dW.as<uint64_t>(), dS.as<unsigned long long>(), n_bases, k, w,
                                  (n_bad || k > PHI_MAX_K_PACKED) ? dB.as<uint8_t>() : nullptr, dH, dP, &total))) break;
@@ -1242,8 +1479,8 @@ int phi_sketch(phi_ctx *c, const char *bases, const int64_t *seq_off, int64_t n_
         *n_out = total;
         if (cap >= total && total > 0) {
             std::vector<int64_t> gpos((size_t)total);
-            if (out_hash && (rc = phi_hip_check(c, hipMemcpy(out_hash, dH.p, (size_t)total * 8, hipMemcpyDeviceToHost), "D2H hash"))) break;
-            if ((rc = phi_hip_check(c, hipMemcpy(gpos.data(), dP.p, (size_t)total * 8, hipMemcpyDeviceToHost), "D2H pos"))) break;
+            if (out_hash && (rc = phi_hip_check(c, phi_copy_sync(c, out_hash, dH.p, (size_t)total * 8, hipMemcpyDeviceToHost), "D2H hash"))) break;
+            if ((rc = phi_hip_check(c, phi_copy_sync(c, gpos.data(), dP.p, (size_t)total * 8, hipMemcpyDeviceToHost), "D2H pos"))) break;
             int64_t s = 0;
             for (int64_t i = 0; i < total; i++) {
                 while (off[s + 1] <= gpos[i]) s++;
@@ -1254,7 +1491,7 @@ int phi_sketch(phi_ctx *c, const char *bases, const int64_t *seq_off, int64_t n_
     } while (0);
     dev_free(dB); dev_free(dO); dev_free(dW); dev_free(dS); dev_free(dH); dev_free(dP);
     // a failed stand-alone sketch must not poison later calls on this context
-    (void)hipMemset(c->d_scalars.p, 0, 16);
+    (void)phi_memset_sync(c, c->d_scalars.p, 0, 16);
     return rc;
 }
 
@@ -1331,7 +1568,7 @@ int phi_solve_stats(phi_ctx *c, phi_solve_info *out)
     if (out->dp_mode == 3 && c->n_blk > 0) {
         HIPCHK(hipSetDevice(c->device));
         std::vector<int32_t> n((size_t)c->n_blk);
-        HIPCHK(hipMemcpy(n.data(), c->d_blk_ncls.p, n.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(phi_copy_sync(c, n.data(), c->d_blk_ncls.p, n.size() * 4, hipMemcpyDeviceToHost));
         int64_t sum = 0;
         for (int32_t v : n) { sum += v; out->max_classes = std::max(out->max_classes, v); }
         out->mean_classes = (double)sum / (double)n.size();
@@ -1362,7 +1599,7 @@ int phi_walk_sharing(phi_ctx *c, int64_t *hist, int32_t cap, int64_t *n_distinct
         if ((rc = phi_hip_check(c, hipGetLastError(), "launch"))) break;
         if ((rc = phi_hip_check(c, hipStreamSynchronize(c->stream), "synchronize"))) break;
         std::vector<unsigned long long> hh(c->n_walks + 1);
-        if ((rc = phi_hip_check(c, hipMemcpy(hh.data(), dh.p, hh.size() * 8, hipMemcpyDeviceToHost), "D2H"))) break;
+        if ((rc = phi_hip_check(c, phi_copy_sync(c, hh.data(), dh.p, hh.size() * 8, hipMemcpyDeviceToHost), "D2H"))) break;
         for (int32_t i = 0; i <= c->n_walks; i++) hist[i] = (int64_t)hh[i];
         if (n_distinct) *n_distinct = c->n_unique;
     } while (0);

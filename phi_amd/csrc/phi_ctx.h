@@ -135,6 +135,28 @@ struct phi_ctx {
     } alt;
     bool next_flag_zeroed = false;                    // a launch of this generation has zeroed the dirty flag of the next one
 
+    // host batches (phi_add_reads): pieces of the batch are copied on aux_stream while the piece before is sketched on `stream`
+    std::vector<hipEvent_t> piece_events;
+    uint32_t *h_err = nullptr;                        // pinned copy of the device error word, fetched behind a batch's last kernel
+    // ---- reads as raw text (phi_add_reads_text, reads_text.hip): the device finds the records
+    struct PhiTextStream {
+        bool active = false, irregular = false, started = false, detached = false;
+        int mode = 0;                                 // 0 FASTA, 1 FASTQ with four lines per record
+        int64_t fed = 0, taken = 0;                   // stream bytes handed over / taken as whole records
+        uint32_t carry_cap = 0, chunk_cap = 0, line_cap = 0;
+        DevBuf text[2], bases[2], roff[2], tile_cnt, ls, pre, blk, sum;   // two slots: chunk i + 1 is copied while chunk i is sketched
+        int slot = 0;                                 // slot of the last chunk
+        uint32_t carry_len = 0, carry_at = 0;         // the carry: text[slot][carry_at, carry_at + carry_len)
+        std::vector<char> h_carry;                    // the same bytes on the host (what phi_reads_text_end hands back)
+        PhiTextSummary *h_sum = nullptr;              // pinned
+        hipEvent_t ev_copy = nullptr;
+        int last_slot = -1;                           // the chunk whose sketch may still be running: replayed if the spectrum set overflowed
+        int64_t last_reads = 0, last_bases = 0;
+        int dbg_slot = 0;                             // what the last piece took (phi_reads_text_last_batch: the parity tests)
+        int64_t dbg_reads = 0, dbg_bases = 0;
+        uint32_t why = 0, first_bad = 0;
+    } text;
+
     // ---- scratch for sketch passes and compaction
     DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2, d_list3, d_walk_last;
     DevBuf d_adj_off, d_adj, d_topo_rank, d_cnt_edge, d_walk_err;   // the walk-entry pass on the GPU (phi_walk_edges_kernel)
@@ -208,6 +230,20 @@ struct PhiStageTimer {
     }
 };
 
+// Blocking copies / fills ON THE CONTEXT'S STREAM.  hipMemcpy / hipMemset would go through the null stream, whose hardware
+// queue the runtime creates at first use (~20 ms, and as much again when the process ends) for nothing: every other
+// piece of work of a context runs on its own streams.
+static inline hipError_t phi_copy_sync(phi_ctx *c, void *dst, const void *src, size_t n, hipMemcpyKind kind)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, n, kind, c->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+}
+static inline hipError_t phi_memset_sync(phi_ctx *c, void *dst, int v, size_t n)
+{
+    const hipError_t e = hipMemsetAsync(dst, v, n, c->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+}
+
 // walk of a walk entry
 static inline int32_t phi_entry_walk(const phi_ctx *c, int64_t e)
 {
@@ -270,6 +306,9 @@ struct PhiHostError {
 
 // phi_solve.cpp: host orchestration of the exact solve on top of the DP kernel
 int phi_solve_impl(phi_ctx *c);
+// one batch of reads resident in HBM; the offsets may be a slice of a longer array (off_bias = its first offset);
+// replay: the same batch again after the spectrum set was regrown
+int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, int64_t off_bias, bool replay);
 // helpers shared between phi_abi.hip and phi_solve.hip
 int phi_fail(phi_ctx *c, int code, const char *fmt, ...);
 int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes);

@@ -56,6 +56,7 @@ struct PhiSketchArgs {
     // PHI_MODE_PROBE reads ASCII: the 2-bit pack, the bases outside ACGTacgt and the read-start bitmap of a chunk
     // are made by the wave that sketches it (no preparation launch): `ascii` + read offsets
     const int64_t *read_off; int64_t n_reads;
+    int64_t off_bias;                      // subtracted from every offset read: a batch may be a slice [r0, r1) of a longer offsets array
     uint32_t reads_per_base_q32;           // n_reads / n_bases in 0.32 fixed point (first guess of the read-start search: no division per wave)
     // ... and, in the first launch after a reset, every wave also empties its share of the buffers the PREVIOUS
     // generation of reads filled (the other half of the context's double buffers), for the generation after this one
@@ -309,6 +310,36 @@ int phi_dp_num_waves(int n_walks);
 void phi_launch_dp_words(hipStream_t st, const uint8_t *e_out, const int64_t *g_off, const uint8_t *g_span,
                          const uint8_t *a_weight, int64_t n_entries, uint64_t *word);
 
+// reads_text.hip: the records of a FASTA / FASTQ text found on the device
+#define PHI_TEXT_IRREGULAR_CR 1u       // a carriage return in the chunk
+#define PHI_TEXT_IRREGULAR_LINES 2u    // more lines than the line tables hold
+#define PHI_TEXT_IRREGULAR_LAYOUT 4u   // a line that does not fit the regular layout (first_bad = its index)
+struct PhiTextSummary {
+    uint32_t n_nl;                       // line feeds = whole lines in the buffer
+    uint32_t n_rec;                      // whole records taken
+    uint32_t err;                        // PHI_TEXT_IRREGULAR_*
+    uint32_t first_bad;
+    uint64_t n_bases;                    // their sequence bytes
+    uint32_t cons_end;                   // buffer offset where the carry (the bytes not taken) begins
+    uint32_t n_cons_lines;
+};
+struct PhiTextArgs {
+    const uint8_t *buf;                  // device buffer [carry | chunk]
+    uint32_t start, end;                 // the text is buf[start, end)
+    int32_t mode;                        // 0 FASTA, 1 FASTQ with four lines per record
+    uint32_t line_cap;                   // lines the tables below hold
+    uint32_t *tile_cnt;                  // [tiles + 1]
+    uint32_t *ls;                        // [line_cap + 2] line starts
+    uint64_t *pre;                       // [line_cap + 2] per line: records begun << 32 | sequence bytes, then their exclusive prefix sums
+    uint64_t *blk;                       // [phi_text_scan_blocks(line_cap)] scratch of the scan
+    int64_t *read_off;                   // out [records + 1]
+    uint8_t *bases;                      // out: the sequence bytes, back to back
+    PhiTextSummary *sum;
+};
+uint32_t phi_text_num_tiles(uint32_t start, uint32_t end);
+uint32_t phi_text_scan_blocks(uint32_t line_cap);
+void phi_launch_reads_text(hipStream_t st, const PhiTextArgs &A);
+
 // code-object warm-up, one per translation unit (phi_ctx_create)
 void phi_warm_sketch(hipStream_t st);
 void phi_warm_table(hipStream_t st);
@@ -317,3 +348,4 @@ void phi_warm_contexts(hipStream_t st);
 void phi_warm_dp(hipStream_t st);
 void phi_warm_dp_events(hipStream_t st);
 void phi_warm_solve_dev(hipStream_t st);
+void phi_warm_reads_text(hipStream_t st);

@@ -231,7 +231,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         auto keep_whole_chain = [&](uint32_t kerr, uint32_t bit) -> int {
             // (both flags: block tasks that ran on clamped classes may have overflowed their queues as well)
             kerr &= ~(bit | PHI_KERR_DP_QUEUE | PHI_KERR_DP_CLASSES);
-            HIPCHK(hipMemcpy(c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
+            HIPCHK(phi_copy_sync(c, c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
             if (bit == PHI_KERR_DP_CLASSES && c->blk_cls_target > 2 && !getenv("PHI_DP_BLOCK_STEPS")) {
                 // a block with more than 64 classes of walks (denser variation than the block length was chosen for):
                 // shorter blocks hold fewer sites; only below two steps per block does the whole chain take over
@@ -375,7 +375,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         // a lane of the four-wave event kernel had more live runs than its queue holds: this graph takes
         // the every-vertex kernel from now on
         kerr &= ~PHI_KERR_DP_QUEUE;
-        HIPCHK(hipMemcpy(c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
+        HIPCHK(phi_copy_sync(c, c->d_scalars.as<uint64_t>() + S_ERR, &kerr, 4, hipMemcpyHostToDevice));
         if (!c->dp_dense_ready) return phi_fail(c, PHI_ERR_DEVICE, "event DP queue overflow without a dense fallback (internal error)");
         c->dp_events = false;
         return run_dp(c, wgt, H, value, segs);
@@ -407,7 +407,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         if (!bulk && guard == 64) PHICHK(fetch_bulk());
         int32_t bs = 0;
         if (bulk) bs = H.bstart[e];
-        else HIPCHK(hipMemcpy(&bs, d_bstart + e, 4, hipMemcpyDeviceToHost));
+        else HIPCHK(phi_copy_sync(c, &bs, d_bstart + e, 4, hipMemcpyDeviceToHost));
         if (bs < 0 && c->dp_blocks && events) {
             // the run crossed into its block: follow it back through the blocks it was carried over
             const int32_t vq = c->h_walk_vtx[e];
@@ -434,8 +434,8 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         int32_t src, h2;
         if (bulk) { src = H.ent_u[step]; h2 = H.ent_h[step]; }
         else {
-            HIPCHK(hipMemcpy(&src, d_ent_src + step, 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(&h2, d_ent_h + step, 4, hipMemcpyDeviceToHost));
+            HIPCHK(phi_copy_sync(c, &src, d_ent_src + step, 4, hipMemcpyDeviceToHost));
+            HIPCHK(phi_copy_sync(c, &h2, d_ent_h + step, 4, hipMemcpyDeviceToHost));
         }
         if (events && src >= 0) src = c->h_kstep[src];          // compact step -> topological step
         const int32_t u = src >= 0 ? c->h_topo[src] : -1;
@@ -482,7 +482,7 @@ int phi_solve_impl(phi_ctx *c)
     PHICHK(phi_sync_check(c));
     PhiStageTimer tm("solve");
     uint64_t sc[S_N];
-    HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
+    HIPCHK(phi_copy_sync(c, sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
     uint64_t n_distinct = 0;
     PHICHK(phi_spectrum_count(c, &n_distinct));
     const int64_t spectrum = c->spectrum_override >= 0 ? c->spectrum_override : (c->sp_cap ? (int64_t)n_distinct : 0);
@@ -530,11 +530,11 @@ int phi_solve_impl(phi_ctx *c)
         phi_launch_group_count(c->stream, F, n_matched);
         HIPCHK(hipStreamSynchronize(c->stream));
         uint32_t err = 0;
-        HIPCHK(hipMemcpy(&err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
+        HIPCHK(phi_copy_sync(c, &err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
         if (err & PHI_KERR_TABLE_FULL) return phi_fail(c, PHI_ERR_OVERFLOW, "anchor group table overflow");
         if (!(err & PHI_KERR_FP_COLLISION)) break;
         if (attempt == 7) return phi_fail(c, PHI_ERR_DEVICE, "anchor fingerprints collide under 8 seeds (internal error)");
-        HIPCHK(hipMemset(scalar(c, S_ERR), 0, 4));
+        HIPCHK(phi_memset_sync(c, scalar(c, S_ERR), 0, 4));
     }
     HIPCHK(hipMemsetAsync(F.slot_maxcnt, 0, n_slot_ids * 4, c->stream));
     HIPCHK(hipMemsetAsync(F.slot_multi, 0, n_slot_ids, c->stream));
@@ -607,7 +607,7 @@ int phi_solve_impl(phi_ctx *c)
         if (const char *e = getenv("PHI_SOLVE_DEVICE")) dev_min = atoi(e) ? 0 : INT64_MAX;     // tests: force either way
         dev = hc[0] == 0 && n_kept >= dev_min && n_kept > 0;
     }
-    HIPCHK(hipMemcpy(sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
+    HIPCHK(phi_copy_sync(c, sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
     const int64_t filtered = (int64_t)sc[S_FILTERED], in_model = (int64_t)sc[S_INMODEL];
     if (!dev) {
         PHICHK(phi_pin_ensure(c, (size_t)std::max<int64_t>(n_kept, 1) * sizeof(PhiAnchorHost)));
@@ -723,7 +723,7 @@ int phi_solve_impl(phi_ctx *c)
             for (int32_t h = 0; h < nw; h++) last[h] = (int32_t)(c->h_walk_off[h + 1] - 1);
             PHICHK(phi_dev_ensure(c, c->d_walk_last, (size_t)nw * 4));
             PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)nw * 4));
-            HIPCHK(hipMemcpy(c->d_walk_last.p, last.data(), (size_t)nw * 4, hipMemcpyHostToDevice));
+            HIPCHK(phi_copy_sync(c, c->d_walk_last.p, last.data(), (size_t)nw * 4, hipMemcpyHostToDevice));
         }
         PHICHK(phi_dev_ensure(c, c->d_dmax, (size_t)c->n_entries * 4));
         PHICHK(phi_dev_ensure(c, c->d_bstart, (size_t)c->n_entries * 4));
@@ -842,7 +842,7 @@ int phi_solve_impl(phi_ctx *c)
         int64_t n_rep = 0;
         PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_ids, c->d_list, &n_rep));
         std::vector<uint32_t> rep((size_t)n_rep);
-        if (n_rep) HIPCHK(hipMemcpy(rep.data(), c->d_list.p, (size_t)n_rep * 4, hipMemcpyDeviceToHost));
+        if (n_rep) HIPCHK(phi_copy_sync(c, rep.data(), c->d_list.p, (size_t)n_rep * 4, hipMemcpyDeviceToHost));
         S0.insert(rep.begin(), rep.end());                     // (ascending: linear-time insertion)
         if (tm.on) fprintf(stderr, "[phi timing] solve: %zu minimisers repeat along a walk\n", S0.size());
     } else if (!getenv("PHI_NO_S0")) {
@@ -965,8 +965,8 @@ int phi_solve_impl(phi_ctx *c)
                 if ((int64_t)hc[2] > twice_cap) return phi_fail(c, PHI_ERR_OVERFLOW, "more than 2^22 minimisers counted twice by one path");
                 add_w = (int64_t)hc[0]; n_touched = (int64_t)hc[1];
                 std::vector<uint32_t> dl((size_t)hc[2]), zl((size_t)hc[3]);
-                if (hc[2]) HIPCHK(hipMemcpy(dl.data(), c->d_list.p, dl.size() * 4, hipMemcpyDeviceToHost));
-                if (hc[3]) HIPCHK(hipMemcpy(zl.data(), c->d_slots2.p, zl.size() * 4, hipMemcpyDeviceToHost));
+                if (hc[2]) HIPCHK(phi_copy_sync(c, dl.data(), c->d_list.p, dl.size() * 4, hipMemcpyDeviceToHost));
+                if (hc[3]) HIPCHK(phi_copy_sync(c, zl.data(), c->d_slots2.p, zl.size() * 4, hipMemcpyDeviceToHost));
                 D.insert(dl.begin(), dl.end());
                 Z.insert(zl.begin(), zl.end());
             } else {

@@ -26,8 +26,11 @@ HOST_SYMBOLS = [
     "phi_graph_walk_vtx", "phi_graph_topo_rank", "phi_graph_hap_name", "phi_graph_seg_name", "phi_reads_read",
     "phi_reads_free", "phi_reads_count", "phi_reads_bases", "phi_reads_off", "phi_reads_name", "phi_hap_name",
     "phi_write_fasta", "phi_reads_stream_open", "phi_reads_stream_next", "phi_reads_stream_reads",
-    "phi_reads_stream_bases", "phi_reads_stream_close",
+    "phi_reads_stream_bases", "phi_reads_stream_close", "phi_reads_stream_open_blocks",
+    "phi_text_stream_open", "phi_text_stream_read", "phi_text_stream_close",
 ]
+
+TEXT_BLOCK_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.POINTER(C.c_void_p))
 
 _host = None
 
@@ -74,6 +77,12 @@ def host_lib():
         f = getattr(L, "phi_reads_stream_" + n)
         f.restype = C.c_int64
         f.argtypes = [vp]
+    L.phi_reads_stream_open_blocks.argtypes = [vp, C.c_int64, vp, vp, C.POINTER(vp), C.c_char_p, C.c_int]
+    L.phi_text_stream_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_int]
+    L.phi_text_stream_read.restype = C.c_int64
+    L.phi_text_stream_read.argtypes = [vp, vp, C.c_int64, C.c_char_p, C.c_int]
+    L.phi_text_stream_close.restype = None
+    L.phi_text_stream_close.argtypes = [vp]
     L.phi_reads_stream_close.restype = None
     L.phi_reads_stream_close.argtypes = [vp]
     L.phi_hap_name.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
@@ -105,6 +114,68 @@ def stream_reads(path, bases_cap=64 << 20, reads_cap=1 << 20):
             yield bases[:off[n]].copy(), off[:n + 1].copy()
     finally:
         L.phi_reads_stream_close(h)
+
+
+def text_chunks(path, chunk_bytes=64 << 20):
+    """The (inflated) text of a reads file, chunk by chunk, through phi_text_stream_*: what the command line hands to
+    phi_add_reads_text."""
+    L = host_lib()
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = L.phi_text_stream_open(os.fsencode(path), C.byref(h), err, 512)
+    if rc:
+        raise HostError(rc, err.value.decode())
+    buf = np.zeros(chunk_bytes, np.uint8)
+    try:
+        while True:
+            n = L.phi_text_stream_read(h, buf.ctypes.data, chunk_bytes, err, 512)
+            if n < 0:
+                raise HostError(int(n), err.value.decode())
+            if n == 0:
+                break
+            yield buf[:n].copy()
+    finally:
+        L.phi_text_stream_close(h)
+
+
+def reads_of_text(prefix, blocks=(), bases_cap=64 << 20, reads_cap=1 << 20):
+    """kseq's records (uint8 bases, int64 offsets) of the text `prefix` followed by the byte blocks `blocks`, through
+    phi_reads_stream_open_blocks: the exact host state machine over text that is in memory."""
+    L = host_lib()
+    it = iter(blocks)
+    keep = []
+
+    def nxt(_user, out):
+        try:
+            b = next(it)
+        except StopIteration:
+            return 0
+        a = np.frombuffer(bytes(b), np.uint8)
+        keep[:] = [a]
+        out[0] = a.ctypes.data
+        return len(a)
+    cb = TEXT_BLOCK_FN(nxt)
+    pre = np.frombuffer(bytes(prefix), np.uint8)
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = L.phi_reads_stream_open_blocks(pre.ctypes.data if len(pre) else None, len(pre), C.cast(cb, C.c_void_p), None, C.byref(h), err, 512)
+    if rc:
+        raise HostError(rc, err.value.decode())
+    bases = np.zeros(bases_cap, np.uint8)
+    off = np.zeros(reads_cap + 1, np.int64)
+    out_b, out_o = [], [np.zeros(1, np.int64)]
+    try:
+        while True:
+            n = L.phi_reads_stream_next(h, bases.ctypes.data, bases_cap, off.ctypes.data, reads_cap, err, 512)
+            if n < 0:
+                raise HostError(int(n), err.value.decode())
+            if n == 0:
+                break
+            out_b.append(bases[:off[n]].copy())
+            out_o.append(off[1:n + 1] + out_o[-1][-1])
+    finally:
+        L.phi_reads_stream_close(h)
+    return (np.concatenate(out_b) if out_b else np.zeros(0, np.uint8)), np.concatenate(out_o)
 
 
 def _view(ptr, n, ctype, dtype):

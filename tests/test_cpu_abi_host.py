@@ -96,6 +96,23 @@ def test_host_gfa_reader_vs_reference_goldens(built, oracle):
     assert g.top_order_map.tolist() == og.top_rank
 
 
+def test_host_reader_over_memory_and_blocks_equals_kseq_vectors(built):
+    """phi_reads_stream_open_blocks (the way a stream whose beginning the device has taken is finished on the exact state
+    machine): the records of prefix + blocks are kseq's records of the whole text, however the text is cut."""
+    from phi_amd import ilp_index as H
+    gold = json.load(open(os.path.join(GOLDEN, "kseq_vectors.json")))
+    rng = np.random.default_rng(3)
+    for case in gold["texts"]:
+        text = bytes.fromhex(case["text_hex"])
+        want = [bytes.fromhex(s_) for _, s_ in case["records"]]
+        for _ in range(4):
+            cuts = sorted(rng.integers(0, len(text) + 1, size=int(rng.integers(0, 5))).tolist())
+            parts = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+            b, o = H.reads_of_text(parts[0], [p for p in parts[1:] if p])
+            raw = bytes(b)
+            assert [raw[o[i]:o[i + 1]] for i in range(len(o) - 1)] == want, (case["text_hex"], cuts)
+
+
 def test_host_gfa_reader_errors(built, tmp_path):
     from phi_amd import ilp_index as H
     with pytest.raises(H.HostError) as e:
@@ -387,12 +404,33 @@ def test_gzip_inputs_plain_block_and_concatenated(built, oracle, tmp_path, monke
     b, o, n = H.read_reads(str(cut))
     assert 100 < len(n) < len(want_n) and n[:len(n) - 1] == want_n[:len(n) - 1]
     assert np.array_equal(o[:len(n)], want_o[:len(n)])
-    # a corrupted BGZF member ends the input (no crash, no garbage past it)
+    # a corrupted BGZF member, or a member whose CRC does not match, is an I/O error -- never a silently shorter read set
     bad = bytearray(_bgzf(text, block=60_000))
     bad[len(bad) // 2] ^= 0xFF
     (tmp_path / "bad.gz").write_bytes(bytes(bad))
-    b, o, n = H.read_reads(str(tmp_path / "bad.gz"))
-    assert len(n) < len(want_n)
+    crc = bytearray(_bgzf(text, block=60_000))
+    first = 18 + int.from_bytes(crc[16:18], "little") + 1 - 18      # size of the first member
+    crc[first - 8] ^= 0x01                                           # its CRC32 field
+    (tmp_path / "crc.gz").write_bytes(bytes(crc))
+    for name in ("bad.gz", "crc.gz"):
+        with pytest.raises(H.HostError) as e:
+            H.read_reads(str(tmp_path / name))
+        assert e.value.status == -1
+        with pytest.raises(H.HostError):
+            list(H.stream_reads(str(tmp_path / name)))
+        with pytest.raises(H.HostError):
+            list(H.text_chunks(str(tmp_path / name), 1 << 20))
+    with pytest.raises(H.HostError):
+        H.Graph(str(tmp_path / "bad.gz"))
+    # block gzip followed by bytes that are no gzip member: ignored, as gzread ignores them -- nothing before them is lost
+    for threads in ("1", "5"):
+        monkeypatch.setenv("PHI_HOST_THREADS", threads)
+        (tmp_path / "bgzf_garbage.gz").write_bytes(_bgzf(text, rng=rng) + b"no gzip member here")
+        b, o, n = H.read_reads(str(tmp_path / "bgzf_garbage.gz"))
+        assert np.array_equal(o, want_o) and np.array_equal(b, want_b) and n == want_n
+        # the raw text source gives the file's bytes whatever the chunk size
+        for name in ("gzip.gz", "bgzf.gz", "members.gz", "bgzf_garbage.gz", "r.fq"):
+            assert b"".join(c.tobytes() for c in H.text_chunks(str(tmp_path / name), 99_991)) == text, name
     # the GFA reader through the same source
     g1 = H.Graph(os.path.join(DATA, "MHC_4.gfa.gz"))
     raw = gzip.open(os.path.join(DATA, "MHC_4.gfa.gz"), "rb").read()

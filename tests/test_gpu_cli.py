@@ -136,16 +136,18 @@ def test_cli_on_synthetic_files(tmp_path):
 
 
 def test_cli_streams_reads_in_chunks(tmp_path):
-    """The command line streams the reads file through three chunk buffers: with chunks of
-    20 kbases (the fixture then takes ~120 of them, pinned from the second on) every log line and the
-    FASTA are those of the single-chunk run."""
+    """The command line streams the reads file as text through three chunk buffers, the records being found
+    on the device: with chunks of 20 kB (the fixture's 5.4 MB of FASTQ text then take ~270 of them, pinned from the
+    second on) every log line and the FASTA are those of the single-chunk run."""
     args = ["-t8", "-g", os.path.join(DATA, "MHC_4.gfa.gz"), "-r", os.path.join(DATA, "CHM13_reads.fq.gz")]
     one = _run_cli(args + ["-o", str(tmp_path / "one.fa")], tmp_path, env={"PHI_TIMING": "1"})
     many = _run_cli(args + ["-o", str(tmp_path / "many.fa")], tmp_path, env={"PHI_READ_CHUNK": "20000", "PHI_TIMING": "1"})
     assert one.returncode == 0 and many.returncode == 0, one.stderr + many.stderr
-    assert "main: 1 read chunk(s)" in one.stderr
-    m = re.search(r"main: (\d+) read chunk\(s\) of up to 20000 bases, pinned", many.stderr)
-    assert m and int(m.group(1)) > 100
+    assert "main: 1 text chunk(s)" in one.stderr
+    m = re.search(r"main: (\d+) text chunk\(s\) of up to 20000 bytes, pinned", many.stderr)
+    assert m and int(m.group(1)) > 200
+    # all of it through the device (a FASTQ file of whole records leaves nothing for the host reader)
+    assert "; 0 bases through the host reader" in one.stderr and "; 0 bases through the host reader" in many.stderr
 
     def lines(log):
         keep = []
@@ -157,9 +159,22 @@ def test_cli_streams_reads_in_chunks(tmp_path):
     assert lines(one.stderr) == lines(many.stderr)
     assert "Graph has 111805 vertices, 5 walks and read has 16401 reads" in many.stderr
     assert (tmp_path / "one.fa").read_text().split("\n")[1:] == (tmp_path / "many.fa").read_text().split("\n")[1:]
-    # a read longer than a chunk is reported, not truncated
-    bad = _run_cli(args + ["-o", str(tmp_path / "bad.fa")], tmp_path, env={"PHI_READ_CHUNK": "1024"})
-    assert bad.returncode == 0 or "does not fit a chunk" in bad.stderr
+    # the same reads as a file the device cannot take -- CRLF line ends -- go through the exact host reader: same result;
+    # so does a file that turns irregular half-way (a wrapped record in its middle)
+    import gzip
+    text = gzip.open(os.path.join(DATA, "CHM13_reads.fq.gz"), "rb").read()
+    (tmp_path / "crlf.fq").write_bytes(text.replace(b"\n", b"\r\n"))
+    recs = text.split(b"\n")
+    mid = (len(recs) // 8) * 4
+    wrapped = recs[:mid] + [recs[mid], recs[mid + 1][:70], recs[mid + 1][70:], recs[mid + 2], recs[mid + 3][:70], recs[mid + 3][70:]] + recs[mid + 4:]
+    (tmp_path / "wrapped.fq").write_bytes(b"\n".join(wrapped))
+    for name in ("crlf.fq", "wrapped.fq"):
+        r = _run_cli(["-t8", "-g", os.path.join(DATA, "MHC_4.gfa.gz"), "-r", str(tmp_path / name), "-o", str(tmp_path / (name + ".fa"))], tmp_path,
+                     env={"PHI_TIMING": "1", "PHI_READ_CHUNK": "700000"})
+        assert r.returncode == 0, r.stderr
+        assert "host reader from the first byte not taken" in r.stderr
+        assert [l for l in lines(r.stderr) if "Loaded graph" not in l] == [l for l in lines(one.stderr) if "Loaded graph" not in l], name
+        assert (tmp_path / (name + ".fa")).read_text().split("\n")[1:] == (tmp_path / "one.fa").read_text().split("\n")[1:]
 
 
 def test_cli_errors(tmp_path):
