@@ -9,7 +9,8 @@ reads).  One STEP = one scoring pass of a rank's read set, reads already residen
     probe of the walk-minimiser table   [+ RCCL all-reduce(MAX) of the hit vector when N > 1]
 The graph index (walk sketch + table) is built once before the timed region and the exact solve
 (filter + DP + certificate) runs once after it; both are timed and reported separately, and
-`end_to_end_s` = index build + one step + solve.
+`gpu_path_s` = index build + one step + solve (inputs in memory); `end_to_end_s` = the command line from files,
+process start to the closed FASTA.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -86,7 +87,8 @@ def cpu_baseline(g_arrays, reads_concat, read_off, k, w, budget_s=6.0):
     out = {"value": vn, "unit": "Gbases/s", "cores": nt, "kind": "port",
            "sample": f"read sketch (oracle/phi_oracle.c orc_sketch_reads, OpenMP over reads as ILP_index.cpp:617): "
                      f"{dn / 1e6:.0f} Mbases of the same 150-bp synthetic reads in {tn:.1f} s on {nt} threads; "
-                     f"{d1 / 1e6:.0f} Mbases in {t1:.1f} s on 1 thread",
+                     f"{d1 / 1e6:.0f} Mbases in {t1:.1f} s on 1 thread.  The port hashes only when the window's minimum changes and allocates nothing: "
+                     f"it is ~20x faster per core than the reference's own loop, measured at 0.0025 Gbases/s/core (BASELINE.md section 3)",
            "value_1core": v1}
     # stages 1-2 of the whole configuration (walk sketch, read sketch + spectrum, anchors, filter)
     L.orc_set_threads(nt)
@@ -108,27 +110,65 @@ def cpu_baseline(g_arrays, reads_concat, read_off, k, w, budget_s=6.0):
     return out
 
 
-def file_to_fasta(g, bases, off, k, w):
-    """Wall clock of the drop-in command line on this configuration's files (GFA 1.1 + FASTA on a tmpfs-like
-    temp dir): `PHI -g -r -o` from process start to FASTA close, parse and H2D included."""
+def _phi_stage_table(stderr):
+    """The stage table PHI prints under PHI_TIMING=1: {stage: [begin_s, end_s]} on the process's own clock, plus the
+    epochs of main() and of the closed FASTA."""
+    import re
+    stages, info = {}, {}
+    for l in stderr.splitlines():
+        m = re.match(r"\[phi timing\] main: stage (.+?)\s+(-?[\d.]+) ->\s+(-?[\d.]+) s", l)
+        if m:
+            stages[m.group(1).strip()] = [float(m.group(2)), float(m.group(3))]
+        m = re.search(r"main: entered at epoch ([\d.]+)", l)
+        if m:
+            info["main_entered_epoch"] = float(m.group(1))
+        m = re.search(r"FASTA closed at epoch ([\d.]+)", l)
+        if m:
+            info["fasta_closed_epoch"] = float(m.group(1))
+        m = re.match(r"\[phi timing\] (ctx_create|gfa_read): (.+?)\s+([\d.]+) ms", l)
+        if m:
+            stages.setdefault("detail", {})[f"{m.group(1)}: {m.group(2).strip()}"] = float(m.group(3))
+    return stages, info
+
+
+def file_to_fasta(g, bases, off, k, w, runs=5, fastq=False):
+    """The drop-in command line on this configuration's files (GFA 1.1 + FASTA / FASTQ in a temp dir, page cache warm):
+    `PHI -g -r -o` from process start to the closed FASTA, parse and H2D included.  Several runs,
+    a pause between them (the driver takes a finished process's GPU state down for ~0.1 s, which the next start would
+    otherwise wait for); the median run's stage table is reported."""
     from phi_amd import synth
     phi = os.path.join(ROOT, "phi_amd", "PHI")
     if not os.path.exists(phi):
         return None
     with tempfile.TemporaryDirectory(prefix="phi_bench_") as d:
-        gfa, rd, fa = os.path.join(d, "g.gfa"), os.path.join(d, "r.fa"), os.path.join(d, "out.fa")
+        gfa, rd, fa = os.path.join(d, "g.gfa"), os.path.join(d, "r.fq" if fastq else "r.fa"), os.path.join(d, "out.fa")
         synth.write_gfa(g, gfa)
-        synth.write_reads(bases, off, rd)
-        best = None
-        for _ in range(2):                                     # second run: page cache warm, as a user's rerun
+        synth.write_reads(bases, off, rd, fastq=fastq)
+        env = dict(os.environ, PHI_TIMING="1")
+        recs = []
+        for i in range(runs + 1):
+            time.sleep(0.4)
+            e = dict(env, PHI_DETACH="0") if i == runs else env       # the last run: one process, teardown inside the wall clock
+            t_spawn = time.time()
             t0 = time.perf_counter()
-            r = subprocess.run([phi, "-g", gfa, "-r", rd, "-o", fa, "-k", str(k), "-w", str(w)], capture_output=True, text=True)
+            r = subprocess.run([phi, "-g", gfa, "-r", rd, "-o", fa, "-k", str(k), "-w", str(w)], capture_output=True, text=True, env=e)
             dt = time.perf_counter() - t0
             if r.returncode != 0:
                 return {"error": r.stderr[-300:]}
-            best = dt if best is None else min(best, dt)
-        return {"seconds": best, "gfa_mb": os.path.getsize(gfa) / 1e6, "reads_mb": os.path.getsize(rd) / 1e6,
-                "note": "best of 2 runs of phi_amd/PHI on uncompressed files, whole process wall clock"}
+            stages, info = _phi_stage_table(r.stderr)
+            recs.append({"wall_s": dt, "spawn_to_main_s": info.get("main_entered_epoch", t_spawn) - t_spawn,
+                         "spawn_to_fasta_closed_s": info.get("fasta_closed_epoch", t_spawn + dt) - t_spawn, "stages": stages})
+        one_process = recs.pop()
+        walls = sorted(x["wall_s"] for x in recs)
+        med = sorted(recs, key=lambda x: x["wall_s"])[len(recs) // 2]
+        return {"seconds": med["wall_s"], "seconds_all_runs": [x["wall_s"] for x in recs], "seconds_min": walls[0], "seconds_first_run": recs[0]["wall_s"],
+                "spawn_to_fasta_closed_s": med["spawn_to_fasta_closed_s"], "spawn_to_main_s": med["spawn_to_main_s"],
+                "stages_s": {k_: v for k_, v in med["stages"].items() if k_ != "detail"}, "detail_ms": med["stages"].get("detail", {}),
+                "one_process_wall_s": one_process["wall_s"],
+                "gfa_mb": os.path.getsize(gfa) / 1e6, "reads_mb": os.path.getsize(rd) / 1e6,
+                "note": f"median of {runs} runs of phi_amd/PHI on uncompressed files (page cache warm, 0.4 s apart): wall clock of the command as its caller sees it "
+                        "= process start -> FASTA closed and log written; the worker's teardown (free of the arrays, the driver taking the GPU state down, ~0.1 s) runs "
+                        "detached behind it -- one_process_wall_s is the same command with PHI_DETACH=0, teardown included; stages_s = [begin, end] on the process's clock"}
 
 
 def main():
@@ -139,9 +179,13 @@ def main():
     ap.add_argument("--config", default="C2", help="workload of phi_amd.synth.CONFIGS, or C1syn (reference MHC_4 graph + generator reads)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--strong-config", default="C3", help="read set that --scaling strong shards (same graph as --config)")
-    ap.add_argument("--prof-period", type=int, default=8,
-                    help="every n-th sketch launch of the timed region carries the HIP events of roofline.kernel_avg_ms "
-                         "(a bracketed launch costs the stream ~5 us more than a plain one; 1 = every launch)")
+    ap.add_argument("--prof-launches", type=int, default=48,
+                    help="sketch launches bracketed by HIP events for roofline.kernel_avg_ms: a leg of its own right after the timed "
+                         "steps, same step, every launch bracketed (a bracketed launch costs the stream ~5 us more than a plain one, "
+                         "so the timed steps themselves carry none)")
+    ap.add_argument("--job-repeats", type=int, default=5,
+                    help="fresh context -> index build -> reads -> solve, this many times after the timed steps: *_cold = this process's "
+                         "first, the plain names = medians over the repeats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the second scaling mode, the H2D-inclusive rate and the command-line run")
@@ -311,11 +355,40 @@ def main():
     primary_step = weak_step if args.scaling == "weak" else strong["step"]
     for _ in range(args.warmup):
         primary_step()
-    ctx.prof_read()                                            # drop warmup timings
-    ctx.prof_enable(args.prof_period)                          # every n-th sketch launch carries timing events
     elapsed = timed(primary_step, args.steps, 0)
+    # the kernel's own duration: a leg of its own, the same step with EVERY sketch launch bracketed by HIP events on the
+    # stream the kernel runs on (the timed steps above carry no events: a bracketed launch costs the stream ~5 us more)
+    ctx.prof_read()                                            # drop earlier timings
+    ctx.prof_enable(1)
+    n_prof = max(24, args.prof_launches) if n_bases < 5e8 else max(3, min(args.prof_launches, args.steps))
+    for _ in range(n_prof):
+        primary_step()
+    torch.cuda.synchronize()
     ctx.prof_enable(False)
     n_launch, kern_ms, kern_bases = ctx.prof_read()
+    # several GPUs: where a step's time goes -- the rank's own scoring, and the exchange (which also absorbs the wait for the slowest rank)
+    step_split = None
+    if world > 1:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        sc, ar = [], []
+        d_b, d_o, nr, nb = (d_bases, d_off, n_reads, n_bases) if args.scaling == "weak" else (strong["d_b"], strong["d_o"], strong["n_reads"], strong["n_bases"])
+        for _ in range(20):
+            ctx.reset_reads()
+            ev[0].record(stream)
+            ctx.add_reads_device(d_b.data_ptr(), d_o.data_ptr(), nr, nb)
+            ev[1].record(stream)
+            allreduce_hits()
+            ev[2].record(stream)
+            stream.synchronize()
+            sc.append(ev[0].elapsed_time(ev[1])); ar.append(ev[1].elapsed_time(ev[2]))
+        t = torch.tensor([float(np.median(sc)), float(np.median(ar))], dtype=torch.float64, device=ctl_dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        step_split = {"score_ms_median_this_rank": float(t[0]), "allreduce_ms_median_this_rank": float(t[1]),
+                      "score_ms_max_over_ranks": float(tmax[0]), "allreduce_ms_max_over_ranks": float(tmax[1]),
+                      "hit_vector_bytes": int(index_info["n_distinct_minimizers"]), "rccl_ranks": ctx.comm_info()[1] if use_lib_comm else world,
+                      "note": "GPU time between events on the stream, 20 steps: reset + sketch launch, then ncclAllReduce(MAX, uint8) of the hit vector; "
+                              "the all-reduce figure includes waiting for the slowest rank's sketch"}
     stats = ctx.reads_stats()
     density = stats["n_emitted"] / max(1, stats["n_bases"])
     ms_per_step = elapsed / args.steps * 1e3
@@ -363,6 +436,34 @@ def main():
             assert int(o[2].item()) == -int(o[3].item()), "ranks disagree on the spectrum size"
         assert res["optimal"] == 1, "the quoted configuration must be solved to proven optimality"
 
+    # ---- the whole GPU path again on FRESH contexts (index build -> one read set -> solve): what the first numbers of
+    #      a process owe to its start (code objects, first allocations of every size, idle clocks) shows as *_cold against
+    #      the medians of the repeats
+    repeats = None
+    if not args.no_solve and world == 1 and args.job_repeats > 0 and walk_bases < 2e9:
+        reps = []
+        for _ in range(args.job_repeats):
+            c2 = phi_amd.Context(local_rank)
+            c2.set_params(k=K, w=W, threshold=1.0, recombination=100)
+            c2.set_stream(stream.cuda_stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c2.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            c2.add_reads_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            r2 = c2.solve()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            assert r2["objective"] == res["objective"] and np.array_equal(r2["path_vtx"], res["path_vtx"]) and np.array_equal(r2["path_hap"], res["path_hap"]), "a fresh context gave another result"
+            reps.append((t1 - t0, t2 - t1, t3 - t2))
+            c2.close()
+        med = lambda i: float(np.median([r[i] for r in reps]))
+        repeats = {"n": len(reps), "index_build_s": med(0), "first_batch_s": med(1), "solve_s": med(2), "gpu_path_s": float(np.median([sum(r) for r in reps])),
+                   "all": [[round(x, 6) for x in r] for r in reps]}
+
     # ---- roofline of the dominant kernel.  Algorithmic bytes per base by SURVEY.md 8d: 1 (ASCII) + 0.5 (packed 2-bit
     #      write + read) + 24 d (an 8-byte record and a 16-byte probe per emitted minimiser, density d).  Since the
     #      fusion of the preparation launch into the sketch kernel the packed form lives in LDS only: the kernel itself
@@ -400,7 +501,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "phi_sketch_kernel<PHI_MODE_PROBE>", "kernel_avg_ms": kern_avg_ms,
-                     "kernel_launches": n_launch, "kernel_timed_every": args.prof_period, "bytes_per_base_algorithmic": b_alg, "minimiser_density": density,
+                     "kernel_launches": n_launch, "kernel_timed": "a leg of its own after the timed steps, every launch bracketed", "bytes_per_base_algorithmic": b_alg, "minimiser_density": density,
                      "bytes_per_base_split": {"moved by phi_sketch_kernel (ASCII read, record, probe)": b_sketch,
                                               "packed 2-bit write + read of the SURVEY formula (stays in LDS since the fusion: not moved)": b_packed},
                      "kernel_own_frac": (launch_bases * b_sketch / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if n_launch else 0.0,
@@ -408,10 +509,19 @@ def main():
                      "note": "achieved/frac price the sketch kernel's time against the SURVEY 8d bytes of a base (1.5 + 24 d); kernel_own_frac prices it against "
                              "the bytes the fused kernel itself moves (1 + 24 d); step_frac = SURVEY bytes / whole step time (the step is this one launch)",
                      "kernel_gbases_per_s": launch_bases / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0},
-        "index_build_s": t_index, "graph_gbases_per_s": walk_bases / t_index / 1e9, "index": index_info,
-        "solve_s": t_solve, "solve": solve_info, "end_to_end_s": (t_index + ms_per_step * 1e-3 + t_solve) if t_solve is not None else None,
+        "index_build_s": repeats["index_build_s"] if repeats else t_index, "index_build_s_cold": t_index,
+        "graph_gbases_per_s": walk_bases / (repeats["index_build_s"] if repeats else t_index) / 1e9, "index": index_info,
+        "solve_s": repeats["solve_s"] if repeats else t_solve, "solve_s_cold": t_solve, "solve": solve_info,
+        # the GPU path alone, inputs in memory: index build + one step + solve (what rounds 1-2 called end_to_end_s)
+        "gpu_path_s": (repeats["gpu_path_s"] if repeats else (t_index + ms_per_step * 1e-3 + t_solve)) if t_solve is not None else None,
+        "gpu_path_s_cold": (t_index + ms_per_step * 1e-3 + t_solve) if t_solve is not None else None,
+        "job_repeats": repeats,
+        # process start -> FASTA closed, from files, with the command line (filled in below)
+        "end_to_end_s": None,
         "synthetic_gen_s": t_gen,
     }
+    if step_split is not None:
+        out["step_split"] = step_split
     if other is not None:
         out[other[0]] = other[1]
     if res is not None:
@@ -439,6 +549,7 @@ def main():
         if walk_bases < 2e9:
             out["file_to_fasta"] = file_to_fasta(g, bases, off, K, W)
             out["file_to_fasta_s"] = (out["file_to_fasta"] or {}).get("seconds")
+            out["end_to_end_s"] = out["file_to_fasta_s"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A, bases, off, K, W)
     elif rank == 0:

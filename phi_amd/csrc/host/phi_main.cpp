@@ -129,6 +129,7 @@ struct Options {
     std::string gfa_file, reads_file, hap_file;
     int argc = 0;
     char **argv = nullptr;
+    bool detached = false;
 };
 
 // ---- the queue of raw text chunks between the reader thread and the device thread(s)
@@ -533,8 +534,9 @@ static int run(const Options &o)
     fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", "main", realtime() - t0_real, cputime(),
             peakrss() / 1024.0 / 1024.0 / 1024.0);
     if (timing) {
-        fprintf(stderr, "[phi timing] main: %d text chunk(s) of up to %lld bytes%s on %d GPU(s); %lld bases through the host reader; FASTA closed at epoch %.6f\n",
-                n_chunks.load(), (long long)chunk_bytes, n_chunks >= 2 && pinned ? ", pinned" : "", n_dev, (long long)host_parsed_bases, realtime());
+        fprintf(stderr, "[phi timing] main: %d text chunk(s) of up to %lld bytes%s on %d GPU(s); %lld bases through the host reader; FASTA closed at epoch %.6f%s\n",
+                n_chunks.load(), (long long)chunk_bytes, n_chunks >= 2 && pinned ? ", pinned" : "", n_dev, (long long)host_parsed_bases, realtime(),
+                o.detached ? "; teardown detached" : "");
         g_marks.print();
     }
     int status = 0;
@@ -609,7 +611,10 @@ int main(int argc, char *argv[])
     // may have started the GPU runtime in this process already (a runtime does not survive a fork), and not when asked.
     bool detach = true;
     if (const char *e = getenv("PHI_DETACH")) detach = atoi(e) != 0;
-    if (getenv("LD_PRELOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("HSA_TOOLS_LIB")) detach = false;
+    if (getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("HSA_TOOLS_LIB") || getenv("ROCPROF_OUTPUT_PATH")) detach = false;
+    if (const char *pl = getenv("LD_PRELOAD"))
+        for (const char *tool : {"rocprof", "roctracer", "roctx", "rocsys", "omnitrace", "rocpd"})
+            if (strstr(pl, tool)) detach = false;
     int report_fd = -1;
     if (detach) {
         int pfd[2];
@@ -628,6 +633,7 @@ int main(int argc, char *argv[])
             } else if (pid == 0) {
                 close(pfd[0]);
                 report_fd = pfd[1];
+                o.detached = true;
                 (void)prctl(PR_SET_PDEATHSIG, SIGTERM);        // a killed parent takes the child with it
             } else { close(pfd[0]); close(pfd[1]); }           // no fork: one process
         }

@@ -13,7 +13,10 @@
 // by any thread, in any order, in chunks, and is the same on every machine.
 #include <stdint.h>
 #include <stdlib.h>
+#include <fcntl.h>
+#include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -338,6 +341,146 @@ int phi_syn_reads(const phi_syn *g, uint64_t seed, int64_t r_lo, int64_t r_hi, i
         }
     });
     return 0;
+}
+
+
+// ---- the same configuration as FILES (the command line's inputs): GFA 1.1 (S / L / W lines, names = 1-based vertex ids,
+//      as phi_amd/synth.py write_gfa) and FASTA / 4-line FASTQ reads.  Formatted by all threads into buffers, written with
+//      pwrite at the offsets their sizes give: 12 GB of W-lines and 10 GB of reads take seconds on a RAM disk.
+}  // extern "C"
+namespace {
+inline char *put_u64(char *p, uint64_t v)
+{
+    char t[24];
+    int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = t[--n];
+    return p;
+}
+struct Part { std::vector<char> buf; };
+// parts[i] made by make(i, buf) on all threads, a wave of `wave` parts at a time, appended to fd in order
+template <class F> int write_parts(int fd, int64_t &at, int64_t n_parts, int threads, int64_t wave, F make)
+{
+    std::vector<Part> parts((size_t)wave);
+    for (int64_t base = 0; base < n_parts; base += wave) {
+        const int64_t m = std::min(wave, n_parts - base);
+        par_for(m, threads, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; i++) { parts[(size_t)i].buf.clear(); make(base + i, parts[(size_t)i].buf); } });
+        std::vector<int64_t> off((size_t)m + 1, at);
+        for (int64_t i = 0; i < m; i++) off[(size_t)i + 1] = off[(size_t)i] + (int64_t)parts[(size_t)i].buf.size();
+        if (ftruncate(fd, off[(size_t)m]) != 0) return -1;
+        std::atomic<int> bad{0};
+        par_for(m, threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) {
+                const char *p = parts[(size_t)i].buf.data();
+                int64_t left = (int64_t)parts[(size_t)i].buf.size(), o = off[(size_t)i];
+                while (left > 0) {
+                    const ssize_t w = pwrite(fd, p, (size_t)std::min<int64_t>(left, (int64_t)1 << 30), (off_t)o);
+                    if (w <= 0) { bad.store(1); return; }
+                    p += w; o += w; left -= w;
+                }
+            }
+        });
+        if (bad.load()) return -1;
+        at = off[(size_t)m];
+    }
+    return 0;
+}
+}  // namespace
+extern "C" {
+
+// returns the bytes written, negative on error
+int64_t phi_syn_write_gfa(const phi_syn *g, const char *path, int32_t threads)
+{
+    if (!g || !path) return -1;
+    if (threads < 1) threads = g->threads;
+    const int fd = open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) return -1;
+    int64_t at = 0;
+    const char hdr[] = "H\tVN:Z:1.1\n";
+    if (pwrite(fd, hdr, sizeof hdr - 1, 0) != (ssize_t)(sizeof hdr - 1)) { close(fd); return -1; }
+    at = sizeof hdr - 1;
+    const int64_t VCH = 1 << 16, n_vch = (g->n_vtx + VCH - 1) / VCH;
+    // S-lines, then L-lines, by chunks of vertices
+    int rc = write_parts(fd, at, n_vch, threads, (int64_t)threads * 4, [&](int64_t c, std::vector<char> &b) {
+        const int64_t lo = c * VCH, hi = std::min<int64_t>(g->n_vtx, lo + VCH);
+        b.resize((size_t)((hi - lo) * 16 + (g->seq_off[(size_t)hi] - g->seq_off[(size_t)lo])));
+        char *p = b.data();
+        for (int64_t v = lo; v < hi; v++) {
+            *p++ = 'S'; *p++ = '\t'; p = put_u64(p, (uint64_t)v + 1); *p++ = '\t';
+            const int64_t n = g->seq_off[(size_t)v + 1] - g->seq_off[(size_t)v];
+            memcpy(p, g->seq.data() + g->seq_off[(size_t)v], (size_t)n); p += n;
+            *p++ = '\n';
+        }
+        b.resize((size_t)(p - b.data()));
+    });
+    if (!rc) rc = write_parts(fd, at, n_vch, threads, (int64_t)threads * 4, [&](int64_t c, std::vector<char> &b) {
+        const int64_t lo = c * VCH, hi = std::min<int64_t>(g->n_vtx, lo + VCH);
+        b.resize((size_t)((g->adj_off[(size_t)hi] - g->adj_off[(size_t)lo]) * 36 + 16));
+        char *p = b.data();
+        for (int64_t u = lo; u < hi; u++)
+            for (int64_t x = g->adj_off[(size_t)u]; x < g->adj_off[(size_t)u + 1]; x++) {
+                *p++ = 'L'; *p++ = '\t'; p = put_u64(p, (uint64_t)u + 1); memcpy(p, "\t+\t", 3); p += 3;
+                p = put_u64(p, (uint64_t)g->adj[(size_t)x] + 1); memcpy(p, "\t+\t0M\n", 6); p += 6;
+            }
+        b.resize((size_t)(p - b.data()));
+    });
+    // W-lines: a walk is one line; pieces of 4 M entries, the first carrying the line's head, the last its line feed
+    struct WP { int32_t h; int64_t lo, hi; };
+    std::vector<WP> wps;
+    const int64_t WCHE = (int64_t)4 << 20;
+    for (int32_t h = 0; h < g->n_walks; h++) {
+        const int64_t e0 = g->walk_off[(size_t)h], e1 = g->walk_off[(size_t)h + 1];
+        for (int64_t lo = e0; lo < e1 || lo == e0; lo += WCHE) { wps.push_back(WP{h, lo, std::min(e1, lo + WCHE)}); if (e1 == e0) break; }
+    }
+    std::vector<int64_t> walk_len((size_t)g->n_walks, 0);
+    par_for(g->n_walks, threads, [&](int64_t lo, int64_t hi) {
+        for (int64_t h = lo; h < hi; h++) {
+            int64_t L = 0;
+            for (int64_t e = g->walk_off[(size_t)h]; e < g->walk_off[(size_t)h + 1]; e++) L += g->seq_off[(size_t)g->walk_vtx[e] + 1] - g->seq_off[(size_t)g->walk_vtx[e]];
+            walk_len[(size_t)h] = L;
+        }
+    });
+    if (!rc) rc = write_parts(fd, at, (int64_t)wps.size(), threads, (int64_t)threads * 2, [&](int64_t i, std::vector<char> &b) {
+        const WP &w = wps[(size_t)i];
+        b.resize((size_t)((w.hi - w.lo) * 11 + 96));
+        char *p = b.data();
+        if (w.lo == g->walk_off[(size_t)w.h]) {
+            p += sprintf(p, "W\tsyn%03d\t%d\tchr\t0\t%lld\t", (int)w.h, (int)(w.h % 2), (long long)walk_len[(size_t)w.h]);
+        }
+        for (int64_t e = w.lo; e < w.hi; e++) { *p++ = '>'; p = put_u64(p, (uint64_t)g->walk_vtx[e] + 1); }
+        if (w.hi == g->walk_off[(size_t)w.h + 1]) *p++ = '\n';
+        b.resize((size_t)(p - b.data()));
+    });
+    close(fd);
+    return rc ? -1 : at;
+}
+
+// reads r_lo .. r_hi-1 of read set `seed` as a FASTA (fastq = 0) or 4-line FASTQ file; returns the bytes written
+int64_t phi_syn_write_reads(const phi_syn *g, uint64_t seed, int64_t r_lo, int64_t r_hi, int32_t read_len, double sub_err, const char *path,
+                            int32_t fastq, int32_t threads)
+{
+    if (!g || !path || r_hi < r_lo) return -1;
+    if (threads < 1) threads = g->threads;
+    const int fd = open(path, O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) return -1;
+    int64_t at = 0;
+    const int64_t RCH = 1 << 16, n_ch = (r_hi - r_lo + RCH - 1) / RCH;
+    std::vector<char> qual((size_t)read_len, 'I');
+    const int rc = write_parts(fd, at, n_ch, threads, (int64_t)threads * 4, [&](int64_t c, std::vector<char> &b) {
+        const int64_t lo = r_lo + c * RCH, hi = std::min(r_hi, lo + RCH);
+        std::vector<char> bases((size_t)((hi - lo) * read_len));
+        phi_syn_reads(g, seed, lo, hi, read_len, sub_err, bases.data(), 1);
+        b.resize((size_t)((hi - lo) * ((fastq ? 2 : 1) * (int64_t)read_len + 32)));
+        char *p = b.data();
+        for (int64_t r = lo; r < hi; r++) {
+            *p++ = fastq ? '@' : '>'; *p++ = 'r'; p = put_u64(p, (uint64_t)r); *p++ = '\n';
+            memcpy(p, bases.data() + (r - lo) * read_len, (size_t)read_len); p += read_len; *p++ = '\n';
+            if (fastq) { *p++ = '+'; *p++ = '\n'; memcpy(p, qual.data(), (size_t)read_len); p += read_len; *p++ = '\n'; }
+        }
+        b.resize((size_t)(p - b.data()));
+    });
+    close(fd);
+    return rc ? -1 : at;
 }
 
 }  // extern "C"

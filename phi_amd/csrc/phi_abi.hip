@@ -186,12 +186,28 @@ int phi_ctx_create(int device_id, phi_ctx **out)
     phi_ctx *c = new (std::nothrow) phi_ctx();
     if (!c) return PHI_ERR_NOMEM;
     c->device = device_id;
-    // A stream is a hardware queue: ~20 ms each to create.  The second one (the host thread's copies inside
-    // phi_set_graph) is made by a thread of its own while this one warms the first up; nothing here touches the null
-    // stream, whose queue would cost as much again (phi_copy_sync / phi_memset_sync in phi_ctx.h).
+    // What a context costs is the runtime's one-time work, all of it latency: a stream is a hardware queue (~20 ms each),
+    // the kernels' code objects load at the first launch of their translation unit (~13 ms), and the first host copies of
+    // every kind -- large through the copy engines' staging buffers, small through the runtime's own copy kernels -- set up
+    // what they go through (~20 ms).  Two threads: this one makes the context's stream and loads the code objects, the other
+    // makes the second stream (the host thread's copies inside phi_set_graph) and warms the copy paths on it.  Nothing
+    // touches the null stream, whose queue would cost as much again (phi_copy_sync / phi_memset_sync in phi_ctx.h).
     std::future<hipError_t> aux = std::async(std::launch::async, [c, device_id]() {
         hipError_t e = hipSetDevice(device_id);
-        return e != hipSuccess ? e : hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        void *d = nullptr;
+        std::vector<char> h((size_t)1 << 20, 0);
+        if (hipMalloc(&d, h.size()) == hipSuccess) {
+            (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, c->aux_stream);
+            (void)hipMemcpyAsync(h.data(), d, h.size(), hipMemcpyDeviceToHost, c->aux_stream);
+            (void)hipMemcpyAsync(d, h.data(), 64, hipMemcpyHostToDevice, c->aux_stream);
+            (void)hipMemcpyAsync(h.data(), d, 64, hipMemcpyDeviceToHost, c->aux_stream);
+            (void)hipMemsetAsync(d, 0, 4096, c->aux_stream);
+            (void)hipStreamSynchronize(c->aux_stream);
+            (void)hipFree(d);
+        }
+        return hipSuccess;
     });
     auto bail = [&](int code) {
         if (aux.valid()) (void)aux.get();
@@ -213,22 +229,9 @@ int phi_ctx_create(int device_id, phi_ctx **out)
     phi_warm_dp(c->stream); phi_warm_dp_events(c->stream); phi_warm_solve_dev(c->stream); phi_warm_reads_text(c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(PHI_ERR_DEVICE);
     tm.lap("scalars + code objects");
-    // the first pageable host-to-device copy of a process sets up the runtime's staging buffers
-    // (several ms): pay that here, once, not inside the first phi_set_graph
-    {
-        DevBuf warm;
-        std::vector<char> h((size_t)1 << 20, 0);
-        if (phi_dev_ensure(c, warm, h.size()) == PHI_OK) {
-            (void)hipMemcpyAsync(warm.p, h.data(), h.size(), hipMemcpyHostToDevice, c->stream);
-            (void)hipMemcpyAsync(h.data(), warm.p, h.size(), hipMemcpyDeviceToHost, c->stream);
-            (void)hipStreamSynchronize(c->stream);
-            dev_free(warm);
-        }
-        c->last_error.clear();
-    }
-    tm.lap("first host copies");
     if (aux.get() != hipSuccess) { c->aux_stream = nullptr; return bail(PHI_ERR_DEVICE); }
-    tm.lap("wait for the second stream");
+    c->last_error.clear();
+    tm.lap("wait for the second stream + first host copies");
     *out = c;
     return PHI_OK;
 }
@@ -254,7 +257,6 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_ent};
     for (DevBuf *b : all) dev_free(*b);
     for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    for (hipEvent_t e : c->piece_events) (void)hipEventDestroy(e);
     if (c->h_err) (void)hipHostFree(c->h_err);
     {
         auto &T = c->text;
@@ -967,14 +969,14 @@ extern "C" {
 
 int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases)
 {
-    return phi_add_reads_device_impl(c, d_bases, d_read_off, n_reads, n_bases, 0, false);
+    return phi_add_reads_device_impl(c, d_bases, d_read_off, n_reads, n_bases, false);
 }
 
 }  // extern "C"
 
 // replay: the same batch again after the spectrum set was regrown (its first pass overflowed the set): everything a
 // batch does is idempotent (hit flags, set inserts) except the count of emitted minimisers, which is not repeated
-int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, int64_t off_bias, bool replay)
+int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, bool replay)
 {
     if (!c) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads before phi_set_graph");
@@ -1003,7 +1005,7 @@ int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_rea
     // take the exact byte-wise routine inside the same wave
     PhiSketchArgs A{};
     A.ascii = (const uint8_t *)d_bases;
-    A.read_off = (const int64_t *)d_read_off; A.n_reads = n_reads; A.off_bias = off_bias;
+    A.read_off = (const int64_t *)d_read_off; A.n_reads = n_reads;
     {
         const double q = (double)n_reads / (double)n_bases * 4294967296.0;      // (a guess: clamped, never wrong to round)
         A.reads_per_base_q32 = q >= 2147483648.0 ? 0x80000000u : (uint32_t)q;
@@ -1056,12 +1058,12 @@ int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_rea
 // After the stream has been waited for: if the spectrum set overflowed under the batch whose data still sits at
 // (d_bases, d_off) -- denser input than the set was sized for; the reference's std::map has no such limit,
 // ILP_index.cpp:622-635 -- regrow the set and replay that batch.  err = the device error word as read behind the batch.
-static int replay_if_full(phi_ctx *c, uint32_t err, const void *d_bases, const void *d_off, int64_t n_reads, int64_t n_bases, int64_t off_bias)
+static int replay_if_full(phi_ctx *c, uint32_t err, const void *d_bases, const void *d_off, int64_t n_reads, int64_t n_bases)
 {
     for (int attempt = 0; attempt < 6 && (err & PHI_KERR_TABLE_FULL); attempt++) {
         err &= ~PHI_KERR_TABLE_FULL;
         HIPCHK(phi_copy_sync(c, scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
-        PHICHK(phi_add_reads_device_impl(c, d_bases, d_off, n_reads, n_bases, off_bias, true));
+        PHICHK(phi_add_reads_device_impl(c, d_bases, d_off, n_reads, n_bases, true));
         HIPCHK(phi_copy_sync(c, &err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost));
     }
     return PHI_OK;
@@ -1095,42 +1097,26 @@ int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_
     HIPCHK(hipSetDevice(c->device));
     PhiStageTimer tm("add_reads");
     // (every call ends with a wait for the stream: nothing of an earlier batch still reads the staging buffers)
-    PHICHK(phi_dev_ensure(c, c->d_rbases, (size_t)std::max<int64_t>(n_bases, 1)));
     PHICHK(phi_dev_ensure(c, c->d_roff, (size_t)(n_reads + 1) * 8));
     if (!c->h_err) HIPCHK(hipHostMalloc((void **)&c->h_err, 64, hipHostMallocDefault));
     tm.lap("buffers");
-    // The batch goes over in PIECES cut at read ends: piece j + 1 is copied (aux_stream) while piece j is sketched
-    // (stream), so that a batch costs its copy time plus one short kernel, not copy + kernel.  The offsets go first,
-    // whole; a piece's kernel reads its slice of them (off_bias).  PCIe moves ~55 GB/s: a 1-MB piece is 19 us of copy
-    // against ~7 us of kernel.
-    static const int64_t piece_bytes = getenv("PHI_H2D_PIECE") ? std::max<int64_t>(1 << 12, atoll(getenv("PHI_H2D_PIECE"))) : ((int64_t)1 << 20);
-    HIPCHK(hipMemcpyAsync(c->d_roff.p, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->aux_stream));
-    int64_t r0 = 0;
-    size_t n_piece = 0;
-    while (r0 < n_reads) {
-        // the piece ends at the last read that starts before its byte budget runs out (a longer read is a piece of its own)
-        int64_t r1 = (int64_t)(std::upper_bound(read_off + r0, read_off + n_reads + 1, read_off[r0] + piece_bytes) - read_off) - 1;
-        if (r1 <= r0) r1 = r0 + 1;
-        if (n_reads - r1 < (r1 - r0) / 4) r1 = n_reads;        // no short last piece
-        const int64_t b0 = read_off[r0], nb = read_off[r1] - b0;
-        if (nb) HIPCHK(hipMemcpyAsync((char *)c->d_rbases.p + b0, bases + b0, (size_t)nb, hipMemcpyHostToDevice, c->aux_stream));
-        if (n_piece == c->piece_events.size()) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->piece_events.push_back(e);
-        }
-        HIPCHK(hipEventRecord(c->piece_events[n_piece], c->aux_stream));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->piece_events[n_piece], 0));
-        n_piece++;
-        PHICHK(phi_add_reads_device_impl(c, (const char *)c->d_rbases.p + b0, c->d_roff.as<int64_t>() + r0, r1 - r0, nb, b0, false));
-        r0 = r1;
-    }
+    // One staged copy, then the kernel, on one stream.  What was measured on the MI355X box before settling for it
+    // (profiles/r03_h2d_experiments.txt; C2 = 5.2 MB per batch, the link moves 52-57 GB/s):
+    //   * pieces of the batch copied on a second stream while the piece before is sketched: every copy-engine -> compute
+    //     dependency (event record + stream wait) costs ~50 us, more than the kernel of a 1-MB piece: 300 us per batch
+    //     with 1-MB pieces, 262 with 2-MB, against 177 for the single copy (C3: 2245 / 1810 / 1277 us);
+    //   * the kernel reading pinned bases in place across the link (every base is loaded exactly once): shader reads of
+    //     host memory reach 25-32 GB/s, half the copy engine's rate: 190 us (C3: 1673 us).
+    PHICHK(phi_dev_ensure(c, c->d_rbases, (size_t)std::max<int64_t>(n_bases, 1)));
+    HIPCHK(hipMemcpyAsync(c->d_roff.p, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (n_bases) HIPCHK(hipMemcpyAsync(c->d_rbases.p, bases, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
+    PHICHK(phi_add_reads_device_impl(c, c->d_rbases.p, c->d_roff.p, n_reads, n_bases, false));
     // the error word behind the last kernel; host buffers are borrowed for the call only: one wait for everything
     HIPCHK(hipMemcpyAsync(c->h_err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    tm.lap("H2D + sketch + probe (pieces)");
+    tm.lap("H2D + sketch + probe");
     if (*c->h_err & PHI_KERR_TABLE_FULL) {
-        PHICHK(replay_if_full(c, *c->h_err, c->d_rbases.p, c->d_roff.p, n_reads, n_bases, 0));
+        PHICHK(replay_if_full(c, *c->h_err, c->d_rbases.p, c->d_roff.p, n_reads, n_bases));
         tm.lap("spectrum set regrown, batch replayed");
     }
     return PHI_OK;
@@ -1176,7 +1162,7 @@ static int text_replay_last(phi_ctx *c, uint32_t err)
 {
     auto &T = c->text;
     if (T.last_slot < 0 || !(err & PHI_KERR_TABLE_FULL)) return PHI_OK;
-    return replay_if_full(c, err, T.bases[T.last_slot].p, T.roff[T.last_slot].p, T.last_reads, T.last_bases, 0);
+    return replay_if_full(c, err, T.bases[T.last_slot].p, T.roff[T.last_slot].p, T.last_reads, T.last_bases);
 }
 
 static int text_piece(phi_ctx *c, const char *p, uint32_t m, int32_t *irregular)
@@ -1223,7 +1209,7 @@ static int text_piece(phi_ctx *c, const char *p, uint32_t m, int32_t *irregular)
         return PHI_OK;
     }
     if (S.n_rec) {
-        PHICHK(phi_add_reads_device_impl(c, T.bases[slot].p, T.roff[slot].p, (int64_t)S.n_rec, (int64_t)S.n_bases, 0, false));
+        PHICHK(phi_add_reads_device_impl(c, T.bases[slot].p, T.roff[slot].p, (int64_t)S.n_rec, (int64_t)S.n_bases, false));
         T.last_slot = slot; T.last_reads = (int64_t)S.n_rec; T.last_bases = (int64_t)S.n_bases;
         T.dbg_slot = slot; T.dbg_reads = (int64_t)S.n_rec; T.dbg_bases = (int64_t)S.n_bases;
     }

@@ -135,8 +135,6 @@ struct phi_ctx {
     } alt;
     bool next_flag_zeroed = false;                    // a launch of this generation has zeroed the dirty flag of the next one
 
-    // host batches (phi_add_reads): pieces of the batch are copied on aux_stream while the piece before is sketched on `stream`
-    std::vector<hipEvent_t> piece_events;
     uint32_t *h_err = nullptr;                        // pinned copy of the device error word, fetched behind a batch's last kernel
     // ---- reads as raw text (phi_add_reads_text, reads_text.hip): the device finds the records
     struct PhiTextStream {
@@ -306,9 +304,8 @@ struct PhiHostError {
 
 // phi_solve.cpp: host orchestration of the exact solve on top of the DP kernel
 int phi_solve_impl(phi_ctx *c);
-// one batch of reads resident in HBM; the offsets may be a slice of a longer array (off_bias = its first offset);
-// replay: the same batch again after the spectrum set was regrown
-int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, int64_t off_bias, bool replay);
+// one batch of reads the device can address; replay: the same batch again after the spectrum set was regrown
+int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, bool replay);
 // helpers shared between phi_abi.hip and phi_solve.hip
 int phi_fail(phi_ctx *c, int code, const char *fmt, ...);
 int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes);

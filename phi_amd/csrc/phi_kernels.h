@@ -56,7 +56,6 @@ struct PhiSketchArgs {
     // PHI_MODE_PROBE reads ASCII: the 2-bit pack, the bases outside ACGTacgt and the read-start bitmap of a chunk
     // are made by the wave that sketches it (no preparation launch): `ascii` + read offsets
     const int64_t *read_off; int64_t n_reads;
-    int64_t off_bias;                      // subtracted from every offset read: a batch may be a slice [r0, r1) of a longer offsets array
     uint32_t reads_per_base_q32;           // n_reads / n_bases in 0.32 fixed point (first guess of the read-start search: no division per wave)
     // ... and, in the first launch after a reset, every wave also empties its share of the buffers the PREVIOUS
     // generation of reads filled (the other half of the context's double buffers), for the generation after this one

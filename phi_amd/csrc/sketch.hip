@@ -529,8 +529,8 @@ __device__ __forceinline__ StartProbe start_probe_issue(const PhiSketchArgs &A, 
     StartProbe p;
     p.base = g;
     const int64_t idx = g + lane;
-    p.v = idx <= A.n_reads ? (A.read_off[idx] - A.off_bias) : INT64_MAX;              // read_off[n_reads] = n_bases closes the array
-    p.nx = idx + 1 <= A.n_reads ? (A.read_off[idx + 1] - A.off_bias) : INT64_MAX;
+    p.v = idx <= A.n_reads ? A.read_off[idx] : INT64_MAX;              // read_off[n_reads] = n_bases closes the array
+    p.nx = idx + 1 <= A.n_reads ? A.read_off[idx + 1] : INT64_MAX;
     return p;
 }
 __device__ __forceinline__ void set_start_bit(unsigned long long *s_bits, int64_t p, int64_t lo_b)
@@ -557,8 +557,8 @@ __device__ __forceinline__ void start_bits_from_offsets(const PhiSketchArgs &A, 
         int64_t g = pr.base + 32 + (int64_t)((double)(lo_b - vm) / mean) - 24;
         g = g < 0 ? 0 : (g > A.n_reads - 63 ? (A.n_reads - 63 > 0 ? A.n_reads - 63 : 0) : g);
         const int64_t idx = g + lane;
-        const int64_t v2 = idx <= A.n_reads ? (A.read_off[idx] - A.off_bias) : INT64_MAX;
-        const int64_t nx2 = idx + 1 <= A.n_reads ? (A.read_off[idx + 1] - A.off_bias) : INT64_MAX;
+        const int64_t v2 = idx <= A.n_reads ? A.read_off[idx] : INT64_MAX;
+        const int64_t nx2 = idx + 1 <= A.n_reads ? A.read_off[idx + 1] : INT64_MAX;
         const unsigned long long ge2 = __ballot(v2 >= lo_b), lt2 = __ballot(v2 < hi_b);
         if ((g == 0 || !(ge2 & 1ull)) && !(lt2 >> 63)) {
             if (idx < A.n_reads && v2 >= lo_b && v2 < hi_b && nx2 > v2) set_start_bit(s_bits, v2, lo_b);
@@ -573,7 +573,7 @@ __device__ __forceinline__ void start_bits_from_offsets(const PhiSketchArgs &A, 
             stride = (hi - lo + 63) / 64;
             base = lo;
             const int64_t idx = base + lane * stride;
-            v = idx <= A.n_reads ? (A.read_off[idx] - A.off_bias) : INT64_MAX;
+            v = idx <= A.n_reads ? A.read_off[idx] : INT64_MAX;
         }
         const unsigned long long g2 = __ballot(v >= lo_b);
         const int f = g2 ? __ffsll((long long)g2) - 1 : 64;              // the true lanes are a suffix
@@ -587,7 +587,7 @@ __device__ __forceinline__ void start_bits_from_offsets(const PhiSketchArgs &A, 
     // every read from r0 = lo on that starts below hi_b and owns a base sets its bit
     for (int64_t r = lo + lane;; r += 64) {
         int64_t p = INT64_MAX, nx = INT64_MAX;
-        if (r < A.n_reads) { p = (A.read_off[r] - A.off_bias); nx = (A.read_off[r + 1] - A.off_bias); }
+        if (r < A.n_reads) { p = A.read_off[r]; nx = A.read_off[r + 1]; }
         if (p >= lo_b && p < hi_b && nx > p) set_start_bit(s_bits, p, lo_b);
         if (__shfl(p, 63, 64) >= hi_b) break;                             // offsets are monotone: nothing further starts here
     }

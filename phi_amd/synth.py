@@ -336,6 +336,10 @@ class NativeGraph(SynGraph):
         L.phi_syn_sample.argtypes = [vp, u64, i32, vp, vp]
         L.phi_syn_sample.restype = i64
         L.phi_syn_reads.argtypes = [vp, u64, i64, i64, i32, C.c_double, vp, i32]
+        L.phi_syn_write_gfa.argtypes = [vp, C.c_char_p, i32]
+        L.phi_syn_write_gfa.restype = i64
+        L.phi_syn_write_reads.argtypes = [vp, u64, i64, i64, i32, C.c_double, C.c_char_p, i32, i32]
+        L.phi_syn_write_reads.restype = i64
         self._L, self._h = L, vp()
         rc = L.phi_syn_graph(backbone_len, n_walks, seed, site_spacing, chop, block_len, n_founders, max_sv, threads, C.byref(self._h))
         if rc:
@@ -374,6 +378,21 @@ class NativeGraph(SynGraph):
         if self.hap_len < 0:
             raise RuntimeError("phi_syn_sample failed")
         return dict(walks=list(walks), cuts=list(cuts)[:n_mosaic - 1], hap_len=self.hap_len)
+
+    def write_gfa(self, path, threads=0):
+        """The graph as a GFA 1.1 file (names = 1-based vertex ids, the layout of write_gfa above), written natively."""
+        import os
+        n = self._L.phi_syn_write_gfa(self._h, os.fsencode(path), threads)
+        if n < 0:
+            raise RuntimeError(f"cannot write {path}")
+        return n
+
+    def write_reads(self, path, seed, r_lo, r_hi, read_len=150, sub_err=0.005, fastq=False, threads=0):
+        import os
+        n = self._L.phi_syn_write_reads(self._h, seed, r_lo, r_hi, read_len, sub_err, os.fsencode(path), int(fastq), threads)
+        if n < 0:
+            raise RuntimeError(f"cannot write {path}")
+        return n
 
     def n_reads(self, coverage, read_len=150):
         return max(1, (int(coverage * self.hap_len) + read_len - 1) // read_len)
