@@ -72,8 +72,10 @@ void phi_reads_stream_close(phi_reads_stream *s);
  * this exact state machine, a stream whose beginning the device has taken (phi_add_reads_text, phi_amd.h).  next returns
  * the length of the next block and its address (valid until the next call), 0 at the end, negative on error; it may be NULL. */
 typedef int64_t (*phi_text_block_fn)(void *user, const char **block);
-int phi_reads_stream_open_blocks(const char *prefix, int64_t n_prefix, phi_text_block_fn next, void *user, phi_reads_stream **out,
-                                 char *err, int err_cap);
+/* stream_offset = bytes of the stream before prefix[0] (what the device took: *n_taken of phi_reads_text_end): kseq reads in
+ * blocks of 65 536 bytes and what it makes of a file's very last bytes depends on the file's size modulo that (kseq.h:81,113,242). */
+int phi_reads_stream_open_blocks(const char *prefix, int64_t n_prefix, phi_text_block_fn next, void *user, int64_t stream_offset,
+                                 phi_reads_stream **out, char *err, int err_cap);
 
 /* The (inflated) text of a reads file as it is -- no parsing on the host: the bytes go to phi_add_reads_text, which finds the
  * records on the device.  phi_text_stream_read fills buf with the next bytes (plain files: several preads at once, so that

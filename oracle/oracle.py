@@ -372,11 +372,20 @@ def read_reads(path):
     pos = 0
     out = []
     last_char = 0
+    # kseq reads blocks of 65 536 bytes and flags the end when a block comes back short (kseq.h:81,113,242): when every byte
+    # is consumed the flag is up already, unless the length is a multiple of the block size -- then only the next read, of
+    # 0 bytes, raises it (zero_read)
+    zero_read = False
+
+    def kseq_eof():
+        return pos >= n and (zero_read or n % 65536 != 0)
 
     def line_into(buf: bytearray):
-        nonlocal pos
-        if pos >= n:
+        nonlocal pos, zero_read
+        if kseq_eof():
             return -1
+        if pos >= n:
+            zero_read = True
         nl = data.find(b"\n", pos)
         end = nl if nl >= 0 else n
         buf += data[pos:end]
@@ -394,8 +403,10 @@ def read_reads(path):
             last_char = data[pos]
             pos += 1
         # name: up to the first white space
-        if pos >= n:
+        if kseq_eof():
             break
+        if pos >= n:
+            zero_read = True
         i = pos
         while i < n and data[i] not in b" \t\n\v\f\r":
             i += 1
@@ -409,6 +420,7 @@ def read_reads(path):
         while True:
             if pos >= n:
                 c = -1
+                zero_read = True
                 break
             c = data[pos]
             pos += 1

@@ -347,13 +347,14 @@ static int run(const Options &o)
     std::mutex turn_mu;
     std::vector<char> carry;                                  // several GPUs: the bytes the last turn left unfinished
     bool stream_done = false;                                 // under turn_mu
+    int64_t stream_fed = 0;                                   // under turn_mu: bytes of the stream taken from the queue so far
     int64_t host_parsed_bases = 0;
     // the host reader over `prefix` + the rest of the queue -> phi_add_reads on this GPU (under turn_mu)
-    auto finish_on_host = [&](phi_ctx *cx, const char *prefix, int64_t n_prefix, bool rest_of_queue) -> int {
+    auto finish_on_host = [&](phi_ctx *cx, const char *prefix, int64_t n_prefix, bool rest_of_queue, int64_t stream_offset) -> int {
         Stage st("host reader (kseq state machine)");
         QueueBlocks qb{&Q, -1};
         phi_reads_stream *rs = nullptr;
-        if (phi_reads_stream_open_blocks(prefix, n_prefix, rest_of_queue ? next_block_from_queue : nullptr, &qb, &rs, rerr, sizeof rerr) != PHI_HOST_OK) return PHI_ERR_INVALID;
+        if (phi_reads_stream_open_blocks(prefix, n_prefix, rest_of_queue ? next_block_from_queue : nullptr, &qb, stream_offset, &rs, rerr, sizeof rerr) != PHI_HOST_OK) return PHI_ERR_INVALID;
         const int64_t cap_b = std::max<int64_t>((int64_t)1 << 20, std::min<int64_t>(chunk_bytes, (int64_t)64 << 20)), cap_r = cap_b / 32 + 1024;
         std::vector<char> hb((size_t)cap_b);
         std::vector<int64_t> ho((size_t)cap_r + 1);
@@ -390,7 +391,7 @@ static int run(const Options &o)
                         r = phi_reads_text_end(cx, &pend, &n_pend, nullptr);
                         open = false;
                         if (!r && n_dev > 1) { pend = carry.data(); n_pend = (int64_t)carry.size(); }
-                        if (!r && n_pend) r = finish_on_host(cx, pend, n_pend, false);
+                        if (!r && n_pend) r = finish_on_host(cx, pend, n_pend, false, stream_fed - n_pend);
                         break;
                     }
                     if (++n_chunks >= 2)
@@ -399,6 +400,7 @@ static int run(const Options &o)
                         std::call_once(pin_once, [&]() {
                             for (auto &b : Q.buf) if (phi_host_register(cx, b.text, (size_t)chunk_bytes) != PHI_OK) pinned = false;
                         });
+                    stream_fed += cb.n;
                     int32_t irr_carry = 0, irr = 0;
                     if (n_dev > 1 && !carry.empty()) r = phi_add_reads_text(cx, carry.data(), (int64_t)carry.size(), &irr_carry);
                     if (!r && !irr_carry) r = phi_add_reads_text(cx, cb.text, cb.n, &irr);
@@ -418,7 +420,7 @@ static int run(const Options &o)
                         Q.give_free(slot);
                         if (!r) {
                             if (timing) fprintf(stderr, "[phi timing] main: the reads text is not regular FASTA / 4-line FASTQ: host reader from the first byte not taken\n");
-                            r = finish_on_host(cx, pend, n_pend, true);
+                            r = finish_on_host(cx, pend, n_pend, true, stream_fed - n_pend);
                         }
                         break;
                     }

@@ -55,7 +55,17 @@ struct ByteSrc {
     bool failed = false;                              // the source broke (corrupt gzip stream, callback error): not a clean end
     std::vector<char> buf;
     size_t begin = 0, end = 0;
-    bool is_eof = false;
+    bool is_eof = false;                              // the source has no more bytes (nothing to do with kseq's flag of that name)
+    // kseq reads its stream in blocks of 65 536 bytes (kseq.h:242) and flags the end when a block comes back short
+    // (kseq.h:81,113): at the moment every byte is consumed its flag is already up -- unless the stream's length is a
+    // multiple of the block size, when only a further read, of 0 bytes, raises it.  What the last bytes of a file mean (a
+    // bare header character, a lone CR) depends on that flag, so it is kept here as kseq has it: `total` counts the bytes
+    // of the stream from its very first one, zero_read says that kseq would have made its read of 0 bytes.
+    static const uint64_t KSEQ_BLOCK = 65536;
+    uint64_t total = 0;
+    bool zero_read = false;
+    bool exhausted() { return begin >= end && !refill(); }
+    bool kseq_eof() { return exhausted() && (zero_read || total % KSEQ_BLOCK != 0); }
 
     static int inflate_threads()
     {
@@ -86,9 +96,10 @@ struct ByteSrc {
         if (gz) { gz->close(); delete gz; }
         fp = nullptr; gz = nullptr;
     }
-    void open_blocks(const char *prefix, size_t n_prefix, phi_text_block_fn fn, void *user)
+    void open_blocks(const char *prefix, size_t n_prefix, phi_text_block_fn fn, void *user, uint64_t stream_offset)
     {
         mem = prefix; mem_n = n_prefix; mem_at = 0; next_block = fn; next_user = user; from_blocks = true;
+        total = stream_offset;
     }
     bool refill()                                     // false: nothing more to read
     {
@@ -108,6 +119,7 @@ struct ByteSrc {
                 }
                 end = buf.size();
             }
+            total += end;
             return true;
         }
         if (gz) {
@@ -115,25 +127,27 @@ struct ByteSrc {
                 if (!gz->next(buf)) { is_eof = true; failed = !gz->ok(); return false; }   // a corrupt stream is an error, not the end of the file
                 end = buf.size();
             }
+            total += end;
             return true;
         }
         const long n = (long)fread(buf.data(), 1, buf.size(), fp);
         end = n > 0 ? (size_t)n : 0;
         if (end < buf.size()) is_eof = true;
+        total += end;
         return end > 0;
     }
     int getc()
     {
-        if (begin >= end && !refill()) return -1;
+        if (begin >= end && !refill()) { zero_read = true; return -1; }   // (kseq.h:78-83)
         return (unsigned char)buf[begin++];
     }
     // the bytes up to the next '\n' (consumed, not stored) appended to out; -1 when the source was already
     // exhausted.  As ks_getuntil2(KS_SEP_LINE): a trailing '\r' is dropped when the string is longer than 1.
     long line(std::vector<char> &out)
     {
-        if (begin >= end && is_eof) return -1;
+        if (kseq_eof()) return -1;
         for (;;) {
-            if (begin >= end && !refill()) break;
+            if (begin >= end && !refill()) { zero_read = true; break; }
             const char *p = buf.data() + begin;
             const char *nl = (const char *)memchr(p, '\n', end - begin);
             const size_t n = nl ? (size_t)(nl - p) : end - begin;
@@ -148,7 +162,7 @@ struct ByteSrc {
     bool skip_line()
     {
         for (;;) {
-            if (begin >= end && !refill()) return false;
+            if (begin >= end && !refill()) { zero_read = true; return false; }
             const char *p = buf.data() + begin;
             const char *nl = (const char *)memchr(p, '\n', end - begin);
             if (nl) { begin += (size_t)(nl - p) + 1; return true; }
@@ -158,9 +172,9 @@ struct ByteSrc {
     // the same for a string whose bytes are not kept: len / last byte stand for it
     long line_len(size_t &len, int &last)
     {
-        if (begin >= end && is_eof) return -1;
+        if (kseq_eof()) return -1;
         for (;;) {
-            if (begin >= end && !refill()) break;
+            if (begin >= end && !refill()) { zero_read = true; break; }
             const char *p = buf.data() + begin;
             const char *nl = (const char *)memchr(p, '\n', end - begin);
             const size_t n = nl ? (size_t)(nl - p) : end - begin;
@@ -176,9 +190,9 @@ struct ByteSrc {
     {
         out.clear();
         *dret = 0;
-        if (begin >= end && is_eof) return -1;
+        if (kseq_eof()) return -1;
         for (;;) {
-            if (begin >= end && !refill()) break;
+            if (begin >= end && !refill()) { zero_read = true; break; }
             size_t i = begin;
             while (i < end && !isspace((unsigned char)buf[i])) i++;
             out.append(buf.data() + begin, i - begin);
@@ -215,7 +229,7 @@ long kseq_next(ByteSrc &ks, KseqState &st)
     } else {
         // name and comment together are the header line (a name that ends with the file ends the record list the
         // same way: ks.word returns the name, the sequence loop below finds nothing)
-        if (ks.begin >= ks.end && ks.is_eof) return -1;
+        if (ks.kseq_eof()) return -1;
         (void)ks.skip_line();
     }
     while ((c = ks.getc()) != -1 && c != '>' && c != '+' && c != '@') {
@@ -279,13 +293,13 @@ int phi_reads_stream_open(const char *path, phi_reads_stream **out, char *err, i
     return PHI_HOST_OK;
 }
 
-int phi_reads_stream_open_blocks(const char *prefix, int64_t n_prefix, phi_text_block_fn next, void *user, phi_reads_stream **out,
-                                 char *err, int err_cap)
+int phi_reads_stream_open_blocks(const char *prefix, int64_t n_prefix, phi_text_block_fn next, void *user, int64_t stream_offset,
+                                 phi_reads_stream **out, char *err, int err_cap)
 {
-    if (!out || n_prefix < 0 || (n_prefix > 0 && !prefix)) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "bad arguments");
+    if (!out || n_prefix < 0 || (n_prefix > 0 && !prefix) || stream_offset < 0) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "bad arguments");
     phi_reads_stream *s = new phi_reads_stream();
     s->st.want_names = false;
-    s->ks.open_blocks(prefix, (size_t)n_prefix, next, user);
+    s->ks.open_blocks(prefix, (size_t)n_prefix, next, user, (uint64_t)stream_offset);
     *out = s;
     return PHI_HOST_OK;
 }

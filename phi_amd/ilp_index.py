@@ -77,7 +77,7 @@ def host_lib():
         f = getattr(L, "phi_reads_stream_" + n)
         f.restype = C.c_int64
         f.argtypes = [vp]
-    L.phi_reads_stream_open_blocks.argtypes = [vp, C.c_int64, vp, vp, C.POINTER(vp), C.c_char_p, C.c_int]
+    L.phi_reads_stream_open_blocks.argtypes = [vp, C.c_int64, vp, vp, C.c_int64, C.POINTER(vp), C.c_char_p, C.c_int]
     L.phi_text_stream_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_int]
     L.phi_text_stream_read.restype = C.c_int64
     L.phi_text_stream_read.argtypes = [vp, vp, C.c_int64, C.c_char_p, C.c_int]
@@ -138,9 +138,10 @@ def text_chunks(path, chunk_bytes=64 << 20):
         L.phi_text_stream_close(h)
 
 
-def reads_of_text(prefix, blocks=(), bases_cap=64 << 20, reads_cap=1 << 20):
+def reads_of_text(prefix, blocks=(), bases_cap=64 << 20, reads_cap=1 << 20, stream_offset=0):
     """kseq's records (uint8 bases, int64 offsets) of the text `prefix` followed by the byte blocks `blocks`, through
-    phi_reads_stream_open_blocks: the exact host state machine over text that is in memory."""
+    phi_reads_stream_open_blocks: the exact host state machine over text that is in memory (stream_offset: bytes of
+    the stream before prefix[0])."""
     L = host_lib()
     it = iter(blocks)
     keep = []
@@ -158,7 +159,7 @@ def reads_of_text(prefix, blocks=(), bases_cap=64 << 20, reads_cap=1 << 20):
     pre = np.frombuffer(bytes(prefix), np.uint8)
     h = C.c_void_p()
     err = C.create_string_buffer(512)
-    rc = L.phi_reads_stream_open_blocks(pre.ctypes.data if len(pre) else None, len(pre), C.cast(cb, C.c_void_p), None, C.byref(h), err, 512)
+    rc = L.phi_reads_stream_open_blocks(pre.ctypes.data if len(pre) else None, len(pre), C.cast(cb, C.c_void_p), None, stream_offset, C.byref(h), err, 512)
     if rc:
         raise HostError(rc, err.value.decode())
     bases = np.zeros(bases_cap, np.uint8)

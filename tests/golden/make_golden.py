@@ -93,10 +93,30 @@ def main():
             fn = os.path.join(td, "k.fq")
             open(fn, "wb").write(t)
             kv.append({"text_hex": t.hex(), "records": [[a.decode("latin1"), b.hex()] for a, b in O.ref_read_reads(fn)]})
+    # kseq reads its stream in blocks of 65 536 bytes (kseq.h:242) and calls a stream ended when a block came back short -- so what it
+    # makes of a file's very last bytes (a bare header character, a lone CR, a '+' line without quality) depends on whether
+    # the file's size is a multiple of 65 536.  Texts of 65 535 / 65 536 / 65 537 / 131 072 bytes with such ends: the padding
+    # is a first record with a name of the length needed, then `count` copies of an 8-byte record, stored run-length coded; of the records only count, digest and the last two.
+    kb = []
+    unit = b">p\nACGT\n"
+    with tempfile.TemporaryDirectory() as td:
+        for tail in (b">", b"@", b">x", b">x\n", b">x\nAC\n\r", b">x\nAC\n\rG", b"@x\nAC\n+", b"@x\nAC\n+\n", b"@x\nAC\n+\nI", b"@x\n\n+\n", b">x\nAC\n\n", b">x\nAC"):
+            for size in (65535, 65536, 65537, 131072):
+                n_unit, rest = divmod(size - len(tail), len(unit))
+                n_unit, rest = n_unit - 1, rest + len(unit)           # 8 .. 15 bytes of padding: a first record whose name fills them
+                head = b">" + b"h" * (rest - 4) + b"\nA\n"
+                t = head + unit * n_unit + tail
+                assert len(t) == size
+                fn = os.path.join(td, "k.fa")
+                open(fn, "wb").write(t)
+                recs_ = O.ref_read_reads(fn)
+                kb.append({"head_hex": head.hex(), "unit_hex": unit.hex(), "count": n_unit, "tail_hex": tail.hex(), "size": size,
+                           "n_records": len(recs_), "sha256_seqs": hashlib.sha256(b"\0".join(b for _, b in recs_)).hexdigest(),
+                           "last_records": [[a.decode("latin1"), b.hex()] for a, b in recs_[-2:]]})
     recs = O.ref_read_reads(os.path.join(data, "CHM13_reads.fq.gz"))
     chm = {"n": len(recs), "sha256_names": hashlib.sha256(b"\0".join(a for a, _ in recs)).hexdigest(),
            "sha256_seqs": hashlib.sha256(b"\0".join(b for _, b in recs)).hexdigest()}
-    json.dump({"texts": kv, "CHM13_reads.fq.gz": chm}, open(os.path.join(HERE, "kseq_vectors.json"), "w"), indent=0)
+    json.dump({"texts": kv, "block_boundary": kb, "CHM13_reads.fq.gz": chm}, open(os.path.join(HERE, "kseq_vectors.json"), "w"), indent=0)
 
 
 if __name__ == "__main__":

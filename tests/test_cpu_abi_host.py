@@ -113,6 +113,52 @@ def test_host_reader_over_memory_and_blocks_equals_kseq_vectors(built):
             assert [raw[o[i]:o[i + 1]] for i in range(len(o) - 1)] == want, (case["text_hex"], cuts)
 
 
+def _boundary_text(c):
+    return bytes.fromhex(c["head_hex"]) + bytes.fromhex(c["unit_hex"]) * c["count"] + bytes.fromhex(c["tail_hex"])
+
+
+def test_kseq_block_boundary_vectors(built, oracle, tmp_path):
+    """kseq flags the end of its stream when a 65 536-byte block comes back short (kseq.h:81,113,242), so what a file's
+    very last bytes mean -- a bare header character, a lone CR -- depends on the file's size modulo 65 536.  The vectors
+    were made by the reference's own kseq.h (tests/golden/make_golden.py); every reader here must agree: from a file, from
+    memory blocks cut anywhere, from the middle of a stream (stream_offset), and the oracle's restatement."""
+    import hashlib
+    from phi_amd import ilp_index as H
+    gold = json.load(open(os.path.join(GOLDEN, "kseq_vectors.json")))["block_boundary"]
+    assert len(gold) == 48 and sum(c["n_records"] == c["count"] + 2 for c in gold if c["tail_hex"] in ("3e", "40")) == 4   # the bare header character at a multiple of 65 536
+    rng = np.random.default_rng(8)
+    for c in gold:
+        text = _boundary_text(c)
+        assert len(text) == c["size"]
+
+        def check(b, o, what):
+            raw = bytes(b)
+            recs = [raw[o[i]:o[i + 1]] for i in range(len(o) - 1)]
+            assert len(recs) == c["n_records"], (what, c["tail_hex"], c["size"], len(recs))
+            assert hashlib.sha256(b"\0".join(recs)).hexdigest() == c["sha256_seqs"], (what, c["tail_hex"], c["size"])
+            assert [r.hex() for r in recs[-2:]] == [x[1] for x in c["last_records"]], (what, c["tail_hex"], c["size"])
+        p = tmp_path / "k.fa"
+        p.write_bytes(text)
+        b, o, names = H.read_reads(str(p))
+        check(b, o, "phi_reads_read")
+        assert names[-1] == c["last_records"][-1][0]
+        got = list(H.stream_reads(str(p), bases_cap=4096, reads_cap=100))
+        lens = np.concatenate([np.diff(y) for _, y in got]) if got else np.zeros(0, np.int64)
+        check(np.concatenate([x for x, _ in got]) if got else np.zeros(0, np.uint8), np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), "phi_reads_stream")
+        # blocks cut anywhere
+        cuts = sorted(rng.integers(0, len(text) + 1, size=3).tolist())
+        parts = [text[a:b_] for a, b_ in zip([0] + cuts, cuts + [len(text)])]
+        check(*H.reads_of_text(parts[0], [x for x in parts[1:] if x]), "blocks")
+        # the middle of a stream: the records before the cut are the device's, the rest is read with the stream's offset
+        n_skip = int(rng.integers(1, c["count"]))
+        at = len(bytes.fromhex(c["head_hex"])) + 8 * n_skip
+        hb, ho = H.reads_of_text(text[at:], stream_offset=at)
+        check(np.concatenate([np.frombuffer(b"A" + b"ACGT" * n_skip, np.uint8), hb]),
+              np.concatenate([[0], 1 + np.arange(n_skip, dtype=np.int64) * 4, ho + 1 + 4 * n_skip]), "from the middle")
+        orc = oracle.read_reads(str(p))
+        assert len(orc) == c["n_records"] and [[a.decode("latin1"), s_.hex()] for a, s_ in orc[-2:]] == c["last_records"], ("oracle", c["tail_hex"], c["size"])
+
+
 def test_host_gfa_reader_errors(built, tmp_path):
     from phi_amd import ilp_index as H
     with pytest.raises(H.HostError) as e:
