@@ -176,6 +176,24 @@ int phi_comm_allreduce_hits(phi_ctx *ctx);
 int phi_comm_exchange(phi_ctx *ctx);
 int phi_comm_destroy(phi_ctx *ctx);
 
+/*
+ * The same exchange for the contexts of ONE process -- one host thread and one context per GPU, the `PHI --devices` mode --
+ * without RCCL: every GPU ORs the peers' hit vectors into its own with one kernel that loads them across xGMI
+ * (hipDeviceEnablePeerAccess), ordered by HIP events; the lists of the other read hashes are imported where they lie.
+ * Meant for hit vectors of a few MB, where an 8-rank ncclAllReduce is latency (tens of microseconds: as long as one GPU
+ * takes to score a whole MHC read set).  All calls but create / destroy are collective over the group's threads.
+ *   phi_peers_create          a group for n_ranks contexts (at most 16)
+ *   phi_peers_join            every rank's thread, after phi_set_graph: peer access, events
+ *   phi_peers_allreduce_hits  step 1 alone, asynchronous on the contexts' streams
+ *   phi_peers_exchange        steps 1 + 2: afterwards phi_solve gives the same result on every rank
+ *   phi_peers_destroy         once, when no rank will call into the group again
+ */
+int phi_peers_create(int32_t n_ranks, void **group);
+int phi_peers_join(phi_ctx *ctx, void *group, int32_t rank);
+int phi_peers_allreduce_hits(phi_ctx *ctx);
+int phi_peers_exchange(phi_ctx *ctx);
+int phi_peers_destroy(void *group);
+
 typedef struct {
     /* ---- solve (ILP_index.cpp:776-1418) */
     int64_t objective;          /* max  #covered minimisers - 2*(R/2)*#recombinations          */

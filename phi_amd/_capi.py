@@ -24,6 +24,7 @@ SYMBOLS = [
     "phi_host_register", "phi_host_unregister", "phi_set_solve_budget",
     "phi_index_stats", "phi_solve_stats", "phi_comm_unique_id", "phi_comm_init", "phi_comm_info", "phi_comm_allreduce_hits", "phi_comm_exchange", "phi_comm_destroy",
     "phi_reads_text_begin", "phi_add_reads_text", "phi_reads_text_end", "phi_reads_text_detach_carry", "phi_reads_text_last_batch",
+    "phi_peers_create", "phi_peers_join", "phi_peers_allreduce_hits", "phi_peers_exchange", "phi_peers_destroy",
 ]
 
 
@@ -94,6 +95,11 @@ def load():
     L.phi_comm_allreduce_hits.argtypes = [vp]
     L.phi_comm_exchange.argtypes = [vp]
     L.phi_comm_destroy.argtypes = [vp]
+    L.phi_peers_create.argtypes = [i32, C.POINTER(vp)]
+    L.phi_peers_join.argtypes = [vp, vp, i32]
+    L.phi_peers_allreduce_hits.argtypes = [vp]
+    L.phi_peers_exchange.argtypes = [vp]
+    L.phi_peers_destroy.argtypes = [vp]
     L.phi_path_sequence.argtypes = [vp, vp, i64]
     L.phi_sketch.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64)]
     L.phi_walk_minimizers.argtypes = [vp, i32, vp, vp, i64, C.POINTER(i64)]

@@ -179,6 +179,28 @@ class Context:
     def comm_exchange(self):
         self._chk(self._L.phi_comm_exchange(self._h))
 
+    # ------------------------------------------------------------------ contexts of one process exchanging through peer-mapped memory
+    @staticmethod
+    def peers_create(n_ranks):
+        g = C.c_void_p()
+        rc = _capi.load().phi_peers_create(n_ranks, C.byref(g))
+        if rc:
+            raise PhiError(rc, "phi_peers_create")
+        return g
+
+    @staticmethod
+    def peers_destroy(group):
+        _capi.load().phi_peers_destroy(group)
+
+    def peers_join(self, group, rank):
+        self._chk(self._L.phi_peers_join(self._h, group, rank))
+
+    def peers_allreduce_hits(self):
+        self._chk(self._L.phi_peers_allreduce_hits(self._h))
+
+    def peers_exchange(self):
+        self._chk(self._L.phi_peers_exchange(self._h))
+
     def comm_destroy(self):
         self._chk(self._L.phi_comm_destroy(self._h))
 

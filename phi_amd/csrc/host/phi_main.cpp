@@ -181,7 +181,7 @@ static int run(const Options &o)
     if (devices.empty()) devices.push_back(o.device);
     for (size_t i = 0; i < devices.size(); i++)
         for (size_t j = 0; j < i; j++)
-            if (devices[i] == devices[j]) { fprintf(stderr, "[E::main] --devices names GPU %d twice\n", devices[i]); return 1; }
+            if (devices[i] == devices[j] && !getenv("PHI_ALLOW_SAME_DEVICE")) { fprintf(stderr, "[E::main] --devices names GPU %d twice\n", devices[i]); return 1; }   // (the tests run two contexts on one GPU)
     // a read set is sharded only over as many GPUs as it can keep busy: every further GPU costs an exchange (~tens of
     // microseconds) and an index build, and one GPU scores 50 Mbases in a fifth of a millisecond
     if (devices.size() > 1) {
@@ -317,7 +317,6 @@ static int run(const Options &o)
     const uint32_t flags = (is_qclp ? PHI_FLAG_QCLP : 0) | (is_mixed ? PHI_FLAG_MIXED : 0);
     // the read shards of a multi-GPU run are merged by the library's own RCCL exchange (phi_comm_*)
     unsigned char comm_id[PHI_COMM_ID_BYTES];
-    if (n_dev > 1 && (rc = phi_comm_unique_id(comm_id, sizeof comm_id))) { fprintf(stderr, "[E::main] RCCL is not available: %s\n", phi_strerror(rc)); stop_reads(); return 1; }
 
     // ---- stage 1a: walks (ILP_index.cpp:556-611) on every GPU, while the reads are still being read
     const int32_t n_walks = phi_graph_n_walks(g);
@@ -333,9 +332,21 @@ static int run(const Options &o)
                 return r;
             })) return 1;
     }
+    // The exchange of a multi-GPU run: hit vectors of a few MB (every MHC-sized graph) go through peer-mapped memory -- one
+    // OR-gather kernel per GPU, no RCCL --; longer ones (chromosome scale: ~100 MB) through the library's RCCL all-reduce,
+    // which is bandwidth-bound there.  PHI_EXCHANGE=rccl|peers overrides.
+    bool use_peers = false;
+    void *peer_group = nullptr;
     if (n_dev > 1) {
-        Stage st("RCCL communicator");
-        if (run_on_all("communicator", [&](int i, phi_ctx *cx) -> int { return phi_comm_init(cx, comm_id, i, n_dev); })) return 1;
+        phi_index_info info;
+        if ((rc = phi_index_stats(ctx, &info))) return die("index", rc);
+        use_peers = info.n_distinct_minimizers <= (int64_t)4 << 20;
+        if (const char *e = getenv("PHI_EXCHANGE")) use_peers = strcmp(e, "peers") == 0;
+        if (use_peers && (rc = phi_peers_create(n_dev, &peer_group))) return die("peer group", rc);
+        Stage st(use_peers ? "peer group (xGMI peer access)" : "RCCL communicator");
+        if (!use_peers && (rc = phi_comm_unique_id(comm_id, sizeof comm_id))) { fprintf(stderr, "[E::main] RCCL is not available: %s\n", phi_strerror(rc)); stop_reads(); return 1; }
+        if (run_on_all("communicator", [&](int i, phi_ctx *cx) -> int { return use_peers ? phi_peers_join(cx, peer_group, i) : phi_comm_init(cx, comm_id, i, n_dev); })) return 1;
+        fprintf(stderr, "[M::main] %d GPUs; hit vector of %lld flags merged through %s\n", n_dev, (long long)info.n_distinct_minimizers, use_peers ? "peer-mapped memory (one OR-gather kernel per GPU)" : "RCCL all-reduce");
     }
 
     // ---- reads (main.cpp:136-137) and stage 1b/2a (:615-655), chunk by chunk.  The chunks are taken in stream order,
@@ -438,8 +449,8 @@ static int run(const Options &o)
     }
     if (f_reads.get() != PHI_HOST_OK) { fprintf(stderr, "[E::%s] %s\n", "main", rerr); return 1; }
     if (n_dev > 1) {
-        Stage st("RCCL exchange");
-        if (run_on_all("exchange", [&](int, phi_ctx *cx) -> int { return phi_comm_exchange(cx); })) return 1;
+        Stage st(use_peers ? "exchange (peer-mapped)" : "exchange (RCCL)");
+        if (run_on_all("exchange", [&](int, phi_ctx *cx) -> int { return use_peers ? phi_peers_exchange(cx) : phi_comm_exchange(cx); })) return 1;
     }
     int64_t total_reads = 0;
     for (phi_ctx *cx : ctxs) {

@@ -249,7 +249,7 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
-                     &c->d_roff, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
+                     &c->d_roff, &c->d_peer_send, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_bstart, &c->d_k_rec, &c->d_k_in, &c->d_cvtx, &c->d_ev_e, &c->d_ev_off, &c->d_ev,

@@ -15,6 +15,7 @@
 // never pays for it (it is the largest shared object of the ROCm stack).
 #include <dlfcn.h>
 #include <string.h>
+#include <condition_variable>
 #include <rccl/rccl.h>
 #include "phi_ctx.h"
 #include "phi_dev.h"
@@ -185,6 +186,177 @@ int phi_comm_exchange(phi_ctx *c)
         if (r != pc->rank && sizes[(size_t)r] > 0)
             PHICHK(phi_spectrum_import(c, pc->d_recv.as<uint64_t>() + (size_t)r * (size_t)mx, sizes[(size_t)r]));
     HIPCHK(hipStreamSynchronize(c->stream));                   // the receive buffer may be reused by the next exchange
+    return PHI_OK;
+}
+
+
+// ---- the same exchange for the contexts of ONE process (one host thread per GPU: `PHI --devices`), without RCCL.
+//
+// An 8-rank ncclAllReduce of a 0.5-3 MB vector is tens of microseconds of launch and proxy latency -- as long as a GPU
+// takes to SCORE a whole read set of the MHC configurations (22 us at C2).  Contexts of one process can do better: every
+// GPU's hit vector is an address the others can load from (hipDeviceEnablePeerAccess: xGMI), OR is idempotent and
+// monotone, so ONE kernel per GPU ORs the peers' vectors into its own, in place -- a peer vector that is itself half
+// way through its update only ever shows bits of the union.  Ordering comes from HIP events, which cross devices inside a
+// process: "my scoring is done" before the gather (recorded, then waited for by every peer's stream), "my gather is done"
+// after it (so that no GPU resets a vector a peer still reads).  The host threads meet twice per exchange, at a
+// barrier of their own, only to know that the events they are about to wait for have been recorded.
+struct PhiPeers {
+    int n = 0;
+    std::vector<phi_ctx *> ctx;
+    std::vector<hipEvent_t> ready, done;
+    std::vector<void *> hits;                        // current hit vector of every rank
+    std::vector<void *> sp_list;                     // exported spectrum list of every rank
+    std::vector<int64_t> sp_n, n_unique;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t phase = 0;
+    int failed = 0;
+    // all n threads meet; returns nonzero when some rank raised `fail` before or at this barrier
+    int barrier(int fail)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (fail) failed = fail;
+        const uint64_t p = phase;
+        if (++arrived == n) { arrived = 0; phase++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return phase != p; });
+        return failed;
+    }
+};
+
+namespace {
+#define PHI_MAX_PEERS 16
+struct PeerPtrs { const unsigned long long *p[PHI_MAX_PEERS]; };
+// out[i] |= OR over the peers' vectors, eight flags at a time
+__global__ void __launch_bounds__(256) phi_or_gather_kernel(unsigned long long *__restrict__ mine, PeerPtrs peers, int n_peers, int64_t n_words)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long v = 0;
+#pragma unroll 4
+        for (int r = 0; r < n_peers; r++) v |= __builtin_nontemporal_load(peers.p[r] + i);
+        if (v & ~mine[i]) mine[i] |= v;
+    }
+}
+}  // namespace
+
+int phi_peers_create(int32_t n_ranks, void **group)
+{
+    if (!group || n_ranks < 1 || n_ranks > PHI_MAX_PEERS) return PHI_ERR_INVALID;
+    PhiPeers *g = new (std::nothrow) PhiPeers();
+    if (!g) return PHI_ERR_NOMEM;
+    g->n = n_ranks;
+    g->ctx.assign((size_t)n_ranks, nullptr);
+    g->ready.assign((size_t)n_ranks, nullptr); g->done.assign((size_t)n_ranks, nullptr);
+    g->hits.assign((size_t)n_ranks, nullptr); g->sp_list.assign((size_t)n_ranks, nullptr);
+    g->sp_n.assign((size_t)n_ranks, 0); g->n_unique.assign((size_t)n_ranks, 0);
+    *group = g;
+    return PHI_OK;
+}
+
+// every rank's thread calls it once, after phi_set_graph (collective: the threads meet inside)
+int phi_peers_join(phi_ctx *c, void *group, int32_t rank)
+{
+    PhiPeers *g = (PhiPeers *)group;
+    if (!c || !g || rank < 0 || rank >= g->n) return PHI_ERR_INVALID;
+    int rc = PHI_OK;
+    if (!c->have_graph) rc = phi_fail(c, PHI_ERR_STATE, "phi_peers_join before phi_set_graph");
+    if (!rc && hipSetDevice(c->device) != hipSuccess) rc = PHI_ERR_DEVICE;
+    if (!rc) {
+        g->ctx[(size_t)rank] = c;
+        g->n_unique[(size_t)rank] = c->n_unique;
+        if (hipEventCreateWithFlags(&g->ready[(size_t)rank], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->done[(size_t)rank], hipEventDisableTiming) != hipSuccess) rc = phi_fail(c, PHI_ERR_DEVICE, "event creation failed");
+    }
+    if (g->barrier(rc)) return rc ? rc : phi_fail(c, PHI_ERR_STATE, "another rank could not join the peer group");
+    // every GPU may load from every other (the same device twice -- two contexts on one GPU, as the tests run it -- needs nothing)
+    for (int r = 0; r < g->n && !rc; r++) {
+        const int dev = g->ctx[(size_t)r]->device;
+        if (dev == c->device) continue;
+        if (g->n_unique[(size_t)r] != c->n_unique) { rc = phi_fail(c, PHI_ERR_INVALID, "the ranks of a peer group hold different graphs"); break; }
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, c->device, dev) != hipSuccess || !can) { rc = phi_fail(c, PHI_ERR_DEVICE, "GPU %d cannot address GPU %d", c->device, dev); break; }
+        const hipError_t e = hipDeviceEnablePeerAccess(dev, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = phi_fail(c, PHI_ERR_DEVICE, "hipDeviceEnablePeerAccess(%d): %s", dev, hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
+    if (g->barrier(rc)) return rc ? rc : phi_fail(c, PHI_ERR_STATE, "another rank could not reach its peers");
+    c->peers = g; c->peer_rank = rank;
+    return PHI_OK;
+}
+
+// collective over the group's threads, once per read set: hit vectors ORed in place, then the lists of read hashes that are
+// no walk minimisers imported from every peer (they are read where they lie).  Afterwards phi_solve gives the same result
+// on every rank, as after phi_comm_exchange.  hits_only: step 1 alone (what a job times per read set).
+static int peers_exchange(phi_ctx *c, bool hits_only)
+{
+    if (!c) return PHI_ERR_INVALID;
+    PhiPeers *g = c->peers;
+    if (!g) return phi_fail(c, PHI_ERR_STATE, "no peer group: call phi_peers_join first");
+    const int me = c->peer_rank;
+    int rc = PHI_OK;
+    void *d_hit = nullptr;
+    int64_t n = 0;
+    if (hipSetDevice(c->device) != hipSuccess) rc = PHI_ERR_DEVICE;
+    if (!rc) rc = phi_hits_buffer(c, &d_hit, &n);
+    if (!rc) {
+        g->hits[(size_t)me] = d_hit;
+        rc = phi_hip_check(c, hipEventRecord(g->ready[(size_t)me], c->stream), "hipEventRecord");
+    }
+    if (g->barrier(rc)) return rc ? rc : phi_fail(c, PHI_ERR_STATE, "a peer failed before the exchange");
+    // ---- step 1: OR of the hit vectors
+    PeerPtrs pp{};
+    int np = 0;
+    for (int r = 0; r < g->n; r++) {
+        if (r == me) continue;
+        HIPCHK(hipStreamWaitEvent(c->stream, g->ready[(size_t)r], 0));
+        pp.p[np++] = (const unsigned long long *)g->hits[(size_t)r];
+    }
+    const int64_t n_words = n / 8 + 1;                         // (the vectors are allocated in whole words)
+    if (np && n > 0) {
+        const unsigned nb = (unsigned)std::min<int64_t>((n_words + 255) / 256, 2048);
+        hipLaunchKernelGGL(phi_or_gather_kernel, dim3(nb), dim3(256), 0, c->stream, (unsigned long long *)d_hit, pp, np, n_words);
+        HIPCHK(hipGetLastError());
+    }
+    c->solved = false;
+    if (hits_only) {
+        HIPCHK(hipEventRecord(g->done[(size_t)me], c->stream));
+        if (g->barrier(0)) return phi_fail(c, PHI_ERR_STATE, "a peer failed in the exchange");
+        for (int r = 0; r < g->n; r++) if (r != me) HIPCHK(hipStreamWaitEvent(c->stream, g->done[(size_t)r], 0));   // nobody resets a vector a peer still reads
+        return PHI_OK;
+    }
+    // ---- step 2: the union of the read hashes that are not walk minimisers
+    void *d_mine = nullptr;
+    int64_t n_mine = 0;
+    rc = phi_spectrum_export(c, &d_mine, &n_mine);             // waits for the stream
+    if (!rc && n_mine) {
+        // a copy the peers read: importing THEIR lists may regrow this context's set, which goes through the export buffer
+        rc = phi_dev_ensure(c, c->d_peer_send, (size_t)n_mine * 8);
+        if (!rc) rc = phi_hip_check(c, hipMemcpyAsync(c->d_peer_send.p, d_mine, (size_t)n_mine * 8, hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync");
+        if (!rc) rc = phi_hip_check(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        d_mine = c->d_peer_send.p;
+    }
+    g->sp_list[(size_t)me] = d_mine; g->sp_n[(size_t)me] = n_mine;
+    if (g->barrier(rc)) return rc ? rc : phi_fail(c, PHI_ERR_STATE, "a peer failed in the exchange");
+    for (int r = 0; r < g->n && !rc; r++)
+        if (r != me && g->sp_n[(size_t)r] > 0) rc = phi_spectrum_import(c, g->sp_list[(size_t)r], g->sp_n[(size_t)r]);
+    if (!rc) rc = phi_hip_check(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");   // the peers' lists and vectors are free again
+    if (g->barrier(rc)) return rc ? rc : phi_fail(c, PHI_ERR_STATE, "a peer failed in the exchange");
+    return PHI_OK;
+}
+int phi_peers_allreduce_hits(phi_ctx *c) { return peers_exchange(c, true); }
+int phi_peers_exchange(phi_ctx *c) { return peers_exchange(c, false); }
+
+// after every rank's last collective, by one thread
+int phi_peers_destroy(void *group)
+{
+    PhiPeers *g = (PhiPeers *)group;
+    if (!g) return PHI_OK;
+    for (int r = 0; r < g->n; r++) {
+        if (g->ctx[(size_t)r]) { (void)hipSetDevice(g->ctx[(size_t)r]->device); g->ctx[(size_t)r]->peers = nullptr; }
+        if (g->ready[(size_t)r]) (void)hipEventDestroy(g->ready[(size_t)r]);
+        if (g->done[(size_t)r]) (void)hipEventDestroy(g->done[(size_t)r]);
+    }
+    delete g;
     return PHI_OK;
 }
 

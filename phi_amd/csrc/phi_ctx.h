@@ -60,10 +60,13 @@ struct PhiAnchorSpan {
 };
 
 struct PhiComm;               // phi_comm.hip: the RCCL communicator of a multi-GPU job
+struct PhiPeers;              // phi_comm.hip: the contexts of one process that exchange through peer-mapped memory
 
 struct phi_ctx {
     int device = 0;
     PhiComm *comm = nullptr;
+    PhiPeers *peers = nullptr;
+    int peer_rank = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t aux_stream = nullptr;    // the host thread's copies inside phi_set_graph, while the GPU thread works on `stream`
     std::string last_error;
@@ -110,7 +113,7 @@ struct phi_ctx {
     int64_t sp_bound = 0;                             // host-side upper bound of the set size
     int64_t reads_bases = 0, reads_count = 0;
     int64_t spectrum_override = -1;
-    DevBuf d_rbases, d_roff, d_export;
+    DevBuf d_rbases, d_roff, d_export, d_peer_send;
     // device scalars: [0] err(u32 in low half) [1] n_bad [2] sp_count [3] n_emitted [4..] scratch
     DevBuf d_scalars;
     DevBuf d_stripes;                                 // [2][PHI_STRIPES][8] u64: distinct read hashes, emitted records
