@@ -293,12 +293,23 @@ def main():
             stream.synchronize()
             pdist.allreduce_hits(torch.as_tensor(pdist.DevArray(hit_ptr, n_unique), device=dev))
 
-    def make_step(d_b, d_o, nr, nb):
+    def make_step(d_b, d_o, nr, nb, with_offsets=False):
+        # reads of one length (the 150-bp sets of C2 / C3 / C5) are handed over WITHOUT offsets, as the command line's device-side
+        # record splitter hands them over: the kernel computes the read starts (include/phi_amd.h, phi_add_reads_device)
+        off_ptr = d_o.data_ptr() if (with_offsets or not _uniform(d_o, nr, nb)) else None
+
         def step():
             ctx.reset_reads()
-            ctx.add_reads_device(d_b.data_ptr(), d_o.data_ptr(), nr, nb)
+            ctx.add_reads_device(d_b.data_ptr(), off_ptr, nr, nb)
             allreduce_hits()
+        step.uses_offsets = off_ptr is not None
         return step
+
+    def _uniform(d_o, nr, nb):
+        if nr == 0 or nb % nr or nb // nr < 32:
+            return False
+        L = nb // nr
+        return bool((d_o[1:] - d_o[:-1] == L).all().item())
 
     def timed(step, steps, warmup):
         for _ in range(warmup):
@@ -389,6 +400,15 @@ def main():
                       "hit_vector_bytes": int(index_info["n_distinct_minimizers"]), "rccl_ranks": ctx.comm_info()[1] if use_lib_comm else world,
                       "note": "GPU time between events on the stream, 20 steps: reset + sketch launch, then ncclAllReduce(MAX, uint8) of the hit vector; "
                               "the all-reduce figure includes waiting for the slowest rank's sketch"}
+    # the same read set handed over WITH its offsets array (reads of uneven lengths always are): the general path, beside `value`
+    value_with_offsets = None
+    if args.scaling == "weak" and not primary_step.uses_offsets:
+        gstep = make_step(d_bases, d_off, n_reads, n_bases, with_offsets=True)
+        g_steps = max(10, args.steps)
+        el_g = timed(gstep, g_steps, max(2, args.warmup))
+        value_with_offsets = n_bases * world * g_steps / el_g / 1e9
+        primary_step()                                         # leave the context holding the primary read set
+        torch.cuda.synchronize()
     stats = ctx.reads_stats()
     density = stats["n_emitted"] / max(1, stats["n_bases"])
     ms_per_step = elapsed / args.steps * 1e3
@@ -509,6 +529,8 @@ def main():
                      "note": "achieved/frac price the sketch kernel's time against the SURVEY 8d bytes of a base (1.5 + 24 d); kernel_own_frac prices it against "
                              "the bytes the fused kernel itself moves (1 + 24 d); step_frac = SURVEY bytes / whole step time (the step is this one launch)",
                      "kernel_gbases_per_s": launch_bases / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0},
+        "reads_handed_over": "without offsets (one length: the kernel computes the read starts)" if not primary_step.uses_offsets else "with an offsets array",
+        "value_with_offsets": value_with_offsets,
         "index_build_s": repeats["index_build_s"] if repeats else t_index, "index_build_s_cold": t_index,
         "graph_gbases_per_s": walk_bases / (repeats["index_build_s"] if repeats else t_index) / 1e9, "index": index_info,
         "solve_s": repeats["solve_s"] if repeats else t_solve, "solve_s_cold": t_solve, "solve": solve_info,

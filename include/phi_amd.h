@@ -90,7 +90,8 @@ int phi_set_graph(phi_ctx *ctx, int32_t n_vtx, const char *seq_concat, const int
  * bases = raw ASCII (upper/lower case; any byte), read r = bases[read_off[r], read_off[r+1]).
  */
 int phi_add_reads(phi_ctx *ctx, const char *bases, const int64_t *read_off, int64_t n_reads);
-/* Same, with both arrays already resident in this GPU's HBM (n_bases = read_off[n_reads]). */
+/* Same, with both arrays already resident in this GPU's HBM (n_bases = read_off[n_reads]).  d_read_off may be NULL for reads of
+ * ONE length (n_bases / n_reads each, as sequencers write short reads): the kernel then computes the read starts and reads no offsets. */
 int phi_add_reads_device(phi_ctx *ctx, const void *d_bases, const void *d_read_off, int64_t n_reads,
                          int64_t n_bases);
 /*

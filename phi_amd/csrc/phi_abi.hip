@@ -249,7 +249,7 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
-                     &c->d_roff, &c->d_peer_send, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
+                     &c->d_roff, &c->d_roff_made, &c->d_peer_send, &c->d_export, &c->d_scalars, &c->d_stripes, &c->d_blk_cnt,
                      &c->d_blk_off, &c->d_flags, &c->d_flags2, &c->d_list, &c->d_list2, &c->d_list3, &c->d_walk_last, &c->d_m_rec, &c->d_m_group,
                      &c->d_g_keys, &c->d_g_rep, &c->d_g_cnt, &c->d_slot_maxcnt, &c->d_slot_multi, &c->d_a_e1,
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_bstart, &c->d_k_rec, &c->d_k_in, &c->d_cvtx, &c->d_ev_e, &c->d_ev_off, &c->d_ev,
@@ -980,7 +980,20 @@ int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_rea
 {
     if (!c) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads before phi_set_graph");
-    if (n_reads < 0 || n_bases < 0 || (n_bases > 0 && (!d_bases || !d_read_off))) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads: bad arguments");
+    if (n_reads < 0 || n_bases < 0 || (n_bases > 0 && !d_bases)) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads: bad arguments");
+    // no offsets: reads of one length, n_bases / n_reads each
+    int64_t uniform_len = 0;
+    if (!d_read_off && n_reads > 0 && n_bases > 0) {
+        if (n_bases % n_reads) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads_device without offsets: %lld bases are not %lld reads of one length", (long long)n_bases, (long long)n_reads);
+        uniform_len = n_bases / n_reads;
+        if (uniform_len < 32 || uniform_len > 0x7FFFFFFF) {
+            // (shorter than the kernel's arithmetic covers, or absurdly long: make the offsets)
+            PHICHK(phi_dev_ensure(c, c->d_roff_made, (size_t)(n_reads + 1) * 8));
+            phi_launch_iota_i64(c->stream, c->d_roff_made.as<int64_t>(), n_reads + 1, uniform_len);
+            d_read_off = c->d_roff_made.p;
+            uniform_len = 0;
+        }
+    }
     if (n_reads == 0 || n_bases == 0) { if (!replay) c->reads_count += n_reads; return PHI_OK; }
     HIPCHK(hipSetDevice(c->device));
     c->solved = false;
@@ -1006,6 +1019,8 @@ int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_rea
     PhiSketchArgs A{};
     A.ascii = (const uint8_t *)d_bases;
     A.read_off = (const int64_t *)d_read_off; A.n_reads = n_reads;
+    A.uniform_len = (int32_t)uniform_len; A.inv_len = uniform_len ? 1.0 / (double)uniform_len : 0.0;
+    A.inv_len_q32 = uniform_len ? (uint32_t)(((uint64_t)1 << 32) / (uint64_t)uniform_len) : 0u;
     {
         const double q = (double)n_reads / (double)n_bases * 4294967296.0;      // (a guess: clamped, never wrong to round)
         A.reads_per_base_q32 = q >= 2147483648.0 ? 0x80000000u : (uint32_t)q;
@@ -1079,6 +1094,15 @@ static bool offsets_monotone(const int64_t *off, int64_t n)
     return !bad.load();
 }
 
+static bool offsets_uniform(const int64_t *off, int64_t n, int64_t len)
+{
+    auto span = [off, len](int64_t lo, int64_t hi) { int bad = 0; for (int64_t r = lo; r < hi; r++) bad |= off[r + 1] - off[r] != len; return bad; };
+    if (n < (1 << 20)) return !span(0, n);
+    std::atomic<int> bad{0};
+    phi_parallel_chunks(n, (int64_t)1 << 20, [&](int64_t lo, int64_t hi, int) { if (span(lo, hi)) bad.store(1); });
+    return !bad.load();
+}
+
 extern "C" {
 
 int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_t n_reads)
@@ -1094,6 +1118,9 @@ int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_
     }
     const int64_t n_bases = read_off[n_reads];
     if (n_bases > 0 && !bases) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads: bases is null");
+    // reads of one length (>= 32): their offsets are r * length -- they need not cross the link, nor be read by the kernel
+    const int64_t len0 = read_off[1];
+    const bool uniform = n_bases > 0 && len0 >= 32 && len0 * n_reads == n_bases && offsets_uniform(read_off, n_reads, len0);
     HIPCHK(hipSetDevice(c->device));
     PhiStageTimer tm("add_reads");
     // (every call ends with a wait for the stream: nothing of an earlier batch still reads the staging buffers)
@@ -1108,15 +1135,15 @@ int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_
     //   * the kernel reading pinned bases in place across the link (every base is loaded exactly once): shader reads of
     //     host memory reach 25-32 GB/s, half the copy engine's rate: 190 us (C3: 1673 us).
     PHICHK(phi_dev_ensure(c, c->d_rbases, (size_t)std::max<int64_t>(n_bases, 1)));
-    HIPCHK(hipMemcpyAsync(c->d_roff.p, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (!uniform) HIPCHK(hipMemcpyAsync(c->d_roff.p, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
     if (n_bases) HIPCHK(hipMemcpyAsync(c->d_rbases.p, bases, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
-    PHICHK(phi_add_reads_device_impl(c, c->d_rbases.p, c->d_roff.p, n_reads, n_bases, false));
+    PHICHK(phi_add_reads_device_impl(c, c->d_rbases.p, uniform ? nullptr : c->d_roff.p, n_reads, n_bases, false));
     // the error word behind the last kernel; host buffers are borrowed for the call only: one wait for everything
     HIPCHK(hipMemcpyAsync(c->h_err, scalar(c, S_ERR), 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     tm.lap("H2D + sketch + probe");
     if (*c->h_err & PHI_KERR_TABLE_FULL) {
-        PHICHK(replay_if_full(c, *c->h_err, c->d_rbases.p, c->d_roff.p, n_reads, n_bases));
+        PHICHK(replay_if_full(c, *c->h_err, c->d_rbases.p, uniform ? nullptr : c->d_roff.p, n_reads, n_bases));
         tm.lap("spectrum set regrown, batch replayed");
     }
     return PHI_OK;
@@ -1162,7 +1189,7 @@ static int text_replay_last(phi_ctx *c, uint32_t err)
 {
     auto &T = c->text;
     if (T.last_slot < 0 || !(err & PHI_KERR_TABLE_FULL)) return PHI_OK;
-    return replay_if_full(c, err, T.bases[T.last_slot].p, T.roff[T.last_slot].p, T.last_reads, T.last_bases);
+    return replay_if_full(c, err, T.bases[T.last_slot].p, T.last_uniform ? nullptr : T.roff[T.last_slot].p, T.last_reads, T.last_bases);
 }
 
 static int text_piece(phi_ctx *c, const char *p, uint32_t m, int32_t *irregular)
@@ -1209,7 +1236,10 @@ static int text_piece(phi_ctx *c, const char *p, uint32_t m, int32_t *irregular)
         return PHI_OK;
     }
     if (S.n_rec) {
-        PHICHK(phi_add_reads_device_impl(c, T.bases[slot].p, T.roff[slot].p, (int64_t)S.n_rec, (int64_t)S.n_bases, false));
+        // records of one length (>= 32): the sketch kernel computes the read starts, no offsets
+        const bool uni = !S.not_uniform && S.n_bases % S.n_rec == 0 && S.n_bases / S.n_rec >= 32;
+        T.last_uniform = uni;
+        PHICHK(phi_add_reads_device_impl(c, T.bases[slot].p, uni ? nullptr : T.roff[slot].p, (int64_t)S.n_rec, (int64_t)S.n_bases, false));
         T.last_slot = slot; T.last_reads = (int64_t)S.n_rec; T.last_bases = (int64_t)S.n_bases;
         T.dbg_slot = slot; T.dbg_reads = (int64_t)S.n_rec; T.dbg_bases = (int64_t)S.n_bases;
     }

@@ -113,7 +113,7 @@ struct phi_ctx {
     int64_t sp_bound = 0;                             // host-side upper bound of the set size
     int64_t reads_bases = 0, reads_count = 0;
     int64_t spectrum_override = -1;
-    DevBuf d_rbases, d_roff, d_export, d_peer_send;
+    DevBuf d_rbases, d_roff, d_roff_made, d_export, d_peer_send;
     // device scalars: [0] err(u32 in low half) [1] n_bad [2] sp_count [3] n_emitted [4..] scratch
     DevBuf d_scalars;
     DevBuf d_stripes;                                 // [2][PHI_STRIPES][8] u64: distinct read hashes, emitted records
@@ -153,6 +153,7 @@ struct phi_ctx {
         hipEvent_t ev_copy = nullptr;
         int last_slot = -1;                           // the chunk whose sketch may still be running: replayed if the spectrum set overflowed
         int64_t last_reads = 0, last_bases = 0;
+        bool last_uniform = false;
         int dbg_slot = 0;                             // what the last piece took (phi_reads_text_last_batch: the parity tests)
         int64_t dbg_reads = 0, dbg_bases = 0;
         uint32_t why = 0, first_bad = 0;

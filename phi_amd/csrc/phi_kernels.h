@@ -57,6 +57,9 @@ struct PhiSketchArgs {
     // are made by the wave that sketches it (no preparation launch): `ascii` + read offsets
     const int64_t *read_off; int64_t n_reads;
     uint32_t reads_per_base_q32;           // n_reads / n_bases in 0.32 fixed point (first guess of the read-start search: no division per wave)
+    int32_t uniform_len;                   // > 0: every read has this length (>= 32) and there are NO offsets: read r starts at r * uniform_len
+    double inv_len;                        // 1.0 / uniform_len
+    uint32_t inv_len_q32;                  // floor(2^32 / uniform_len)
     // ... and, in the first launch after a reset, every wave also empties its share of the buffers the PREVIOUS
     // generation of reads filled (the other half of the context's double buffers), for the generation after this one
     int32_t q_clean, q_full;
@@ -93,6 +96,7 @@ void phi_launch_slot_uid(hipStream_t st, const int32_t *rep_list, int64_t n_uniq
 void phi_launch_table_pairs(hipStream_t st, const uint64_t *keys, const uint32_t *uid, int64_t cap, uint64_t *kv);
 void phi_launch_fill_u64(hipStream_t st, uint64_t *p, int64_t n, uint64_t v);
 void phi_launch_fill_u32(hipStream_t st, uint32_t *p, int64_t n, uint32_t v);
+void phi_launch_iota_i64(hipStream_t st, int64_t *p, int64_t n, int64_t step);   // p[i] = i * step
 // insert a list of hashes into the spectrum set (multi-GPU spectrum merge)
 void phi_launch_spectrum_insert(hipStream_t st, const uint64_t *hashes, int64_t n, uint64_t *sp_keys,
                                 uint64_t sp_mask, unsigned long long *sp_count, const uint64_t *u_keys, uint64_t u_mask,
@@ -321,6 +325,8 @@ struct PhiTextSummary {
     uint64_t n_bases;                    // their sequence bytes
     uint32_t cons_end;                   // buffer offset where the carry (the bytes not taken) begins
     uint32_t n_cons_lines;
+    uint32_t not_uniform;                // some record's sequence is of another length than the first one's
+    uint32_t pad_;
 };
 struct PhiTextArgs {
     const uint8_t *buf;                  // device buffer [carry | chunk]

@@ -275,6 +275,16 @@ __global__ void __launch_bounds__(256) phi_text_finish_kernel(PhiTextArgs A)
     }
 }
 
+// are the records all of one length?  (then the sketch kernel needs no offsets: phi_sketch_kernel's uniform_len)
+__global__ void __launch_bounds__(256) phi_text_uniform_kernel(PhiTextArgs A)
+{
+    const uint32_t n_rec = A.sum->n_rec;
+    if (A.sum->err || n_rec < 2) return;
+    const int64_t len0 = A.read_off[1] - A.read_off[0];
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1; j < n_rec; j += gridDim.x * blockDim.x)
+        if (A.read_off[j + 1] - A.read_off[j] != len0) { A.sum->not_uniform = 1; return; }
+}
+
 // the sequence bytes of the records, gathered: every wave fills 2 KB of the output
 #define GATHER_WAVE_BYTES 2048u
 __global__ void __launch_bounds__(256) phi_text_gather_kernel(PhiTextArgs A)
@@ -329,6 +339,7 @@ void phi_launch_reads_text(hipStream_t st, const PhiTextArgs &A)
     hipLaunchKernelGGL(phi_text_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, A);
     hipLaunchKernelGGL(phi_text_scan_apply_kernel, dim3(scan_blocks), dim3(256), 0, st, A);
     hipLaunchKernelGGL(phi_text_finish_kernel, dim3(line_blocks), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(phi_text_uniform_kernel, dim3(std::min<uint32_t>(line_blocks, 1024)), dim3(256), 0, st, A);
     const uint32_t n_bytes = A.end - A.start;
     const uint32_t gather_blocks = (n_bytes + 4 * GATHER_WAVE_BYTES - 1) / (4 * GATHER_WAVE_BYTES);
     hipLaunchKernelGGL(phi_text_gather_kernel, dim3(gather_blocks), dim3(256), 0, st, A);

@@ -593,6 +593,35 @@ __device__ __forceinline__ void start_bits_from_offsets(const PhiSketchArgs &A, 
     }
 }
 
+// Reads of ONE length (short-read sets as sequencers write them): no offsets array at all -- read r starts at r * len.  The
+// starts inside a chunk's bitmap are the multiples of len in its base range: one division per lane (in double precision,
+// corrected), lane j sets the j-th of them.  ~25 instructions and no memory access instead of a probe of 64 offsets.
+__device__ __forceinline__ void start_bits_uniform(const PhiSketchArgs &A, int64_t c0, int lane, unsigned long long *s_bits)
+{
+    const int64_t org = c0 - 64, hi_b = org + 64 * SBW;
+    const int64_t from = org > 0 ? org : 0;
+    const uint32_t L = (uint32_t)A.uniform_len;
+    if (A.n_bases <= 0xFFFFFFFFll) {
+        // batches below 4 Gbases (all but whole-genome sets in one batch): the chunk's first base is the same for the whole
+        // wave, so the division runs on the SCALAR unit -- a multiply by floor(2^32 / L), one correction -- and a lane adds its
+        // multiple of L: no vector instruction but the last few
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)from);
+        uint32_t q = __umulhi(x, A.inv_len_q32);               // floor(x / L) or one less
+        uint32_t r = x - q * L;
+        if (r >= L) { q++; r -= L; }
+        const uint32_t first = x + (r ? L - r : 0u);             // the first multiple of L at or after x (may wrap past 2^32: then it is past the batch)
+        const uint64_t p = (uint64_t)first + (uint64_t)(uint32_t)lane * (uint64_t)L;
+        if (first >= x && (int64_t)p < hi_b && (int64_t)p < A.n_bases) set_start_bit(s_bits, (int64_t)p, org);
+        return;
+    }
+    int64_t q = (int64_t)((double)from * A.inv_len);
+    int64_t r = from - q * (int64_t)L;
+    if (r < 0) { q--; r += L; }
+    if (r >= (int64_t)L) { q++; r -= L; }
+    const int64_t p = (q + (r != 0) + lane) * (int64_t)L;       // the (lane)-th multiple of L at or after `from`
+    if (p < hi_b && p < A.n_bases) set_start_bit(s_bits, p, org);  // (64 lanes cover the range: L >= 32 > 1024 / 63)
+}
+
 // WIDE: w > Q (windows of one lane overlap in a common core); otherwise brute force per window.
 // KT/WT: compile-time k and w of the specialised instance (0 = take them from the arguments).
 template <int MODE, bool WIDE, int KT, int WT>
@@ -650,7 +679,7 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
             for (int j = 0; j < 16; j++)
                 if (b + j >= 0 && b + j < N) x[j >> 2] = (x[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((uint32_t)A.ascii[b + j] << (8 * (j & 3)));
         }
-        probe = start_probe_issue(A, c0, lane);           // the first probe of the read-start search travels with the bases
+        if (!A.uniform_len) probe = start_probe_issue(A, c0, lane);   // the first probe of the read-start search travels with the bases
         uint32_t code = 0, bad = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -696,7 +725,8 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     if (FUSED && KT < 0) {
         // k > 32 (an instantiation of its own: KT = -1): no 2-bit k-mers; every window of the chunk takes the exact byte-wise routine.  The
         // slots it fills are not logged: slow_windows raises the dirty flag, the next reset empties the whole set.
-        start_bits_from_offsets(A, c0, lane, probe, s_bits);
+        if (A.uniform_len) start_bits_uniform(A, c0, lane, s_bits);
+        else start_bits_from_offsets(A, c0, lane, probe, s_bits);
         wave_sync();
         int n_emit_slow = 0, n_new_lane = 0;
         slow_windows<MODE, true>(A, c0, chunk, lane, k, w, s_bits, s_bad, true, 0, n_emit_slow, n_new_lane);
@@ -845,7 +875,8 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
 #endif
     if (FUSED) {
         // the read starts inside this chunk's base range, from the read offsets (answer of the probe issued in phase 0)
-        start_bits_from_offsets(A, c0, lane, probe, s_bits);
+        if (A.uniform_len) start_bits_uniform(A, c0, lane, s_bits);
+        else start_bits_from_offsets(A, c0, lane, probe, s_bits);
         wave_sync();
     }
 #if PHI_ABL == 13

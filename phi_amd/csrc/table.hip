@@ -47,6 +47,15 @@ void phi_launch_fill_u64(hipStream_t st, uint64_t *p, int64_t n, uint64_t v)
 {
     if (n > 0) hipLaunchKernelGGL(phi_fill_u64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, n, v);
 }
+__global__ void phi_iota_i64_kernel(int64_t *p, int64_t n, int64_t step)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = i * step;
+}
+void phi_launch_iota_i64(hipStream_t st, int64_t *p, int64_t n, int64_t step)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_iota_i64_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, p, n, step);
+}
+
 void phi_launch_fill_u32(hipStream_t st, uint32_t *p, int64_t n, uint32_t v)
 {
     if (n > 0) hipLaunchKernelGGL(phi_fill_u32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, p, n, v);

@@ -240,3 +240,63 @@ def test_chunks_taken_in_turn_by_two_contexts(ctx_factory, oracle):
             assert pend == b"" or pend == carry
         got += kseq_records(carry)
         assert got == want, chunk
+
+
+def test_reads_of_one_length_without_offsets(ctx_factory, oracle):
+    """Reads of one length need no offsets array (phi_add_reads_device with d_read_off = NULL; phi_add_reads detects them;
+    the device-side record splitter hands them over that way): the kernel computes the read starts.  Same counters, hit
+    vector, spectrum and solve as the same reads with their offsets -- for lengths around the kernel's limits (32: the
+    shortest it takes, below: offsets are made), lengths that divide a chunk and lengths that do not, bases outside ACGT."""
+    import torch
+    from phi_amd import dist as pdist
+    from phi_amd import ilp_index as H
+    g = oracle.parse_gfa(os.path.join(DATA, "MHC_4.gfa.gz"))
+    A = g.arrays()
+    c = ctx_factory(k=31, w=25, threshold=1.0, recombination=100)
+    c.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
+    hap = np.frombuffer(bytes(A["seq_concat"][:3_000_000]), np.uint8).copy()
+    rng = np.random.default_rng(11)
+
+    def state():
+        st = c.reads_stats()
+        p, n = c.hits_buffer()
+        hits = torch.as_tensor(pdist.DevArray(p, n), device="cuda").cpu().numpy().copy()
+        p, m = c.spectrum_export()
+        sp = np.sort(torch.as_tensor(pdist.DevArray(p, m, "<i8"), device="cuda").clone().cpu().numpy().view(np.uint64)) if m else np.zeros(0, np.uint64)
+        return st, hits, sp
+
+    for L, n in ((150, 20_000), (32, 5_000), (33, 5_000), (31, 3_000), (64, 9_000), (512, 3_000), (1000, 2_000), (4099, 700), (55, 1)):
+        starts = rng.integers(0, len(hap) - L, size=n)
+        bases = hap[(starts[:, None] + np.arange(L)[None, :])].reshape(-1).copy()
+        bad = rng.integers(0, len(bases), size=max(1, len(bases) // 5000))
+        bases[bad] = ord("N")
+        low = rng.integers(0, len(bases), size=len(bases) // 50)
+        bases[low] |= 0x20
+        off = np.arange(n + 1, dtype=np.int64) * L
+        d_b, d_o = torch.from_numpy(bases).cuda(), torch.from_numpy(off).cuda()
+        c.reset_reads()
+        c.add_reads_device(d_b.data_ptr(), d_o.data_ptr(), n, n * L)
+        want = state()
+        c.reset_reads()
+        c.add_reads_device(d_b.data_ptr(), None, n, n * L)
+        got = state()
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (L, n)
+        c.reset_reads()
+        c.add_reads((bases, off))                              # the host path finds the one length by itself
+        got = state()
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (L, n, "host")
+        # as FASTQ text through the device-side splitter
+        text = b"".join(b"@r\n" + bases[i * L:(i + 1) * L].tobytes() + b"\n+\n" + b"I" * L + b"\n" for i in range(min(n, 4000)))
+        c.reset_reads()
+        c.add_reads((bases[:min(n, 4000) * L], off[:min(n, 4000) + 1]))
+        want_t = state()
+        c.reset_reads()
+        c.reads_text_begin(1 << 20)
+        for i in range(0, len(text), 1 << 20):
+            assert not c.add_reads_text(text[i:i + (1 << 20)])
+        pend, _ = c.reads_text_end()
+        assert pend == b""
+        got = state()
+        assert got[0] == want_t[0] and np.array_equal(got[1], want_t[1]) and np.array_equal(got[2], want_t[2]), (L, n, "text")
+    with pytest.raises(Exception):
+        c.add_reads_device(d_b.data_ptr(), None, 7, 100)        # 100 bases are not 7 reads of one length
