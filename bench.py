@@ -356,14 +356,15 @@ def main():
 
     # clock ramp: a fresh box runs its first launches at idle clocks (a third slower for the first tens
     # of milliseconds); untimed, before the W warmup steps (no collective inside: ranks need not agree on its length)
+    primary_step = weak_step if args.scaling == "weak" else strong["step"]
+    ramp_off = d_off.data_ptr() if weak_step.uses_offsets else None
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.25:
         for _ in range(50 if n_bases < 5e7 else 1):
             ctx.reset_reads()
-            ctx.add_reads_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases)
+            ctx.add_reads_device(d_bases.data_ptr(), ramp_off, n_reads, n_bases)
         torch.cuda.synchronize()
 
-    primary_step = weak_step if args.scaling == "weak" else strong["step"]
     for _ in range(args.warmup):
         primary_step()
     elapsed = timed(primary_step, args.steps, 0)
@@ -402,7 +403,7 @@ def main():
                               "the all-reduce figure includes waiting for the slowest rank's sketch"}
     # the same read set handed over WITH its offsets array (reads of uneven lengths always are): the general path, beside `value`
     value_with_offsets = None
-    if args.scaling == "weak" and not primary_step.uses_offsets:
+    if args.scaling == "weak" and not primary_step.uses_offsets and not args.no_extra_legs:
         gstep = make_step(d_bases, d_off, n_reads, n_bases, with_offsets=True)
         g_steps = max(10, args.steps)
         el_g = timed(gstep, g_steps, max(2, args.warmup))

@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
     __shared__ uint4 s_ev[D][3][64];
     __shared__ int4 s_res[D][64];                   // (best score, run start, entry) of consumed events
     __shared__ int32_t s_qs[QD][64], s_qE[QD][64], s_qK[QD][64];
-    __shared__ int32_t s_vi[64];
+    __shared__ int32_t s_vi[2][64];              // the consumer's position at each barrier, double-buffered: written for period p + 1 while the producers still read period p's
 
     const int wave = threadIdx.x >> 6, h = threadIdx.x & 63;
     // the block of steps of this workgroup, and (DP_ROW) the lane the unit vector sits on.  DP_ROW may run on CLASS
@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
         int32_t vprev = vb;                          // consumer position one barrier ago
         __syncthreads();                             // B_0
         for (int p = 0;; p++) {
-            const int32_t vi = has_walk ? s_vi[h] : 0;
+            const int32_t vi = has_walk ? s_vi[p & 1][h] : 0;
             if (MODE != DP_ROW) {
                 // 1. results of the events consumed during the previous period
 #pragma unroll
@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
 
     // ==================================================================== the consumer
     int32_t vi = vb;                                 // next event
-    s_vi[h] = vi;
+    s_vi[0][h] = vi;
     __syncthreads();                                 // B_0
     uint4 cA = make_uint4(0xFFFFFFFFu, 0, 0, 0);     // the next event of this lane, in registers
     if (vi < ve) cA = s_ev[vi & (D - 1)][0][h];
@@ -941,7 +941,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             if (pair) { ra = n2a; rb = n2b; r += 2; }
             else { ra = na; rb = nb; r += 1; }
         }
-        s_vi[h] = vi;
+        s_vi[(p + 1) & 1][h] = vi;
         __syncthreads();                             // B_{p+1}
     }
     if (MODE != DP_SEQ) {

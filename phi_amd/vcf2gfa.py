@@ -42,9 +42,15 @@ def read_fasta_single(path):
     return name, b"".join(chunks)
 
 
-def read_vcf(path, ref_len):
-    """-> (sample names, records); record = (start0, end0, [alt bytes...], [(a1, a2) per sample]) sorted by start."""
-    samples, recs = [], []
+def read_vcf(path, ref_seq, contig=None, warn=None):
+    """-> (sample names, records, ploidy per sample); record = (start0, end0, [alt bytes...], [(a1, a2) per sample])
+    sorted by start.  Records of another contig than the first one seen (or `contig`), and records whose REF column is
+    not what the FASTA holds at POS, are skipped with a warning: a VCF of another assembly must not be applied silently.
+    ploidy[s] = the largest number of GT alleles any record gives sample s (1 for haploid calls: no second walk then)."""
+    warn = warn or (lambda msg: sys.stderr.write("[W::vcf2gfa] " + msg + "\n"))
+    ref_len = len(ref_seq)
+    samples, recs, ploidy = [], [], []
+    n_other, n_mismatch = 0, 0
     with _open(path) as f:
         for line in f:
             if line.startswith(b"##"):
@@ -52,30 +58,51 @@ def read_vcf(path, ref_len):
             cols = line.rstrip(b"\r\n").split(b"\t")
             if line.startswith(b"#CHROM"):
                 samples = [c.decode() for c in cols[9:]]
+                ploidy = [0] * len(samples)
                 continue
             if len(cols) < 10:
+                continue
+            if contig is None:
+                contig = cols[0]
+            if cols[0] != contig:
+                n_other += 1
                 continue
             pos, ref, alts = int(cols[1]) - 1, cols[3].upper(), [a.upper() for a in cols[4].split(b",")]
             fmt = cols[8].split(b":")
             if b"GT" not in fmt or pos < 0 or pos + len(ref) > ref_len:
+                continue
+            if ref_seq[pos:pos + len(ref)] != ref:
+                n_mismatch += 1
                 continue
             gi = fmt.index(b"GT")
             ok = [a for a in alts if a and not a.startswith(b"<") and a != b"*" and b"[" not in a and b"]" not in a]
             if len(ok) != len(alts):                           # symbolic / breakend / spanning-deletion alleles: not a sequence
                 continue
             gts = []
-            for c in cols[9:9 + len(samples)]:
+            for si, c in enumerate(cols[9:9 + len(samples)]):
                 g = c.split(b":")[gi].replace(b"/", b"|").split(b"|")
+                ploidy[si] = max(ploidy[si], min(2, sum(1 for x in g if x != b".")))
                 g = [int(x) if x.isdigit() else 0 for x in g] + [0, 0]
                 gts.append((g[0], g[1]))
             recs.append((pos, pos + len(ref), alts, gts))
+    if n_other:
+        warn(f"{n_other} record(s) of other contigs than {contig.decode()} skipped (vcf2gfa handles one contig)")
+    if n_mismatch:
+        warn(f"{n_mismatch} record(s) skipped: their REF column is not what the FASTA holds at POS (another assembly?)")
     recs.sort(key=lambda r: (r[0], r[1]))
-    return samples, recs
+    return samples, recs, ploidy
 
 
-def build(ref_seq, samples, recs):
-    """-> (segments [bytes], links set[(a, b)], walks [(sample, hap, [segment ids])]); ids are 0-based here."""
+class InputError(ValueError):
+    """An input the construction cannot turn into a graph PHI accepts (the command line reports it, without a traceback)."""
+
+
+def build(ref_seq, samples, recs, ploidy=None):
+    """-> (segments [bytes], links set[(a, b)], walks [(sample, hap, [segment ids])]); ids are 0-based here.  A walk is made
+    for every GT column a sample actually has (ploidy: 2 unless given): a haploid call gives one walk, not a second one that
+    would merely repeat the reference."""
     n_hap = 1 + 2 * len(samples)                               # haplotype 0 = reference, then (sample, GT column)
+    ploidy = ploidy if ploidy is not None else [2] * len(samples)
     # sites: maximal runs of records that overlap or touch
     sites, cur = [], None
     for r in recs:
@@ -124,16 +151,19 @@ def build(ref_seq, samples, recs):
         if len(spelled) == 1:
             continue                                           # nobody differs here: stays backbone
         if s <= pos and pos == 0:
-            raise ValueError("a variant at the first base of the contig leaves the graph without a single source")
+            raise InputError("a variant at the first base of the contig would leave the graph without a single source vertex "
+                             "(PHI's walks must start at one): trim the record or pad the reference by a base")
         add_unit(ref_seq[pos:s], all_haps)                     # backbone up to the site (>= 1 base: sites do not touch)
         for seq in sorted(spelled, key=lambda q: (q != ref_seq[s:e], q)):     # reference allele first: ids in a stable order
             add_unit(seq, spelled[seq])
         pos = e
     if pos >= len(ref_seq):
-        raise ValueError("a variant at the last base of the contig leaves the graph without a single sink")
+        raise InputError("a variant at the last base of the contig would leave the graph without a single sink vertex: "
+                         "trim the record or pad the reference by a base")
     add_unit(ref_seq[pos:], all_haps)
     names = [("REF", 0)] + [(smp, col + 1) for smp in samples for col in range(2)]
-    return segs, links, [(names[h][0], names[h][1], walks[h]) for h in all_haps]
+    keep = [0] + [1 + 2 * si + col for si in range(len(samples)) for col in range(2) if col < max(1, ploidy[si])]
+    return segs, links, [(names[h][0], names[h][1], walks[h]) for h in keep]
 
 
 def write_gfa(out, contig, segs, links, walks):
@@ -152,12 +182,17 @@ def main(argv=None):
     ap.add_argument("-v", "--vcf", required=True, help="Input VCF file (can be gzipped).")
     ap.add_argument("-r", "--ref", required=True, help="Input reference FASTA/FA file (can be gzipped).")
     args = ap.parse_args(argv)
-    _, ref_seq = read_fasta_single(args.ref)
-    ref_seq = ref_seq.upper()
-    samples, recs = read_vcf(args.vcf, len(ref_seq))
-    segs, links, walks = build(ref_seq, samples, recs)
+    try:
+        _, ref_seq = read_fasta_single(args.ref)
+        ref_seq = ref_seq.upper()
+        samples, recs, ploidy = read_vcf(args.vcf, ref_seq)
+        segs, links, walks = build(ref_seq, samples, recs, ploidy)
+    except (InputError, ValueError, OSError) as e:
+        sys.stderr.write(f"[E::vcf2gfa] {e}\n")
+        return 1
     write_gfa(sys.stdout.buffer, "REF#0", segs, links, walks)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -103,8 +103,9 @@ def test_vcf_route_on_overlapping_multiallelic_and_conflicting_records(built, tm
         fa = tmp_path / f"c{case}.fa"
         fa.write_bytes(b">chr\n" + b"\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + b"\n")
         _, ref_seq = vcf2gfa.read_fasta_single(str(fa))
-        samples, parsed = vcf2gfa.read_vcf(str(vcf), len(ref_seq))
-        segs, links, walks = vcf2gfa.build(ref_seq, samples, parsed)
+        samples, parsed, ploidy = vcf2gfa.read_vcf(str(vcf), ref_seq)
+        assert ploidy == [2] * n_s
+        segs, links, walks = vcf2gfa.build(ref_seq, samples, parsed, ploidy)
         srecs = sorted(recs, key=lambda x: (x[0], x[0] + len(x[1])))
         want = [ref] + [_consensus(ref, srecs, s, c) for s in range(n_s) for c in range(2)]
         got = [b"".join(segs[i] for i in ids) for _, _, ids in walks]
@@ -119,6 +120,39 @@ def test_vcf_route_on_overlapping_multiallelic_and_conflicting_records(built, tm
         p.write_bytes(buf.getvalue())
         _, w = _walk_seqs(str(p))
         assert list(w.values()) == want
+
+
+def test_vcf_route_refuses_or_skips_what_it_cannot_apply(built, tmp_path, capsys):
+    """Records of another contig, and records whose REF is not what the FASTA holds, are skipped with a warning (a VCF of
+    another assembly is not applied silently); a haploid GT column gives ONE walk for that sample; a variant at the first
+    or last base of the contig is a clear error of the command line, not a traceback."""
+    from phi_amd import vcf2gfa
+    ref = b"ACGTTGCAAGGCTTAACCGGATCGATCGGCTAAGCTTAGGCTA" * 3
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(b">chr\n" + ref + b"\n")
+    hdr = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tD\tH\n"
+    vcf = tmp_path / "v.vcf"
+    vcf.write_bytes(hdr + b"chr\t11\t.\t" + ref[10:11] + b"\tT\t60\t.\t.\tGT\t0|1\t1\n"        # D diploid, H haploid
+                    b"other\t20\t.\tA\tC\t60\t.\t.\tGT\t1|1\t1\n"                               # another contig
+                    b"chr\t31\t.\tN\tC\t60\t.\t.\tGT\t1|1\t1\n")                                # REF is not what the FASTA holds
+    _, ref_seq = vcf2gfa.read_fasta_single(str(fa))
+    msgs = []
+    samples, recs, ploidy = vcf2gfa.read_vcf(str(vcf), ref_seq, warn=msgs.append)
+    assert len(recs) == 1 and ploidy == [2, 1]
+    assert any("other contigs" in m for m in msgs) and any("REF column" in m for m in msgs)
+    segs, links, walks = vcf2gfa.build(ref_seq, samples, recs, ploidy)
+    assert [(s_, h) for s_, h, _ in walks] == [("REF", 0), ("D", 1), ("D", 2), ("H", 1)]
+    alt = ref[:10] + b"T" + ref[11:]
+    assert [b"".join(segs[i] for i in ids) for _, _, ids in walks] == [ref, ref, alt, alt]
+    # a variant at the very first base: the command line says what is wrong and returns 1
+    first = tmp_path / "first.vcf"
+    first.write_bytes(hdr + b"chr\t1\t.\t" + ref[0:1] + b"\tT\t60\t.\t.\tGT\t0|1\t1\n")
+    assert vcf2gfa.main(["-v", str(first), "-r", str(fa)]) == 1
+    assert "first base of the contig" in capsys.readouterr().err
+    last = tmp_path / "last.vcf"
+    last.write_bytes(hdr + b"chr\t%d\t.\t" % len(ref) + ref[-1:] + b"\tG\t60\t.\t.\tGT\t0|1\t1\n")
+    assert vcf2gfa.main(["-v", str(last), "-r", str(fa)]) == 1
+    assert "last base of the contig" in capsys.readouterr().err
 
 
 def test_eval_log_scrapes_what_the_harness_scrapes():
