@@ -169,8 +169,10 @@ struct ByteSrc {
             begin = end;
         }
     }
-    // the same for a string whose bytes are not kept: len / last byte stand for it
-    long line_len(size_t &len, int &last)
+    // the same for a string whose bytes are not kept (the quality): its length and the number of carriage returns it
+    // ends with stand for it -- kseq strips ONE trailing CR from the ACCUMULATED string after every line it appends
+    // (kseq.h:146), so "..~\r\r" followed by an empty line loses both
+    long line_len(size_t &len, size_t &trail_cr)
     {
         if (kseq_eof()) return -1;
         for (;;) {
@@ -178,11 +180,16 @@ struct ByteSrc {
             const char *p = buf.data() + begin;
             const char *nl = (const char *)memchr(p, '\n', end - begin);
             const size_t n = nl ? (size_t)(nl - p) : end - begin;
-            if (n) { len += n; last = (unsigned char)p[n - 1]; }
+            if (n) {
+                size_t t = 0;
+                while (t < n && p[n - 1 - t] == '\r') t++;
+                trail_cr = t == n ? trail_cr + n : t;
+                len += n;
+            }
             begin += n + (nl ? 1 : 0);
             if (nl) break;
         }
-        if (len > 1 && last == '\r') { len--; last = 0; }
+        if (len > 1 && trail_cr > 0) { len--; trail_cr--; }
         return (long)len;
     }
     // the bytes up to the next white space (ks_getuntil with KS_SEP_SPACE); *dret = the delimiter
@@ -240,9 +247,8 @@ long kseq_next(ByteSrc &ks, KseqState &st)
     if (c == '>' || c == '@') st.last_char = c;
     if (c != '+') return (long)st.seq.size();         // FASTA
     if (!ks.skip_line()) return -2;                   // the rest of the '+' line
-    size_t ql = 0;
-    int qlast = 0;
-    while (ks.line_len(ql, qlast) >= 0 && ql < st.seq.size()) {}
+    size_t ql = 0, q_cr = 0;
+    while (ks.line_len(ql, q_cr) >= 0 && ql < st.seq.size()) {}
     st.last_char = 0;
     if (ql != st.seq.size()) return -2;
     return (long)st.seq.size();

@@ -68,6 +68,10 @@ def main():
         b"junk @x >y\n>a\nAC GT\tA\n>b\n\r\nAC\n",           # header bytes inside a line, white space kept, a CR-only line
         b">a\nACGT", b"@a\nACGT\n+", b"@a\nACGT\n+\n", b">\nAC\n> x\nGG\n", b"", b"\n\n", b">a\n>b\n>c\nA\n",
         b">a\nAC\n+\nII\n>b\nGG\n", b"@a\nAC\r\n+\r\nI\r\n",
+        # kseq strips ONE trailing CR from the accumulated string after every line: two CRs and an empty line lose both (found by
+        # fuzz_reads_reader at seed 9507: the host reader's quality length kept one)
+        b"@a\nACGTA\n+\nIIIII\r\r\n\n@b\nAC\n+\nII\n", b"@a\nACGTA\n+\nIII\r\r\nII\n@b\nAC\n+\nII\n", b"@a\nACG\n+\n\r\r\r\n\r\nI\n@b\nA\n+\nI\n",
+        b">a\nAC\r\r\n\r\n\nGT\n>b\n\r\r\nA\n",
     ]
     rnd2 = random.Random(7)
     for _ in range(40):                                            # random mixtures of the same ingredients
