@@ -4,7 +4,10 @@
  * These are the steps on either side of the GPU path (SURVEY.md section 8f "next"):
  *   phi_gfa_read     gfa_read() + ILP_index::read_gfa()   src/gfa-io.cpp:462-508, src/ILP_index.cpp:20-155
  *   phi_reads_read   ILP_index::read_ip_reads()           src/ILP_index.cpp:313-328 (kseq FASTA/FASTQ, gz)
- *   phi_reads_stream_*  the same records in chunks, for files larger than one buffer
+ *   phi_reads_stream_*  the same records in chunks, for files larger than one buffer; phi_reads_stream_open_blocks: over text
+ *                       in memory + blocks a callback hands over (the rest of a stream whose beginning the device has taken)
+ *   phi_text_stream_*   the (inflated) text of a reads file as it is, for phi_add_reads_text (phi_amd.h): the records are
+ *                       found on the device, no host core parses a regular FASTA / FASTQ file
  *   phi_hap_name     get_hap_name()                       src/misc.cpp:58-87
  *   phi_write_fasta  the FASTA writer                     src/ILP_index.cpp:1590-1598
  * The arrays phi_gfa_read returns are exactly the arguments of phi_set_graph (phi_amd.h).

@@ -21,9 +21,10 @@
 //     reader is the output arrays only.  A gzip file is inflated first (gz_source.h: on many threads when it
 //     is block gzip) and then parsed the same way;
 //   * lines are found and split into fields by all host threads over slices of the text cut at line ends;
-//   * segment ids are first-seen order, so names are entered by ONE thread, over the S/L records the slices
-//     found -- into a table that maps names of the form <prefix><decimal number> (the names of every chopped
-//     pangenome graph: "17", "s17") by direct indexing and any other name by open addressing;
+//   * segment ids are first-seen order over S- and L-lines: ONE thread enters the names of the S-lines -- into a
+//     table that maps names of the form <prefix><decimal number> (the names of every chopped pangenome graph:
+//     "17", "s17") by direct indexing and any other name by open addressing --, then all threads resolve the
+//     L-lines against it, checking that each name's S-line stands before the line (else: one thread, in order);
 //   * the walks are resolved by all threads over PIECES of the W-lines (a 170-Mbp walk is one line of 60 MB):
 //     a counting pass fixes where every piece writes, the second pass looks the names up and writes the
 //     vertices straight into the final array.
@@ -351,45 +352,94 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
     parallel_for(n_slices, [&](int64_t i) { scan_slice(cut[(size_t)i], cut[(size_t)i + 1], so[(size_t)i]); });
     tm.lap("lines + fields (threads)");
 
-    // ---- segment ids in first-seen order: one thread, over the records in file order
+    // ---- segment ids in first-seen order over S- and L-lines.  In every graph a tool writes, an L-line names segments whose
+    //      S-lines stand before it, so the ids are the order of the S-lines: one thread enters the S-line names (and fixes what
+    //      each W-line may name), then all threads resolve the L-lines against the finished table, checking for each name that
+    //      its S-line does come first.  A file where that does not hold (an L-line that introduces a segment) is done again
+    //      by one thread, record by record.
     NameTable table;
     std::vector<Slice> seqs;                                         // per segment; n = 0: no sequence
     std::vector<std::pair<uint32_t, uint32_t>> arcs;                 // oriented vertices v = seg<<1 | strand
-    {
-        size_t n_rec = 0;
-        for (const SliceOut &s : so) n_rec += s.recs.size();
-        seqs.reserve(n_rec);
-        arcs.reserve(n_rec);
-    }
+    std::vector<WRec *> walks;
+    size_t n_rec = 0;
+    std::vector<size_t> rec_base((size_t)n_slices + 1, 0);
+    for (int i = 0; i < n_slices; i++) { n_rec += so[(size_t)i].recs.size(); rec_base[(size_t)i + 1] = n_rec; }
     auto add_seg = [&](const char *p, uint32_t n) {
         const int32_t id = table.add(p, n);
         if ((size_t)id == seqs.size()) seqs.push_back(Slice{nullptr, 0});
         return id;
     };
-    std::vector<WRec *> walks;
-    for (SliceOut &s : so) {
-        size_t wi = 0;
-        for (size_t i = 0; i <= s.recs.size(); i++) {
-            while (wi < s.walks.size() && s.walks[wi].before == i) {
-                s.walks[wi].n_known = table.size();                  // names are resolved against the segments seen so far
-                walks.push_back(&s.walks[wi++]);
-            }
-            if (i == s.recs.size()) break;
-            const Rec &r = s.recs[i];
-            if (r.type == 'S') {
-                const int32_t id = add_seg(r.a, r.an);
-                seqs[(size_t)id] = Slice{r.b, r.bn};                  // a later S-line of the same name replaces the sequence
-            } else {
-                const uint32_t v = (uint32_t)add_seg(r.a, r.an) << 1 | (r.ov != '+');
-                const uint32_t w = (uint32_t)add_seg(r.b, r.bn) << 1 | (r.ow != '+');
-                arcs.emplace_back(v, w);
+    auto one_thread = [&]() {
+        table = NameTable();
+        seqs.clear(); arcs.clear(); walks.clear();
+        seqs.reserve(n_rec); arcs.reserve(n_rec);
+        for (SliceOut &s : so) {
+            size_t wi = 0;
+            for (size_t i = 0; i <= s.recs.size(); i++) {
+                while (wi < s.walks.size() && s.walks[wi].before == i) {
+                    s.walks[wi].n_known = table.size();              // names are resolved against the segments seen so far
+                    walks.push_back(&s.walks[wi++]);
+                }
+                if (i == s.recs.size()) break;
+                const Rec &r = s.recs[i];
+                if (r.type == 'S') {
+                    const int32_t id = add_seg(r.a, r.an);
+                    seqs[(size_t)id] = Slice{r.b, r.bn};              // a later S-line of the same name replaces the sequence
+                } else {
+                    const uint32_t v = (uint32_t)add_seg(r.a, r.an) << 1 | (r.ov != '+');
+                    const uint32_t w = (uint32_t)add_seg(r.b, r.bn) << 1 | (r.ow != '+');
+                    arcs.emplace_back(v, w);
+                }
             }
         }
-        std::vector<Rec>().swap(s.recs);
+    };
+    {
+        // S-lines and W-lines, in file order
+        std::vector<size_t> first_rec;                               // per segment: the record that introduced it
+        seqs.reserve(n_rec);
+        for (int si = 0; si < n_slices; si++) {
+            SliceOut &s = so[(size_t)si];
+            size_t wi = 0;
+            for (size_t i = 0; i <= s.recs.size(); i++) {
+                while (wi < s.walks.size() && s.walks[wi].before == i) {
+                    s.walks[wi].n_known = table.size();
+                    walks.push_back(&s.walks[wi++]);
+                }
+                if (i == s.recs.size()) break;
+                const Rec &r = s.recs[i];
+                if (r.type != 'S') continue;
+                const int32_t id = add_seg(r.a, r.an);
+                if ((size_t)id == first_rec.size()) first_rec.push_back(rec_base[(size_t)si] + i);
+                seqs[(size_t)id] = Slice{r.b, r.bn};
+            }
+        }
+        // L-lines, all threads: both names known, and known BEFORE the line
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> part((size_t)n_slices);
+        std::atomic<int> hazard{0};
+        parallel_for(n_slices, [&](int64_t si) {
+            const SliceOut &s = so[(size_t)si];
+            auto &out = part[(size_t)si];
+            for (size_t i = 0; i < s.recs.size(); i++) {
+                const Rec &r = s.recs[i];
+                if (r.type != 'L') continue;
+                const int32_t a = table.find(r.a, r.an), b2 = table.find(r.b, r.bn);
+                const size_t at = rec_base[(size_t)si] + i;
+                if (a < 0 || b2 < 0 || first_rec[(size_t)a] > at || first_rec[(size_t)b2] > at) { hazard.store(1); return; }
+                out.emplace_back((uint32_t)a << 1 | (r.ov != '+'), (uint32_t)b2 << 1 | (r.ow != '+'));
+            }
+        });
+        if (hazard.load()) one_thread();
+        else {
+            size_t n_arc = 0;
+            for (auto &p : part) n_arc += p.size();
+            arcs.reserve(n_arc);
+            for (auto &p : part) arcs.insert(arcs.end(), p.begin(), p.end());
+        }
     }
+    for (SliceOut &s : so) std::vector<Rec>().swap(s.recs);
     const int32_t n_seg = table.size();
     const int64_t n_walks = (int64_t)walks.size();
-    tm.lap("segment ids (one thread)");
+    tm.lap("segment ids, links");
 
     // ---- the walks' vertices: pieces of the W-lines, cut at steps, on all threads
     std::vector<Piece> pieces;

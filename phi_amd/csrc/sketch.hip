@@ -686,7 +686,8 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
             const uint32_t t = ((x[q] >> 1) ^ (x[q] >> 2)) & 0x03030303u;      // 2-bit code of each byte
             const uint32_t c8 = (t * 0x40100401u) >> 24;                        // the four codes, first base on top
             code = (code << 8) | c8;
-            if (phi_ascii4(c8) != (x[q] & 0xDFDFDFDFu)) {                       // a byte outside ACGTacgt (rare)
+            // spelled back from the per-byte codes (one byte lookup: no gather needed) against the upper-cased bytes
+            if (__builtin_amdgcn_perm(0x54474341u, 0x54474341u, t) != (x[q] & 0xDFDFDFDFu)) {   // a byte outside ACGTacgt (rare)
 #pragma unroll
                 for (int j = 0; j < 4; j++) bad |= (uint32_t)(!phi_is_acgt((x[q] >> (8 * j)) & 0xFFu)) << (4 * q + j);
             }
