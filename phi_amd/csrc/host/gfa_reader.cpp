@@ -167,6 +167,10 @@ class NameTable {
 public:
     NameTable() { grow(1 << 12); }
     int32_t size() const { return (int32_t)keys_.size(); }
+    // every name is a plain decimal number in the direct index: the W-line parser then reads the digits and looks the
+    // number up in one pass over the text
+    bool all_direct() const { return n_hashed_ == 0 && prefix_n_ == 0 && !keys_.empty(); }
+    int32_t by_number(uint64_t num) const { return num < direct_.size() ? direct_[(size_t)num] : -1; }
     const std::vector<Slice> &keys() const { return keys_; }
 
     int32_t find(const char *p, size_t n) const
@@ -486,10 +490,17 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
         uint32_t *dst = wv + pc.out;
         const char *q = pc.lo;
         while (q < pc.hi && !is_step(*q)) q++;                       // (bytes before the first step of a walk)
+        const bool numeric = table.all_direct();
         while (q < pc.hi) {
             const char *nm = q + 1, *r = nm;
-            while (r < e && !is_step(*r)) r++;
-            const int32_t id = table.find(nm, (size_t)(r - nm));
+            int32_t id;
+            uint64_t num = 0;
+            if (numeric) while (r < e && (unsigned)(*r - '0') <= 9u && r - nm < 10) num = num * 10 + (unsigned)(*r++ - '0');
+            if (numeric && r > nm && (r == e || is_step(*r)) && (nm[0] != '0' || r - nm == 1)) id = table.by_number(num);
+            else {
+                while (r < e && !is_step(*r)) r++;
+                id = table.find(nm, (size_t)(r - nm));
+            }
             if (id >= 0 && id < n_known) { *dst++ = (uint32_t)id << 1 | (*q == '<'); pc.any_rev |= *q == '<'; }
             else { *dst++ = DROP; pc.dropped++; }
             q = r;

@@ -24,8 +24,14 @@ COMP = {"+": "-", "-": "+"}
 def write_random_gfa(rng, g, path, complemented):
     n = len(g.node_seq)
     names = [f"s{i + 1}" for i in range(n)]
-    if rng.random() < 0.5:
+    u = rng.random()
+    if u < 0.4:
         names = [f"{rng.choice(['utg', 'n', 'x'])}{int(x)}" for x in rng.permutation(10 * n)[:n]]
+    elif u < 0.7:                                   # plain numbers (the names of chopped pangenome graphs): the reader's one-pass numeric path
+        names = [str(int(x)) for x in rng.permutation(10 * n)[:n]]
+        if rng.random() < 0.2:                      # ... some with a leading zero, or too long to be an index: the general path beside it
+            k_ = int(rng.integers(0, n))
+            names[k_] = ("0" + names[k_]) if rng.random() < 0.5 else "12345678901234"
     lines = []
     seg = [f"S\t{names[v]}\t{g.node_seq[v].decode()}" + ("\tLN:i:%d" % len(g.node_seq[v]) if rng.random() < 0.3 else "") for v in range(n)]
     lnk = []
