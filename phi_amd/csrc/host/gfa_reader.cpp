@@ -445,6 +445,78 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
     const int64_t n_walks = (int64_t)walks.size();
     tm.lap("segment ids, links");
 
+    // ---- nothing of the walks is needed for the sequences, the names, the adjacency and the topological order: one thread
+    //      makes them while the others resolve the W-lines (99 % of a pangenome GFA's bytes)
+    phi_graph *g = new phi_graph();
+    int side_rc = 0;                                               // 1: out of memory, 2: cycle
+    int32_t side_sorted = 0;
+    bool side_joined = false;
+    std::thread side([&]() {
+            g->n_seg = n_seg;
+        const std::vector<Slice> &names = table.keys();
+        g->name_off.assign((size_t)n_seg + 1, 0);
+        for (int32_t i = 0; i < n_seg; i++) g->name_off[(size_t)i + 1] = g->name_off[(size_t)i] + (int64_t)names[(size_t)i].n + 1;
+        g->name_arena.resize((size_t)g->name_off[(size_t)n_seg]);
+        g->seq_off.assign((size_t)n_seg + 1, 0);
+        for (int32_t i = 0; i < n_seg; i++) g->seq_off[(size_t)i + 1] = g->seq_off[(size_t)i] + (int64_t)seqs[(size_t)i].n;
+        g->seq_concat = (char *)malloc(std::max<size_t>(1, (size_t)g->seq_off[(size_t)n_seg]));
+        if (!g->seq_concat) { side_rc = 1; return; }
+        for (int64_t i = 0; i < n_seg; i++) {                          // (one thread: the others are on the W-lines)
+            if (seqs[(size_t)i].n) memcpy(g->seq_concat + g->seq_off[(size_t)i], seqs[(size_t)i].p, seqs[(size_t)i].n);
+            char *d = g->name_arena.data() + g->name_off[(size_t)i];
+            memcpy(d, names[(size_t)i].p, names[(size_t)i].n);
+            d[names[(size_t)i].n] = '\0';
+        }
+        for (int64_t w = 0; w < n_walks; w++)
+            g->hap_names.push_back(std::string(walks[(size_t)w]->sample.p, walks[(size_t)w]->sample.n) + "." + std::to_string(walks[(size_t)w]->hap));
+        // arcs: those touching a segment without sequence are dropped; an arc v -> w and its complement w' -> v' give the
+        // forward-strand adjacency (target orientation dropped): u -> w when v = u+, and w -> v when w is a reverse strand
+        {
+            std::vector<int64_t> cnt((size_t)n_seg + 1, 0);
+            auto each = [&](auto fn) {
+                for (const auto &a : arcs) {
+                    const uint32_t v = a.first, w = a.second;
+                    if (seqs[v >> 1].n == 0 || seqs[w >> 1].n == 0) continue;
+                    if (!(v & 1)) fn(v >> 1, w >> 1);
+                    if (w & 1) fn(w >> 1, v >> 1);
+                }
+            };
+            each([&](uint32_t u, uint32_t) { cnt[(size_t)u + 1]++; });
+            for (int32_t i = 0; i < n_seg; i++) cnt[(size_t)i + 1] += cnt[(size_t)i];
+            std::vector<int32_t> tgt((size_t)cnt[(size_t)n_seg]);
+            std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+            each([&](uint32_t u, uint32_t x) { tgt[(size_t)cur[u]++] = (int32_t)x; });
+            // duplicate links, and oriented targets that collapse onto one segment, are merged
+            g->adj_off.assign((size_t)n_seg + 1, 0);
+            int64_t o = 0;
+            for (int32_t u = 0; u < n_seg; u++) {
+                int32_t *b = tgt.data() + cnt[(size_t)u], *e = tgt.data() + cnt[(size_t)u + 1];
+                if (e - b > 1) { std::sort(b, e); e = std::unique(b, e); }
+                g->adj_off[(size_t)u] = o;
+                for (; b < e; b++) tgt[(size_t)o++] = *b;             // (o never passes the read position)
+            }
+            g->adj_off[(size_t)n_seg] = o;
+            tgt.resize((size_t)o);
+            g->adj.swap(tgt);
+        }
+        // Kahn's algorithm, FIFO
+        {
+            std::vector<int32_t> indeg((size_t)n_seg, 0), q((size_t)n_seg);
+            for (int32_t v : g->adj) indeg[(size_t)v]++;
+            int32_t head = 0, tail = 0;
+            for (int32_t i = 0; i < n_seg; i++) if (indeg[(size_t)i] == 0) q[(size_t)tail++] = i;
+            g->topo_rank.assign((size_t)n_seg, 0);
+            while (head < tail) {
+                const int32_t u = q[(size_t)head];
+                g->topo_rank[(size_t)u] = head++;
+                for (int64_t x = g->adj_off[(size_t)u]; x < g->adj_off[(size_t)u + 1]; x++)
+                    if (--indeg[(size_t)g->adj[(size_t)x]] == 0) q[(size_t)tail++] = g->adj[(size_t)x];
+            }
+            if (head != n_seg) { side_rc = 2; side_sorted = head; return; }
+        }
+    });
+    struct Joiner { std::thread &t; bool &done; ~Joiner() { if (!done && t.joinable()) t.join(); } } joiner{side, side_joined};
+
     // ---- the walks' vertices: pieces of the W-lines, cut at steps, on all threads
     std::vector<Piece> pieces;
     {
@@ -467,7 +539,6 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
         for (const char *q = pc.lo; q < pc.hi; q++) n += is_step(*q);
         pc.n = n;
     });
-    phi_graph *g = new phi_graph();
     g->walk_off.assign((size_t)n_walks + 1, 0);
     {
         int64_t o = 0;
@@ -480,7 +551,7 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
     }
     const int64_t n_entries = g->walk_off[(size_t)n_walks];
     uint32_t *wv = (uint32_t *)malloc(std::max<size_t>(1, (size_t)n_entries) * 4);
-    if (!wv) { delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory for %lld walk entries", (long long)n_entries); }
+    if (!wv) { side.join(); side_joined = true; delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory for %lld walk entries", (long long)n_entries); }
     g->walk_vtx = (int32_t *)wv;
     const uint32_t DROP = 0xFFFFFFFFu;
     parallel_for((int64_t)pieces.size(), [&](int64_t i) {
@@ -556,86 +627,23 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
             const int64_t w = (int64_t)(std::upper_bound(g->walk_off.begin(), g->walk_off.end(), x) - g->walk_off.begin()) - 1;
             // (entries before x in other chunks may already be converted; x itself is not)
             const int code = fail(err, err_cap, PHI_HOST_ERR_WALK, "Error: Walk %d has reverse strand vertices %u", (int)w, wv[x]);
+            side.join(); side_joined = true;
             delete g;
             return code;
         }
     }
     tm.lap("walk flips, vertex ids");
 
-    // ---- arrays
-    g->n_seg = n_seg;
-    const std::vector<Slice> &names = table.keys();
-    g->name_off.assign((size_t)n_seg + 1, 0);
-    for (int32_t i = 0; i < n_seg; i++) g->name_off[(size_t)i + 1] = g->name_off[(size_t)i] + (int64_t)names[(size_t)i].n + 1;
-    g->name_arena.resize((size_t)g->name_off[(size_t)n_seg]);
-    g->seq_off.assign((size_t)n_seg + 1, 0);
-    for (int32_t i = 0; i < n_seg; i++) g->seq_off[(size_t)i + 1] = g->seq_off[(size_t)i] + (int64_t)seqs[(size_t)i].n;
-    g->seq_concat = (char *)malloc(std::max<size_t>(1, (size_t)g->seq_off[(size_t)n_seg]));
-    if (!g->seq_concat) { delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory"); }
-    {
-        const int64_t CH = 1 << 16, n_ch = ((int64_t)n_seg + CH - 1) / CH;
-        parallel_for(n_ch, [&](int64_t c) {
-            for (int64_t i = c * CH, hi = std::min<int64_t>(n_seg, (c + 1) * CH); i < hi; i++) {
-                if (seqs[(size_t)i].n) memcpy(g->seq_concat + g->seq_off[(size_t)i], seqs[(size_t)i].p, seqs[(size_t)i].n);
-                char *d = g->name_arena.data() + g->name_off[(size_t)i];
-                memcpy(d, names[(size_t)i].p, names[(size_t)i].n);
-                d[names[(size_t)i].n] = '\0';
-            }
-        });
+    // ---- what the side thread made meanwhile
+    side.join();
+    side_joined = true;
+    if (side_rc == 1) { delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory"); }
+    if (side_rc == 2) {
+        const int code = fail(err, err_cap, PHI_HOST_ERR_CYCLE, "graph is not acyclic: %d of %d vertices sorted", side_sorted, n_seg);
+        delete g;
+        return code;
     }
-    for (int64_t w = 0; w < n_walks; w++)
-        g->hap_names.push_back(std::string(walks[(size_t)w]->sample.p, walks[(size_t)w]->sample.n) + "." + std::to_string(walks[(size_t)w]->hap));
-    // arcs: those touching a segment without sequence are dropped; an arc v -> w and its complement w' -> v' give the
-    // forward-strand adjacency (target orientation dropped): u -> w when v = u+, and w -> v when w is a reverse strand
-    {
-        std::vector<int64_t> cnt((size_t)n_seg + 1, 0);
-        auto each = [&](auto fn) {
-            for (const auto &a : arcs) {
-                const uint32_t v = a.first, w = a.second;
-                if (seqs[v >> 1].n == 0 || seqs[w >> 1].n == 0) continue;
-                if (!(v & 1)) fn(v >> 1, w >> 1);
-                if (w & 1) fn(w >> 1, v >> 1);
-            }
-        };
-        each([&](uint32_t u, uint32_t) { cnt[(size_t)u + 1]++; });
-        for (int32_t i = 0; i < n_seg; i++) cnt[(size_t)i + 1] += cnt[(size_t)i];
-        std::vector<int32_t> tgt((size_t)cnt[(size_t)n_seg]);
-        std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
-        each([&](uint32_t u, uint32_t x) { tgt[(size_t)cur[u]++] = (int32_t)x; });
-        // duplicate links, and oriented targets that collapse onto one segment, are merged
-        g->adj_off.assign((size_t)n_seg + 1, 0);
-        int64_t o = 0;
-        for (int32_t u = 0; u < n_seg; u++) {
-            int32_t *b = tgt.data() + cnt[(size_t)u], *e = tgt.data() + cnt[(size_t)u + 1];
-            if (e - b > 1) { std::sort(b, e); e = std::unique(b, e); }
-            g->adj_off[(size_t)u] = o;
-            for (; b < e; b++) tgt[(size_t)o++] = *b;             // (o never passes the read position)
-        }
-        g->adj_off[(size_t)n_seg] = o;
-        tgt.resize((size_t)o);
-        g->adj.swap(tgt);
-    }
-    tm.lap("arrays");
-    // Kahn's algorithm, FIFO
-    {
-        std::vector<int32_t> indeg((size_t)n_seg, 0), q((size_t)n_seg);
-        for (int32_t v : g->adj) indeg[(size_t)v]++;
-        int32_t head = 0, tail = 0;
-        for (int32_t i = 0; i < n_seg; i++) if (indeg[(size_t)i] == 0) q[(size_t)tail++] = i;
-        g->topo_rank.assign((size_t)n_seg, 0);
-        while (head < tail) {
-            const int32_t u = q[(size_t)head];
-            g->topo_rank[(size_t)u] = head++;
-            for (int64_t x = g->adj_off[(size_t)u]; x < g->adj_off[(size_t)u + 1]; x++)
-                if (--indeg[(size_t)g->adj[(size_t)x]] == 0) q[(size_t)tail++] = g->adj[(size_t)x];
-        }
-        if (head != n_seg) {
-            const int code = fail(err, err_cap, PHI_HOST_ERR_CYCLE, "graph is not acyclic: %d of %d vertices sorted", head, n_seg);
-            delete g;
-            return code;
-        }
-    }
-    tm.lap("topological order");
+    tm.lap("wait for arrays + topological order (side thread)");
     *out = g;
     return PHI_HOST_OK;
 }
