@@ -55,7 +55,7 @@ def main():
         phi = os.path.join(ROOT, "phi_amd", "PHI")
         runs = []
         for i in range(args.runs):
-            time.sleep(1.0)
+            time.sleep(6.0)                                    # (the run before is still giving back 65 GB of HBM behind its detached exit)
             t_spawn = time.time()
             t0 = time.perf_counter()
             r = subprocess.run([phi, "-g", gfa, "-r", rd, "-o", fa], capture_output=True, text=True, env=dict(os.environ, PHI_TIMING="1"))
