@@ -81,7 +81,7 @@ void phi_launch_walk_edges(hipStream_t st, const int32_t *walk_vtx, const int64_
 // The certificate on the host walks the anchors of each minimiser; grouping 10^6-10^7 anchors by
 // minimiser id is a scatter the GPU does in microseconds: count per id, scan (phi_launch_scan_i32),
 // scatter through atomic cursors, then put every short list in ascending anchor order (deterministic).
-__global__ void __launch_bounds__(256) phi_csr_count_kernel(const int32_t *__restrict__ triples, int64_t n, int64_t n_ids,
+__global__ void __launch_bounds__(256) phi_csr_count_kernel(const uint32_t *__restrict__ triples, int64_t n, int64_t n_ids,
                                                             int32_t *__restrict__ cnt, uint32_t *__restrict__ err)
 {
     GRID_STRIDE(i, n) {
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) phi_csr_count_kernel(const int32_t *__res
         atomicAdd(&cnt[id], 1);
     }
 }
-__global__ void __launch_bounds__(256) phi_csr_scatter_kernel(const int32_t *__restrict__ triples, int64_t n, int64_t n_ids,
+__global__ void __launch_bounds__(256) phi_csr_scatter_kernel(const uint32_t *__restrict__ triples, int64_t n, int64_t n_ids,
                                                               const int32_t *__restrict__ off, int32_t *__restrict__ cur,
                                                               int32_t *__restrict__ idx)
 {
@@ -113,11 +113,11 @@ __global__ void __launch_bounds__(256) phi_csr_sort_kernel(const int32_t *__rest
     }
 }
 
-void phi_launch_csr_count(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, int32_t *cnt, uint32_t *err)
+void phi_launch_csr_count(hipStream_t st, const uint32_t *triples, int64_t n, int64_t n_ids, int32_t *cnt, uint32_t *err)
 {
     if (n > 0) hipLaunchKernelGGL(phi_csr_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, triples, n, n_ids, cnt, err);
 }
-void phi_launch_csr_scatter(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, const int32_t *off, int32_t *cur,
+void phi_launch_csr_scatter(hipStream_t st, const uint32_t *triples, int64_t n, int64_t n_ids, const int32_t *off, int32_t *cur,
                             int32_t *idx)
 {
     if (n > 0) hipLaunchKernelGGL(phi_csr_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, triples, n, n_ids, off, cur, idx);
@@ -207,21 +207,21 @@ void phi_launch_match_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_
 }
 
 // ------------------------------------------------------------------------- filter groups
-__device__ __forceinline__ uint64_t group_key(uint32_t slot, const int32_t *__restrict__ walk_vtx, int32_t e0,
-                                              int32_t e1, uint64_t seed)
+__device__ __forceinline__ uint64_t group_key(uint32_t slot, const int32_t *__restrict__ walk_vtx, phi_ent_t e0,
+                                              phi_ent_t e1, uint64_t seed)
 {
     uint64_t h = seed ^ ((uint64_t)slot * 0x9E3779B97F4A7C15ull);
     h = phi_fmix64(h ^ (uint64_t)(e1 - e0 + 1));
-    for (int32_t e = e0; e <= e1; e++) h = phi_fmix64(h ^ (uint64_t)(uint32_t)walk_vtx[e]) + 0x632BE59BD9B4E019ull;
+    for (phi_ent_t e = e0; e <= e1; e++) h = phi_fmix64(h ^ (uint64_t)(uint32_t)walk_vtx[e]) + 0x632BE59BD9B4E019ull;
     return h == PHI_EMPTY_KEY ? 0 : h;
 }
 
 __device__ __forceinline__ bool same_group(const PhiFilterArgs &A, int32_t ra, int32_t rb)
 {
     if (A.rec_slot[ra] != A.rec_slot[rb]) return false;
-    const int32_t a0 = A.rec_e0[ra], a1 = A.rec_e1[ra], b0 = A.rec_e0[rb], b1 = A.rec_e1[rb];
+    const phi_ent_t a0 = A.rec_e0[ra], a1 = A.rec_e1[ra], b0 = A.rec_e0[rb], b1 = A.rec_e1[rb];
     if (a1 - a0 != b1 - b0) return false;
-    for (int32_t d = 0; d <= a1 - a0; d++)
+    for (uint32_t d = 0; d <= a1 - a0; d++)
         if (A.walk_vtx[a0 + d] != A.walk_vtx[b0 + d]) return false;
     return true;
 }
@@ -323,12 +323,12 @@ void phi_launch_kept_flags(hipStream_t st, const PhiFilterArgs &A, int64_t n, ui
 
 // ------------------------------------------------------------------------- gathers for the DP
 // out[j] = src[idx[j]]
-__global__ void phi_gather_i32_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int64_t n,
+__global__ void phi_gather_i32_kernel(const int32_t *__restrict__ src, const uint32_t *__restrict__ idx, int64_t n,
                                       int32_t *__restrict__ out)
 {
     GRID_STRIDE(j, n) out[j] = src[idx[j]];
 }
-void phi_launch_gather_i32(hipStream_t st, const int32_t *src, const int32_t *idx, int64_t n, int32_t *out)
+void phi_launch_gather_i32(hipStream_t st, const int32_t *src, const uint32_t *idx, int64_t n, int32_t *out)
 {
     if (n > 0) hipLaunchKernelGGL(phi_gather_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, src, idx, n, out);
 }
@@ -345,7 +345,7 @@ void phi_launch_gather_u64(hipStream_t st, const uint64_t *src, const int32_t *i
 
 // CSR over walk entries of the dp anchors, which arrive sorted by their last entry e1:
 // g_off[e] = first anchor with e1 >= e.
-__global__ void phi_entry_csr_kernel(const int32_t *__restrict__ a_e1, int64_t n_a, int64_t n_entries,
+__global__ void phi_entry_csr_kernel(const phi_ent_t *__restrict__ a_e1, int64_t n_a, int64_t n_entries,
                                      int64_t *__restrict__ g_off)
 {
     GRID_STRIDE(j, n_a + 1) {
@@ -354,7 +354,7 @@ __global__ void phi_entry_csr_kernel(const int32_t *__restrict__ a_e1, int64_t n
         for (int64_t e = lo; e <= hi; e++) g_off[e] = j;
     }
 }
-void phi_launch_entry_csr(hipStream_t st, const int32_t *a_e1, int64_t n_a, int64_t n_entries, int64_t *g_off)
+void phi_launch_entry_csr(hipStream_t st, const phi_ent_t *a_e1, int64_t n_a, int64_t n_entries, int64_t *g_off)
 {
     hipLaunchKernelGGL(phi_entry_csr_kernel, dim3(grid_for(n_a + 1, 256)), dim3(256), 0, st, a_e1, n_a, n_entries,
                        g_off);

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) phi_class_verify_kernel(PhiClassArgs A, u
 }
 
 // classes in the order of their representatives: slot -> class id, class multiplicity
-__global__ void __launch_bounds__(256) phi_class_ids_kernel(const int32_t *__restrict__ cls_rep, int64_t n_cls,
+__global__ void __launch_bounds__(256) phi_class_ids_kernel(const phi_ent_t *__restrict__ cls_rep, int64_t n_cls,
                                                             const uint32_t *__restrict__ ent_slot, const uint32_t *__restrict__ t_mult,
                                                             uint32_t *__restrict__ t_cid, int32_t *__restrict__ cls_mult)
 {
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) phi_entry_class_kernel(const uint32_t *en
 }
 
 // bases of every class in class space: [left base] + the vertex + up to tail_need following bases
-__global__ void __launch_bounds__(256) phi_class_len_kernel(PhiClassArgs A, const int32_t *__restrict__ cls_rep, int64_t n_cls,
+__global__ void __launch_bounds__(256) phi_class_len_kernel(PhiClassArgs A, const phi_ent_t *__restrict__ cls_rep, int64_t n_cls,
                                                             int32_t *__restrict__ cls_len, uint8_t *__restrict__ cls_left)
 {
     GRID_STRIDE(c, n_cls) {
@@ -244,7 +244,7 @@ void phi_launch_class_verify(hipStream_t st, const PhiClassArgs &A, uint8_t *is_
 {
     if (A.n_entries > 0) hipLaunchKernelGGL(phi_class_verify_kernel, dim3(grid_for(A.n_entries, 256)), dim3(256), 0, st, A, is_rep);
 }
-void phi_launch_class_ids(hipStream_t st, const int32_t *cls_rep, int64_t n_cls, const uint32_t *ent_slot, int64_t n_entries,
+void phi_launch_class_ids(hipStream_t st, const phi_ent_t *cls_rep, int64_t n_cls, const uint32_t *ent_slot, int64_t n_entries,
                           const uint32_t *t_mult, uint32_t *t_cid, int32_t *cls_mult, int32_t *ent_cls)
 {
     if (n_cls > 0)
@@ -252,7 +252,7 @@ void phi_launch_class_ids(hipStream_t st, const int32_t *cls_rep, int64_t n_cls,
     if (n_entries > 0)
         hipLaunchKernelGGL(phi_entry_class_kernel, dim3(grid_for(n_entries, 256)), dim3(256), 0, st, ent_slot, n_entries, t_cid, ent_cls);
 }
-void phi_launch_class_len(hipStream_t st, const PhiClassArgs &A, const int32_t *cls_rep, int64_t n_cls, int32_t *cls_len, uint8_t *cls_left)
+void phi_launch_class_len(hipStream_t st, const PhiClassArgs &A, const phi_ent_t *cls_rep, int64_t n_cls, int32_t *cls_len, uint8_t *cls_left)
 {
     if (n_cls > 0) hipLaunchKernelGGL(phi_class_len_kernel, dim3(grid_for(n_cls, 256)), dim3(256), 0, st, A, cls_rep, n_cls, cls_len, cls_left);
 }
@@ -261,7 +261,7 @@ void phi_launch_class_len(hipStream_t st, const PhiClassArgs &A, const int32_t *
 // lane -> 32 bases of class space.  cls_base[c] = first base of class c (cls_base[n_cls] = total).
 __global__ void __launch_bounds__(256) phi_pack_classes_kernel(const uint8_t *__restrict__ seq, const int64_t *__restrict__ seq_off,
                                                                const int32_t *__restrict__ walk_vtx, const int32_t *__restrict__ vlen,
-                                                               const int32_t *__restrict__ cls_rep, const uint8_t *__restrict__ cls_left,
+                                                               const phi_ent_t *__restrict__ cls_rep, const uint8_t *__restrict__ cls_left,
                                                                const int64_t *__restrict__ cls_base, int64_t n_cls,
                                                                uint64_t *__restrict__ words, int64_t n_words, uint32_t *__restrict__ badbits,
                                                                uint8_t *__restrict__ ascii, unsigned long long *__restrict__ n_bad)
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256) phi_pack_classes_kernel(const uint8_t *__
 }
 
 void phi_launch_pack_classes(hipStream_t st, const uint8_t *seq, const int64_t *seq_off, const int32_t *walk_vtx, const int32_t *vlen,
-                             const int32_t *cls_rep, const uint8_t *cls_left, const int64_t *cls_base, int64_t n_cls, uint64_t *words,
+                             const phi_ent_t *cls_rep, const uint8_t *cls_left, const int64_t *cls_base, int64_t n_cls, uint64_t *words,
                              int64_t n_words, uint32_t *badbits, uint8_t *ascii, unsigned long long *n_bad)
 {
     if (n_words <= 0) return;
@@ -339,10 +339,10 @@ void phi_launch_pack_classes(hipStream_t st, const uint8_t *seq, const int64_t *
 // list, ILP_index.cpp:419-438).
 __global__ void __launch_bounds__(256) phi_class_rec_kernel(const int64_t *__restrict__ raw_pos, int64_t n_raw,
                                                             const int64_t *__restrict__ cls_base, int64_t n_cls,
-                                                            const int32_t *__restrict__ cls_rep, const uint8_t *__restrict__ cls_left,
+                                                            const phi_ent_t *__restrict__ cls_rep, const uint8_t *__restrict__ cls_left,
                                                             const int32_t *__restrict__ walk_vtx, const int32_t *__restrict__ vlen,
                                                             int32_t k, uint8_t *__restrict__ keep, int32_t *__restrict__ r_cls,
-                                                            int32_t *__restrict__ r_rel, int32_t *__restrict__ r_e0, int32_t *__restrict__ r_e1)
+                                                            int32_t *__restrict__ r_rel, phi_ent_t *__restrict__ r_e0, phi_ent_t *__restrict__ r_e1)
 {
     GRID_STRIDE(i, n_raw) {
         const int64_t p = raw_pos[i];
@@ -361,13 +361,13 @@ __global__ void __launch_bounds__(256) phi_class_rec_kernel(const int64_t *__res
         while (cum + vlen[walk_vtx[e]] <= last) { cum += vlen[walk_vtx[e]]; e++; }
         r_cls[i] = (int32_t)c;
         r_rel[i] = rel;
-        r_e0[i] = (int32_t)e0;
-        r_e1[i] = (int32_t)e;
+        r_e0[i] = (phi_ent_t)e0;
+        r_e1[i] = (phi_ent_t)e;
     }
 }
 void phi_launch_class_rec(hipStream_t st, const int64_t *raw_pos, int64_t n_raw, const int64_t *cls_base, int64_t n_cls,
-                          const int32_t *cls_rep, const uint8_t *cls_left, const int32_t *walk_vtx, const int32_t *vlen, int32_t k,
-                          uint8_t *keep, int32_t *r_cls, int32_t *r_rel, int32_t *r_e0, int32_t *r_e1)
+                          const phi_ent_t *cls_rep, const uint8_t *cls_left, const int32_t *walk_vtx, const int32_t *vlen, int32_t k,
+                          uint8_t *keep, int32_t *r_cls, int32_t *r_rel, phi_ent_t *r_e0, phi_ent_t *r_e1)
 {
     if (n_raw > 0)
         hipLaunchKernelGGL(phi_class_rec_kernel, dim3(grid_for(n_raw, 256)), dim3(256), 0, st, raw_pos, n_raw, cls_base, n_cls, cls_rep,
@@ -377,9 +377,9 @@ void phi_launch_class_rec(hipStream_t st, const int64_t *raw_pos, int64_t n_raw,
 // out[j] = src[idx[j]] for the kept raw records
 __global__ void __launch_bounds__(256) phi_class_rec_gather_kernel(const int32_t *__restrict__ idx, int64_t n, const uint64_t *__restrict__ raw_hash,
                                                                    const int32_t *__restrict__ r_cls, const int32_t *__restrict__ r_rel,
-                                                                   const int32_t *__restrict__ r_e0, const int32_t *__restrict__ r_e1,
+                                                                   const phi_ent_t *__restrict__ r_e0, const phi_ent_t *__restrict__ r_e1,
                                                                    uint64_t *__restrict__ o_hash, int32_t *__restrict__ o_cls,
-                                                                   int32_t *__restrict__ o_rel, int32_t *__restrict__ o_e0, int32_t *__restrict__ o_e1)
+                                                                   int32_t *__restrict__ o_rel, phi_ent_t *__restrict__ o_e0, phi_ent_t *__restrict__ o_e1)
 {
     GRID_STRIDE(j, n) {
         const int32_t i = idx[j];
@@ -387,8 +387,8 @@ __global__ void __launch_bounds__(256) phi_class_rec_gather_kernel(const int32_t
     }
 }
 void phi_launch_class_rec_gather(hipStream_t st, const int32_t *idx, int64_t n, const uint64_t *raw_hash, const int32_t *r_cls,
-                                 const int32_t *r_rel, const int32_t *r_e0, const int32_t *r_e1, uint64_t *o_hash, int32_t *o_cls,
-                                 int32_t *o_rel, int32_t *o_e0, int32_t *o_e1)
+                                 const int32_t *r_rel, const phi_ent_t *r_e0, const phi_ent_t *r_e1, uint64_t *o_hash, int32_t *o_cls,
+                                 int32_t *o_rel, phi_ent_t *o_e0, phi_ent_t *o_e1)
 {
     if (n > 0)
         hipLaunchKernelGGL(phi_class_rec_gather_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, idx, n, raw_hash, r_cls, r_rel, r_e0, r_e1,
@@ -463,9 +463,9 @@ __global__ void __launch_bounds__(256) phi_expand_kernel(PhiExpandArgs A)
                 A.out_hash[o] = A.rec_hash[r];
                 A.out_pos[o] = A.ent_base[e - A.e_lo] + A.rec_rel[r];
             } else {
-                A.out_tri[3 * o + 0] = (int32_t)A.u_uid[A.rec_slot[r]];
-                A.out_tri[3 * o + 1] = (int32_t)(e + (A.rec_e0[r] - rep));
-                A.out_tri[3 * o + 2] = (int32_t)(e + (A.rec_e1[r] - rep));
+                A.out_tri[3 * o + 0] = A.u_uid[A.rec_slot[r]];
+                A.out_tri[3 * o + 1] = (phi_ent_t)(e + ((int64_t)A.rec_e0[r] - rep));
+                A.out_tri[3 * o + 2] = (phi_ent_t)(e + ((int64_t)A.rec_e1[r] - rep));
             }
             o++;
         }

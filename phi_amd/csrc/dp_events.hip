@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) phi_event_flags_kernel(const int32_t *__r
 }
 
 // ev_off[h] = first event of walk h (ev_e ascending, walk_off[n_walks] = n_entries)
-__global__ void phi_event_off_kernel(const int32_t *__restrict__ ev_e, int64_t n_ev, const int64_t *__restrict__ walk_off,
+__global__ void phi_event_off_kernel(const phi_ent_t *__restrict__ ev_e, int64_t n_ev, const int64_t *__restrict__ walk_off,
                                      int32_t n_walks, int64_t *__restrict__ ev_off)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,7 +52,7 @@ __global__ void phi_event_off_kernel(const int32_t *__restrict__ ev_e, int64_t n
     int64_t lo = 0, hi = n_ev;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (ev_e[mid] < key) lo = mid + 1; else hi = mid;
+        if ((int64_t)ev_e[mid] < key) lo = mid + 1; else hi = mid;
     }
     ev_off[h] = lo;
 }
@@ -65,7 +65,7 @@ void phi_launch_event_flags(hipStream_t st, const int32_t *walk_vtx, int64_t n_e
     hipLaunchKernelGGL(phi_event_flags_kernel, dim3((unsigned)nb), dim3(256), 0, st, walk_vtx, n_entries, cvtx, flags);
 }
 
-void phi_launch_event_off(hipStream_t st, const int32_t *ev_e, int64_t n_ev, const int64_t *walk_off, int32_t n_walks,
+void phi_launch_event_off(hipStream_t st, const phi_ent_t *ev_e, int64_t n_ev, const int64_t *walk_off, int32_t n_walks,
                           int64_t *ev_off)
 {
     hipLaunchKernelGGL(phi_event_off_kernel, dim3((unsigned)((n_walks + 1 + 63) / 64)), dim3(64), 0, st, ev_e, n_ev,
@@ -74,13 +74,13 @@ void phi_launch_event_off(hipStream_t st, const int32_t *ev_e, int64_t n_ev, con
 
 // ------------------------------------------------------------------ per run: counts, prefix sums, event records
 // cnt_end[e] / cnt_start[e] += 1 for every weight-1 anchor ending / starting at entry e (arrays zeroed by the caller)
-__global__ void __launch_bounds__(256) phi_dp_counts_kernel(const int32_t *__restrict__ a_e1, const uint8_t *__restrict__ a_span,
+__global__ void __launch_bounds__(256) phi_dp_counts_kernel(const phi_ent_t *__restrict__ a_e1, const uint8_t *__restrict__ a_span,
                                                             const uint8_t *__restrict__ a_weight, int64_t n_a,
                                                             int32_t *__restrict__ cnt_end, int32_t *__restrict__ cnt_start)
 {
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_a; g += (int64_t)gridDim.x * blockDim.x) {
         if (!a_weight[g]) continue;
-        const int32_t e1 = a_e1[g];
+        const phi_ent_t e1 = a_e1[g];
         atomicAdd(&cnt_end[e1], 1);
         atomicAdd(&cnt_start[e1 - a_span[g]], 1);
     }
@@ -221,11 +221,11 @@ void phi_launch_scan_i32(hipStream_t st, const int32_t *cnt, int64_t n, int32_t 
 }
 
 // One 48-byte record per event:
-//   int4  A = { compact step, entry | overflow << 31, End (inclusive), SB }
+//   int4  A = { compact step | overflow << 31, entry (phi_ent_t), End (inclusive), SB }
 //   32 B  G : byte a (1..30) = #{weight-1 anchors of the walk inside [entry - a, entry]}, byte 0 = 0,
 //             byte 31 = out-edge index of the entry (255: the walk ends here)
 // overflow: more than 255 anchors end inside the window (the DP then counts from the CSR).
-__global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const int32_t *__restrict__ ev_e, int64_t n_ev,
+__global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const phi_ent_t *__restrict__ ev_e, int64_t n_ev,
                                                                 const int32_t *__restrict__ walk_vtx,
                                                                 const int32_t *__restrict__ cvtx,
                                                                 const int64_t *__restrict__ walk_off, int32_t n_walks,
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const int32_t *_
                                                                 uint4 *__restrict__ ev)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ev; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t e = ev_e[i];
+        const int64_t e = ev_e[i];
         // walk of e: last h with walk_off[h] <= e
         int lo = 0, hi = n_walks;
         while (hi - lo > 1) {
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const int32_t *_
         const int64_t eb = walk_off[lo];
         unsigned long long w[4] = {0, 0, 0, 0};
         int total = 0;
-        const int64_t x0 = (int64_t)e - 29 > eb ? (int64_t)e - 29 : eb;
+        const int64_t x0 = e - 29 > eb ? e - 29 : eb;
         for (int64_t x = x0; x <= e; x++) {
             for (int64_t g = g_off[x]; g < g_off[x + 1]; g++) {
                 if (!a_weight[g]) continue;
@@ -272,8 +272,8 @@ __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const int32_t *_
         // the two prefix sums agree at it): keys E - SB stay within the score range whatever the number of walks
         const int32_t base = off_start[eb];
         uint4 A;
-        A.x = (uint32_t)cvtx[walk_vtx[e]];
-        A.y = (uint32_t)e | (ovf ? 0x80000000u : 0u);
+        A.x = (uint32_t)cvtx[walk_vtx[e]] | (ovf ? 0x80000000u : 0u);
+        A.y = (uint32_t)e;
         A.z = (uint32_t)(off_end[e + 1] - base);
         A.w = (uint32_t)(off_start[e] - base);
         ev[i * 3 + 0] = A;
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const int32_t *_
     }
 }
 
-void phi_launch_dp_counts(hipStream_t st, const int32_t *a_e1, const uint8_t *a_span, const uint8_t *a_weight, int64_t n_a,
+void phi_launch_dp_counts(hipStream_t st, const phi_ent_t *a_e1, const uint8_t *a_span, const uint8_t *a_weight, int64_t n_a,
                           int32_t *cnt_end, int32_t *cnt_start)
 {
     if (n_a <= 0) return;
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
             }
             const int32_t k = s0 + i;
             const int32_t flags = ra.x;
-            const bool active = (int32_t)cA.x == k;
+            const bool active = (int32_t)(cA.x & 0x7FFFFFFFu) == k;      // (no event: 0xFFFFFFFF, a step no block reaches)
 
             // ---- recombination entry into this vertex (uniform over the workgroup)
             int32_t E = NEG, Eh = -1, Esrc = -1;
@@ -507,8 +507,8 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
             int32_t dmax = NEG;
             int32_t oidx = 255;
             if (active) {
-                const int64_t e = (int64_t)(cA.y & 0x7FFFFFFFu);
-                const bool ovf = (cA.y >> 31) != 0;
+                const int64_t e = (int64_t)cA.y;
+                const bool ovf = (cA.x >> 31) != 0;
                 const int32_t t = (int32_t)(e - eb);
                 const int32_t End = (int32_t)cA.z, SB = (int32_t)cA.w;
                 const int sl = (int)(vi & (D - 1));
@@ -671,8 +671,8 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
     const int32_t k0 = MODE == DP_SEQ ? 0 : A.blk_lo[sb];
     const int32_t k1 = MODE == DP_SEQ ? A.n_k : A.blk_lo[sb + 1];
     const int32_t n_steps = k1 - k0;
-    const int32_t eb = has_walk ? (int32_t)A.walk_off[w] : 0;
-    const int32_t ee = has_walk ? (int32_t)A.walk_off[w + 1] : 0;
+    const phi_ent_t eb = has_walk ? (phi_ent_t)A.walk_off[w] : 0;
+    const phi_ent_t e_last = has_walk ? (phi_ent_t)(A.walk_off[w + 1] - 1) : 0xFFFFFFFFu;     // (0xFFFFFFFF: no entry, PHI_MAX_ENTRIES)
     const int32_t v0 = has_walk ? (int32_t)A.ev_off[w] : 0;     // events of this lane's walk: [v0, ve)
     const int32_t ve = has_walk ? (int32_t)A.ev_off[w + 1] : 0;
     const int32_t vb = MODE == DP_SEQ ? v0 : (has_walk ? A.blk_ev[(int64_t)sb * A.lane_stride + w] : 0);   // first event inside the block
@@ -723,7 +723,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                     const int32_t x = vprev + pw + n * NPW;
                     if (x < vi) {
                         const int4 r = s_res[x & (D - 1)][h];
-                        A.dmax[r.z] = r.x; A.bstart[r.z] = r.y;
+                        A.dmax[(phi_ent_t)r.z] = r.x; A.bstart[(phi_ent_t)r.z] = r.y;
                     }
                 }
                 // 2. tops and entry choices of the previous period's steps (values of steps without
@@ -834,7 +834,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             const int4 n2a = s_rec[(r + 2) & (2 * CHK - 1)][0], n2b = s_rec[(r + 2) & (2 * CHK - 1)][1];
             // two alleles of one site (PHI_DP_PAIR: neither leaves states, no walk visits both): one iteration
             const bool pair = (ra.x & PHI_DP_PAIR) && r + 1 < r_end;
-            const int32_t stepk = (int32_t)cA.x;
+            const int32_t stepk = (int32_t)(cA.x & 0x7FFFFFFFu);    // (no event: 0xFFFFFFFF, a step no block reaches)
             const bool second = pair && stepk == k + 1;
             const bool active = stepk == k || second;
             const int32_t flags = second ? na.x : ra.x;
@@ -852,9 +852,9 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             int32_t oidx = 255;
             if (active) {
                 const int sl = (int)(vi & (D - 1));
-                const int32_t e = (int32_t)(cA.y & 0x7FFFFFFFu);
-                const bool ovf = (cA.y >> 31) != 0;
-                const int32_t t = e - eb;
+                const phi_ent_t e = cA.y;
+                const bool ovf = (cA.x >> 31) != 0;
+                const int32_t t = (int32_t)(e - eb);
                 const int32_t End = (int32_t)cA.z, SB = (int32_t)cA.w;
                 const uint8_t *gb = reinterpret_cast<const uint8_t *>(&s_ev[sl][1][h]);   // byte a of G at gb[(a & 15) + (a >> 4) * 1024]
                 oidx = gb[15 + 1024];
@@ -885,7 +885,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                     if (MODE == DP_ROW && key > Kn) Kn = key;
                 }
                 int32_t bs = 0;
-                if ((flags & PHI_DP_NEED_TOPS) || e == ee - 1) {
+                if ((flags & PHI_DP_NEED_TOPS) || e == e_last) {
                     // oldest first, strict improvement: ties keep the older run
                     int32_t best = M > NEGK / 2 ? M + End : NEG;
                     bs = sL;
@@ -898,9 +898,9 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
                         if (val > best) { best = val; bs = s; }
                     }
                     if (best > NEG / 2) dmax = best; else bs = 0;
-                    if (MODE == DP_ROW && e == ee - 1) endbest = max(endbest, dmax);
+                    if (MODE == DP_ROW && e == e_last) endbest = max(endbest, dmax);
                 }
-                s_res[sl][h] = make_int4(dmax, bs, e, 0);
+                s_res[sl][h] = make_int4(dmax, bs, (int32_t)e, 0);
                 vi++;
                 cA = make_uint4(0xFFFFFFFFu, 0, 0, 0);
                 if (vi < ve) cA = s_ev[vi & (D - 1)][0][h];
@@ -971,11 +971,12 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
 // ------------------------------------------------------------------ where the chain may be cut (per solve)
 // diff[e0 + 1] += 1, diff[e1 + 1] -= 1 for every dp anchor (first / last entry e0 < e1): the prefix sum at entry e
 // is the number of anchors with e0 < e <= e1, i.e. that a cut right before e would split
-__global__ void __launch_bounds__(256) phi_cut_cov_kernel(const int32_t *__restrict__ a_e1, const uint8_t *__restrict__ a_span, int64_t n_a,
+__global__ void __launch_bounds__(256) phi_cut_cov_kernel(const phi_ent_t *__restrict__ a_e1, const uint8_t *__restrict__ a_span, int64_t n_a,
                                                           int32_t *__restrict__ diff)
 {
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_a; g += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t e1 = a_e1[g], sp = a_span[g];
+        const int64_t e1 = a_e1[g];
+        const int32_t sp = a_span[g];
         if (sp <= 0) continue;
         atomicAdd(&diff[e1 - sp + 1], 1);
         atomicAdd(&diff[e1 + 1], -1);
@@ -990,20 +991,20 @@ __global__ void __launch_bounds__(256) phi_cut_clean_kernel(const int32_t *__res
 // Between two consecutive events of a walk (entries l < p on compact steps a < b) the walk only runs along chain
 // vertices: a cut before any step in (a, b] is fine for this walk iff some entry in (l, p] is clean.  Where none is,
 // the steps a+1 .. b are closed: stepdiff[a + 1] += 1, stepdiff[b + 1] -= 1.
-__global__ void __launch_bounds__(256) phi_cut_events_kernel(const int32_t *__restrict__ ev_e, int64_t n_ev, const int64_t *__restrict__ ev_off,
+__global__ void __launch_bounds__(256) phi_cut_events_kernel(const phi_ent_t *__restrict__ ev_e, int64_t n_ev, const int64_t *__restrict__ ev_off,
                                                              const int64_t *__restrict__ walk_off, int32_t n_walks,
                                                              const int32_t *__restrict__ walk_vtx, const int32_t *__restrict__ cvtx,
                                                              const int32_t *__restrict__ ncl_excl, int32_t *__restrict__ stepdiff)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ev; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t p = ev_e[i];
+        const int64_t p = ev_e[i];
         int lo = 0, hi = n_walks;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (walk_off[mid] <= p) lo = mid; else hi = mid;
         }
         if (i == ev_off[lo]) continue;                         // the walk's first event: nothing before it
-        const int32_t l = ev_e[i - 1];
+        const int64_t l = ev_e[i - 1];
         if (ncl_excl[p + 1] - ncl_excl[l + 1] > 0) continue;   // a clean entry in (l, p]
         const int32_t a = cvtx[walk_vtx[l]], b = cvtx[walk_vtx[p]];
         atomicAdd(&stepdiff[a + 1], 1);
@@ -1011,7 +1012,7 @@ __global__ void __launch_bounds__(256) phi_cut_events_kernel(const int32_t *__re
     }
 }
 // blk_ev[b][h] = first event of walk h on a compact step >= blk_lo[b]
-__global__ void __launch_bounds__(256) phi_blk_ev_kernel(const int32_t *__restrict__ blk_lo, int32_t n_blk, const int32_t *__restrict__ ev_e,
+__global__ void __launch_bounds__(256) phi_blk_ev_kernel(const int32_t *__restrict__ blk_lo, int32_t n_blk, const phi_ent_t *__restrict__ ev_e,
                                                          const int64_t *__restrict__ ev_off, int32_t n_walks, const int32_t *__restrict__ walk_vtx,
                                                          const int32_t *__restrict__ cvtx, int32_t *__restrict__ blk_ev)
 {
@@ -1029,7 +1030,7 @@ __global__ void __launch_bounds__(256) phi_blk_ev_kernel(const int32_t *__restri
     }
     blk_ev[(int64_t)b * blockDim.x + h] = out;
 }
-void phi_launch_cut_cov(hipStream_t st, const int32_t *a_e1, const uint8_t *a_span, int64_t n_a, int32_t *diff)
+void phi_launch_cut_cov(hipStream_t st, const phi_ent_t *a_e1, const uint8_t *a_span, int64_t n_a, int32_t *diff)
 {
     if (n_a <= 0) return;
     int64_t nb = (n_a + 255) / 256;
@@ -1042,7 +1043,7 @@ void phi_launch_cut_clean(hipStream_t st, const int32_t *cov_excl, int64_t n_ent
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(phi_cut_clean_kernel, dim3((unsigned)nb), dim3(256), 0, st, cov_excl, n_entries, clean);
 }
-void phi_launch_cut_events(hipStream_t st, const int32_t *ev_e, int64_t n_ev, const int64_t *ev_off, const int64_t *walk_off, int32_t n_walks,
+void phi_launch_cut_events(hipStream_t st, const phi_ent_t *ev_e, int64_t n_ev, const int64_t *ev_off, const int64_t *walk_off, int32_t n_walks,
                            const int32_t *walk_vtx, const int32_t *cvtx, const int32_t *ncl_excl, int32_t *stepdiff)
 {
     if (n_ev <= 0) return;
@@ -1051,7 +1052,7 @@ void phi_launch_cut_events(hipStream_t st, const int32_t *ev_e, int64_t n_ev, co
     hipLaunchKernelGGL(phi_cut_events_kernel, dim3((unsigned)nb), dim3(256), 0, st, ev_e, n_ev, ev_off, walk_off, n_walks, walk_vtx, cvtx,
                        ncl_excl, stepdiff);
 }
-void phi_launch_blk_ev(hipStream_t st, const int32_t *blk_lo, int32_t n_blk, const int32_t *ev_e, const int64_t *ev_off, int32_t n_walks,
+void phi_launch_blk_ev(hipStream_t st, const int32_t *blk_lo, int32_t n_blk, const phi_ent_t *ev_e, const int64_t *ev_off, int32_t n_walks,
                        const int32_t *walk_vtx, const int32_t *cvtx, int32_t *blk_ev)
 {
     if (n_blk > 0)
@@ -1101,7 +1102,7 @@ __global__ void __launch_bounds__(256) phi_blk_classes_kernel(PhiBlkClassArgs G)
         int64_t e_first = 0;
         for (int64_t i = vb; i < vend; i++) {
             const uint4 A = evg[i * 3 + 0], B = evg[i * 3 + 1], C = evg[i * 3 + 2];
-            const int64_t e = (int64_t)(A.y & 0x7FFFFFFFu);
+            const int64_t e = (int64_t)A.y;
             if (i == vb) { e_first = e; c0 = (int32_t)A.w; }
             const int64_t rel = e - e_first;
             unsigned long long w[4] = {(unsigned long long)B.x | ((unsigned long long)B.y << 32), (unsigned long long)B.z | ((unsigned long long)B.w << 32),
@@ -1113,10 +1114,10 @@ __global__ void __launch_bounds__(256) phi_blk_classes_kernel(PhiBlkClassArgs G)
                 if (q == 3) m |= 0xFF00000000000000ull;            // byte 31: the out-edge
                 w[q] &= m;
             }
-            const unsigned long long f0 = ((unsigned long long)(uint32_t)((int32_t)A.x - k0) << 32) | (unsigned long long)(uint32_t)rel;
+            const unsigned long long f0 = ((unsigned long long)(uint32_t)((int32_t)(A.x & 0x7FFFFFFFu) - k0) << 32) | (unsigned long long)(uint32_t)rel;
             const unsigned long long f1 = ((unsigned long long)(uint32_t)((int32_t)A.z - c0) << 32) | (unsigned long long)(uint32_t)((int32_t)A.w - c0);
             unsigned long long f2 = (e == eb ? 1u : 0u) | (e == ee - 1 ? 2u : 0u);
-            if (A.y >> 31) f2 |= 4u | ((unsigned long long)(h + 1) << 8);   // counted from the walk's own anchors: a class of its own
+            if (A.x >> 31) f2 |= 4u | ((unsigned long long)(h + 1) << 8);   // counted from the walk's own anchors: a class of its own
             const unsigned long long f[7] = {f0, f1, f2, w[0], w[1], w[2], w[3]};
 #pragma unroll
             for (int q = 0; q < 7; q++) { ha = cls_mix(ha, f[q], 0x9E3779B97F4A7C15ull); hb = cls_mix(hb, f[q], 0xC2B2AE3D27D4EB4Full); }

@@ -239,7 +239,7 @@ int phi_syn_graph(int64_t backbone_len, int32_t n_walks, uint64_t seed, int32_t 
         for (int32_t h = 0; h < n_walks; h++) g->walk_off[(size_t)h + 1] = g->walk_off[(size_t)h] + cnt[(size_t)h];
     }
     const int64_t n_entries = g->walk_off[(size_t)n_walks];
-    if (n_entries >= (int64_t)1 << 31) { delete g; return -3; }
+    if (n_entries > ((int64_t)1 << 32) - 64) { delete g; return -3; }     // (PHI_MAX_ENTRIES of the library)
     g->walk_vtx = (int32_t *)malloc((size_t)std::max<int64_t>(n_entries, 1) * 4);
     if (!g->walk_vtx) { delete g; return -2; }
     {

@@ -405,10 +405,10 @@ static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_e
     PHICHK(phi_dev_ensure(c, c->d_cls_base, (size_t)(nc + 1) * 8));
     PHICHK(phi_dev_ensure(c, c->d_cls_rec_off, (size_t)(nc + 1) * 4));
     // (the rep slot array t_rep is reused as slot -> class id)
-    phi_launch_class_ids(c->stream, c->d_cls_rep.as<int32_t>(), nc, A.ent_slot, n_entries, A.t_mult, A.t_rep, c->d_cls_mult.as<int32_t>(),
+    phi_launch_class_ids(c->stream, c->d_cls_rep.as<phi_ent_t>(), nc, A.ent_slot, n_entries, A.t_mult, A.t_rep, c->d_cls_mult.as<int32_t>(),
                          c->d_ent_cls.as<int32_t>());
     PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)nc * 4));
-    phi_launch_class_len(c->stream, A, c->d_cls_rep.as<int32_t>(), nc, c->d_list3.as<int32_t>(), c->d_cls_left.as<uint8_t>());
+    phi_launch_class_len(c->stream, A, c->d_cls_rep.as<phi_ent_t>(), nc, c->d_list3.as<int32_t>(), c->d_cls_left.as<uint8_t>());
     {
         const int64_t nb = phi_scan_i32_num_blocks(nc);
         PHICHK(phi_dev_ensure(c, c->d_scan_blk64, (size_t)nb * 8));
@@ -430,7 +430,7 @@ static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_e
     PHICHK(phi_dev_ensure(c, c->d_wbad, (size_t)(n_words + 6) * 4));
     auto pack = [&](uint8_t *ascii) {
         phi_launch_pack_classes(c->stream, c->d_seq.as<uint8_t>(), c->d_seq_off.as<int64_t>(), c->d_walk_vtx.as<int32_t>(), c->d_vlen.as<int32_t>(),
-                                c->d_cls_rep.as<int32_t>(), c->d_cls_left.as<uint8_t>(), c->d_cls_base.as<int64_t>(), nc,
+                                c->d_cls_rep.as<phi_ent_t>(), c->d_cls_left.as<uint8_t>(), c->d_cls_base.as<int64_t>(), nc,
                                 c->d_wwords.as<uint64_t>(), n_words, c->d_wbad.as<uint32_t>(), ascii, (unsigned long long *)scalar(c, S_NBAD));
     };
     pack(nullptr);
@@ -468,9 +468,9 @@ static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_e
     PHICHK(phi_dev_ensure(c, r_e0, (size_t)nr0 * 4));
     PHICHK(phi_dev_ensure(c, r_e1, (size_t)nr0 * 4));
     PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)std::max<int64_t>(nr0, n_entries)));
-    phi_launch_class_rec(c->stream, c->d_rec_pos.as<int64_t>(), n_raw, c->d_cls_base.as<int64_t>(), nc, c->d_cls_rep.as<int32_t>(),
+    phi_launch_class_rec(c->stream, c->d_rec_pos.as<int64_t>(), n_raw, c->d_cls_base.as<int64_t>(), nc, c->d_cls_rep.as<phi_ent_t>(),
                          c->d_cls_left.as<uint8_t>(), c->d_walk_vtx.as<int32_t>(), c->d_vlen.as<int32_t>(), c->k, c->d_flags.as<uint8_t>(),
-                         r_cls.as<int32_t>(), r_rel.as<int32_t>(), r_e0.as<int32_t>(), r_e1.as<int32_t>());
+                         r_cls.as<int32_t>(), r_rel.as<int32_t>(), r_e0.as<phi_ent_t>(), r_e1.as<phi_ent_t>());
     PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_raw, c->d_list2, &c->n_rec));
     const int64_t nr = std::max<int64_t>(c->n_rec, 1);
     PHICHK(phi_dev_ensure(c, c->d_rec_hash, (size_t)nr * 8));
@@ -479,8 +479,8 @@ static int build_classes(phi_ctx *c, int32_t n_vtx, int32_t n_walks, int64_t n_e
     PHICHK(phi_dev_ensure(c, c->d_rec_e0, (size_t)nr * 4));
     PHICHK(phi_dev_ensure(c, c->d_rec_e1, (size_t)nr * 4));
     phi_launch_class_rec_gather(c->stream, c->d_list2.as<int32_t>(), c->n_rec, raw_hash.as<uint64_t>(), r_cls.as<int32_t>(), r_rel.as<int32_t>(),
-                                r_e0.as<int32_t>(), r_e1.as<int32_t>(), c->d_rec_hash.as<uint64_t>(), c->d_rec_cls.as<int32_t>(),
-                                c->d_rec_rel.as<int32_t>(), c->d_rec_e0.as<int32_t>(), c->d_rec_e1.as<int32_t>());
+                                r_e0.as<phi_ent_t>(), r_e1.as<phi_ent_t>(), c->d_rec_hash.as<uint64_t>(), c->d_rec_cls.as<int32_t>(),
+                                c->d_rec_rel.as<int32_t>(), c->d_rec_e0.as<phi_ent_t>(), c->d_rec_e1.as<phi_ent_t>());
     phi_launch_class_rec_off(c->stream, c->d_rec_cls.as<int32_t>(), c->n_rec, nc, c->d_cls_rec_off.as<int32_t>());
     HIPCHK(hipEventRecord(ev1, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));                  // the temporaries above go out of scope
@@ -511,7 +511,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     if (c->pin_future.valid()) c->pin_future.wait();
     {
         int64_t ne = walk_off[n_walks];                      // not validated yet: clamp
-        ne = ne < 0 ? 0 : (ne > ((int64_t)1 << 31) ? ((int64_t)1 << 31) : ne);
+        ne = ne < 0 ? 0 : (ne > PHI_MAX_ENTRIES ? PHI_MAX_ENTRIES : ne);
         const size_t want = ((size_t)ne / 4 + 4096) * sizeof(PhiAnchorHost);
         // (only for graphs whose solve is likely to take the host copy of the anchors: a model of 2^16 anchors or more
         //  stays on the device, solve_dev.hip, and pinning tens of MB here holds up the other threads' HIP calls)
@@ -533,7 +533,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     for (int32_t h = 0; h < n_walks; h++)
         if (walk_off[h + 1] <= walk_off[h]) return phi_fail(c, PHI_ERR_INVALID, "walk %d is empty", h);
     const int64_t n_edges = adj_off[n_vtx], n_entries = walk_off[n_walks];
-    if (n_entries >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk entries");
+    if (n_entries > PHI_MAX_ENTRIES) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^32 - 64 walk entries");
     // The DP's per-entry buffers of a chromosome-scale graph (5 x 4-8 bytes per walk entry: 26 GB at 1.3 G entries) are
     // allocated now, on a thread of their own: the driver clears device memory as it hands it out (tens of GB/s), which
     // otherwise shows up as half a second at the start of phi_solve.  Joined before this call returns.
@@ -903,8 +903,11 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)n_entries));
         phi_launch_event_flags(c->stream, c->d_walk_vtx.as<int32_t>(), n_entries, c->d_cvtx.as<int32_t>(), c->d_flags.as<uint8_t>());
         PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_entries, c->d_ev_e, &c->n_ev));
+        // (event indices are 32-bit signed in the block tables and on the DP lanes; events are the entries on vertices where a
+        //  recombination can enter or leave or a walk begins or ends: 18 % of the entries of a chromosome-scale graph)
+        if (c->n_ev >= (int64_t)1 << 31) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 walk entries on vertices with recombination edges");
         PHICHK(phi_dev_ensure(c, c->d_ev_off, (size_t)(n_walks + 1) * 8));
-        phi_launch_event_off(c->stream, c->d_ev_e.as<int32_t>(), c->n_ev, c->d_walk_off.as<int64_t>(), n_walks,
+        phi_launch_event_off(c->stream, c->d_ev_e.as<phi_ent_t>(), c->n_ev, c->d_walk_off.as<int64_t>(), n_walks,
                              c->d_ev_off.as<int64_t>());
     }
     HIPCHK(hipGetLastError());
@@ -1537,7 +1540,7 @@ int phi_walk_minimizers(phi_ctx *c, int32_t walk, uint64_t *out_hash, int64_t *o
     }
     PhiExpandArgs X{};
     X.ent_cls = c->d_ent_cls.as<int32_t>(); X.e_lo = e_lo; X.e_hi = e_hi;
-    X.cls_rec_off = c->d_cls_rec_off.as<int32_t>(); X.cls_rep = c->d_cls_rep.as<int32_t>();
+    X.cls_rec_off = c->d_cls_rec_off.as<int32_t>(); X.cls_rep = c->d_cls_rep.as<phi_ent_t>();
     X.rec_hash = c->d_rec_hash.as<uint64_t>(); X.rec_rel = c->d_rec_rel.as<int32_t>(); X.ent_base = base.as<int64_t>();
     X.out_hash = oh.as<uint64_t>(); X.out_pos = op.as<int64_t>();
     const int64_t nb = phi_expand_num_blocks(ne);
@@ -1649,8 +1652,8 @@ int phi_kept_anchors(phi_ctx *c, uint64_t *out_hash, int32_t *out_walk, int32_t 
         const int32_t h = phi_entry_walk(c, a.e0);
         if (out_hash) out_hash[i] = c->h_kept_hash[i];
         if (out_walk) out_walk[i] = h;
-        if (out_t0) out_t0[i] = a.e0 - (int32_t)c->h_walk_off[h];
-        if (out_t1) out_t1[i] = a.e1 - (int32_t)c->h_walk_off[h];
+        if (out_t0) out_t0[i] = (int32_t)((int64_t)a.e0 - c->h_walk_off[h]);
+        if (out_t1) out_t1[i] = (int32_t)((int64_t)a.e1 - c->h_walk_off[h]);
     }
     return PHI_OK;
 }

@@ -25,7 +25,7 @@ struct DevBuf {
 
 struct PhiAnchorHost {       // one dp anchor on the host (certificate / branch-and-bound)
     uint32_t slot;           // minimiser identity: dense id (rank of first occurrence among the walk minimisers)
-    int32_t e0, e1;          // first / last walk entry
+    uint32_t e0, e1;         // first / last walk entry (phi_ent_t of phi_kernels.h: unsigned, below PHI_MAX_ENTRIES)
 };
 
 // host array that is NOT value-initialised on allocation: the threads that fill it touch its pages

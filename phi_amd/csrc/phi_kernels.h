@@ -17,6 +17,12 @@
                                  // serialises at ~12 ns per atomic (MI355X_MICROARCH.md "fanin")
 #define PHI_RCAP 32            // DP run-length states 0..31 (an anchor spans <= k-1 <= 31 edges)
 
+// A walk entry is an index into the concatenated walks (walk_off / walk_vtx of phi_set_graph).  Entries are held in
+// 32 bits, UNSIGNED, wherever they are stored (class representatives, record and anchor entries, events, path
+// stretches): every load widens to 64 bits before it indexes anything.  Per-entry arrays are indexed with 64 bits.
+typedef uint32_t phi_ent_t;
+#define PHI_MAX_ENTRIES (((int64_t)1 << 32) - 64)   // (a little below 2^32: loops like `for (e = e0; e <= e1; e++)` and e + 1 never wrap)
+
 enum { PHI_MODE_COUNT = 0, PHI_MODE_WRITE = 1, PHI_MODE_PROBE = 2 };
 
 // bits of the device error word
@@ -119,13 +125,13 @@ struct PhiClassArgs {
 };
 struct PhiExpandArgs {
     const int32_t *ent_cls; int64_t e_lo, e_hi;
-    const int32_t *cls_rec_off; const int32_t *cls_rep;
+    const int32_t *cls_rec_off; const phi_ent_t *cls_rep;
     const uint8_t *sel; const int32_t *sel_cnt;          // optional: selected records, and their number per class
     int32_t *block_cnt; const int64_t *block_off;
     // kind 0: minimisers of one walk
     const uint64_t *rec_hash; const int32_t *rec_rel; const int64_t *ent_base; uint64_t *out_hash; int64_t *out_pos;
     // kind 1: anchors (dense minimiser id, first entry, last entry)
-    const uint32_t *rec_slot; const uint32_t *u_uid; const int32_t *rec_e0; const int32_t *rec_e1; int32_t *out_tri;
+    const uint32_t *rec_slot; const uint32_t *u_uid; const phi_ent_t *rec_e0; const phi_ent_t *rec_e1; uint32_t *out_tri;
 };
 void phi_launch_vlen(hipStream_t st, const int64_t *seq_off, int64_t n_vtx, int32_t *vlen);
 void phi_launch_walk_bases(hipStream_t st, const int32_t *walk_vtx, const int32_t *vlen, const int64_t *walk_off, int32_t n_walks,
@@ -134,18 +140,18 @@ void phi_launch_walk_rec_counts(hipStream_t st, const int32_t *ent_cls, const in
                                 int32_t n_walks, int64_t n_entries, unsigned long long *out);
 void phi_launch_class_insert(hipStream_t st, const PhiClassArgs &A);
 void phi_launch_class_verify(hipStream_t st, const PhiClassArgs &A, uint8_t *is_rep);
-void phi_launch_class_ids(hipStream_t st, const int32_t *cls_rep, int64_t n_cls, const uint32_t *ent_slot, int64_t n_entries,
+void phi_launch_class_ids(hipStream_t st, const phi_ent_t *cls_rep, int64_t n_cls, const uint32_t *ent_slot, int64_t n_entries,
                           const uint32_t *t_mult, uint32_t *t_cid, int32_t *cls_mult, int32_t *ent_cls);
-void phi_launch_class_len(hipStream_t st, const PhiClassArgs &A, const int32_t *cls_rep, int64_t n_cls, int32_t *cls_len, uint8_t *cls_left);
+void phi_launch_class_len(hipStream_t st, const PhiClassArgs &A, const phi_ent_t *cls_rep, int64_t n_cls, int32_t *cls_len, uint8_t *cls_left);
 void phi_launch_pack_classes(hipStream_t st, const uint8_t *seq, const int64_t *seq_off, const int32_t *walk_vtx, const int32_t *vlen,
-                             const int32_t *cls_rep, const uint8_t *cls_left, const int64_t *cls_base, int64_t n_cls, uint64_t *words,
+                             const phi_ent_t *cls_rep, const uint8_t *cls_left, const int64_t *cls_base, int64_t n_cls, uint64_t *words,
                              int64_t n_words, uint32_t *badbits, uint8_t *ascii, unsigned long long *n_bad);
 void phi_launch_class_rec(hipStream_t st, const int64_t *raw_pos, int64_t n_raw, const int64_t *cls_base, int64_t n_cls,
-                          const int32_t *cls_rep, const uint8_t *cls_left, const int32_t *walk_vtx, const int32_t *vlen, int32_t k,
-                          uint8_t *keep, int32_t *r_cls, int32_t *r_rel, int32_t *r_e0, int32_t *r_e1);
+                          const phi_ent_t *cls_rep, const uint8_t *cls_left, const int32_t *walk_vtx, const int32_t *vlen, int32_t k,
+                          uint8_t *keep, int32_t *r_cls, int32_t *r_rel, phi_ent_t *r_e0, phi_ent_t *r_e1);
 void phi_launch_class_rec_gather(hipStream_t st, const int32_t *idx, int64_t n, const uint64_t *raw_hash, const int32_t *r_cls,
-                                 const int32_t *r_rel, const int32_t *r_e0, const int32_t *r_e1, uint64_t *o_hash, int32_t *o_cls,
-                                 int32_t *o_rel, int32_t *o_e0, int32_t *o_e1);
+                                 const int32_t *r_rel, const phi_ent_t *r_e0, const phi_ent_t *r_e1, uint64_t *o_hash, int32_t *o_cls,
+                                 int32_t *o_rel, phi_ent_t *o_e0, phi_ent_t *o_e1);
 void phi_launch_class_rec_off(hipStream_t st, const int32_t *rec_cls, int64_t n_rec, int64_t n_cls, int32_t *off);
 int64_t phi_expand_num_blocks(int64_t n_entries);
 void phi_launch_expand_count(hipStream_t st, const PhiExpandArgs &A);
@@ -163,8 +169,8 @@ void phi_launch_walk_edges(hipStream_t st, const int32_t *walk_vtx, const int64_
                            const int64_t *adj_off, const int32_t *adj, const int64_t *seq_off, const int32_t *topo_rank,
                            uint8_t *e_out, int32_t *cnt_edge, unsigned long long *st_mask, int32_t nw64, int32_t *err);
 // CSR minimiser id -> anchor indices of a triple list (id, e0, e1): cnt / cur zeroed by the caller, off from a scan of cnt
-void phi_launch_csr_count(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, int32_t *cnt, uint32_t *err);
-void phi_launch_csr_scatter(hipStream_t st, const int32_t *triples, int64_t n, int64_t n_ids, const int32_t *off, int32_t *cur,
+void phi_launch_csr_count(hipStream_t st, const uint32_t *triples, int64_t n, int64_t n_ids, int32_t *cnt, uint32_t *err);
+void phi_launch_csr_scatter(hipStream_t st, const uint32_t *triples, int64_t n, int64_t n_ids, const int32_t *off, int32_t *cur,
                             int32_t *idx);
 void phi_launch_csr_sort(hipStream_t st, const int32_t *off, int64_t n_ids, int32_t *idx);
 int64_t phi_compact_num_blocks(int64_t n);
@@ -174,7 +180,7 @@ void phi_launch_match_flags(hipStream_t st, const uint32_t *rec_slot, int64_t n_
                             const uint8_t *hit, uint8_t *flags);
 
 struct PhiFilterArgs {
-    const uint32_t *rec_slot; const int32_t *rec_e0; const int32_t *rec_e1;   // per class record (entries of the class representative)
+    const uint32_t *rec_slot; const phi_ent_t *rec_e0; const phi_ent_t *rec_e1;   // per class record (entries of the class representative)
     const int32_t *walk_vtx;
     const int32_t *rec_cls; const int32_t *cls_mult;   // class of a record, walk entries in a class (its multiplicity)
     const int32_t *m_rec;                          // matched records (ascending)
@@ -192,9 +198,9 @@ void phi_launch_group_count(hipStream_t st, const PhiFilterArgs &A, int64_t n_ma
 void phi_launch_group_max(hipStream_t st, const PhiFilterArgs &A, int64_t n_matched);
 void phi_launch_slot_count(hipStream_t st, const PhiFilterArgs &A, int64_t u_cap);
 void phi_launch_kept_flags(hipStream_t st, const PhiFilterArgs &A, int64_t n_matched, uint8_t *kept, uint8_t *dp);
-void phi_launch_gather_i32(hipStream_t st, const int32_t *src, const int32_t *idx, int64_t n, int32_t *out);
+void phi_launch_gather_i32(hipStream_t st, const int32_t *src, const uint32_t *idx, int64_t n, int32_t *out);
 void phi_launch_gather_u64(hipStream_t st, const uint64_t *src, const int32_t *idx, int64_t n, uint64_t *out);
-void phi_launch_entry_csr(hipStream_t st, const int32_t *a_e1, int64_t n_a, int64_t n_entries, int64_t *g_off);
+void phi_launch_entry_csr(hipStream_t st, const phi_ent_t *a_e1, int64_t n_a, int64_t n_entries, int64_t *g_off);
 
 // dp.hip
 #define PHI_DP_CHUNK 128        // steps staged through LDS at a time
@@ -235,7 +241,7 @@ struct PhiDpEventArgs {
     const int32_t *k_rec;                // [n_k][8]: flags | n_in<<8, overflow start, 3 inline in-edges (compact steps back<<8 | out-edge), vertex
     const int32_t *k_in_packed;
     const int64_t *walk_off;
-    const int32_t *ev_e;                 // [n_ev] walk entry of each event, ascending
+    const phi_ent_t *ev_e;               // [n_ev] walk entry of each event, ascending
     const int64_t *ev_off;               // [n_walks + 1] first event of each walk
     // per run
     void *ev;                            // [n_ev] 48-byte event records (phi_dp_event_fill_kernel)
@@ -264,14 +270,14 @@ void phi_launch_dp_events(hipStream_t st, const PhiDpEventArgs &A);
 void phi_launch_dp_block_rows(hipStream_t st, const PhiDpEventArgs &A);
 void phi_launch_dp_block_paths(hipStream_t st, const PhiDpEventArgs &A);
 // the solve's bookkeeping on the device copy of the anchors (solve_dev.hip)
-void phi_launch_anchor_prep(hipStream_t st, const int32_t *tri, int64_t n, const int64_t *walk_off, int32_t n_walks, int32_t *a_e1, uint8_t *a_span,
+void phi_launch_anchor_prep(hipStream_t st, const uint32_t *tri, int64_t n, const int64_t *walk_off, int32_t n_walks, phi_ent_t *a_e1, uint8_t *a_span,
                             unsigned long long *walk_cnt, unsigned long long *out);
 void phi_launch_vertex_most(hipStream_t st, const int64_t *g_off, int64_t n_entries, const int32_t *walk_vtx, int32_t *vmax);
 void phi_launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long long *out);
-void phi_launch_repeat_slots(hipStream_t st, const int32_t *sa_off, const int32_t *sa_idx, const int32_t *tri, const int64_t *walk_off, int32_t n_walks,
+void phi_launch_repeat_slots(hipStream_t st, const int32_t *sa_off, const int32_t *sa_idx, const uint32_t *tri, const int64_t *walk_off, int32_t n_walks,
                              int64_t n_ids, uint8_t *flags);
 void phi_launch_zero_slots(hipStream_t st, const uint32_t *slots, int64_t n, const int32_t *sa_off, const int32_t *sa_idx, uint8_t *wgt);
-void phi_launch_path_cover(hipStream_t st, bool clear, const int32_t *segs, int32_t n_seg, const int64_t *g_off, const int32_t *tri, const uint8_t *wgt,
+void phi_launch_path_cover(hipStream_t st, bool clear, const phi_ent_t *segs, int32_t n_seg, const int64_t *g_off, const uint32_t *tri, const uint8_t *wgt,
                            int32_t *cov_all, int32_t *cov_w, unsigned long long *ctr, uint32_t *twice, int64_t twice_cap);
 void phi_launch_uncovered_slots(hipStream_t st, const uint32_t *slots, int64_t n, const int32_t *cov_all, unsigned long long *ctr, uint32_t *out);
 // more than 64 walks: the blocks' rows on class lanes (dp_events.hip)
@@ -291,16 +297,16 @@ void phi_launch_blk_chain(hipStream_t st, const PhiBlkClassArgs &G, const int32_
 void phi_launch_blk_check(hipStream_t st, const int32_t *keys, const int32_t *S, int32_t n_blk, int32_t LS, int32_t n_walks, int32_t *bad);
 void phi_launch_carry_resolve(hipStream_t st, const int32_t *carry, int32_t LS, int32_t b_from, int32_t h, int32_t *out);
 void phi_launch_dp_block_paths_wide(hipStream_t st, const PhiDpEventArgs &A);
-void phi_launch_cut_cov(hipStream_t st, const int32_t *a_e1, const uint8_t *a_span, int64_t n_a, int32_t *diff);
+void phi_launch_cut_cov(hipStream_t st, const phi_ent_t *a_e1, const uint8_t *a_span, int64_t n_a, int32_t *diff);
 void phi_launch_cut_clean(hipStream_t st, const int32_t *cov_excl, int64_t n_entries, int32_t *clean);
-void phi_launch_cut_events(hipStream_t st, const int32_t *ev_e, int64_t n_ev, const int64_t *ev_off, const int64_t *walk_off, int32_t n_walks,
+void phi_launch_cut_events(hipStream_t st, const phi_ent_t *ev_e, int64_t n_ev, const int64_t *ev_off, const int64_t *walk_off, int32_t n_walks,
                            const int32_t *walk_vtx, const int32_t *cvtx, const int32_t *ncl_excl, int32_t *stepdiff);
-void phi_launch_blk_ev(hipStream_t st, const int32_t *blk_lo, int32_t n_blk, const int32_t *ev_e, const int64_t *ev_off, int32_t n_walks,
+void phi_launch_blk_ev(hipStream_t st, const int32_t *blk_lo, int32_t n_blk, const phi_ent_t *ev_e, const int64_t *ev_off, int32_t n_walks,
                        const int32_t *walk_vtx, const int32_t *cvtx, int32_t *blk_ev);
 void phi_launch_event_flags(hipStream_t st, const int32_t *walk_vtx, int64_t n_entries, const int32_t *cvtx, uint8_t *flags);
-void phi_launch_event_off(hipStream_t st, const int32_t *ev_e, int64_t n_ev, const int64_t *walk_off, int32_t n_walks,
+void phi_launch_event_off(hipStream_t st, const phi_ent_t *ev_e, int64_t n_ev, const int64_t *walk_off, int32_t n_walks,
                           int64_t *ev_off);
-void phi_launch_dp_counts(hipStream_t st, const int32_t *a_e1, const uint8_t *a_span, const uint8_t *a_weight, int64_t n_a,
+void phi_launch_dp_counts(hipStream_t st, const phi_ent_t *a_e1, const uint8_t *a_span, const uint8_t *a_weight, int64_t n_a,
                           int32_t *cnt_end, int32_t *cnt_start);
 int64_t phi_scan_i32_num_blocks(int64_t n);
 void phi_launch_scan_i32(hipStream_t st, const int32_t *cnt, int64_t n, int32_t *off, int32_t *blk, int64_t *blk_off);

@@ -31,7 +31,7 @@ enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INM
 static uint64_t *scalar(phi_ctx *c, int i) { return c->d_scalars.as<uint64_t>() + i; }
 static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
-struct Seg { int32_t h; int32_t es, ee; };     // path segment: walk h, entries es..ee (inclusive)
+struct Seg { int32_t h; int64_t es, ee; };     // path segment: walk h, entries es..ee (inclusive)
 
 // flags[n] -> ascending indices in out; *n_out = count
 int phi_compact(phi_ctx *c, const uint8_t *flags, int64_t n, DevBuf &out, int64_t *n_out)
@@ -97,11 +97,11 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
     int32_t *d_a = c->d_off_end.as<int32_t>(), *d_b = c->d_off_start.as<int32_t>();
     HIPCHK(hipMemsetAsync(d_a, 0, (size_t)(ne + 3) * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->d_stepdiff.p, 0, (size_t)(nk + 2) * 4, c->stream));
-    phi_launch_cut_cov(c->stream, c->d_a_e1.as<int32_t>(), c->d_g_span.as<uint8_t>(), n_dp, d_a);
+    phi_launch_cut_cov(c->stream, c->d_a_e1.as<phi_ent_t>(), c->d_g_span.as<uint8_t>(), n_dp, d_a);
     phi_launch_scan_i32(c->stream, d_a, ne + 1, d_b, c->d_scan_blk.as<int32_t>(), c->d_scan_blkoff.as<int64_t>());     // d_b[e + 1] = anchors a cut before e splits
     phi_launch_cut_clean(c->stream, d_b, ne, d_a);                                                                       // d_a[e] = clean
     phi_launch_scan_i32(c->stream, d_a, ne + 1, d_b, c->d_scan_blk.as<int32_t>(), c->d_scan_blkoff.as<int64_t>());     // d_b[e] = clean entries before e
-    phi_launch_cut_events(c->stream, c->d_ev_e.as<int32_t>(), c->n_ev, c->d_ev_off.as<int64_t>(), c->d_walk_off.as<int64_t>(), c->n_walks,
+    phi_launch_cut_events(c->stream, c->d_ev_e.as<phi_ent_t>(), c->n_ev, c->d_ev_off.as<int64_t>(), c->d_walk_off.as<int64_t>(), c->n_walks,
                           c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(), d_b, c->d_stepdiff.as<int32_t>());
     std::vector<int32_t> closed((size_t)nk + 2);
     HIPCHK(hipMemcpyAsync(closed.data(), c->d_stepdiff.p, (size_t)(nk + 2) * 4, hipMemcpyDeviceToHost, c->stream));
@@ -171,7 +171,7 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
         PHICHK(phi_dev_ensure(c, c->d_blk_bad, 64));
     }
     HIPCHK(hipMemcpyAsync(c->d_blk_lo.p, c->h_blk_lo.data(), (nbk + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    phi_launch_blk_ev(c->stream, c->d_blk_lo.as<int32_t>(), c->n_blk, c->d_ev_e.as<int32_t>(), c->d_ev_off.as<int64_t>(), c->n_walks,
+    phi_launch_blk_ev(c->stream, c->d_blk_lo.as<int32_t>(), c->n_blk, c->d_ev_e.as<phi_ent_t>(), c->d_ev_off.as<int64_t>(), c->n_walks,
                       c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(), c->d_blk_ev.as<int32_t>());
     HIPCHK(hipStreamSynchronize(c->stream));                   // h_blk_lo is a member, but the launch above must have its copy
     c->dp_blocks = true;
@@ -205,7 +205,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         //  array of this size is 5 GB)
         HIPCHK(hipMemsetAsync(c->d_off_end.p, 0, (size_t)(ne + 1) * 4, c->stream));
         HIPCHK(hipMemsetAsync(c->d_off_start.p, 0, (size_t)(ne + 1) * 4, c->stream));
-        phi_launch_dp_counts(c->stream, c->d_a_e1.as<int32_t>(), c->d_g_span.as<uint8_t>(), c->d_a_weight.as<uint8_t>(), n_dp,
+        phi_launch_dp_counts(c->stream, c->d_a_e1.as<phi_ent_t>(), c->d_g_span.as<uint8_t>(), c->d_a_weight.as<uint8_t>(), n_dp,
                              c->d_off_end.as<int32_t>(), c->d_off_start.as<int32_t>());
         phi_launch_scan_i32(c->stream, c->d_off_end.as<int32_t>(), ne, c->d_off_end.as<int32_t>(), c->d_scan_blk.as<int32_t>(),
                             c->d_scan_blkoff.as<int64_t>());
@@ -215,7 +215,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         A.n_k = c->n_k; A.n_walks = c->n_walks; A.n_ev = c->n_ev;
         A.k_rec = c->d_k_rec.as<int32_t>(); A.k_in_packed = c->d_k_in.as<int32_t>();
         A.walk_off = c->d_walk_off.as<int64_t>();
-        A.ev_e = c->d_ev_e.as<int32_t>(); A.ev_off = c->d_ev_off.as<int64_t>();
+        A.ev_e = c->d_ev_e.as<phi_ent_t>(); A.ev_off = c->d_ev_off.as<int64_t>();
         A.ev = c->d_ev.p;
         A.g_off = c->d_g_off.as<int64_t>(); A.g_span = c->d_g_span.as<uint8_t>(); A.a_weight = c->d_a_weight.as<uint8_t>();
         A.cost = 2 * (c->recombination / 2);                   // (c_1/2) twice, ILP_index.cpp:1276,1299
@@ -365,7 +365,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
     // instead of downloading them per walk entry; a path with very many switches (tiny R) falls
     // back to one bulk download.
     H.ends.resize(c->n_walks);
-    phi_launch_gather_i32(c->stream, d_dmax, c->d_walk_last.as<int32_t>(), c->n_walks, c->d_list3.as<int32_t>());
+    phi_launch_gather_i32(c->stream, d_dmax, c->d_walk_last.as<phi_ent_t>(), c->n_walks, c->d_list3.as<int32_t>());
     HIPCHK(hipMemcpyAsync(H.ends.data(), c->d_list3.p, (size_t)c->n_walks * 4, hipMemcpyDeviceToHost, c->stream));
     uint32_t kerr = 0;
     if (events) HIPCHK(hipMemcpyAsync(&kerr, c->d_scalars.as<uint64_t>() + S_ERR, 4, hipMemcpyDeviceToHost, c->stream));
@@ -426,7 +426,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         }
         const int64_t es = c->h_walk_off[h] + bs;
         if (es < c->h_walk_off[h] || es > e) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack left the walk (internal error)");
-        segs->push_back(Seg{h, (int32_t)es, (int32_t)e});
+        segs->push_back(Seg{h, es, e});
         if (es == c->h_walk_off[h]) break;                     // reached s_{first(h),h}
         const int32_t v = c->h_walk_vtx[es];
         const int32_t step = events ? c->h_cstep[c->h_topo_rank[v]] : c->h_topo_rank[v];
@@ -463,9 +463,9 @@ template <class F> static void for_covered(const phi_ctx *c, const std::vector<S
 {
     const PhiAnchorSpan &A = c->h_dp;                         // sorted by e1
     for (const Seg &s : segs) {
-        auto lo = std::lower_bound(A.begin(), A.end(), s.es, [](const PhiAnchorHost &a, int32_t e) { return a.e1 < e; });
-        for (auto it = lo; it != A.end() && it->e1 <= s.ee; ++it)
-            if (it->e0 >= s.es) f((int64_t)(it - A.begin()));
+        auto lo = std::lower_bound(A.begin(), A.end(), s.es, [](const PhiAnchorHost &a, int64_t e) { return (int64_t)a.e1 < e; });
+        for (auto it = lo; it != A.end() && (int64_t)it->e1 <= s.ee; ++it)
+            if ((int64_t)it->e0 >= s.es) f((int64_t)(it - A.begin()));
     }
 }
 
@@ -501,7 +501,7 @@ int phi_solve_impl(phi_ctx *c)
     PhiFilterArgs F{};
     // (over the CLASS records of contexts.hip: a record stands for cls_mult walk entries; its vertex list is read
     //  at the class representative's entries)
-    F.rec_slot = c->d_rec_slot.as<uint32_t>(); F.rec_e0 = c->d_rec_e0.as<int32_t>(); F.rec_e1 = c->d_rec_e1.as<int32_t>();
+    F.rec_slot = c->d_rec_slot.as<uint32_t>(); F.rec_e0 = c->d_rec_e0.as<phi_ent_t>(); F.rec_e1 = c->d_rec_e1.as<phi_ent_t>();
     F.walk_vtx = c->d_walk_vtx.as<int32_t>();
     F.rec_cls = c->d_rec_cls.as<int32_t>(); F.cls_mult = c->d_cls_mult.as<int32_t>();
     F.m_rec = c->d_m_rec.as<int32_t>();
@@ -559,10 +559,10 @@ int phi_solve_impl(phi_ctx *c)
         phi_launch_class_sel_count(c->stream, c->d_flags2.as<uint8_t>(), c->d_cls_rec_off.as<int32_t>(), c->n_cls, c->d_list3.as<int32_t>());
         PhiExpandArgs X{};
         X.ent_cls = c->d_ent_cls.as<int32_t>(); X.e_lo = 0; X.e_hi = c->n_entries;
-        X.cls_rec_off = c->d_cls_rec_off.as<int32_t>(); X.cls_rep = c->d_cls_rep.as<int32_t>();
+        X.cls_rec_off = c->d_cls_rec_off.as<int32_t>(); X.cls_rep = c->d_cls_rep.as<phi_ent_t>();
         X.sel = c->d_flags2.as<uint8_t>(); X.sel_cnt = c->d_list3.as<int32_t>();
         X.rec_slot = c->d_rec_slot.as<uint32_t>(); X.u_uid = c->d_u_uid.as<uint32_t>();
-        X.rec_e0 = c->d_rec_e0.as<int32_t>(); X.rec_e1 = c->d_rec_e1.as<int32_t>();
+        X.rec_e0 = c->d_rec_e0.as<phi_ent_t>(); X.rec_e1 = c->d_rec_e1.as<phi_ent_t>();
         const int64_t nb = phi_expand_num_blocks(c->n_entries);
         PHICHK(phi_dev_ensure(c, c->d_blk_cnt, (size_t)nb * 4));
         PHICHK(phi_dev_ensure(c, c->d_blk_off, (size_t)(nb + 1) * 8));
@@ -578,14 +578,14 @@ int phi_solve_impl(phi_ctx *c)
         PHICHK(phi_dev_ensure(c, c->d_anchors, (size_t)std::max<int64_t>(n_kept, 1) * 12));
         static_assert(sizeof(PhiAnchorHost) == 12, "PhiAnchorHost is the device triple");
         if (n_kept) {
-            X.out_tri = c->d_anchors.as<int32_t>();
+            X.out_tri = c->d_anchors.as<uint32_t>();
             phi_launch_expand_write(c->stream, X, 1);
         }
     }
     // The DP's per-anchor arrays (last entry, span), the anchors per walk and the checks on them, on the device.
     // A large model whose anchors all span an edge (vertices shorter than k: every graph chopped to 30 bp) stays
     // there: the host copy (6 GB at 5 * 10^8 anchors) is fetched only if the branch and bound proper needs it.
-    const int32_t *d_tri = c->d_anchors.as<int32_t>();
+    const uint32_t *d_tri = c->d_anchors.as<uint32_t>();
     bool dev = false;
     {
         PHICHK(phi_dev_ensure(c, c->d_a_e1, (size_t)std::max<int64_t>(n_kept, 1) * 4));
@@ -593,7 +593,7 @@ int phi_solve_impl(phi_ctx *c)
         PHICHK(phi_dev_ensure(c, c->d_ctr, (size_t)(nw + 8) * 8));
         HIPCHK(hipMemsetAsync(c->d_ctr.p, 0, (size_t)(nw + 8) * 8, c->stream));
         unsigned long long *d_ctr = c->d_ctr.as<unsigned long long>();
-        phi_launch_anchor_prep(c->stream, d_tri, n_kept, c->d_walk_off.as<int64_t>(), nw, c->d_a_e1.as<int32_t>(), c->d_g_span.as<uint8_t>(), d_ctr + 8, d_ctr);
+        phi_launch_anchor_prep(c->stream, d_tri, n_kept, c->d_walk_off.as<int64_t>(), nw, c->d_a_e1.as<phi_ent_t>(), c->d_g_span.as<uint8_t>(), d_ctr + 8, d_ctr);
         std::vector<unsigned long long> hc((size_t)nw + 8);
         HIPCHK(hipMemcpyAsync(hc.data(), d_ctr, hc.size() * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -620,7 +620,7 @@ int phi_solve_impl(phi_ctx *c)
     tm.lap(dev ? "anchor arrays (device)" : "anchors D2H");
     // dp anchors (span >= 1 edge; single-vertex anchors are ignored, :795/:846), anchors per walk and the
     // DP's per-anchor arrays: host threads over chunks of the kept list, order preserved
-    std::vector<int32_t> a_e1;
+    std::vector<phi_ent_t> a_e1;
     std::vector<uint8_t> a_span;
     std::vector<int16_t> dp_walk;                              // walk of every dp anchor
     if (dev) c->n_dp = n_kept;
@@ -660,7 +660,7 @@ int phi_solve_impl(phi_ctx *c)
                 while (k.e0 >= c->h_walk_off[hw + 1]) hw++;
                 if (k.e1 <= k.e0) continue;
                 dp_walk[o] = (int16_t)hw;
-                if (k.e1 - k.e0 >= PHI_RCAP) { herr.set(c->k > PHI_RCAP ? PHI_ERR_UNSUPPORTED : PHI_ERR_DEVICE, "an anchor spans %d edges (at most %d are supported)", k.e1 - k.e0, PHI_RCAP - 1); return; }
+                if (k.e1 - k.e0 >= (uint32_t)PHI_RCAP) { herr.set(c->k > PHI_RCAP ? PHI_ERR_UNSUPPORTED : PHI_ERR_DEVICE, "an anchor spans %u edges (at most %d are supported)", k.e1 - k.e0, PHI_RCAP - 1); return; }
                 if (!same) c->h_dp[o] = k;
                 a_e1[o] = k.e1;
                 a_span[o] = (uint8_t)(k.e1 - k.e0);
@@ -704,7 +704,7 @@ int phi_solve_impl(phi_ctx *c)
             HIPCHK(hipMemcpyAsync(c->d_a_e1.p, a_e1.data(), (size_t)n_dp * 4, hipMemcpyHostToDevice, c->stream));
             HIPCHK(hipMemcpyAsync(c->d_g_span.p, a_span.data(), (size_t)n_dp, hipMemcpyHostToDevice, c->stream));
         }
-        phi_launch_entry_csr(c->stream, c->d_a_e1.as<int32_t>(), n_dp, c->n_entries, c->d_g_off.as<int64_t>());
+        phi_launch_entry_csr(c->stream, c->d_a_e1.as<phi_ent_t>(), n_dp, c->n_entries, c->d_g_off.as<int64_t>());
         if (dev && n_dp >= ((int64_t)1 << 27)) {
             // the score range, as above: sum over vertices of the most anchors that end there on one walk
             PHICHK(phi_dev_ensure(c, c->d_vmax, (size_t)c->n_vtx * 4));
@@ -719,8 +719,8 @@ int phi_solve_impl(phi_ctx *c)
         }
         HIPCHK(hipStreamSynchronize(c->stream));
         {
-            std::vector<int32_t> last(nw);
-            for (int32_t h = 0; h < nw; h++) last[h] = (int32_t)(c->h_walk_off[h + 1] - 1);
+            std::vector<phi_ent_t> last(nw);
+            for (int32_t h = 0; h < nw; h++) last[h] = (phi_ent_t)(c->h_walk_off[h + 1] - 1);
             PHICHK(phi_dev_ensure(c, c->d_walk_last, (size_t)nw * 4));
             PHICHK(phi_dev_ensure(c, c->d_list3, (size_t)nw * 4));
             HIPCHK(phi_copy_sync(c, c->d_walk_last.p, last.data(), (size_t)nw * 4, hipMemcpyHostToDevice));
@@ -754,7 +754,7 @@ int phi_solve_impl(phi_ctx *c)
     if (dp_is_kept && n_dp > 0) {
         // the dp list is the kept list, whose triples are on the device: count / scan / scatter /
         // sort there (1-2 ms for 10^7 anchors; the host loop below takes 4 ms per million)
-        const int32_t *tri = d_tri;
+        const uint32_t *tri = d_tri;
         PHICHK(phi_dev_ensure(c, c->d_sa_cnt, (size_t)(n_ids + 1) * 4));
         PHICHK(phi_dev_ensure(c, c->d_sa_cur, (size_t)(n_ids + 1) * 4));
         PHICHK(phi_dev_ensure(c, c->d_sa_off, (size_t)(n_ids + 2) * 4));
@@ -946,18 +946,18 @@ int phi_solve_impl(phi_ctx *c)
             std::set<uint32_t> D, Z;
             if (dev) {
                 // cover counts per minimiser on the device; back come the two sums and the two short lists
-                std::vector<int32_t> sg(segs.size() * 2);
-                for (size_t i = 0; i < segs.size(); i++) { sg[2 * i] = segs[i].es; sg[2 * i + 1] = segs[i].ee; }
+                std::vector<phi_ent_t> sg(segs.size() * 2);
+                for (size_t i = 0; i < segs.size(); i++) { sg[2 * i] = (phi_ent_t)segs[i].es; sg[2 * i + 1] = (phi_ent_t)segs[i].ee; }
                 const int64_t twice_cap = (int64_t)1 << 22;
                 PHICHK(phi_dev_ensure(c, c->d_segs, std::max<size_t>(sg.size(), 2) * 4));
                 PHICHK(phi_dev_ensure(c, c->d_list, (size_t)twice_cap * 4));
                 unsigned long long *d_ctr = c->d_ctr.as<unsigned long long>();
                 HIPCHK(hipMemcpyAsync(c->d_segs.p, sg.data(), sg.size() * 4, hipMemcpyHostToDevice, c->stream));
                 HIPCHK(hipMemsetAsync(d_ctr, 0, 32, c->stream));
-                phi_launch_path_cover(c->stream, false, c->d_segs.as<int32_t>(), (int32_t)segs.size(), c->d_g_off.as<int64_t>(), d_tri, c->d_a_weight.as<uint8_t>(),
+                phi_launch_path_cover(c->stream, false, c->d_segs.as<phi_ent_t>(), (int32_t)segs.size(), c->d_g_off.as<int64_t>(), d_tri, c->d_a_weight.as<uint8_t>(),
                                       c->d_cov_all.as<int32_t>(), c->d_cov_w.as<int32_t>(), d_ctr, c->d_list.as<uint32_t>(), twice_cap);
                 phi_launch_uncovered_slots(c->stream, c->d_slots.as<uint32_t>(), (int64_t)Sv.size(), c->d_cov_all.as<int32_t>(), d_ctr, c->d_slots2.as<uint32_t>());
-                phi_launch_path_cover(c->stream, true, c->d_segs.as<int32_t>(), (int32_t)segs.size(), c->d_g_off.as<int64_t>(), d_tri, c->d_a_weight.as<uint8_t>(),
+                phi_launch_path_cover(c->stream, true, c->d_segs.as<phi_ent_t>(), (int32_t)segs.size(), c->d_g_off.as<int64_t>(), d_tri, c->d_a_weight.as<uint8_t>(),
                                       c->d_cov_all.as<int32_t>(), c->d_cov_w.as<int32_t>(), d_ctr, c->d_list.as<uint32_t>(), twice_cap);
                 unsigned long long hc[4];
                 HIPCHK(hipMemcpyAsync(hc, d_ctr, 32, hipMemcpyDeviceToHost, c->stream));
@@ -1041,7 +1041,7 @@ int phi_solve_impl(phi_ctx *c)
     tm.lap("DP runs + certificate");
     // ---- 5. decode (:1431-1525)
     int64_t n_path_vtx = 0;
-    for (const Seg &s : best_segs) n_path_vtx += (int64_t)s.ee - s.es + 1;
+    for (const Seg &s : best_segs) n_path_vtx += s.ee - s.es + 1;
     c->h_path_vtx.resize((size_t)n_path_vtx);
     c->h_path_hap.resize((size_t)n_path_vtx);
     int64_t hap_len = 0;
@@ -1050,8 +1050,8 @@ int phi_solve_impl(phi_ctx *c)
         for (const Seg &s : best_segs) {
             memcpy(c->h_path_vtx.data() + o, c->h_walk_vtx.data() + s.es, (size_t)(s.ee - s.es + 1) * 4);
             std::fill(c->h_path_hap.begin() + o, c->h_path_hap.begin() + o + (s.ee - s.es + 1), s.h);
-            for (int32_t e = s.es; e <= s.ee; e++) { const int32_t v = c->h_walk_vtx[e]; hap_len += c->h_seq_off[v + 1] - c->h_seq_off[v]; }
-            o += (int64_t)s.ee - s.es + 1;
+            for (int64_t e = s.es; e <= s.ee; e++) { const int32_t v = c->h_walk_vtx[e]; hap_len += c->h_seq_off[v + 1] - c->h_seq_off[v]; }
+            o += s.ee - s.es + 1;
         }
     }
     // adjacent label changes (:1517-1519): the labels change exactly between the path's stretches

@@ -41,18 +41,18 @@ __device__ __forceinline__ void wave_count(bool pred, unsigned long long *ctr)
 
 // ---- the DP's per-anchor arrays, the anchors per walk, and what would make the device path unusable
 // out[0] = anchors inside one vertex (e1 <= e0: not dp anchors), out[1] |= 1 unsorted, |= 2 span >= PHI_RCAP
-__global__ void __launch_bounds__(256) phi_anchor_prep_kernel(const int32_t *__restrict__ tri, int64_t n, const int64_t *__restrict__ walk_off,
-                                                              int32_t n_walks, int32_t *__restrict__ a_e1, uint8_t *__restrict__ a_span,
+__global__ void __launch_bounds__(256) phi_anchor_prep_kernel(const uint32_t *__restrict__ tri, int64_t n, const int64_t *__restrict__ walk_off,
+                                                              int32_t n_walks, phi_ent_t *__restrict__ a_e1, uint8_t *__restrict__ a_span,
                                                               unsigned long long *__restrict__ walk_cnt, unsigned long long *__restrict__ out)
 {
     GRID_STRIDE(i0, (n + 63) & ~(int64_t)63) {
         const bool in = i0 < n;
         const int64_t i = in ? i0 : n - 1;
-        const int32_t e0 = tri[i * 3 + 1], e1 = tri[i * 3 + 2];
+        const phi_ent_t e0 = tri[i * 3 + 1], e1 = tri[i * 3 + 2];
         wave_count(in && e1 <= e0, &out[0]);
         uint32_t bad = 0;
         if (in && i > 0 && e1 < tri[(i - 1) * 3 + 2]) bad |= 1u;
-        if (in && e1 - e0 >= PHI_RCAP) bad |= 2u;
+        if (in && e1 > e0 && e1 - e0 >= PHI_RCAP) bad |= 2u;
         if (bad) atomicOr(&out[1], (unsigned long long)bad);
         if (in) { a_e1[i] = e1; a_span[i] = (uint8_t)(e1 > e0 ? e1 - e0 : 0); }
         // anchors come in walk order: a wave is almost always inside one walk
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) phi_anchor_prep_kernel(const int32_t *__r
         else if (in) atomicAdd(&walk_cnt[h], 1ull);
     }
 }
-void phi_launch_anchor_prep(hipStream_t st, const int32_t *tri, int64_t n, const int64_t *walk_off, int32_t n_walks, int32_t *a_e1, uint8_t *a_span,
+void phi_launch_anchor_prep(hipStream_t st, const uint32_t *tri, int64_t n, const int64_t *walk_off, int32_t n_walks, phi_ent_t *a_e1, uint8_t *a_span,
                             unsigned long long *walk_cnt, unsigned long long *out)
 {
     if (n > 0) hipLaunchKernelGGL(phi_anchor_prep_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, tri, n, walk_off, n_walks, a_e1, a_span, walk_cnt, out);
@@ -95,7 +95,7 @@ void phi_launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned lo
 
 // ---- minimisers with two anchors on one walk (adjacent in the minimiser's anchor list, which is in walk order)
 __global__ void __launch_bounds__(256) phi_repeat_slots_kernel(const int32_t *__restrict__ sa_off, const int32_t *__restrict__ sa_idx,
-                                                               const int32_t *__restrict__ tri, const int64_t *__restrict__ walk_off, int32_t n_walks,
+                                                               const uint32_t *__restrict__ tri, const int64_t *__restrict__ walk_off, int32_t n_walks,
                                                                int64_t n_ids, uint8_t *__restrict__ flags)
 {
     GRID_STRIDE(u, n_ids) {
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) phi_repeat_slots_kernel(const int32_t *__
         flags[u] = f;
     }
 }
-void phi_launch_repeat_slots(hipStream_t st, const int32_t *sa_off, const int32_t *sa_idx, const int32_t *tri, const int64_t *walk_off, int32_t n_walks,
+void phi_launch_repeat_slots(hipStream_t st, const int32_t *sa_off, const int32_t *sa_idx, const uint32_t *tri, const int64_t *walk_off, int32_t n_walks,
                              int64_t n_ids, uint8_t *flags)
 {
     if (n_ids > 0)
@@ -136,19 +136,19 @@ void phi_launch_zero_slots(hipStream_t st, const uint32_t *slots, int64_t n, con
 //        minimisers covered, ctr[2] = length of `twice` = minimisers whose weight-1 anchors are covered at least twice.
 // CLEAR: the same anchors again, their counters back to zero.
 template <bool CLEAR>
-__global__ void __launch_bounds__(256) phi_path_cover_kernel(const int32_t *__restrict__ segs, int32_t n_seg, const int64_t *__restrict__ g_off,
-                                                             const int32_t *__restrict__ tri, const uint8_t *__restrict__ wgt,
+__global__ void __launch_bounds__(256) phi_path_cover_kernel(const phi_ent_t *__restrict__ segs, int32_t n_seg, const int64_t *__restrict__ g_off,
+                                                             const uint32_t *__restrict__ tri, const uint8_t *__restrict__ wgt,
                                                              int32_t *__restrict__ cov_all, int32_t *__restrict__ cov_w,
                                                              unsigned long long *__restrict__ ctr, uint32_t *__restrict__ twice, int64_t twice_cap)
 {
     for (int32_t q = blockIdx.y; q < n_seg; q += gridDim.y) {
-        const int32_t es = segs[2 * q], ee = segs[2 * q + 1];
+        const phi_ent_t es = segs[2 * q], ee = segs[2 * q + 1];
         const int64_t lo = g_off[es], hi = g_off[(int64_t)ee + 1];
         const int64_t span = (hi - lo + 63) & ~(int64_t)63;
         for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < span; i0 += (int64_t)gridDim.x * blockDim.x) {
             const int64_t a = lo + i0;
             const bool in = a < hi && tri[a * 3 + 1] >= es;
-            const uint32_t s = in ? (uint32_t)tri[a * 3] : 0;
+            const uint32_t s = in ? tri[a * 3] : 0;
             if (CLEAR) {
                 if (in) { cov_all[s] = 0; cov_w[s] = 0; }
                 continue;
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) phi_path_cover_kernel(const int32_t *__re
         }
     }
 }
-void phi_launch_path_cover(hipStream_t st, bool clear, const int32_t *segs, int32_t n_seg, const int64_t *g_off, const int32_t *tri, const uint8_t *wgt,
+void phi_launch_path_cover(hipStream_t st, bool clear, const phi_ent_t *segs, int32_t n_seg, const int64_t *g_off, const uint32_t *tri, const uint8_t *wgt,
                            int32_t *cov_all, int32_t *cov_w, unsigned long long *ctr, uint32_t *twice, int64_t twice_cap)
 {
     if (n_seg <= 0) return;
