@@ -34,6 +34,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+# sketch.hip: the read kernel loops over a wave's chunks at exactly 80 VGPRs (six waves per SIMD); hoisting constants and
+# addresses out of that loop (machine LICM) keeps them in registers through every turn and pushes others into scratch
+EXTRA_FLAGS = {"sketch.hip": ["-mllvm", "-disable-machine-licm"]}
+
+
 def build_device(force=False):
     objdir = os.path.join(ROOT, "build", "obj")
     os.makedirs(objdir, exist_ok=True)
@@ -43,8 +48,8 @@ def build_device(force=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-                  "-c", s, "-o", o])
+            _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+                 + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
         objs.append(o)
     lib = os.path.join(ROOT, "phi_amd", "libphi_amd.so")
     if force or _stale(lib, objs):

@@ -66,6 +66,7 @@ struct PhiSketchArgs {
     int32_t uniform_len;                   // > 0: every read has this length (>= 32) and there are NO offsets: read r starts at r * uniform_len
     double inv_len;                        // 1.0 / uniform_len
     uint32_t inv_len_q32;                  // floor(2^32 / uniform_len)
+    int32_t wave_stride;                   // reads, k <= 32: wave g takes the chunks g, g + wave_stride, ... (set by the launcher)
     // ... and, in the first launch after a reset, every wave also empties its share of the buffers the PREVIOUS
     // generation of reads filled (the other half of the context's double buffers), for the generation after this one
     int32_t q_clean, q_full;

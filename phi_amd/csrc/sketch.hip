@@ -218,7 +218,8 @@ __device__ __forceinline__ MinEnt take_right(MinEnt a, MinEnt b) { return (b.v <
 // that resembles the graph never pay the atomic.
 // returns the spectrum slot it filled, or PHI_NO_SLOT (the set has fewer than 2^32 slots)
 #define PHI_NO_SLOT 0xFFFFFFFFu
-__device__ __forceinline__ uint32_t probe_tables(const PhiSketchArgs &A, uint64_t h, int &n_new)
+struct ProbeArgs { const uint64_t *u_kv; uint64_t u_mask; uint8_t *hit; uint64_t *sp_keys; uint64_t sp_mask; uint32_t *err; };
+__device__ __forceinline__ uint32_t probe_tables(const ProbeArgs &A, uint64_t h, int &n_new)
 {
     if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return PHI_NO_SLOT; }
     uint64_t su = h & A.u_mask;
@@ -247,6 +248,23 @@ __device__ __forceinline__ uint32_t probe_tables(const PhiSketchArgs &A, uint64_
         ss = (ss + 1) & A.sp_mask;
     }
     return PHI_NO_SLOT;
+}
+
+__device__ __forceinline__ uint32_t probe_tables(const PhiSketchArgs &A, uint64_t h, int &n_new)
+{
+    const ProbeArgs P{A.u_kv, A.u_mask, A.hit, A.sp_keys, A.sp_mask, A.err};
+    return probe_tables(P, h, n_new);
+}
+// The kernel's arguments where the launch put them (the kernarg segment; the one struct parameter sits at its start), through
+// a pointer the compiler cannot see through: what is read this way is loaded (scalar loads) where it is used instead of
+// living in scalar registers from the start of the kernel -- the read kernel's loop over a wave's chunks runs with every
+// scalar register taken, and each value too many costs v_writelane / v_readlane pairs in every turn.
+typedef const __attribute__((address_space(4))) PhiSketchArgs *KArgs;
+__device__ __forceinline__ KArgs kargs_now()
+{
+    KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
 }
 
 // "something filled a spectrum slot without logging it": a flag thousands of waves may want to raise at
@@ -495,7 +513,8 @@ __device__ __forceinline__ CleanLoad clean_issue(const PhiSketchArgs &A, int64_t
     }
     return c;
 }
-__device__ __forceinline__ void clean_finish(const PhiSketchArgs &A, int64_t gw, int64_t n_waves, int lane, const CleanLoad &c)
+template <class AT>
+__device__ __forceinline__ void clean_finish(const AT &A, int64_t gw, int64_t n_waves, int lane, const CleanLoad &c)
 {
     if (gw == 0 && lane == 0 && A.dirty_zero) *A.dirty_zero = 0;        // the flag of the generation after this one
     if (A.q_sp_keys) {
@@ -553,7 +572,9 @@ __device__ __forceinline__ void start_bits_from_offsets(const PhiSketchArgs &A, 
         // the distance in bases from its middle offset, over the mean length -- and probe 64 reads there
         int64_t vm = __shfl(pr.v, 32, 64);
         if (vm == INT64_MAX) vm = A.n_bases;
-        const double mean = (double)A.n_bases / (double)A.n_reads;
+        int64_t nb_all = A.n_bases, nr_all = A.n_reads;
+        asm volatile("" : "+s"(nb_all), "+s"(nr_all));    // (not hoisted out of the loop over a wave's chunks: a division kept in registers through every turn)
+        const double mean = (double)nb_all / (double)nr_all;
         int64_t g = pr.base + 32 + (int64_t)((double)(lo_b - vm) / mean) - 24;
         g = g < 0 ? 0 : (g > A.n_reads - 63 ? (A.n_reads - 63 > 0 ? A.n_reads - 63 : 0) : g);
         const int64_t idx = g + lane;
@@ -622,6 +643,20 @@ __device__ __forceinline__ void start_bits_uniform(const PhiSketchArgs &A, int64
     if (p < hi_b && p < A.n_bases) set_start_bit(s_bits, p, org);  // (64 lanes cover the range: L >= 32 > 1024 / 63)
 }
 
+// phase 0 of a read chunk: lane -> the 16 bases c0 - 32 + 16 lane .. + 15 as four words ('A' beyond the batch)
+__device__ __forceinline__ uint4 load_bases16(const uint8_t *__restrict__ ascii, int64_t N, int64_t c0, int lane)
+{
+    const int64_t b = c0 - 32 + 16 * (int64_t)lane;
+    if (b >= 0 && b + 16 <= N && (((uintptr_t)ascii + (uintptr_t)b) & 15) == 0) return *reinterpret_cast<const uint4 *>(ascii + b);
+    uint32_t x[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+    if (b + 16 > 0 && b < N) {
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (b + j >= 0 && b + j < N) x[j >> 2] = (x[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((uint32_t)ascii[b + j] << (8 * (j & 3)));
+    }
+    return make_uint4(x[0], x[1], x[2], x[3]);
+}
+
 // WIDE: w > Q (windows of one lane overlap in a common core); otherwise brute force per window.
 // KT/WT: compile-time k and w of the specialised instance (0 = take them from the arguments).
 template <int MODE, bool WIDE, int KT, int WT>
@@ -630,23 +665,35 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     constexpr bool FUSED = MODE == PHI_MODE_PROBE;      // read batches come as ASCII + read offsets (see phase 0)
     constexpr bool NEED_POS = MODE == PHI_MODE_WRITE;   // only the ordered write stores positions (ILP_index.cpp:423)
     constexpr bool FMIN = !NEED_POS && KT > 0 && KT <= 31;   // values < 2^62: minima by v_min_f64
+    // POOL (reads, k <= 32): wave g of A.wave_stride takes the chunks g, g + stride, g + 2 stride, ... and hashes their items
+    // in rounds of 64 FULL lanes -- the items a round leaves over (fewer than 64) wait in one register pair per lane for
+    // the next chunk's.  A chunk of short reads yields ~40 items: hashed chunk by chunk the rounds run at 61 % of their
+    // lanes.  The launcher makes the stride at most the number of waves the machine holds at once: every
+    // wave then has the same number of chunks, give or take one, and the launch has no tail of a few late waves.
+    constexpr bool POOL = FUSED && KT >= 0;
     extern __shared__ uint64_t s_dyn[];
 
     // (wid stays a vector register: as a scalar -- readfirstlane -- the values derived from it overflow the SGPR file,
     //  +9 % VALU instructions of v_writelane / v_readlane traffic; reading the output phase's arguments late, through
     //  a laundered kernarg pointer, frees the SGPRs but pushes four VGPRs into scratch at the 80-register bound: -35 %)
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k = KT > 0 ? KT : A.k, w = WT ? WT : A.w;       // (KT = -1: the instantiation for k > 32, see below)
     const int64_t N = A.n_bases;
-    const int64_t chunk = (int64_t)blockIdx.x * (TPB / 64) + wid;
-    const int64_t c0 = chunk * WCH;                       // first window start of this chunk
+    const int64_t n_chunks_all = (N + WCH - 1) / WCH;
+    const int64_t stride = POOL ? (int64_t)A.wave_stride : n_chunks_all;
     // read batches, first launch after a reset: this wave's share of the buffers the previous generation of
-    // reads filled (stores into buffers nothing in this launch reads: no ordering needed)
+    // reads filled (stores into buffers nothing in this launch reads: no ordering needed).  Its loads are issued when
+    // the wave starts
     CleanLoad cl{};
-    if (FUSED && A.q_clean) cl = clean_issue(A, chunk, lane);
-    if (c0 >= N) {                                        // wave-uniform
-        if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
-        return;
+    int mine;                                             // chunks of this wave (wave-uniform)
+    {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + wid;      // this wave's job
+        if (FUSED && A.q_clean) cl = clean_issue(A, gw, lane);
+        if (gw >= n_chunks_all || (POOL && gw >= stride)) {      // wave-uniform
+            if (FUSED && A.q_clean) clean_finish(A, gw, (int64_t)gridDim.x * (TPB / 64), lane, cl);
+            return;
+        }
+        mine = POOL ? __builtin_amdgcn_readfirstlane((int)((n_chunks_all - gw + stride - 1) / stride)) : 1;
     }
     const uint64_t kmask = phi_kmask(k);
     const int M = WCH + w;                                // canonical values m[l], l -> k-mer c0-1+l
@@ -656,28 +703,62 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     using MetaT = typename std::conditional<NEED_POS, uint32_t, uint16_t>::type;
     constexpr uint32_t ITEM_FIRST = NEED_POS ? 1u << 31 : 1u << 15;        // the first window of its sequence
     constexpr uint32_t ITEM_NOEMIT = NEED_POS ? 1u << 30 : 1u << 14;       // only its hash is needed (the window before a candidate)
+    int n_emit = 0, n_log = 0, n_new_slow = 0;
+    // POOL: the items waiting for a full round -- lane j < pend holds item j: its minimum and its flags (for k <= 31 in
+    // the two bits a value leaves free) -- and the hash of the last item hashed
+    uint64_t pv = 0;
+    uint32_t pf = 0;
+    int pend = 0;
+    uint64_t carry = PHI_EMPTY_KEY;
+
+#if PHI_ABL == 7
+    if (POOL && (threadIdx.x & 63) == 0) A.out_pos[2 * ((int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6))] = (int64_t)wall_clock64();
+#endif
+    uint4 xn = make_uint4(0, 0, 0, 0);                    // POOL: the 16 bases of this lane in the NEXT chunk, loaded a turn ahead
+    if (POOL) {
+        const int64_t gw0 = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+        xn = load_bases16(A.ascii, N, gw0 * WCH, (int)(threadIdx.x & 63));
+    }
+    // (POOL: one more turn after the wave's last chunk, for the round of the items still waiting -- so that the code of a
+    //  round exists once)
+    for (int ci = 0; ci < mine + (POOL ? 1 : 0); ci++) {
+    // (POOL: what depends on the lane is worked out again in every turn -- the compiler would otherwise keep all of it,
+    //  addresses, masks, the chunk's 64-bit position, in registers across the loop: 106 VGPRs in scratch at the
+    //  80-register bound)
+    uint32_t tid = threadIdx.x;
+    if (POOL) asm volatile("" : "+v"(tid));
+    // (POOL: the wave's index as a scalar -- the chunk's position and the wave's LDS region are scalar arithmetic then)
+    const int lane = (int)(tid & 63u), wid = POOL ? __builtin_amdgcn_readfirstlane((int)(tid >> 6)) : (int)(tid >> 6);
+    const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + wid;
+    const int64_t chunk = gw + ci * stride;
+    const int64_t c0 = chunk * WCH;                       // first window start of this chunk
+    int ncand = 0, n_new = 0;                             // (n_new: per-lane count kept by probe_tables, unused here)
+    bool chunk_bad = false;
+    int64_t out_base = 0;
     uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w, k, NEED_POS);   // k-mers; later the window minima
     uint64_t *s_words = s_mp + phi_wave_mp_u64(w);
     unsigned long long *s_bits = (unsigned long long *)(s_words + SWW);
     unsigned long long *s_bad = s_bits + SBW;
     MetaT *s_meta = (MetaT *)(s_bad + SBW);               // WCH + 1 items + 8 trash slots
     uint64_t *s_q = s_mp + lane * (Q + 1);                // SM(lane * Q + x) == s_q[x + (x >> 3)]
-
+    if (ci) wave_sync();                                  // the rounds of the chunk before have read its items
+    if (!POOL || ci < mine) {
     // ---- phase 0: stage the chunk's packed words and bitmaps (the only global reads up to the
     //      output phase).  Local base lb <-> base c0-32+lb; local bit lp <-> base c0-64+lp.
     unsigned long long my_bad = 0;
     StartProbe probe{};
     if (FUSED) {
         // straight from ASCII: lane -> 16 bases = one 32-bit half of a packed word + 16 flags of bases outside ACGTacgt
-        const int64_t b = c0 - 32 + 16 * (int64_t)lane;
-        uint32_t x[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};      // beyond the batch: 'A'
-        if (b >= 0 && b + 16 <= N && (((uintptr_t)A.ascii + (uintptr_t)b) & 15) == 0) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(A.ascii + b);
+        uint32_t x[4];
+        if (POOL) {
+            // this chunk's bases were asked for a turn ago; ask for the next chunk's now: the load travels under this
+            // turn's arithmetic (the waves of a SIMD run their turns nearly in step -- a load at the top of a turn finds
+            // no other wave to hide behind)
+            x[0] = xn.x; x[1] = xn.y; x[2] = xn.z; x[3] = xn.w;
+            if (ci + 1 < mine) xn = load_bases16(A.ascii, N, c0 + stride * WCH, lane);
+        } else {
+            const uint4 v = load_bases16(A.ascii, N, c0, lane);
             x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-        } else if (b + 16 > 0 && b < N) {
-#pragma unroll
-            for (int j = 0; j < 16; j++)
-                if (b + j >= 0 && b + j < N) x[j >> 2] = (x[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((uint32_t)A.ascii[b + j] << (8 * (j & 3)));
         }
         if (!A.uniform_len) probe = start_probe_issue(A, c0, lane);   // the first probe of the read-start search travels with the bases
         uint32_t code = 0, bad = 0;
@@ -713,11 +794,9 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
             s_bad[lane - SWW - SBW] = my_bad;
         }
     }
-    const bool chunk_bad = have_bad && __ballot(my_bad != 0) != 0ull;   // wave-uniform
+    chunk_bad = have_bad && __ballot(my_bad != 0) != 0ull;   // wave-uniform
     wave_sync();
 
-    int n_emit = 0, n_new = 0, n_log = 0, n_new_slow = 0;   // (n_new: per-lane count kept by probe_tables, unused here)
-    int64_t out_base = 0;
     if (MODE == PHI_MODE_WRITE) out_base = A.block_off[chunk];
 
 #if PHI_ABL == 10
@@ -987,7 +1066,7 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
       asm volatile("" :: "v"(acc)); return; }
 #endif
     // wave prefix sum of the per-lane candidate counts
-    int ncand, coff;
+    int coff;
     {
         const int cnt = __popc(cflag) + __popc(pflag);
         const int v = wave_scan_inclusive(cnt);
@@ -1044,7 +1123,65 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
 #if PHI_ABL == 2
     ncand = 0;
 #endif
-    if (ncand > 0) {
+    }   // phases 0 - 3b of a chunk
+    if (POOL) {
+        // items of this chunk: 0 .. ncand (none when it has no candidate, none in the last turn).  Full rounds while there
+        // are 64 items between the waiting ones and these; what is left joins (or becomes) the waiting ones; the last
+        // turn's round takes the waiting ones as they are
+        const int n_items = ncand > 0 ? ncand + 1 : 0;
+        const bool flush = ci == mine;
+        int taken = 0;
+        while (pend + (n_items - taken) >= 64 || (flush && pend > 0)) {
+            uint64_t v = pv;
+            uint32_t f = pf;
+            if (lane >= pend && !flush) {
+                const uint32_t meta = s_meta[taken + lane - pend];
+                v = SM((int)(meta & 0x3FFu));
+                f = meta >> 14;                           // ITEM_FIRST, ITEM_NOEMIT: bits 15, 14 of a 16-bit item
+                if (FMIN) v |= (uint64_t)f << 62;
+            }
+            const bool valid = !flush || lane < pend;
+            taken += 64 - pend;
+            pend = 0;
+            // one round: hash, hash-change test against the item before, probes, slot log
+            const uint64_t h = phi_kmer_hash(FMIN ? (v & 0x3FFFFFFFFFFFFFFFull) : v, k);
+            const uint32_t flg = FMIN ? (uint32_t)(v >> 62) : f;              // bit 1: first window of its sequence, bit 0: only its hash is needed
+            const uint64_t hp = wave_prev_u64(h, carry, lane);
+            carry = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), 63) << 32) |
+                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, 63);
+            const bool emit = valid && !(flg & 1u) && ((flg & 2u) || h != hp);
+            const unsigned long long bal = __ballot(emit);
+            uint32_t filled = PHI_NO_SLOT;
+            const KArgs R = kargs_now();
+#if PHI_ABL == 5
+            asm volatile("" :: "v"(h));                   // (experiment: hash, no probe)
+#else
+            if (emit) {
+                const ProbeArgs P{R->u_kv, R->u_mask, R->hit, R->sp_keys, R->sp_mask, R->err};
+                filled = probe_tables(P, h, n_new);
+            }
+#endif
+            // the slots this wave fills (= its new spectrum entries, counted for the whole wave), for the next reset:
+            // logged in the entries of the wave's chunks, one after the other
+            const unsigned long long ib = __ballot(filled != PHI_NO_SLOT);
+            uint32_t *const sp_log = R->sp_log;
+            if (sp_log && filled != PHI_NO_SLOT) {
+                const int pos = n_log + __popcll(ib & ((1ull << lane) - 1));
+                // (entry pos of the wave's log: entry pos % PHI_SPLOG of its chunk number pos / PHI_SPLOG)
+                if (pos < mine * PHI_SPLOG) sp_log[(R->log_base + gw + (pos / PHI_SPLOG) * stride) * PHI_SPLOG + (pos & (PHI_SPLOG - 1))] = filled;
+            }
+            n_log += __popcll(ib);
+            n_emit += __popcll(bal);
+        }
+        const int rem = flush ? 0 : n_items - taken;      // < 64 - pend
+        if (lane >= pend && lane < pend + rem) {
+            const uint32_t meta = s_meta[taken + lane - pend];
+            pv = SM((int)(meta & 0x3FFu));
+            pf = meta >> 14;
+            if (FMIN) pv |= (uint64_t)pf << 62;
+        }
+        pend += rem;
+    } else if (ncand > 0) {
         uint64_t carry = PHI_EMPTY_KEY;
         for (int r0 = 0; r0 <= ncand; r0 += 64) {
             const int t = r0 + lane;
@@ -1091,22 +1228,36 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
         n_emit += n_emit_slow;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) n_new_lane += __shfl_xor(n_new_lane, d, 64);
-        n_new_slow = n_new_lane;
+        n_new_slow += n_new_lane;
     }
-    if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
     if (MODE == PHI_MODE_COUNT) {
         if (lane == 0) A.block_cnt[chunk] = n_emit;
-    } else if (MODE == PHI_MODE_PROBE) {
-        if (A.sp_log && lane == 0) {
-            A.sp_log_cnt[A.log_base + chunk] = (uint8_t)(n_log < PHI_SPLOG ? n_log : PHI_SPLOG);
-            if (n_log > PHI_SPLOG) raise_sp_dirty(A.sp_dirty);
+    }
+    }   // chunks of this wave
+    uint32_t tid_end = threadIdx.x;
+    if (POOL) asm volatile("" : "+v"(tid_end));           // (worked out again: not kept from the wave's start in two registers)
+    const int lane = (int)(tid_end & 63u);
+    const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + __builtin_amdgcn_readfirstlane((int)(tid_end >> 6));
+    if (POOL) {
+        const KArgs R = kargs_now();
+#if PHI_ABL == 7
+        if (lane == 0) R->out_pos[2 * gw + 1] = (int64_t)wall_clock64();
+#endif
+        if (R->q_clean) clean_finish(*R, gw, (int64_t)gridDim.x * (TPB / 64), lane, cl);
+        if (R->sp_log) {
+            // entries of the log: PHI_SPLOG per chunk of this wave, filled in order
+            for (int j = lane; j < mine; j += 64) {
+                const int left = n_log - j * PHI_SPLOG;
+                R->sp_log_cnt[R->log_base + gw + j * stride] = (uint8_t)(left < 0 ? 0 : left < PHI_SPLOG ? left : PHI_SPLOG);
+            }
+            if (lane == 0 && n_log > mine * PHI_SPLOG) raise_sp_dirty(R->sp_dirty);
         }
         // one atomic per wave for the number of new spectrum entries (n_log counts them: wave-uniform) and emitted records
         const int n_new_wave = n_log + n_new_slow;
         if (lane == 0) {
-            const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
-            if (n_new_wave) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new_wave);
-            if (n_emit && A.n_emitted) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
+            const int stripe = (int)(gw & (PHI_STRIPES - 1)) * 8;
+            if (n_new_wave) atomicAdd(R->sp_count + stripe, (unsigned long long)n_new_wave);
+            if (n_emit && R->n_emitted) atomicAdd(R->n_emitted + stripe, (unsigned long long)n_emit);
         }
     }
 }
@@ -1219,8 +1370,20 @@ void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A0, hipEve
 {
     const int64_t nchunks = phi_sketch_num_blocks(A0.n_bases);
     if (nchunks <= 0) return;
-    const PhiSketchArgs &A = A0;
-    const unsigned nb = (unsigned)((nchunks + TPB / 64 - 1) / (TPB / 64));
+    PhiSketchArgs A = A0;
+    // reads (k <= 32): wave g of `njobs` takes the chunks g, g + njobs, ...  As many waves as the machine holds at once (256
+    // CUs x 4 SIMDs x 6 waves of this kernel), or fewer so that every wave has the same number of chunks: no second round
+    // of waves, no tail
+    int64_t njobs = nchunks;
+    if (mode == PHI_MODE_PROBE && A.k <= PHI_MAX_K_PACKED) {
+        int64_t slots = 256 * 4 * 6;
+        if (const char *e = getenv("PHI_SKETCH_WAVES")) slots = atoll(e) > 0 ? atoll(e) : slots;
+        const int64_t m = (nchunks + slots - 1) / slots;          // chunks per wave
+        njobs = (nchunks + m - 1) / m;
+        if (njobs > 0x7FFFFFFF) njobs = 0x7FFFFFFF;
+        A.wave_stride = (int32_t)njobs;
+    }
+    const unsigned nb = (unsigned)((njobs + TPB / 64 - 1) / (TPB / 64));
     const size_t lds = (size_t)phi_wave_region_u64(A.w, A.k, mode == PHI_MODE_WRITE) * 8 * (TPB / 64);
     if (mode == PHI_MODE_COUNT) launch_sketch_mode<PHI_MODE_COUNT>(st, nb, lds, A, t0, t1);
     else if (mode == PHI_MODE_WRITE) launch_sketch_mode<PHI_MODE_WRITE>(st, nb, lds, A, t0, t1);
