@@ -18,8 +18,8 @@ CSRC = os.path.join(ROOT, "phi_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["sketch.hip", "table.hip", "anchors.hip", "contexts.hip", "dp.hip", "dp_events.hip", "phi_abi.hip", "phi_solve.hip", "solve_dev.hip", "phi_comm.hip", "reads_text.hip"]
-HIP_HEADERS = ["phi_dev.h", "phi_kernels.h", "phi_ctx.h", os.path.join("..", "..", "include", "phi_amd.h")]
+HIP_SOURCES = ["sketch.hip", "sketch_pooled.hip", "table.hip", "anchors.hip", "contexts.hip", "dp.hip", "dp_events.hip", "phi_abi.hip", "phi_solve.hip", "solve_dev.hip", "phi_comm.hip", "reads_text.hip"]
+HIP_HEADERS = ["phi_dev.h", "phi_kernels.h", "phi_ctx.h", "sketch.hip", "sketch_phases.inc", os.path.join("..", "..", "include", "phi_amd.h")]
 
 
 def _run(cmd, cwd=None):
@@ -34,9 +34,10 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-# sketch.hip: the read kernel loops over a wave's chunks at exactly 80 VGPRs (six waves per SIMD); hoisting constants and
-# addresses out of that loop (machine LICM) keeps them in registers through every turn and pushes others into scratch
-EXTRA_FLAGS = {"sketch.hip": ["-mllvm", "-disable-machine-licm"]}
+# sketch_pooled.hip: the read kernel's instances that loop over a wave's chunks, at exactly 80 VGPRs (six waves per SIMD);
+# hoisting constants and addresses out of that loop (machine LICM) keeps them in registers through every turn and pushes
+# others into scratch
+EXTRA_FLAGS = {"sketch_pooled.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def build_device(force=False):

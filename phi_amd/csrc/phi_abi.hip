@@ -1066,23 +1066,7 @@ int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_rea
         c->prof_used++;
         c->prof_bases += n_bases;
     }
-#ifdef PHI_TRACE_WAVES
-    // (experiment, never in the product build: start / end time of every wave of the sketch launch, 100 MHz clock)
-    static DevBuf trace; static int n_launch = 0;
-    PHICHK(phi_dev_ensure(c, trace, (size_t)(1 << 20) * 16));
-    HIPCHK(hipMemsetAsync(trace.p, 0, (size_t)(1 << 20) * 16, c->stream));
-    A.out_pos = trace.as<int64_t>();
-#endif
     phi_launch_sketch(c->stream, PHI_MODE_PROBE, A, t0, t1);
-#ifdef PHI_TRACE_WAVES
-    if (++n_launch == 20 && getenv("PHI_TRACE_OUT")) {
-        std::vector<int64_t> h((size_t)(1 << 20) * 2);
-        HIPCHK(hipStreamSynchronize(c->stream));
-        HIPCHK(hipMemcpy(h.data(), trace.p, h.size() * 8, hipMemcpyDeviceToHost));
-        FILE *f = fopen(getenv("PHI_TRACE_OUT"), "wb");
-        if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-    }
-#endif
     HIPCHK(hipGetLastError());
     if (!replay) { c->reads_bases += n_bases; c->reads_count += n_reads; }
     return PHI_OK;

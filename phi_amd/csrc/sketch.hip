@@ -84,6 +84,7 @@ static __device__ __forceinline__ void pack_ascii_word(int64_t wi, const uint8_t
     if (bad) atomicAdd(n_bad, (unsigned long long)__popc(bad));
 }
 
+#ifndef PHI_SKETCH_POOLED_TU
 __global__ void __launch_bounds__(256) phi_pack_ascii_kernel(const uint8_t *__restrict__ bases, int64_t n,
                                                              uint64_t *__restrict__ words, int64_t n_words,
                                                              uint32_t *__restrict__ badbits,
@@ -102,6 +103,8 @@ __global__ void phi_mark_starts_kernel(const int64_t *__restrict__ seq_off, int6
     if (seq_off[i + 1] > p)                 // empty sequences own no base
         atomicOr(&starts[p >> 6], 1ull << (p & 63));
 }
+
+#endif
 
 // Same bitmap, one whole word per lane: no memset, no atomics.  Word j covers bases [64j, 64j+64).
 static __device__ __forceinline__ void start_bitmap_word(int64_t j, const int64_t *__restrict__ seq_off, int64_t n_seq,
@@ -166,6 +169,7 @@ static __device__ __forceinline__ void reset_reads_part(int64_t t, int64_t strid
     for (int64_t i = t; i < n_stripe_words; i += stride) stripes[i] = 0;
 }
 
+#ifndef PHI_SKETCH_POOLED_TU
 __global__ void __launch_bounds__(256) phi_reset_reads_kernel(uint64_t *__restrict__ sp_keys, int64_t sp_cap,
                                                               uint64_t *__restrict__ hit_words, int64_t n_hit_words,
                                                               uint64_t *__restrict__ stripes, int64_t n_stripe_words)
@@ -173,6 +177,8 @@ __global__ void __launch_bounds__(256) phi_reset_reads_kernel(uint64_t *__restri
     reset_reads_part((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, sp_keys, sp_cap,
                      hit_words, n_hit_words, stripes, n_stripe_words);
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------- helpers
 
@@ -659,41 +665,30 @@ __device__ __forceinline__ uint4 load_bases16(const uint8_t *__restrict__ ascii,
 
 // WIDE: w > Q (windows of one lane overlap in a common core); otherwise brute force per window.
 // KT/WT: compile-time k and w of the specialised instance (0 = take them from the arguments).
+#ifndef PHI_SKETCH_POOLED_TU
 template <int MODE, bool WIDE, int KT, int WT>
 __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketch_kernel(PhiSketchArgs A)   // (reads: six waves per SIMD, at most 80 VGPRs)
 {
     constexpr bool FUSED = MODE == PHI_MODE_PROBE;      // read batches come as ASCII + read offsets (see phase 0)
     constexpr bool NEED_POS = MODE == PHI_MODE_WRITE;   // only the ordered write stores positions (ILP_index.cpp:423)
     constexpr bool FMIN = !NEED_POS && KT > 0 && KT <= 31;   // values < 2^62: minima by v_min_f64
-    // POOL (reads, k <= 32): wave g of A.wave_stride takes the chunks g, g + stride, g + 2 stride, ... and hashes their items
-    // in rounds of 64 FULL lanes -- the items a round leaves over (fewer than 64) wait in one register pair per lane for
-    // the next chunk's.  A chunk of short reads yields ~40 items: hashed chunk by chunk the rounds run at 61 % of their
-    // lanes.  The launcher makes the stride at most the number of waves the machine holds at once: every
-    // wave then has the same number of chunks, give or take one, and the launch has no tail of a few late waves.
-    constexpr bool POOL = FUSED && KT >= 0;
     extern __shared__ uint64_t s_dyn[];
 
     // (wid stays a vector register: as a scalar -- readfirstlane -- the values derived from it overflow the SGPR file,
     //  +9 % VALU instructions of v_writelane / v_readlane traffic; reading the output phase's arguments late, through
     //  a laundered kernarg pointer, frees the SGPRs but pushes four VGPRs into scratch at the 80-register bound: -35 %)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k = KT > 0 ? KT : A.k, w = WT ? WT : A.w;       // (KT = -1: the instantiation for k > 32, see below)
     const int64_t N = A.n_bases;
-    const int64_t n_chunks_all = (N + WCH - 1) / WCH;
-    const int64_t stride = POOL ? (int64_t)A.wave_stride : n_chunks_all;
+    const int64_t chunk = (int64_t)blockIdx.x * (TPB / 64) + wid;
+    const int64_t c0 = chunk * WCH;                       // first window start of this chunk
     // read batches, first launch after a reset: this wave's share of the buffers the previous generation of
-    // reads filled (stores into buffers nothing in this launch reads: no ordering needed).  Its loads are issued when
-    // the wave starts
+    // reads filled (stores into buffers nothing in this launch reads: no ordering needed)
     CleanLoad cl{};
-    int mine;                                             // chunks of this wave (wave-uniform)
-    {
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + wid;      // this wave's job
-        if (FUSED && A.q_clean) cl = clean_issue(A, gw, lane);
-        if (gw >= n_chunks_all || (POOL && gw >= stride)) {      // wave-uniform
-            if (FUSED && A.q_clean) clean_finish(A, gw, (int64_t)gridDim.x * (TPB / 64), lane, cl);
-            return;
-        }
-        mine = POOL ? __builtin_amdgcn_readfirstlane((int)((n_chunks_all - gw + stride - 1) / stride)) : 1;
+    if (FUSED && A.q_clean) cl = clean_issue(A, chunk, lane);
+    if (c0 >= N) {                                        // wave-uniform
+        if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
+        return;
     }
     const uint64_t kmask = phi_kmask(k);
     const int M = WCH + w;                                // canonical values m[l], l -> k-mer c0-1+l
@@ -703,416 +698,22 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     using MetaT = typename std::conditional<NEED_POS, uint32_t, uint16_t>::type;
     constexpr uint32_t ITEM_FIRST = NEED_POS ? 1u << 31 : 1u << 15;        // the first window of its sequence
     constexpr uint32_t ITEM_NOEMIT = NEED_POS ? 1u << 30 : 1u << 14;       // only its hash is needed (the window before a candidate)
-    int n_emit = 0, n_log = 0, n_new_slow = 0;
-    // POOL: the items waiting for a full round -- lane j < pend holds item j: its minimum and its flags (for k <= 31 in
-    // the two bits a value leaves free) -- and the hash of the last item hashed
-    uint64_t pv = 0;
-    uint32_t pf = 0;
-    int pend = 0;
-    uint64_t carry = PHI_EMPTY_KEY;
-
-#if PHI_ABL == 7
-    if (POOL && (threadIdx.x & 63) == 0) A.out_pos[2 * ((int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6))] = (int64_t)wall_clock64();
-#endif
-    uint4 xn = make_uint4(0, 0, 0, 0);                    // POOL: the 16 bases of this lane in the NEXT chunk, loaded a turn ahead
-    if (POOL) {
-        const int64_t gw0 = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-        xn = load_bases16(A.ascii, N, gw0 * WCH, (int)(threadIdx.x & 63));
-    }
-    // (POOL: one more turn after the wave's last chunk, for the round of the items still waiting -- so that the code of a
-    //  round exists once)
-    for (int ci = 0; ci < mine + (POOL ? 1 : 0); ci++) {
-    // (POOL: what depends on the lane is worked out again in every turn -- the compiler would otherwise keep all of it,
-    //  addresses, masks, the chunk's 64-bit position, in registers across the loop: 106 VGPRs in scratch at the
-    //  80-register bound)
-    uint32_t tid = threadIdx.x;
-    if (POOL) asm volatile("" : "+v"(tid));
-    // (POOL: the wave's index as a scalar -- the chunk's position and the wave's LDS region are scalar arithmetic then)
-    const int lane = (int)(tid & 63u), wid = POOL ? __builtin_amdgcn_readfirstlane((int)(tid >> 6)) : (int)(tid >> 6);
-    const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + wid;
-    const int64_t chunk = gw + ci * stride;
-    const int64_t c0 = chunk * WCH;                       // first window start of this chunk
-    int ncand = 0, n_new = 0;                             // (n_new: per-lane count kept by probe_tables, unused here)
-    bool chunk_bad = false;
-    int64_t out_base = 0;
     uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w, k, NEED_POS);   // k-mers; later the window minima
     uint64_t *s_words = s_mp + phi_wave_mp_u64(w);
     unsigned long long *s_bits = (unsigned long long *)(s_words + SWW);
     unsigned long long *s_bad = s_bits + SBW;
     MetaT *s_meta = (MetaT *)(s_bad + SBW);               // WCH + 1 items + 8 trash slots
     uint64_t *s_q = s_mp + lane * (Q + 1);                // SM(lane * Q + x) == s_q[x + (x >> 3)]
-    if (ci) wave_sync();                                  // the rounds of the chunk before have read its items
-    if (!POOL || ci < mine) {
-    // ---- phase 0: stage the chunk's packed words and bitmaps (the only global reads up to the
-    //      output phase).  Local base lb <-> base c0-32+lb; local bit lp <-> base c0-64+lp.
-    unsigned long long my_bad = 0;
-    StartProbe probe{};
-    if (FUSED) {
-        // straight from ASCII: lane -> 16 bases = one 32-bit half of a packed word + 16 flags of bases outside ACGTacgt
-        uint32_t x[4];
-        if (POOL) {
-            // this chunk's bases were asked for a turn ago; ask for the next chunk's now: the load travels under this
-            // turn's arithmetic (the waves of a SIMD run their turns nearly in step -- a load at the top of a turn finds
-            // no other wave to hide behind)
-            x[0] = xn.x; x[1] = xn.y; x[2] = xn.z; x[3] = xn.w;
-            if (ci + 1 < mine) xn = load_bases16(A.ascii, N, c0 + stride * WCH, lane);
-        } else {
-            const uint4 v = load_bases16(A.ascii, N, c0, lane);
-            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-        }
-        if (!A.uniform_len) probe = start_probe_issue(A, c0, lane);   // the first probe of the read-start search travels with the bases
-        uint32_t code = 0, bad = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t t = ((x[q] >> 1) ^ (x[q] >> 2)) & 0x03030303u;      // 2-bit code of each byte
-            const uint32_t c8 = (t * 0x40100401u) >> 24;                        // the four codes, first base on top
-            code = (code << 8) | c8;
-            // spelled back from the per-byte codes (one byte lookup: no gather needed) against the upper-cased bytes
-            if (__builtin_amdgcn_perm(0x54474341u, 0x54474341u, t) != (x[q] & 0xDFDFDFDFu)) {   // a byte outside ACGTacgt (rare)
-#pragma unroll
-                for (int j = 0; j < 4; j++) bad |= (uint32_t)(!phi_is_acgt((x[q] >> (8 * j)) & 0xFFu)) << (4 * q + j);
-            }
-        }
-        reinterpret_cast<uint32_t *>(s_words)[lane ^ 1] = code;                 // word = (even lane's half << 32) | odd lane's
-        uint16_t *s_bad16 = reinterpret_cast<uint16_t *>(s_bad);
-        if (lane < 62) s_bad16[lane + 2] = (uint16_t)bad;                       // bit of base b+j = 32 + 16 lane + j
-        else { s_bad16[lane - 62] = 0; bad = 0; }                               // bases before c0-32 / past c0+960 are never looked at
-        if (lane < SBW) s_bits[lane] = 0;
-        my_bad = bad;
-    } else {
-        const int64_t n_words = (N + 31) / 32 + 2;        // the buffer carries two zero padding words
-        const int64_t n_sw = N / 64 + 2;
-        if (lane < SWW) {
-            const int64_t wi = (c0 >> 5) - 1 + lane;
-            s_words[lane] = (wi >= 0 && wi < n_words) ? A.words[wi] : 0;
-        } else if (lane - SWW < SBW) {
-            const int64_t wi = (c0 >> 6) - 1 + (lane - SWW);
-            s_bits[lane - SWW] = (wi >= 0 && wi < n_sw) ? A.starts[wi] : 0;
-        } else {
-            const int64_t wi = (c0 >> 6) - 1 + (lane - SWW - SBW);
-            if (have_bad) my_bad = (wi >= 0 && wi < n_sw) ? A.badbits[wi] : 0;
-            s_bad[lane - SWW - SBW] = my_bad;
-        }
-    }
-    chunk_bad = have_bad && __ballot(my_bad != 0) != 0ull;   // wave-uniform
-    wave_sync();
 
-    if (MODE == PHI_MODE_WRITE) out_base = A.block_off[chunk];
-
-#if PHI_ABL == 10
-    return;
-#endif
-    if (FUSED && KT < 0) {
-        // k > 32 (an instantiation of its own: KT = -1): no 2-bit k-mers; every window of the chunk takes the exact byte-wise routine.  The
-        // slots it fills are not logged: slow_windows raises the dirty flag, the next reset empties the whole set.
-        if (A.uniform_len) start_bits_uniform(A, c0, lane, s_bits);
-        else start_bits_from_offsets(A, c0, lane, probe, s_bits);
-        wave_sync();
-        int n_emit_slow = 0, n_new_lane = 0;
-        slow_windows<MODE, true>(A, c0, chunk, lane, k, w, s_bits, s_bad, true, 0, n_emit_slow, n_new_lane);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) n_new_lane += __shfl_xor(n_new_lane, d, 64);
-        if (A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
-        if (lane == 0) {
-            if (A.sp_log) A.sp_log_cnt[A.log_base + chunk] = 0;
-            const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
-            if (n_new_lane) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new_lane);
-            if (n_emit_slow && A.n_emitted) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit_slow);
-        }
-        return;
-    }
-    // ---- phase 1: canonical k-mers, P consecutive per lane
-    {
-        const int P = KT > 0 ? (WCH + WT + 63) / 64 : (M + 63) / 64;
-        const int l0 = lane * P;
-        if (c0 >= 1 && c0 - 1 + (int64_t)P * 64 + k <= N) {
-            // interior chunk (all but the first and last of a batch): every k-mer a lane touches
-            // exists, so the roll needs no per-position checks, and every lane stores all P of its
-            // k-mers (the slots past M are spare).  Slot of l0+i: a0 + i + carry of (l0 & 7) + i.
-            // (the last lanes, whose k-mers nobody reads, sit the roll out: one branch around all of it)
-            if (l0 < M) {
-                uint64_t F = lds_extract64(s_words, l0 + 31) >> (64 - 2 * k);
-                uint64_t R = phi_revcomp(F, k);
-                uint64_t nxt = lds_extract64(s_words, l0 + 31 + k);     // bases j+k .. j+k+31
-                uint64_t *s_p = s_mp + l0 + (l0 >> 3);
-                const int lo7 = l0 & 7;
-#pragma unroll
-                for (int i = 0; i < P; i++) {
-                    if (i) {
-                        const uint64_t b = nxt >> 62;
-                        nxt <<= 2;
-                        F = ((F << 2) | b) & kmask;
-                        R = (R >> 2) | ((3 - b) << (2 * k - 2));
-                    }
-#if PHI_ABL == 3
-                    if (i == 0)
-#endif
-                    s_p[i + ((lo7 + i) >> 3)] = FMIN ? min_u62(F, R) : (F < R ? F : R);
-                }
-            }
-        } else {
-            const int l1 = min(l0 + P, M);
-            const int64_t j0 = c0 - 1 + l0;
-            uint64_t F = 0, R = 0, nxt = 0;
-            bool live = false;
-            for (int l = l0; l < l1; l++) {
-                const int64_t j = j0 + (l - l0);
-                uint64_t m = ~0ull;
-                if (j >= 0 && j + k <= N) {
-                    if (!live) {
-                        F = lds_extract64(s_words, l + 31) >> (64 - 2 * k);
-                        R = phi_revcomp(F, k);
-                        nxt = lds_extract64(s_words, l + 31 + k);   // bases j+k .. j+k+31
-                        live = true;
-                    } else {
-                        const uint64_t b = nxt >> 62;
-                        nxt <<= 2;
-                        F = ((F << 2) | b) & kmask;
-                        R = (R >> 2) | ((3 - b) << (2 * k - 2));
-                    }
-                    m = F < R ? F : R;
-                }
-                SM(l) = m;
-            }
-        }
-    }
-    wave_sync();
-
-#if PHI_ABL == 11
-    return;
-#endif
-    // ---- phase 2: minima of windows la = lane*Q .. lane*Q+Q  (window la = m[la .. la+w)); the
-    //      k-mer of slot lane*Q + x is s_q[x + (x >> 3)]: constant offsets from one address
-#define SQ(x) s_q[(x) + ((x) >> 3)]
-    uint64_t wv[Q + 1];
-    int wp[Q + 1];
-    {
-        const int base = lane * Q;
-        if (WIDE && FMIN) {
-            // values only (no positions): the rightmost-tie rule does not change a minimum's value
-            uint64_t L[Q];                        // L[i] = min of m[base+i .. base+Q)
-            L[Q - 1] = SQ(Q - 1);
-#pragma unroll
-            for (int i = Q - 2; i >= 0; i--) L[i] = min_u62(SQ(i), L[i + 1]);
-            uint64_t core = SQ(Q);
-#if PHI_ABL != 1
-#pragma unroll
-            for (int x = Q + 1; x < WT; x++) core = min_u62(core, SQ(x));
-#endif
-            uint64_t Rr = 0;                      // min of m[base+w .. base+w+i)
-#pragma unroll
-            for (int i = 0; i <= Q; i++) {
-                uint64_t t = (i < Q) ? min_u62(L[i], core) : core;
-                if (i > 0) {
-                    const uint64_t e = SQ(WT + i - 1);
-                    Rr = (i == 1) ? e : min_u62(Rr, e);
-                    t = min_u62(t, Rr);
-                }
-                wv[i] = t; wp[i] = 0;
-            }
-        } else if (WIDE) {
-            MinEnt L[Q + 1];                      // L[i] = min of m[base+i .. base+Q), ties right
-            L[Q].v = 0; L[Q].i = -1;
-#pragma unroll
-            for (int i = Q - 1; i >= 0; i--) {
-                MinEnt e; e.v = SQ(i); e.i = NEED_POS ? base + i : 0;
-                L[i] = (i == Q - 1) ? e : take_right(e, L[i + 1]);
-            }
-            MinEnt core; core.v = SQ(Q); core.i = NEED_POS ? base + Q : 0;
-            for (int x = Q + 1; x < w; x++) {
-                MinEnt e; e.v = SQ(x); e.i = NEED_POS ? base + x : 0;
-                core = take_right(core, e);
-            }
-            MinEnt Rr; Rr.v = 0; Rr.i = -1;       // min of m[base+w .. base+w+i)
-#pragma unroll
-            for (int i = 0; i <= Q; i++) {
-                MinEnt t = (i < Q) ? take_right(L[i], core) : core;
-                if (i > 0) {
-                    MinEnt e; e.v = SQ(w + i - 1); e.i = NEED_POS ? base + w + i - 1 : 0;
-                    Rr = (i == 1) ? e : take_right(Rr, e);
-                    t = take_right(t, Rr);
-                }
-                wv[i] = t.v; wp[i] = t.i;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i <= Q; i++) {
-                MinEnt t; t.v = SQ(i); t.i = NEED_POS ? base + i : 0;
-                for (int x = 1; x < w; x++) {
-                    MinEnt e; e.v = SQ(i + x); e.i = NEED_POS ? base + i + x : 0;
-                    t = take_right(t, e);
-                }
-                wv[i] = t.v; wp[i] = t.i;
-            }
-        }
-    }
-
-#if PHI_ABL == 12
-    { uint64_t acc = 0;
-#pragma unroll
-      for (int i = 0; i <= Q; i++) acc ^= wv[i] + (uint64_t)i;
-      asm volatile("" :: "v"(acc)); return; }
-#endif
-    if (FUSED) {
-        // the read starts inside this chunk's base range, from the read offsets (answer of the probe issued in phase 0)
-        if (A.uniform_len) start_bits_uniform(A, c0, lane, s_bits);
-        else start_bits_from_offsets(A, c0, lane, probe, s_bits);
-        wave_sync();
-    }
-#if PHI_ABL == 13
-    { uint64_t acc = 0;
-#pragma unroll
-      for (int i = 0; i <= Q; i++) acc ^= wv[i] + (uint64_t)i;
-      asm volatile("" :: "v"(acc)); return; }
-#endif
-    // ---- phase 3: candidate windows of this lane: outputs i = 1..Q, window start a = c0-1+lane*Q+i
-    //      (local bit of base a = la + 63 with la = lane*Q + i)
-    uint32_t cflag = 0, fflag = 0, pflag = 0;             // candidates; first windows; candidates that carry their predecessor
-    {
-        const int64_t a0 = c0 - 1 + (int64_t)lane * Q;
-        const int lp0 = lane * Q + 63;                    // local bit of base a0
-        // windows a0+i with i <= imax end inside the batch
-        const int64_t room = N - span - a0;
-        const int imax = room > Q ? Q : (int)room;
-        if (span <= 64 - Q) {
-            // sb bit j <-> base a0+1+j: one funnel shift serves all Q windows of this lane
-            const int lb = lp0 + 1;
-            const int wi = lb >> 6, sh = lb & 63;
-            const unsigned long long lo = s_bits[wi];
-            const unsigned long long sb = sh ? (lo >> sh) | (s_bits[wi + 1] << (64 - sh)) : lo;
-            // bb bit j <-> base a0+j is outside ACGT: window a and its predecessor cover a-1 .. a+span-1
-            unsigned long long bb = 0;
-            if (chunk_bad) {
-                const int wj = lp0 >> 6, sj = lp0 & 63;
-                const unsigned long long lo2 = s_bad[wj];
-                bb = sj ? (lo2 >> sj) | (s_bad[wj + 1] << (64 - sj)) : lo2;
-            }
-            // bit i of `blocked`: some sequence starts at bases a+1 .. a+span-1 of window i, i.e. sb has a
-            // bit in [i, i+span-2]: OR over a sliding range by doubling (1,2,4,...,32, then the rest)
-            unsigned long long t = sb;
-            t |= t >> 1; t |= t >> 2; t |= t >> 4; t |= t >> 8; t |= t >> 16;     // ranges of 32
-            const int len1 = span - 1;                                              // 1 .. 55
-            unsigned long long blocked;
-            if (len1 >= 32) blocked = t | (t >> (len1 - 32));
-            else {
-                // shorter ranges: rebuild from the powers of two below len1
-                unsigned long long u = sb, acc = 0;
-                int have = 0;
-                for (int b = 0; b < 5; b++) {
-                    if (len1 & (1 << b)) { acc |= u >> have; have += 1 << b; }
-                    u |= u >> (1 << b);
-                }
-                blocked = len1 > 0 ? acc : 0ull;
-            }
-            // bit i of `dirty`: a base outside ACGT under window i or its predecessor: bb bit in [i-1, i+span-1]
-            unsigned long long dirty = 0;
-            if (chunk_bad) {
-                unsigned long long v = bb;
-                v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
-                const int len2 = span + 1;                                          // 2 .. 57
-                if (len2 >= 32) v = v | (v >> (len2 - 32));
-                else {
-                    unsigned long long u = bb, acc = 0;
-                    int have = 0;
-                    for (int b = 0; b < 5; b++) {
-                        if (len2 & (1 << b)) { acc |= u >> have; have += 1 << b; }
-                        u |= u >> (1 << b);
-                    }
-                    v = acc;
-                }
-                dirty = v << 1;                                                     // bit i <-> range starting at i-1
-            }
-            uint32_t changed = 0;
-#pragma unroll
-            for (int i = 1; i <= Q; i++) changed |= (uint32_t)(wv[i] != wv[i - 1]) << i;
-            const uint32_t first = ((uint32_t)sb & ((1u << Q) - 1)) << 1;           // bit i <-> sb bit i-1
-            const uint32_t in_batch = imax >= 1 ? ((2u << imax) - 2u) : 0u;        // bits 1 .. imax
-            // the first window after a stretch left to the byte-wise path: the candidate before it is not its
-            // predecessor window, so it becomes a candidate that carries its own predecessor (whose value
-            // is valid: a window that is not dirty has no such base under its predecessor either)
-            uint32_t reseed = 0;
-            if (chunk_bad) {
-                const uint32_t dall = (uint32_t)dirty | (uint32_t)range_has_bit(s_bad, lp0 - 1, lp0 + span - 1);   // bit 0: window 0
-                reseed = ~dall & (dall << 1);
-            }
-            cflag = in_batch & ~(uint32_t)blocked & ~(uint32_t)dirty & (first | changed | reseed) & ((2u << Q) - 2u);
-            fflag = cflag & first;
-            pflag = cflag & reseed & ~first;
-        } else {
-            const int lim = lp0 + Q + span + 1;
-            int ns = next_start_lds(s_bits, lp0 + 2, lim);
-#pragma unroll
-            for (int i = 1; i <= Q; i++) {
-                const int lp = lp0 + i;
-                if (ns <= lp) ns = next_start_lds(s_bits, lp + 1, lim);
-                bool valid = (i <= imax) && (ns > lp + span - 1);
-                if (valid && chunk_bad) valid = !range_has_bit(s_bad, lp - 1, lp + span - 1);
-                if (valid) {
-                    const bool first = (s_bits[lp >> 6] >> (lp & 63)) & 1ull;
-                    const bool reseed = chunk_bad && !first && range_has_bit(s_bad, lp - 2, lp + span - 2);   // the window before is byte-wise
-                    if (first || reseed || wv[i] != wv[i - 1]) {
-                        cflag |= 1u << i;
-                        if (first) fflag |= 1u << i;
-                        if (reseed) pflag |= 1u << i;
-                    }
-                }
-            }
-        }
-    }
-#if PHI_ABL == 14
-    { uint64_t acc = cflag ^ (fflag << 9) ^ ((uint64_t)pflag << 20);
-#pragma unroll
-      for (int i = 0; i <= Q; i++) acc ^= wv[i] + (uint64_t)i;
-      asm volatile("" :: "v"(acc)); return; }
-#endif
-    // wave prefix sum of the per-lane candidate counts
-    int coff;
-    {
-        const int cnt = __popc(cflag) + __popc(pflag);
-        const int v = wave_scan_inclusive(cnt);
-        ncand = __builtin_amdgcn_readlane(v, 63);
-        coff = v - cnt;
-    }
-    wave_sync();                                          // every lane has read its k-mers
-    {
-        // the minimum of window slot s = lane*Q + i goes to SM(s) (constant offsets again); slot 0 is
-        // the window before the chunk's first
-        if (lane == 0) s_q[0] = wv[0];
-#pragma unroll
-        for (int i = 1; i <= Q; i++) SQ(i) = wv[i];
-        // item list: item 0 = the window before the chunk's first candidate (only its hash is needed),
-        // item 1 + c = candidate c.  Every lane stores all Q windows, the non-candidates into trash
-        // slots past the last item: no divergent branch per window
-        int c = coff + 1;
-        const int trash = phi_wave_items(w, k) + (lane & 3);
-        if (!chunk_bad && !NEED_POS) {
-            // a lane has 0.6 candidates on average, rarely more than three: a loop over the set bits issues fewer
-            // instructions than eight predicated stores
-            for (uint32_t f = cflag; f; f &= f - 1) {
-                const uint32_t i = (uint32_t)__ffs((int)f) - 1;
-                s_meta[c++] = (MetaT)((uint32_t)(lane * Q) + i + (((fflag >> i) & 1u) ? ITEM_FIRST : 0u));
-            }
-        } else if (!chunk_bad) {
-#pragma unroll
-            for (int i = 1; i <= Q; i++) {
-                const bool on = (cflag >> i) & 1u;
-                s_meta[on ? c : trash] = (MetaT)((uint32_t)(lane * Q + i) | (NEED_POS ? (uint32_t)wp[i] << 10 : 0u) | (((fflag >> i) & 1u) ? ITEM_FIRST : 0u));
-                c += on;
-            }
-        } else {
-            // (rare) a candidate after a byte-wise stretch is preceded by the window before it
-#pragma unroll
-            for (int i = 1; i <= Q; i++) {
-                if ((cflag >> i) & 1u) {
-                    if ((pflag >> i) & 1u) s_meta[c++] = (MetaT)((uint32_t)(lane * Q + i - 1) | ITEM_NOEMIT);
-                    s_meta[c++] = (MetaT)((uint32_t)(lane * Q + i) | (NEED_POS ? (uint32_t)wp[i] << 10 : 0u) | (((fflag >> i) & 1u) ? ITEM_FIRST : 0u));
-                }
-            }
-        }
-        if (coff == 0 && cflag) s_meta[0] = (MetaT)((uint32_t)(lane * Q + __ffs((int)cflag) - 2) | ITEM_NOEMIT);
-    }
-    wave_sync();
-#undef SQ
+    // (names the shared phases use; the last four only matter in the pooled kernel)
+    constexpr bool POOL = false;
+    bool chunk_bad = false;
+    int ncand = 0, n_emit = 0, n_new = 0, n_log = 0, n_new_slow = 0;
+    int64_t out_base = 0;
+    uint4 xn = make_uint4(0, 0, 0, 0);
+    const int ci = 0, mine = 1;
+    const int64_t stride = 0;
+#include "sketch_phases.inc"
 
 #if PHI_ABL == 15
     { asm volatile("" :: "v"(ncand)); return; }
@@ -1123,8 +724,163 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
 #if PHI_ABL == 2
     ncand = 0;
 #endif
+    if (ncand > 0) {
+        uint64_t carry = PHI_EMPTY_KEY;
+        for (int r0 = 0; r0 <= ncand; r0 += 64) {
+            const int t = r0 + lane;
+            const bool valid = t <= ncand;
+            uint32_t meta = 0;
+            uint64_t h = 0;
+            if (valid) {
+                meta = s_meta[t];
+                h = phi_kmer_hash(SM((int)(meta & 0x3FFu)), k);
+            }
+            const uint64_t hp = wave_prev_u64(h, carry, lane);
+            carry = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), 63) << 32) |
+                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, 63);
+            const bool emit = valid && !(meta & ITEM_NOEMIT) && ((meta & ITEM_FIRST) || h != hp);
+            const unsigned long long bal = __ballot(emit);
+            uint32_t filled = PHI_NO_SLOT;
+            if (emit) {
+                const int rank = n_emit + __popcll(bal & ((1ull << lane) - 1));
+                if (MODE == PHI_MODE_WRITE) {
+                    A.out_hash[out_base + rank] = h;
+                    A.out_pos[out_base + rank] = c0 - 1 + (int64_t)((meta >> 10) & 0x3FFu);
+                } else if (MODE == PHI_MODE_PROBE) {
+                    filled = probe_tables(A, h, n_new);
+                }
+            }
+            if (MODE == PHI_MODE_PROBE) {
+                // the slots this chunk fills (= its new spectrum entries, counted for the whole wave), for the next reset
+                const unsigned long long ib = __ballot(filled != PHI_NO_SLOT);
+                if (A.sp_log && filled != PHI_NO_SLOT) {
+                    const int pos = n_log + __popcll(ib & ((1ull << lane) - 1));
+                    if (pos < PHI_SPLOG) A.sp_log[(A.log_base + chunk) * PHI_SPLOG + pos] = filled;
+                }
+                n_log += __popcll(ib);
+            }
+            n_emit += __popcll(bal);
+        }
+    }
+
+    if (FUSED && chunk_bad) {
+        // (rare) windows over a base outside ACGTacgt, or right after one: the exact byte-wise routine, by the wave
+        // that owns the chunk (its inserts are not logged: slow_windows raises the dirty flag)
+        int n_emit_slow = 0, n_new_lane = 0;
+        slow_windows<MODE>(A, c0, chunk, lane, k, w, s_bits, s_bad, false, 0, n_emit_slow, n_new_lane);
+        n_emit += n_emit_slow;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n_new_lane += __shfl_xor(n_new_lane, d, 64);
+        n_new_slow = n_new_lane;
+    }
+    if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
+    if (MODE == PHI_MODE_COUNT) {
+        if (lane == 0) A.block_cnt[chunk] = n_emit;
+    } else if (MODE == PHI_MODE_PROBE) {
+        if (A.sp_log && lane == 0) {
+            A.sp_log_cnt[A.log_base + chunk] = (uint8_t)(n_log < PHI_SPLOG ? n_log : PHI_SPLOG);
+            if (n_log > PHI_SPLOG) raise_sp_dirty(A.sp_dirty);
+        }
+        // one atomic per wave for the number of new spectrum entries (n_log counts them: wave-uniform) and emitted records
+        const int n_new_wave = n_log + n_new_slow;
+        if (lane == 0) {
+            const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
+            if (n_new_wave) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new_wave);
+            if (n_emit && A.n_emitted) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
+        }
+    }
+}
+
+#else
+// The read kernel (PHI_MODE_PROBE) for batches of 12 Mbases and more, k <= 32 (phi_launch_sketch); compiled in
+// sketch_pooled.hip only.  Wave g of A.wave_stride takes the chunks g, g + stride, g + 2 stride, ... and hashes their items
+// in rounds of 64 FULL lanes -- the items a round leaves over (fewer than 64) wait in one register pair per lane for the
+// next chunk's.  A chunk of short reads yields ~40 items: hashed chunk by chunk (phi_sketch_kernel) the rounds run at 61 %
+// of their lanes, and hash + probe are 38 % of that kernel's instructions.  Phases 0 - 3b of a chunk are
+// those of phi_sketch_kernel (sketch_phases.inc).
+template <bool WIDE, int KT, int WT>
+__global__ void __launch_bounds__(TPB, 6) phi_sketch_pool_kernel(PhiSketchArgs A)   // (six waves per SIMD, at most 80 VGPRs)
+{
+    constexpr int MODE = PHI_MODE_PROBE;
+    constexpr bool FUSED = true, NEED_POS = false, POOL = true;      // (names of the shared phases)
+    constexpr bool FMIN = KT > 0 && KT <= 31;            // values < 2^62: minima by v_min_f64
+    static_assert(KT >= 0, "k <= 32");
+    extern __shared__ uint64_t s_dyn[];
+
+    const int k = KT > 0 ? KT : A.k, w = WT ? WT : A.w;
+    const int64_t N = A.n_bases;
+    const int64_t n_chunks_all = (N + WCH - 1) / WCH;
+    const int64_t stride = (int64_t)A.wave_stride;
+    // read batches, first launch after a reset: this wave's share of the buffers the previous generation of
+    // reads filled (stores into buffers nothing in this launch reads: no ordering needed).  Its loads are issued when
+    // the wave starts
+    CleanLoad cl{};
+    int mine;                                             // chunks of this wave (wave-uniform)
+    {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + wid;      // this wave's job
+        if (A.q_clean) cl = clean_issue(A, gw, lane);
+        if (gw >= n_chunks_all || gw >= stride) {         // wave-uniform
+            if (A.q_clean) clean_finish(A, gw, (int64_t)gridDim.x * (TPB / 64), lane, cl);
+            return;
+        }
+        mine = __builtin_amdgcn_readfirstlane((int)((n_chunks_all - gw + stride - 1) / stride));
+    }
+    const uint64_t kmask = phi_kmask(k);
+    const int M = WCH + w;                                // canonical values m[l], l -> k-mer c0-1+l
+    const int span = w + k - 1;                           // bases under one window
+    const bool have_bad = true;
+
+    using MetaT = uint16_t;
+    constexpr uint32_t ITEM_FIRST = 1u << 15;            // the first window of its sequence
+    constexpr uint32_t ITEM_NOEMIT = 1u << 14;           // only its hash is needed (the window before a candidate)
+    int n_emit = 0, n_log = 0, n_new_slow = 0;
+    // the items waiting for a full round -- lane j < pend holds item j: its minimum and its flags (for k <= 31 in
+    // the two bits a value leaves free) -- and the hash of the last item hashed
+    uint64_t pv = 0;
+    uint32_t pf = 0;
+    int pend = 0;
+    uint64_t carry = PHI_EMPTY_KEY;
+
+    // the 16 bases of this lane in the NEXT chunk, loaded a turn ahead
+    uint4 xn = load_bases16(A.ascii, N, ((int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6)) * WCH, (int)(threadIdx.x & 63));
+    // (one more turn after the wave's last chunk, for the round of the items still waiting -- so that the code of a round
+    //  exists once)
+    for (int ci = 0; ci <= mine; ci++) {
+    // (what depends on the lane is worked out again in every turn -- the compiler would otherwise keep all of it, addresses,
+    //  masks, the chunk's 64-bit position, in registers across the loop: 106 VGPRs in scratch at the 80-register bound;
+    //  for the same reason this file is compiled with machine LICM off, see phi_launch_sketch_pooled)
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    // (the wave's index as a scalar: the chunk's position and the wave's LDS region are scalar arithmetic)
+    const int lane = (int)(tid & 63u), wid = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + wid;
+    const int64_t chunk = gw + ci * stride;
+    const int64_t c0 = chunk * WCH;                       // first window start of this chunk
+    int ncand = 0, n_new = 0;                             // (n_new: per-lane count kept by probe_tables, unused here)
+    bool chunk_bad = false;
+    int64_t out_base = 0;                                 // (a name of the shared phases: the ordered write of the walks)
+    (void)out_base;
+    uint64_t *s_mp = s_dyn + (size_t)wid * phi_wave_region_u64(w, k, NEED_POS);   // k-mers; later the window minima
+    uint64_t *s_words = s_mp + phi_wave_mp_u64(w);
+    unsigned long long *s_bits = (unsigned long long *)(s_words + SWW);
+    unsigned long long *s_bad = s_bits + SBW;
+    MetaT *s_meta = (MetaT *)(s_bad + SBW);               // WCH + 1 items + 8 trash slots
+    uint64_t *s_q = s_mp + lane * (Q + 1);                // SM(lane * Q + x) == s_q[x + (x >> 3)]
+    if (ci) wave_sync();                                  // the rounds of the chunk before have read its items
+    if (ci < mine) {
+#include "sketch_phases.inc"
+
+#if PHI_ABL == 15
+    { asm volatile("" :: "v"(ncand)); return; }
+#endif
+#if PHI_ABL == 2
+    ncand = 0;
+#endif
     }   // phases 0 - 3b of a chunk
-    if (POOL) {
+    // ---- phases 4 + 5: items on dense lanes, 64 per round: murmur3 of the item's minimum, the hash-change test against
+    //      the item before it (the lane below; lane 0 takes the last lane of the round before), table probes
+    {
         // items of this chunk: 0 .. ncand (none when it has no candidate, none in the last turn).  Full rounds while there
         // are 64 items between the waiting ones and these; what is left joins (or becomes) the waiting ones; the last
         // turn's round takes the waiting ones as they are
@@ -1181,46 +937,9 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
             if (FMIN) pv |= (uint64_t)pf << 62;
         }
         pend += rem;
-    } else if (ncand > 0) {
-        uint64_t carry = PHI_EMPTY_KEY;
-        for (int r0 = 0; r0 <= ncand; r0 += 64) {
-            const int t = r0 + lane;
-            const bool valid = t <= ncand;
-            uint32_t meta = 0;
-            uint64_t h = 0;
-            if (valid) {
-                meta = s_meta[t];
-                h = phi_kmer_hash(SM((int)(meta & 0x3FFu)), k);
-            }
-            const uint64_t hp = wave_prev_u64(h, carry, lane);
-            carry = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), 63) << 32) |
-                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, 63);
-            const bool emit = valid && !(meta & ITEM_NOEMIT) && ((meta & ITEM_FIRST) || h != hp);
-            const unsigned long long bal = __ballot(emit);
-            uint32_t filled = PHI_NO_SLOT;
-            if (emit) {
-                const int rank = n_emit + __popcll(bal & ((1ull << lane) - 1));
-                if (MODE == PHI_MODE_WRITE) {
-                    A.out_hash[out_base + rank] = h;
-                    A.out_pos[out_base + rank] = c0 - 1 + (int64_t)((meta >> 10) & 0x3FFu);
-                } else if (MODE == PHI_MODE_PROBE) {
-                    filled = probe_tables(A, h, n_new);
-                }
-            }
-            if (MODE == PHI_MODE_PROBE) {
-                // the slots this chunk fills (= its new spectrum entries, counted for the whole wave), for the next reset
-                const unsigned long long ib = __ballot(filled != PHI_NO_SLOT);
-                if (A.sp_log && filled != PHI_NO_SLOT) {
-                    const int pos = n_log + __popcll(ib & ((1ull << lane) - 1));
-                    if (pos < PHI_SPLOG) A.sp_log[(A.log_base + chunk) * PHI_SPLOG + pos] = filled;
-                }
-                n_log += __popcll(ib);
-            }
-            n_emit += __popcll(bal);
-        }
     }
 
-    if (FUSED && chunk_bad) {
+    if (chunk_bad) {
         // (rare) windows over a base outside ACGTacgt, or right after one: the exact byte-wise routine, by the wave
         // that owns the chunk (its inserts are not logged: slow_windows raises the dirty flag)
         int n_emit_slow = 0, n_new_lane = 0;
@@ -1230,19 +949,14 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
         for (int d = 32; d >= 1; d >>= 1) n_new_lane += __shfl_xor(n_new_lane, d, 64);
         n_new_slow += n_new_lane;
     }
-    if (MODE == PHI_MODE_COUNT) {
-        if (lane == 0) A.block_cnt[chunk] = n_emit;
-    }
     }   // chunks of this wave
     uint32_t tid_end = threadIdx.x;
-    if (POOL) asm volatile("" : "+v"(tid_end));           // (worked out again: not kept from the wave's start in two registers)
+    asm volatile("" : "+v"(tid_end));                     // (worked out again: not kept from the wave's start in two registers)
     const int lane = (int)(tid_end & 63u);
     const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + __builtin_amdgcn_readfirstlane((int)(tid_end >> 6));
-    if (POOL) {
+    {
+        // (the arguments of this part are loaded now, not kept in scalar registers through the loop)
         const KArgs R = kargs_now();
-#if PHI_ABL == 7
-        if (lane == 0) R->out_pos[2 * gw + 1] = (int64_t)wall_clock64();
-#endif
         if (R->q_clean) clean_finish(*R, gw, (int64_t)gridDim.x * (TPB / 64), lane, cl);
         if (R->sp_log) {
             // entries of the log: PHI_SPLOG per chunk of this wave, filled in order
@@ -1261,6 +975,21 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
         }
     }
 }
+
+#endif
+
+#ifdef PHI_SKETCH_POOLED_TU
+// sketch_pooled.hip: this file again, compiled for the POOLED instances of the read kernel alone, with machine LICM off --
+// their loop over a wave's chunks runs at the 80-register bound of six waves per SIMD, and constants and addresses hoisted
+// out of it stay in registers through every turn (106 VGPRs in scratch).  The one-chunk instances keep the default.
+void phi_launch_sketch_pooled(hipStream_t st, unsigned nb, size_t lds, const PhiSketchArgs &A, hipEvent_t t0, hipEvent_t t1)
+{
+    if (A.k == 31 && A.w == 25) hipExtLaunchKernelGGL((phi_sketch_pool_kernel<true, 31, 25>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
+    else if (A.w > Q) hipExtLaunchKernelGGL((phi_sketch_pool_kernel<true, 0, 0>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
+    else hipExtLaunchKernelGGL((phi_sketch_pool_kernel<false, 0, 0>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
+}
+#else
+void phi_launch_sketch_pooled(hipStream_t st, unsigned nb, size_t lds, const PhiSketchArgs &A, hipEvent_t t0, hipEvent_t t1);   // sketch_pooled.hip
 
 // Exact byte-wise kernel: every wave walks chunks in a grid-stride loop.
 //   allslow = 0 (reads): launched after the 2-bit kernel with a small grid; leaves at once when the
@@ -1346,10 +1075,13 @@ int64_t phi_sketch_num_blocks(int64_t n_bases) { return n_bases <= 0 ? 0 : (n_ba
 // t0 / t1 (optional): events that take the kernel's own start / end timestamps (hipExtLaunchKernelGGL:
 // no extra marker packets on the stream, unlike hipEventRecord around the launch)
 template <int MODE>
-static void launch_sketch_mode(hipStream_t st, unsigned nb, size_t lds, const PhiSketchArgs &A, hipEvent_t t0, hipEvent_t t1)
+static void launch_sketch_mode(hipStream_t st, unsigned nb, size_t lds, const PhiSketchArgs &A, hipEvent_t t0, hipEvent_t t1, bool pooled)
 {
     // the reference's defaults (options.cpp:7-8) get a fully unrolled instance, except for the
     // ordered write whose position tracking would push it past 128 VGPRs
+    if constexpr (MODE == PHI_MODE_PROBE) {
+        if (pooled) { phi_launch_sketch_pooled(st, nb, lds, A, t0, t1); return; }      // (k <= 32: see phi_launch_sketch)
+    }
     if constexpr (MODE != PHI_MODE_WRITE) {
         if (A.k == 31 && A.w == 25) {
             hipExtLaunchKernelGGL((phi_sketch_kernel<MODE, true, 31, 25>), dim3(nb), dim3(TPB), lds, st, t0, t1, 0, A);
@@ -1371,23 +1103,33 @@ void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A0, hipEve
     const int64_t nchunks = phi_sketch_num_blocks(A0.n_bases);
     if (nchunks <= 0) return;
     PhiSketchArgs A = A0;
-    // reads (k <= 32): wave g of `njobs` takes the chunks g, g + njobs, ...  As many waves as the machine holds at once (256
-    // CUs x 4 SIMDs x 6 waves of this kernel), or fewer so that every wave has the same number of chunks: no second round
-    // of waves, no tail
+    // Reads (k <= 32), batches of 12 Mbases and more: wave g of `njobs` takes the chunks g, g + njobs, ... and hashes their
+    // items in full rounds (POOL in the kernel).  Four times as many waves as the machine holds at once (256 CUs x 4 SIMDs
+    // x 6 waves of this kernel): the SIMDs serve their oldest wave first, so waves of equal shares end far apart (the first
+    // in half the time of the last) and it takes waves in waiting to fill the slots they leave -- measured at C3 / C5s:
+    // 6 144 waves 417 / -, 12 288 424 / 439, 18 432 433 / 443, 24 576 447 / 451, 36 864 439 / 442 Gbases/s.  Fewer than
+    // three chunks per wave are not worth a loop: smaller batches run one chunk per wave as before.
     int64_t njobs = nchunks;
+    bool pooled = false;
     if (mode == PHI_MODE_PROBE && A.k <= PHI_MAX_K_PACKED) {
-        int64_t slots = 256 * 4 * 6;
+        int64_t slots = 4 * 256 * 4 * 6;
+        int64_t min_chunks = 4 * 6144;
         if (const char *e = getenv("PHI_SKETCH_WAVES")) slots = atoll(e) > 0 ? atoll(e) : slots;
-        const int64_t m = (nchunks + slots - 1) / slots;          // chunks per wave
-        njobs = (nchunks + m - 1) / m;
-        if (njobs > 0x7FFFFFFF) njobs = 0x7FFFFFFF;
-        A.wave_stride = (int32_t)njobs;
+        if (const char *e = getenv("PHI_SKETCH_POOL_MIN")) min_chunks = atoll(e);
+        if (nchunks >= min_chunks) {
+            int64_t m = (nchunks + slots - 1) / slots;          // chunks per wave
+            if (m < 3) m = 3;
+            njobs = (nchunks + m - 1) / m;
+            if (njobs > 0x7FFFFFFF) njobs = 0x7FFFFFFF;
+            A.wave_stride = (int32_t)njobs;
+            pooled = true;
+        }
     }
     const unsigned nb = (unsigned)((njobs + TPB / 64 - 1) / (TPB / 64));
     const size_t lds = (size_t)phi_wave_region_u64(A.w, A.k, mode == PHI_MODE_WRITE) * 8 * (TPB / 64);
-    if (mode == PHI_MODE_COUNT) launch_sketch_mode<PHI_MODE_COUNT>(st, nb, lds, A, t0, t1);
-    else if (mode == PHI_MODE_WRITE) launch_sketch_mode<PHI_MODE_WRITE>(st, nb, lds, A, t0, t1);
-    else launch_sketch_mode<PHI_MODE_PROBE>(st, nb, lds, A, t0, t1);
+    if (mode == PHI_MODE_COUNT) launch_sketch_mode<PHI_MODE_COUNT>(st, nb, lds, A, t0, t1, false);
+    else if (mode == PHI_MODE_WRITE) launch_sketch_mode<PHI_MODE_WRITE>(st, nb, lds, A, t0, t1, false);
+    else launch_sketch_mode<PHI_MODE_PROBE>(st, nb, lds, A, t0, t1, pooled);
 }
 
 void phi_launch_scan_counts(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off)
@@ -1400,3 +1142,4 @@ void phi_launch_scan_counts(hipStream_t st, const int32_t *cnt, int64_t n, int64
 // phi_ctx_create did it up front).
 __global__ void phi_warm_sketch_kernel() {}
 void phi_warm_sketch(hipStream_t st) { hipLaunchKernelGGL(phi_warm_sketch_kernel, dim3(1), dim3(64), 0, st); }
+#endif

@@ -436,6 +436,38 @@ def test_streaming_batches_equal_one_batch(oracle, ctx_factory):
     assert rc["objective"] == ra["objective"] and rc["spectrum_size"] == ra["spectrum_size"]
 
 
+@pytest.mark.parametrize("waves", ["1", "3", "64", "6144"])
+def test_pooled_read_kernel_on_small_batches(oracle, ctx_factory, monkeypatch, waves):
+    """Read batches of 12 Mbases and more go through phi_sketch_pool_kernel: a wave takes several chunks (g, g + waves, ...)
+    and hashes their items in full rounds of 64, what a round leaves over waiting in registers for the next chunk's.
+    PHI_SKETCH_POOL_MIN=1 sends every batch that way and PHI_SKETCH_WAVES sets how many waves share a batch (1: one wave
+    takes every chunk; more waves than chunks: waves with nothing to do), so that the batches the oracle finishes exercise
+    the rounds that span chunks, the last partial round, the per-wave slot log and its use by the next reset.  Reads with
+    bases outside ACGT, reads shorter than a window, of one length (no offsets) and of mixed lengths; several batches and
+    a reset between them; k and w of the specialised and of the generic instances."""
+    monkeypatch.setenv("PHI_SKETCH_POOL_MIN", "1")
+    monkeypatch.setenv("PHI_SKETCH_WAVES", waves)
+    rng = np.random.default_rng(9100 + int(waves))
+    for (k, w) in ((31, 25), (15, 10), (7, 3), (32, 9)):
+        g = random_graph(rng, n_sites=12, n_walks=4, seg_len=(30, 80), alt_len=(2, 9))
+        reads = mosaic_reads(rng, g, n_reads=160, read_len=150, n_seg=2, err=0.02)
+        reads += [bytes(rng.choice(list(b"ACGTNacgtn"), size=int(rng.integers(1, 400))).tolist()) for _ in range(60)]
+        reads += [bytes(rng.choice(list(b"ACGT"), size=150).tolist()) for _ in range(700)]        # several chunks of novel sequence: rounds full of new slots
+        uniform = [r for r in reads if len(r) == 150]
+        ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=5)
+        _set_graph(ctx, g)
+        for batch in (uniform, reads[:50], reads[50:]):
+            ctx.add_reads(batch)
+        sk = [oracle.sketch(r, k, w)[0] for r in uniform + reads]
+        st = ctx.reads_stats()
+        assert st["n_emitted"] == sum(len(x) for x in sk) and st["n_distinct"] == len(np.unique(np.concatenate(sk)))
+        # a reset (the next launch empties what this generation logged), then the mixed reads alone, against the oracle
+        ctx.reset_reads()
+        ctx.add_reads(reads[:90])
+        ctx.add_reads(reads[90:])
+        _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 5)
+
+
 @pytest.mark.parametrize("n_walks", [70, 130, 300])
 def test_more_than_64_walks_vs_highs(oracle, ctx_factory, n_walks):
     """lane <-> walk: more than 64 walks take the multi-wave instances of the DP kernel.  Brute
