@@ -521,7 +521,7 @@ def main():
                    "exchange": "none (1 GPU)" if world == 1 else ("gloo through the host (rehearsal)" if args.rehearse_gloo else "RCCL all-reduce(MAX, uint8) of the hit vector per step, inside libphi_amd.so")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "phi_sketch_kernel<PHI_MODE_PROBE>", "kernel_avg_ms": kern_avg_ms,
+                     "kernel": "phi_sketch_pool_kernel (batches of 12 Mbases and more)" if per_rank_bases >= 4 * 6144 * 512 else "phi_sketch_kernel<PHI_MODE_PROBE>", "kernel_avg_ms": kern_avg_ms,
                      "kernel_launches": n_launch, "kernel_timed": "a leg of its own after the timed steps, every launch bracketed", "bytes_per_base_algorithmic": b_alg, "minimiser_density": density,
                      "bytes_per_base_split": {"moved by phi_sketch_kernel (ASCII read, record, probe)": b_sketch,
                                               "packed 2-bit write + read of the SURVEY formula (stays in LDS since the fusion: not moved)": b_packed},

@@ -30,7 +30,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     res[ctr] = {k: tot[k] / n[k] for k in tot}
 json.dump(res, open(f"{out}/pmc_hbm_counters.json", "w"), indent=1)
 for k in res.get("FETCH_SIZE", {}):
-    if "phi_sketch_kernel<2" in k:
+    if "phi_sketch_kernel<2" in k or "phi_sketch_pool_kernel" in k:
         print(k[:60], "FETCH_SIZE kB", res["FETCH_SIZE"][k], "WRITE_SIZE kB", res["WRITE_SIZE"].get(k))
 P
 # 3b. the same three collections for the larger read sets (C3: 10x short reads, C4: long noisy reads, C5s: 200 walks, 30x):
@@ -52,7 +52,7 @@ for cfg in ("C3", "C4", "C5s"):
     per = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(f"{out}/pmc_{cfg}_*/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "phi_sketch_kernel<2" in r["Kernel_Name"] or "phi_sketch_kernel<(int)2" in r["Kernel_Name"]:
+            if "phi_sketch_kernel<2" in r["Kernel_Name"] or "phi_sketch_kernel<(int)2" in r["Kernel_Name"] or "phi_sketch_pool_kernel" in r["Kernel_Name"]:
                 k = per[r["Counter_Name"]]; k[0] += float(r["Counter_Value"]); k[1] += 1
     res[cfg] = {c: v[0] / max(1, v[1]) for c, v in per.items()}
     res[cfg]["launches_averaged"] = {c: v[1] for c, v in per.items()}
