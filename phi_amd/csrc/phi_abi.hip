@@ -225,6 +225,18 @@ int phi_ctx_create(int device_id, phi_ctx **out)
         phi_dev_ensure(c, c->alt.stripes, 2 * STRIPE_BYTES) || hipMemsetAsync(c->alt.stripes.p, 0, 2 * STRIPE_BYTES, c->stream) != hipSuccess)
         return bail(PHI_ERR_DEVICE);
     // the kernels' code objects are loaded lazily, per translation unit, at their first launch: do that here, once
+    if (tm.on && getenv("PHI_TIMING_UNITS")) {
+        // (diagnostics: what each unit's code object costs to load)
+        (void)hipStreamSynchronize(c->stream); tm.lap("  scalars");
+        phi_warm_sketch(c->stream); (void)hipStreamSynchronize(c->stream); tm.lap("  code object: sketch");
+        phi_warm_table(c->stream); (void)hipStreamSynchronize(c->stream); tm.lap("  code object: table");
+        phi_warm_anchors(c->stream); (void)hipStreamSynchronize(c->stream); tm.lap("  code object: anchors");
+        phi_warm_contexts(c->stream); (void)hipStreamSynchronize(c->stream); tm.lap("  code object: contexts");
+        phi_warm_dp(c->stream); (void)hipStreamSynchronize(c->stream); tm.lap("  code object: dp");
+        phi_warm_dp_events(c->stream); (void)hipStreamSynchronize(c->stream); tm.lap("  code object: dp_events");
+        phi_warm_solve_dev(c->stream); (void)hipStreamSynchronize(c->stream); tm.lap("  code object: solve_dev");
+        phi_warm_reads_text(c->stream); (void)hipStreamSynchronize(c->stream); tm.lap("  code object: reads_text");
+    }
     phi_warm_sketch(c->stream); phi_warm_table(c->stream); phi_warm_anchors(c->stream); phi_warm_contexts(c->stream);
     phi_warm_dp(c->stream); phi_warm_dp_events(c->stream); phi_warm_solve_dev(c->stream); phi_warm_reads_text(c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(PHI_ERR_DEVICE);
