@@ -245,7 +245,13 @@ __device__ __forceinline__ uint32_t probe_tables(const ProbeArgs &A, uint64_t h,
         }
     }
     // not a walk minimiser: open-addressed insert into the spectrum set
+#if PHI_ABL == 21
+    return PHI_NO_SLOT;                                   // (experiment: no insert)
+#endif
     uint64_t ss = h & A.sp_mask;
+#if PHI_ABL == 22
+    { const uint64_t v = __builtin_nontemporal_load(&A.sp_keys[ss]); if (v == h) return PHI_NO_SLOT; if (v == PHI_EMPTY_KEY) { A.sp_keys[ss] = h; n_new++; return (uint32_t)ss; } return PHI_NO_SLOT; }   // (experiment: load + plain store instead of the CAS)
+#endif
     for (int probes = 0;; probes++) {
         const unsigned long long prev = atomicCAS((unsigned long long *)&A.sp_keys[ss], PHI_EMPTY_KEY, h);
         if (prev == PHI_EMPTY_KEY) { n_new++; return (uint32_t)ss; }
