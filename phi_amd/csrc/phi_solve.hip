@@ -751,7 +751,9 @@ int phi_solve_impl(phi_ctx *c)
     std::vector<int32_t> sa_off, sa_idx;                       // (device mode: on the device only, until the host needs them)
     if (!dev) { sa_off.assign((size_t)n_ids + 1, 0); sa_idx.resize((size_t)std::max<int64_t>(n_dp, 1)); }
     const bool dp_is_kept = dev || (c->h_dp.p == c->h_kept.p && c->h_dp.size() == c->h_kept.size());
-    if (dp_is_kept && n_dp > 0) {
+    // (device mode does without the map -- repeats walk by walk, weights from a flag per minimiser -- until the branch and
+    //  bound proper asks for the host copies: at chromosome scale building it is 0.16 of the solve's 0.95 s)
+    auto build_csr = [&](bool to_host_too) -> int {
         // the dp list is the kept list, whose triples are on the device: count / scan / scatter /
         // sort there (1-2 ms for 10^7 anchors; the host loop below takes 4 ms per million)
         const uint32_t *tri = d_tri;
@@ -770,7 +772,8 @@ int phi_solve_impl(phi_ctx *c)
         phi_launch_csr_scatter(c->stream, tri, n_dp, n_ids, c->d_sa_off.as<int32_t>(), c->d_sa_cur.as<int32_t>(), c->d_sa_idx.as<int32_t>());
         phi_launch_csr_sort(c->stream, c->d_sa_off.as<int32_t>(), n_ids, c->d_sa_idx.as<int32_t>());
         int32_t total = 0;
-        if (!dev) {
+        if (to_host_too) {
+            sa_off.resize((size_t)n_ids + 1); sa_idx.resize((size_t)std::max<int64_t>(n_dp, 1));
             HIPCHK(hipMemcpyAsync(sa_off.data(), c->d_sa_off.p, (size_t)(n_ids + 1) * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipMemcpyAsync(sa_idx.data(), c->d_sa_idx.p, (size_t)n_dp * 4, hipMemcpyDeviceToHost, c->stream));
         }
@@ -780,6 +783,12 @@ int phi_solve_impl(phi_ctx *c)
         HIPCHK(hipStreamSynchronize(c->stream));
         if ((kerr & PHI_KERR_CSR_ID) || total != (int32_t)n_dp)
             return phi_fail(c, PHI_ERR_DEVICE, "minimiser id out of range (internal error)");
+        return PHI_OK;
+    };
+    if (dev) {
+        // (nothing yet)
+    } else if (dp_is_kept && n_dp > 0) {
+        PHICHK(build_csr(true));
     } else {
         // (tried on host threads with atomic counters and per-list sorts: 7.5 ms against 4.3 ms for this loop)
         for (const PhiAnchorHost &a : c->h_dp) {
@@ -837,8 +846,17 @@ int phi_solve_impl(phi_ctx *c)
     std::set<uint32_t> S0;
     if (!getenv("PHI_NO_S0") && dev) {
         PHICHK(phi_dev_ensure(c, c->d_flags, (size_t)std::max<int64_t>(n_ids, 1)));
-        phi_launch_repeat_slots(c->stream, c->d_sa_off.as<int32_t>(), c->d_sa_idx.as<int32_t>(), d_tri, c->d_walk_off.as<int64_t>(), nw, n_ids,
-                                c->d_flags.as<uint8_t>());
+        PHICHK(phi_dev_ensure(c, c->d_last_walk, (size_t)std::max<int64_t>(n_ids, 1) * 4));
+        HIPCHK(hipMemsetAsync(c->d_flags.p, 0, (size_t)std::max<int64_t>(n_ids, 1), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_last_walk.p, 0xFF, (size_t)std::max<int64_t>(n_ids, 1) * 4, c->stream));
+        {
+            int64_t lo = 0;                                    // the kept anchors come in walk order: walk h has h_n_anchors[h] of them
+            for (int32_t h = 0; h < nw; h++) {
+                phi_launch_repeat_walk(c->stream, d_tri, lo, lo + c->h_n_anchors[h], h, c->d_last_walk.as<int32_t>(), c->d_flags.as<uint8_t>());
+                lo += c->h_n_anchors[h];
+            }
+            if (lo != n_dp) return phi_fail(c, PHI_ERR_DEVICE, "anchors per walk do not add up (internal error)");
+        }
         int64_t n_rep = 0;
         PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_ids, c->d_list, &n_rep));
         std::vector<uint32_t> rep((size_t)n_rep);
@@ -875,10 +893,8 @@ int phi_solve_impl(phi_ctx *c)
         if (!dev) return PHI_OK;
         PhiStageTimer th("solve");
         PHICHK(phi_host_anchors(c));
-        sa_off.resize((size_t)n_ids + 1); sa_idx.resize((size_t)std::max<int64_t>(n_dp, 1));
-        HIPCHK(hipMemcpyAsync(sa_off.data(), c->d_sa_off.p, (size_t)(n_ids + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-        if (n_dp) HIPCHK(hipMemcpyAsync(sa_idx.data(), c->d_sa_idx.p, (size_t)n_dp * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (n_dp) PHICHK(build_csr(true));                      // (the minimiser -> anchors map, made now that it is needed)
+        else { sa_off.assign((size_t)n_ids + 1, 0); sa_idx.assign(1, 0); }
         wgt.assign((size_t)n_dp, 1);
         cov_all.assign((size_t)n_ids, 0); cov_w.assign((size_t)n_ids, 0);
         touched.clear();
@@ -917,12 +933,14 @@ int phi_solve_impl(phi_ctx *c)
             if (dev) {
                 // (no assignments in device mode: to_host() runs before the first node that has one)
                 Sv.assign(S.begin(), S.end());
-                HIPCHK(hipMemsetAsync(c->d_a_weight.p, 1, (size_t)n_dp, c->stream));
                 PHICHK(phi_dev_ensure(c, c->d_slots, std::max<size_t>(Sv.size(), 1) * 4));
                 PHICHK(phi_dev_ensure(c, c->d_slots2, std::max<size_t>(Sv.size(), 1) * 4));
+                PHICHK(phi_dev_ensure(c, c->d_in_s, (size_t)std::max<int64_t>(n_ids, 1)));
                 if (!Sv.empty()) HIPCHK(hipMemcpyAsync(c->d_slots.p, Sv.data(), Sv.size() * 4, hipMemcpyHostToDevice, c->stream));
-                phi_launch_zero_slots(c->stream, c->d_slots.as<uint32_t>(), (int64_t)Sv.size(), c->d_sa_off.as<int32_t>(), c->d_sa_idx.as<int32_t>(),
-                                      c->d_a_weight.as<uint8_t>());
+                // a flag per minimiser of S, then one pass over the anchors (no minimiser -> anchors map in device mode)
+                HIPCHK(hipMemsetAsync(c->d_in_s.p, 0, (size_t)std::max<int64_t>(n_ids, 1), c->stream));
+                phi_launch_mark_list(c->stream, c->d_slots.as<int32_t>(), nullptr, (int64_t)Sv.size(), c->d_in_s.as<uint8_t>());
+                phi_launch_weights(c->stream, d_tri, n_dp, c->d_in_s.as<uint8_t>(), c->d_a_weight.as<uint8_t>());
                 HIPCHK(hipStreamSynchronize(c->stream));       // Sv is read by the copy
             } else {
                 std::fill(wgt.begin(), wgt.end(), 1);

@@ -116,6 +116,31 @@ void phi_launch_repeat_slots(hipStream_t st, const int32_t *sa_off, const int32_
         hipLaunchKernelGGL(phi_repeat_slots_kernel, dim3(grid_for(n_ids, 256)), dim3(256), 0, st, sa_off, sa_idx, tri, walk_off, n_walks, n_ids, flags);
 }
 
+// The same without the minimiser -> anchors map (which costs 0.16 s to build at chromosome scale and is only needed by
+// the branch and bound proper): the anchors come in walk order, so ONE launch per walk over that walk's anchors --
+// last[id] holds the last walk in which minimiser id was met; meeting it again in the same launch is a repeat.
+__global__ void __launch_bounds__(256) phi_repeat_walk_kernel(const uint32_t *__restrict__ tri, int64_t lo, int64_t hi, int32_t walk,
+                                                              int32_t *__restrict__ last, uint8_t *__restrict__ flags)
+{
+    for (int64_t a = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < hi; a += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t id = tri[a * 3];
+        if (atomicExch(&last[id], walk) == walk) flags[id] = 1;
+    }
+}
+void phi_launch_repeat_walk(hipStream_t st, const uint32_t *tri, int64_t lo, int64_t hi, int32_t walk, int32_t *last, uint8_t *flags)
+{
+    if (hi > lo) hipLaunchKernelGGL(phi_repeat_walk_kernel, dim3(grid_for(hi - lo, 256)), dim3(256), 0, st, tri, lo, hi, walk, last, flags);
+}
+// weights of a relaxation from a flag per minimiser (in_s[id] != 0: its anchors count 0), over all anchors
+__global__ void __launch_bounds__(256) phi_weights_kernel(const uint32_t *__restrict__ tri, int64_t n, const uint8_t *__restrict__ in_s, uint8_t *__restrict__ wgt)
+{
+    GRID_STRIDE(a, n) wgt[a] = in_s[tri[a * 3]] ? 0 : 1;
+}
+void phi_launch_weights(hipStream_t st, const uint32_t *tri, int64_t n, const uint8_t *in_s, uint8_t *wgt)
+{
+    if (n > 0) hipLaunchKernelGGL(phi_weights_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, tri, n, in_s, wgt);
+}
+
 // ---- weights of a relaxation: the anchors of the minimisers in `slots` count 0 (the caller set all weights to 1)
 __global__ void __launch_bounds__(256) phi_zero_slots_kernel(const uint32_t *__restrict__ slots, int64_t n, const int32_t *__restrict__ sa_off,
                                                              const int32_t *__restrict__ sa_idx, uint8_t *__restrict__ wgt)
