@@ -275,11 +275,8 @@ void phi_launch_anchor_prep(hipStream_t st, const uint32_t *tri, int64_t n, cons
                             unsigned long long *walk_cnt, unsigned long long *out);
 void phi_launch_vertex_most(hipStream_t st, const int64_t *g_off, int64_t n_entries, const int32_t *walk_vtx, int32_t *vmax);
 void phi_launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long long *out);
-void phi_launch_repeat_slots(hipStream_t st, const int32_t *sa_off, const int32_t *sa_idx, const uint32_t *tri, const int64_t *walk_off, int32_t n_walks,
-                             int64_t n_ids, uint8_t *flags);
 void phi_launch_repeat_walk(hipStream_t st, const uint32_t *tri, int64_t lo, int64_t hi, int32_t walk, int32_t *last, uint8_t *flags);
 void phi_launch_weights(hipStream_t st, const uint32_t *tri, int64_t n, const uint8_t *in_s, uint8_t *wgt);
-void phi_launch_zero_slots(hipStream_t st, const uint32_t *slots, int64_t n, const int32_t *sa_off, const int32_t *sa_idx, uint8_t *wgt);
 void phi_launch_path_cover(hipStream_t st, bool clear, const phi_ent_t *segs, int32_t n_seg, const int64_t *g_off, const uint32_t *tri, const uint8_t *wgt,
                            int32_t *cov_all, int32_t *cov_w, unsigned long long *ctr, uint32_t *twice, int64_t twice_cap);
 void phi_launch_uncovered_slots(hipStream_t st, const uint32_t *slots, int64_t n, const int32_t *cov_all, unsigned long long *ctr, uint32_t *out);

@@ -93,30 +93,7 @@ void phi_launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned lo
     if (n > 0) hipLaunchKernelGGL(phi_sum_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, v, n, out);
 }
 
-// ---- minimisers with two anchors on one walk (adjacent in the minimiser's anchor list, which is in walk order)
-__global__ void __launch_bounds__(256) phi_repeat_slots_kernel(const int32_t *__restrict__ sa_off, const int32_t *__restrict__ sa_idx,
-                                                               const uint32_t *__restrict__ tri, const int64_t *__restrict__ walk_off, int32_t n_walks,
-                                                               int64_t n_ids, uint8_t *__restrict__ flags)
-{
-    GRID_STRIDE(u, n_ids) {
-        uint8_t f = 0;
-        int32_t prev = -1;
-        for (int32_t j = sa_off[u]; j < sa_off[u + 1]; j++) {
-            const int32_t h = walk_of_entry(walk_off, n_walks, tri[(int64_t)sa_idx[j] * 3 + 1]);
-            if (h == prev) { f = 1; break; }
-            prev = h;
-        }
-        flags[u] = f;
-    }
-}
-void phi_launch_repeat_slots(hipStream_t st, const int32_t *sa_off, const int32_t *sa_idx, const uint32_t *tri, const int64_t *walk_off, int32_t n_walks,
-                             int64_t n_ids, uint8_t *flags)
-{
-    if (n_ids > 0)
-        hipLaunchKernelGGL(phi_repeat_slots_kernel, dim3(grid_for(n_ids, 256)), dim3(256), 0, st, sa_off, sa_idx, tri, walk_off, n_walks, n_ids, flags);
-}
-
-// The same without the minimiser -> anchors map (which costs 0.16 s to build at chromosome scale and is only needed by
+// ---- minimisers with two anchors on one walk.  Without the minimiser -> anchors map (which costs 0.16 s to build at chromosome scale and is only needed by
 // the branch and bound proper): the anchors come in walk order, so ONE launch per walk over that walk's anchors --
 // last[id] holds the last walk in which minimiser id was met; meeting it again in the same launch is a repeat.
 __global__ void __launch_bounds__(256) phi_repeat_walk_kernel(const uint32_t *__restrict__ tri, int64_t lo, int64_t hi, int32_t walk,
@@ -139,20 +116,6 @@ __global__ void __launch_bounds__(256) phi_weights_kernel(const uint32_t *__rest
 void phi_launch_weights(hipStream_t st, const uint32_t *tri, int64_t n, const uint8_t *in_s, uint8_t *wgt)
 {
     if (n > 0) hipLaunchKernelGGL(phi_weights_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, tri, n, in_s, wgt);
-}
-
-// ---- weights of a relaxation: the anchors of the minimisers in `slots` count 0 (the caller set all weights to 1)
-__global__ void __launch_bounds__(256) phi_zero_slots_kernel(const uint32_t *__restrict__ slots, int64_t n, const int32_t *__restrict__ sa_off,
-                                                             const int32_t *__restrict__ sa_idx, uint8_t *__restrict__ wgt)
-{
-    GRID_STRIDE(i, n) {
-        const uint32_t s = slots[i];
-        for (int32_t j = sa_off[s]; j < sa_off[s + 1]; j++) wgt[sa_idx[j]] = 0;
-    }
-}
-void phi_launch_zero_slots(hipStream_t st, const uint32_t *slots, int64_t n, const int32_t *sa_off, const int32_t *sa_idx, uint8_t *wgt)
-{
-    if (n > 0) hipLaunchKernelGGL(phi_zero_slots_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, slots, n, sa_off, sa_idx, wgt);
 }
 
 // ---- what a path covers.  segs = (first entry, last entry) of the path's stretches along single walks; the anchors
