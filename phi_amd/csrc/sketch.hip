@@ -1009,26 +1009,43 @@ __global__ void __launch_bounds__(TPB) phi_sketch_bytes_kernel(PhiSketchArgs A, 
     bytes_role<MODE>(A, batch_bad, blockIdx.x, gridDim.x, s_all);
 }
 
-// single-workgroup exclusive scan of the per-chunk counts (launch-bound, tiny)
+// single-workgroup exclusive scan of per-block counts (off[n] = total).  Tiles of 4096 counts, four consecutive per thread:
+// the loads are coalesced whatever n is -- a chromosome-scale graph scans 1.3 M block counts here, six times per solve
+// (a thread summing its own contiguous share of the array, as before, read with a stride of 5 KB between lanes: 4.4 ms a call).
 __global__ void __launch_bounds__(1024) phi_scan_counts_kernel(const int32_t *__restrict__ cnt, int64_t n,
                                                                int64_t *__restrict__ off)
 {
-    __shared__ int64_t s_part[1024];
-    const int tid = threadIdx.x;
-    const int64_t per = (n + 1023) / 1024;
-    const int64_t lo = min(n, tid * per), hi = min(n, lo + per);
-    int64_t s = 0;
-    for (int64_t i = lo; i < hi; i++) s += cnt[i];
-    s_part[tid] = s;
+    __shared__ int64_t s_w[16];
+    __shared__ int64_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    if (tid == 0) {
-        int64_t run = 0;
-        for (int i = 0; i < 1024; i++) { const int64_t t = s_part[i]; s_part[i] = run; run += t; }
-        off[n] = run;
+    for (int64_t base = 0; base < n; base += 4096) {
+        const int64_t i0 = base + 4 * (int64_t)tid;
+        int32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = i0 + j < n ? cnt[i0 + j] : 0;
+        const int64_t c = (int64_t)v[0] + v[1] + v[2] + v[3];
+        int64_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) s_w[wid] = inc;
+        const int64_t carry = s_carry;
+        __syncthreads();
+        int64_t run = carry + inc - c;
+        for (int x = 0; x < wid; x++) run += s_w[x];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i0 + j < n) off[i0 + j] = run;
+            run += v[j];
+        }
+        if (tid == 1023) s_carry = run;                   // (the last thread's running sum = everything up to the tile's end)
+        __syncthreads();
     }
-    __syncthreads();
-    int64_t run = s_part[tid];
-    for (int64_t i = lo; i < hi; i++) { off[i] = run; run += cnt[i]; }
+    if (tid == 0) off[n] = s_carry;
 }
 
 // ---------------------------------------------------------------------------------- launchers
