@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
         if (jb <= (int32_t)A.ev_off[wj] || jb >= (int32_t)A.ev_off[wj + 1]) {            // uniform over the workgroup
             if (wave == 0) {
                 A.row_out[(int64_t)blockIdx.x * 64 + h] = NEGK;
-                if (h == 0) { A.rowend_out[blockIdx.x] = NEG; if (A.rownew_out) A.rownew_out[blockIdx.x] = NEGK; }
+                if (h == 0) { A.rowend_out[blockIdx.x] = NEG; if (A.rownew_out) A.rownew_out[blockIdx.x] = NEGK; if (A.rowdiag_out) A.rowdiag_out[(int64_t)sb * 64 + row_j] = NEGK; }
             }
             return;
         }
@@ -953,7 +953,11 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             if (key > best) { best = key; bs = s_qs[(qh + j) & (QD - 1)][h]; }
         }
         if (MODE == DP_ROW) {
-            A.row_out[(int64_t)blockIdx.x * 64 + h] = has_walk ? best : NEGK;
+            // (class lanes: the row's own column goes to an array of its own and leaves NEGK behind -- the chain then takes the
+            //  other classes' maximum over the whole row without looking for the diagonal)
+            const bool on_diag = A.rowdiag_out && h == row_j;
+            if (on_diag) A.rowdiag_out[(int64_t)sb * 64 + h] = has_walk ? best : NEGK;
+            A.row_out[(int64_t)blockIdx.x * 64 + h] = has_walk && !on_diag ? best : NEGK;
             const int32_t eb_all = ev_wave_max_i32(endbest);
             if (h == 0) A.rowend_out[blockIdx.x] = eb_all;
             // what a walk of the unit lane's class other than the one that carries the key gets: the new runs of that lane
@@ -1166,11 +1170,14 @@ __global__ void __launch_bounds__(256) phi_blk_classes_kernel(PhiBlkClassArgs G)
 // of block b + DEPTH are on their way while block b is chained.  All sums stay far inside int32: keys and offsets are
 // bounded by the anchors of one walk (< 2^27, phi_solve.hip).
 __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, const int32_t *__restrict__ rows, const int32_t *__restrict__ rownew,
-                                                            int32_t *__restrict__ blk_S)
+                                                            const int32_t *__restrict__ rowdiag, int32_t *__restrict__ blk_S)
 {
     constexpr int NR = 65 * 64;
     constexpr int DEPTH = 4;
-    constexpr int32_t NONE = INT32_MIN;
+    // "no value" is NEGK everywhere: NEGK + a key (|key| < 2^27) and NEGK + NEGK stay below NEGK / 2 and inside int32, so a
+    // maximum of sums needs no test of its operands (the loop is the longest dependent chain of an iteration: one
+    // workgroup walks 10^5 blocks, 1.1 us each, and what it costs is its instruction count -- C5: 112 ms per DP run)
+    constexpr int32_t NONE = NEGK;
     __shared__ int32_t s_b1[2][64], s_b2[2][64], s_n1[2][64];  // per class: best S + d, second best, walks that reach the best
     __shared__ int32_t s_diag[2][64], s_start[2][64], s_new[2][64];
     __shared__ int32_t s_part[2][4][64];
@@ -1180,15 +1187,15 @@ __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, c
     int32_t S = NEGK;
     int32_t st_row[DEPTH][16], st_x[DEPTH], st_lx[DEPTH], st_dx[DEPTH];
     const int32_t *p_row = rows + wid * 64 + lane;   // + b * NR + 256 * i
-    const int32_t *p_x = wid == 0 ? rows + 64 * 64 + lane : rownew + lane;   // + b * (NR | 65): walk starts (wave 0), new-run keys (wave 1)
-    const int32_t x_stride = wid == 0 ? NR : 65;
+    const int32_t *p_x = wid == 0 ? rows + 64 * 64 + lane : wid == 1 ? rownew + lane : rowdiag + lane;   // + b * (NR | 65 | 64): walk starts (wave 0), new-run keys (wave 1), the rows' own columns (wave 2)
+    const int32_t x_stride = wid == 0 ? NR : wid == 1 ? 65 : 64;
     const int32_t xs = has_walk ? x : 0;
     auto issue = [&](auto J, int32_t b) {
         constexpr int j = decltype(J)::value;
         const int32_t *src = p_row + (int64_t)b * NR;
 #pragma unroll
         for (int i = 0; i < 16; i++) st_row[j][i] = src[256 * i];
-        st_x[j] = wid < 2 ? p_x[(int64_t)b * x_stride] : NEGK;
+        st_x[j] = wid < 3 ? p_x[(int64_t)b * x_stride] : NEGK;
         st_lx[j] = G.walk_lane[(int64_t)b * LS + xs];
         st_dx[j] = G.coff[(int64_t)b * LS + xs];
     };
@@ -1198,6 +1205,7 @@ __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, c
         const int32_t lx = st_lx[j], dx = st_dx[j];
         if (wid == 0) s_start[p][lane] = st_x[j];               // (lanes past the block's classes are never read)
         if (wid == 1) s_new[p][lane] = st_x[j];
+        if (wid == 2) s_diag[p][lane] = st_x[j];
         if (has_walk) blk_S[(int64_t)b * LS + x] = S;
         const bool live = has_walk && S > NEGK / 2;
         const int32_t v = S + dx;
@@ -1207,22 +1215,16 @@ __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, c
         if (live) { if (v == b1) atomicAdd(&s_n1[p][lx], 1); else atomicMax(&s_b2[p][lx], v); }
         if (x < 64) { s_b1[p ^ 1][x] = NONE; s_b2[p ^ 1][x] = NONE; s_n1[p ^ 1][x] = 0; }   // for the next iteration (last read before this iteration's first barrier)
         // partial maxima over this wave's classes, for class lane `lane`
-        int32_t part = NONE, diag = NEGK;
-        // (branch-free: the sixteen LDS reads go out together.  Classes past the block's count have no live walk, so
-        //  their maximum is NONE and whatever lies in their rows is ignored)
+        int32_t part = NONE;
+        // (branch-free: the sixteen LDS reads go out together.  Classes past the block's count have no live walk: their
+        //  maximum is NONE, and NONE plus whatever lies in their rows -- keys of an earlier solve at most -- stays "no
+        //  value"; the row's own column holds NEGK, see the row pass)
         int32_t o16[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) o16[i] = s_b1[p][wid + 4 * i];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int32_t C = wid + 4 * i;
-            const int32_t r = st_row[j][i], o = o16[i];
-            diag = C == lane ? r : diag;
-            const bool ok = C != lane && o != NONE && r > NEGK / 2;
-            part = ok && o + r > part ? o + r : part;
-        }
+        for (int i = 0; i < 16; i++) part = max(part, o16[i] + st_row[j][i]);
         s_part[p][wid][lane] = part;
-        if ((lane & 3) == wid) s_diag[p][lane] = diag;         // (row[l][l] is held by wave l mod 4)
         issue(J, min(b + DEPTH, nb - 1));                      // (always: the compiler can then count the loads in flight instead of draining them)
         __syncthreads();
         int32_t best = NEGK;
@@ -1232,10 +1234,10 @@ __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, c
                 // the best of the other walks of the class
                 const int32_t o = (live && v == b1 && s_n1[p][lx] == 1) ? s_b2[p][lx] : b1;
                 const int32_t kn = s_new[p][lx];
-                if (o != NONE && kn > NEGK / 2 && o + kn - dx > best) best = o + kn - dx;
+                if (o > NEGK / 2 && kn > NEGK / 2 && o + kn - dx > best) best = o + kn - dx;
             }
             const int32_t d = max(max(s_part[p][0][lx], s_part[p][1][lx]), max(s_part[p][2][lx], s_part[p][3][lx]));
-            if (d != NONE && d - dx > best) best = d - dx;
+            if (d > NEGK / 2 && d - dx > best) best = d - dx;
             { const int32_t r = s_start[p][lx]; if (r > NEGK / 2 && r - dx > best) best = r - dx; }
         }
         S = best > NEGK / 2 ? best : NEGK;
@@ -1302,9 +1304,9 @@ void phi_launch_blk_classes(hipStream_t st, const PhiBlkClassArgs &G)
 {
     if (G.n_blk > 0) hipLaunchKernelGGL(phi_blk_classes_kernel, dim3((unsigned)G.n_blk), dim3(256), 0, st, G);
 }
-void phi_launch_blk_chain(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, int32_t *blk_S)
+void phi_launch_blk_chain(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, const int32_t *rowdiag, int32_t *blk_S)
 {
-    hipLaunchKernelGGL(phi_blk_chain_kernel, dim3(1), dim3(256), 0, st, G, rows, rownew, blk_S);
+    hipLaunchKernelGGL(phi_blk_chain_kernel, dim3(1), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S);
 }
 void phi_launch_blk_check(hipStream_t st, const int32_t *keys, const int32_t *S, int32_t n_blk, int32_t LS, int32_t n_walks, int32_t *bad)
 {

@@ -259,6 +259,7 @@ struct PhiDpEventArgs {
     int32_t lane_stride;                 // row length of the per-(block, walk) tables: 64 (<= 64 walks) or 256
     const int32_t *lane_walk;            // DP_ROW on class lanes (> 64 walks): [n_blk][64] the walk that plays class lane l (-1: none)
     int32_t *rownew_out;                 // DP_ROW on class lanes: [n_blk * 65] best key of a run begun inside the block on the unit lane
+    int32_t *rowdiag_out;                // DP_ROW on class lanes: [n_blk][64] row l's own column l (row_out holds NEGK there)
     const int32_t *blk_lo;               // [n_blk + 1]
     const int32_t *blk_ev;               // [n_blk][lane_stride]: first event of each walk inside the block
     const int32_t *blk_S;                // DP_PATH in: [n_blk][lane_stride] key of each walk entering the block (NEGK: none)
@@ -293,7 +294,7 @@ struct PhiBlkClassArgs {
     uint32_t *err;                       // PHI_KERR_DP_CLASSES
 };
 void phi_launch_blk_classes(hipStream_t st, const PhiBlkClassArgs &G);
-void phi_launch_blk_chain(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, int32_t *blk_S);
+void phi_launch_blk_chain(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, const int32_t *rowdiag, int32_t *blk_S);
 void phi_launch_blk_check(hipStream_t st, const int32_t *keys, const int32_t *S, int32_t n_blk, int32_t LS, int32_t n_walks, int32_t *bad);
 void phi_launch_carry_resolve(hipStream_t st, const int32_t *carry, int32_t LS, int32_t b_from, int32_t h, int32_t *out);
 void phi_launch_dp_block_paths_wide(hipStream_t st, const PhiDpEventArgs &A);

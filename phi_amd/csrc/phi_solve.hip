@@ -168,6 +168,7 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
         PHICHK(phi_dev_ensure(c, c->d_coff, nbk * ls * 4));
         PHICHK(phi_dev_ensure(c, c->d_blk_ncls, nbk * 4));
         PHICHK(phi_dev_ensure(c, c->d_rownew, nbk * nrow * 4));
+        PHICHK(phi_dev_ensure(c, c->d_rowdiag, nbk * 64 * 4));
         PHICHK(phi_dev_ensure(c, c->d_blk_bad, 64));
     }
     HIPCHK(hipMemcpyAsync(c->d_blk_lo.p, c->h_blk_lo.data(), (nbk + 1) * 4, hipMemcpyHostToDevice, c->stream));
@@ -257,6 +258,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
             const int32_t nb = c->n_blk;
             A.n_blk = nb; A.blk_ring = c->blk_ring; A.blk_lo = c->d_blk_lo.as<int32_t>(); A.blk_ev = c->d_blk_ev.as<int32_t>(); A.blk_S = c->d_blk_S.as<int32_t>();
             A.row_out = c->d_row_out.as<int32_t>(); A.rowend_out = c->d_rowend.as<int32_t>(); A.rownew_out = c->d_rownew.as<int32_t>();
+            A.rowdiag_out = c->d_rowdiag.as<int32_t>();
             A.blk_keys_out = c->d_blk_keys.as<int32_t>(); A.blk_carry = c->d_blk_carry.as<int32_t>();
             A.lane_walk = c->d_lane_walk.as<int32_t>();
             PhiBlkClassArgs G{};
@@ -274,7 +276,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
             }
             phi_launch_dp_block_rows(c->stream, A);
             if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("block rows"); }
-            phi_launch_blk_chain(c->stream, G, A.row_out, A.rownew_out, c->d_blk_S.as<int32_t>());
+            phi_launch_blk_chain(c->stream, G, A.row_out, A.rownew_out, A.rowdiag_out, c->d_blk_S.as<int32_t>());
             if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("block chain"); }
             A.lane_walk = nullptr;
             phi_launch_dp_block_paths_wide(c->stream, A);
