@@ -315,7 +315,7 @@ void phi_launch_scan_i32(hipStream_t st, const int32_t *cnt, int64_t n, int32_t 
 void phi_launch_scan_i64(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off, int64_t *blk, int64_t *blk_off);
 void phi_launch_scan_sums_i64(hipStream_t st, const int64_t *v, int64_t n, int64_t *off);
 void phi_launch_dp_event_fill(hipStream_t st, const PhiDpEventArgs &A, const uint8_t *e_out, const int32_t *walk_vtx,
-                              const int32_t *cvtx, const int32_t *off_end, const int32_t *off_start);
+                              const int32_t *cvtx, const phi_ent_t *a_e1, const int32_t *off_end, const int32_t *off_start);
 int phi_dp_num_waves(int n_walks);
 void phi_launch_dp_words(hipStream_t st, const uint8_t *e_out, const int64_t *g_off, const uint8_t *g_span,
                          const uint8_t *a_weight, int64_t n_entries, uint64_t *word);

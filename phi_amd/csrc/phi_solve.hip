@@ -226,7 +226,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         A.err = (uint32_t *)(c->d_scalars.as<uint64_t>() + S_ERR);
         A.q_limit = getenv("PHI_DP_QLIMIT") ? atoi(getenv("PHI_DP_QLIMIT")) : 0;      // tests: provoke the fallback
         phi_launch_dp_event_fill(c->stream, A, c->d_e_out.as<uint8_t>(), c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(),
-                                 c->d_off_end.as<int32_t>(), c->d_off_start.as<int32_t>());
+                                 c->d_a_e1.as<phi_ent_t>(), c->d_off_end.as<int32_t>(), c->d_off_start.as<int32_t>());
         if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("weights + per-run records"); }
         A.lane_stride = c->blk_ls;
         auto keep_whole_chain = [&](uint32_t kerr, uint32_t bit) -> int {
