@@ -73,21 +73,9 @@ void phi_launch_event_off(hipStream_t st, const phi_ent_t *ev_e, int64_t n_ev, c
 }
 
 // ------------------------------------------------------------------ per run: counts, prefix sums, event records
-// cnt_end[e] / cnt_start[e] += 1 for every weight-1 anchor ending / starting at entry e (arrays zeroed by the caller)
-__global__ void __launch_bounds__(256) phi_dp_counts_kernel(const phi_ent_t *__restrict__ a_e1, const uint8_t *__restrict__ a_span,
-                                                            const uint8_t *__restrict__ a_weight, int64_t n_a,
-                                                            int32_t *__restrict__ cnt_end, int32_t *__restrict__ cnt_start)
-{
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_a; g += (int64_t)gridDim.x * blockDim.x) {
-        if (!a_weight[g]) continue;
-        const phi_ent_t e1 = a_e1[g];
-        atomicAdd(&cnt_end[e1], 1);
-        atomicAdd(&cnt_start[e1 - a_span[g]], 1);
-    }
-}
-
 // exclusive prefix sums of int32 counts, three phases (1024 items per workgroup)
-__global__ void __launch_bounds__(256) phi_scan_blocksum_kernel(const int32_t *__restrict__ cnt, int64_t n,
+template <class T>
+__global__ void __launch_bounds__(256) phi_scan_blocksum_kernel(const T *__restrict__ cnt, int64_t n,
                                                                 int32_t *__restrict__ blk)
 {
     __shared__ int s_w[4];
@@ -103,7 +91,8 @@ __global__ void __launch_bounds__(256) phi_scan_blocksum_kernel(const int32_t *_
 }
 
 // (off may be cnt itself: a thread reads its four counts before it writes its four sums, and nobody else's)
-__global__ void __launch_bounds__(256) phi_scan_apply_kernel(const int32_t *cnt, int64_t n,
+template <class T>
+__global__ void __launch_bounds__(256) phi_scan_apply_kernel(const T *cnt, int64_t n,
                                                              const int64_t *__restrict__ blk_off, int32_t *off)
 {
     __shared__ int s_w[4];
@@ -215,13 +204,26 @@ void phi_launch_scan_i64(hipStream_t st, const int32_t *cnt, int64_t n, int64_t 
 void phi_launch_scan_i32(hipStream_t st, const int32_t *cnt, int64_t n, int32_t *off, int32_t *blk, int64_t *blk_off)
 {
     const int64_t nb = phi_scan_i32_num_blocks(n);
-    hipLaunchKernelGGL(phi_scan_blocksum_kernel, dim3((unsigned)nb), dim3(256), 0, st, cnt, n, blk);
+    hipLaunchKernelGGL(phi_scan_blocksum_kernel<int32_t>, dim3((unsigned)nb), dim3(256), 0, st, cnt, n, blk);
     phi_launch_scan_counts(st, blk, nb, blk_off);
-    hipLaunchKernelGGL(phi_scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, cnt, n, blk_off, off);
+    hipLaunchKernelGGL(phi_scan_apply_kernel<int32_t>, dim3((unsigned)nb), dim3(256), 0, st, cnt, n, blk_off, off);
+}
+// the same over bytes (the anchor weights of a DP run)
+void phi_launch_scan_u8(hipStream_t st, const uint8_t *cnt, int64_t n, int32_t *off, int32_t *blk, int64_t *blk_off)
+{
+    const int64_t nb = phi_scan_i32_num_blocks(n);
+    hipLaunchKernelGGL(phi_scan_blocksum_kernel<uint8_t>, dim3((unsigned)nb), dim3(256), 0, st, cnt, n, blk);
+    phi_launch_scan_counts(st, blk, nb, blk_off);
+    hipLaunchKernelGGL(phi_scan_apply_kernel<uint8_t>, dim3((unsigned)nb), dim3(256), 0, st, cnt, n, blk_off, off);
 }
 
 // One 48-byte record per event:
 //   int4  A = { compact step | overflow << 31, entry (phi_ent_t), End (inclusive), SB }
+//         End / SB = weight-1 anchors of the walk that end at or before / begin before the entry.  With the anchors sorted by
+//         last entry and W = prefix sums of their weights (wpre), "end before entry x" is W[g_off[x]]; an anchor that
+//         begins before e and ends at or after it ends within the next 30 entries (span <= 31): a short range to look at.
+//         (Until round 3 both came from per-ENTRY counters -- two arrays of 4 bytes per walk entry zeroed, filled by an
+//          atomic per anchor and prefix-summed in every DP run: 35 of a run's 204 ms at chromosome scale.)
 //   32 B  G : byte a (1..30) = #{weight-1 anchors of the walk inside [entry - a, entry]}, byte 0 = 0,
 //             byte 31 = out-edge index of the entry (255: the walk ends here)
 // overflow: more than 255 anchors end inside the window (the DP then counts from the CSR).
@@ -234,8 +236,7 @@ __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const phi_ent_t 
                                                                 const uint8_t *__restrict__ g_span,
                                                                 const uint8_t *__restrict__ a_weight,
                                                                 const phi_ent_t *__restrict__ a_e1,
-                                                                const int32_t *__restrict__ off_end,
-                                                                const int32_t *__restrict__ off_start,
+                                                                const int32_t *__restrict__ wpre, int64_t n_entries,
                                                                 uint4 *__restrict__ ev)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ev; i += (int64_t)gridDim.x * blockDim.x) {
@@ -283,38 +284,35 @@ __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const phi_ent_t 
             carry = w[q] >> 56;
         }
         w[3] = (w[3] & 0x00FFFFFFFFFFFFFFull) | ((unsigned long long)e_out[e] << 56);
-        // End and SB count from the walk's first entry (anchors of earlier walks have both begun and ended there, so
-        // the two prefix sums agree at it): keys E - SB stay within the score range whatever the number of walks
-        const int32_t base = off_start[eb];
+        // End and SB count from the walk's first entry (anchors of earlier walks have both begun and ended before it):
+        // keys E - SB stay within the score range whatever the number of walks
+        const int64_t g_e = g_off[e];
+        const int32_t base = wpre[g_off[eb]];
+        int32_t sb = wpre[g_e] - base;
+        {
+            const int64_t xe = e + 31 < n_entries ? e + 31 : n_entries;
+            const int64_t g_fe = g_off[xe];
+            for (int64_t g = g_e; g < g_fe; g++) sb += a_weight[g] && (int64_t)a_e1[g] - g_span[g] < e;
+        }
         uint4 A;
         A.x = (uint32_t)cvtx[walk_vtx[e]] | (ovf ? 0x80000000u : 0u);
         A.y = (uint32_t)e;
-        A.z = (uint32_t)(off_end[e + 1] - base);
-        A.w = (uint32_t)(off_start[e] - base);
+        A.z = (uint32_t)(wpre[g_hi] - base);
+        A.w = (uint32_t)sb;
         ev[i * 3 + 0] = A;
         ev[i * 3 + 1] = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
         ev[i * 3 + 2] = make_uint4((uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32));
     }
 }
 
-void phi_launch_dp_counts(hipStream_t st, const phi_ent_t *a_e1, const uint8_t *a_span, const uint8_t *a_weight, int64_t n_a,
-                          int32_t *cnt_end, int32_t *cnt_start)
-{
-    if (n_a <= 0) return;
-    int64_t nb = (n_a + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(phi_dp_counts_kernel, dim3((unsigned)nb), dim3(256), 0, st, a_e1, a_span, a_weight, n_a, cnt_end,
-                       cnt_start);
-}
-
 void phi_launch_dp_event_fill(hipStream_t st, const PhiDpEventArgs &A, const uint8_t *e_out, const int32_t *walk_vtx,
-                              const int32_t *cvtx, const phi_ent_t *a_e1, const int32_t *off_end, const int32_t *off_start)
+                              const int32_t *cvtx, const phi_ent_t *a_e1, const int32_t *wpre, int64_t n_entries)
 {
     if (A.n_ev <= 0) return;
     int64_t nb = (A.n_ev + 255) / 256;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(phi_dp_event_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, A.ev_e, A.n_ev, walk_vtx, cvtx,
-                       A.walk_off, A.n_walks, e_out, A.g_off, A.g_span, A.a_weight, a_e1, off_end, off_start,
+                       A.walk_off, A.n_walks, e_out, A.g_off, A.g_span, A.a_weight, a_e1, wpre, n_entries,
                        reinterpret_cast<uint4 *>(A.ev));
 }
 

@@ -103,6 +103,7 @@ struct phi_ctx {
     int64_t n_rec = 0;
     DevBuf d_u_keys, d_u_rep, d_u_uid, d_u_replist;   // walk-minimiser table: keys, first record, dense id; dense id -> first record
     DevBuf d_u_kv;                                    // the same table as (key, id) pairs, for the read probes
+    DevBuf d_wpre;                                    // per DP run: prefix sums of the anchor weights (dp_events.hip)
     DevBuf d_rowdiag;                                 // class-lane blocks: the rows' own columns (dp_events.hip)
     DevBuf d_in_s, d_last_walk;                       // solve on the device copy of the anchors: a flag / the last walk per minimiser
     int64_t n_unique = 0;                             // distinct walk minimisers

@@ -307,15 +307,14 @@ void phi_launch_blk_ev(hipStream_t st, const int32_t *blk_lo, int32_t n_blk, con
 void phi_launch_event_flags(hipStream_t st, const int32_t *walk_vtx, int64_t n_entries, const int32_t *cvtx, uint8_t *flags);
 void phi_launch_event_off(hipStream_t st, const phi_ent_t *ev_e, int64_t n_ev, const int64_t *walk_off, int32_t n_walks,
                           int64_t *ev_off);
-void phi_launch_dp_counts(hipStream_t st, const phi_ent_t *a_e1, const uint8_t *a_span, const uint8_t *a_weight, int64_t n_a,
-                          int32_t *cnt_end, int32_t *cnt_start);
 int64_t phi_scan_i32_num_blocks(int64_t n);
 void phi_launch_scan_i32(hipStream_t st, const int32_t *cnt, int64_t n, int32_t *off, int32_t *blk, int64_t *blk_off);
 // same with 64-bit sums: off[0..n] int64, blk int64 scratch
 void phi_launch_scan_i64(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off, int64_t *blk, int64_t *blk_off);
 void phi_launch_scan_sums_i64(hipStream_t st, const int64_t *v, int64_t n, int64_t *off);
 void phi_launch_dp_event_fill(hipStream_t st, const PhiDpEventArgs &A, const uint8_t *e_out, const int32_t *walk_vtx,
-                              const int32_t *cvtx, const phi_ent_t *a_e1, const int32_t *off_end, const int32_t *off_start);
+                              const int32_t *cvtx, const phi_ent_t *a_e1, const int32_t *wpre, int64_t n_entries);
+void phi_launch_scan_u8(hipStream_t st, const uint8_t *cnt, int64_t n, int32_t *off, int32_t *blk, int64_t *blk_off);
 int phi_dp_num_waves(int n_walks);
 void phi_launch_dp_words(hipStream_t st, const uint8_t *e_out, const int64_t *g_off, const uint8_t *g_span,
                          const uint8_t *a_weight, int64_t n_entries, uint64_t *word);

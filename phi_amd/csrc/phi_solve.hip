@@ -201,17 +201,14 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
     int32_t *d_dmax = c->d_dmax.as<int32_t>(), *d_bstart = c->d_bstart.as<int32_t>();
     int32_t *d_ent_src = c->d_ent.as<int32_t>(), *d_ent_h = c->d_ent.as<int32_t>() + n_ent;
     if (events) {
-        // per run: anchors ending / starting per entry -> prefix sums -> one record per event
-        // (counted into the buffers that then hold the prefix sums: the scan works in place, and at chromosome scale every
-        //  array of this size is 5 GB)
-        HIPCHK(hipMemsetAsync(c->d_off_end.p, 0, (size_t)(ne + 1) * 4, c->stream));
-        HIPCHK(hipMemsetAsync(c->d_off_start.p, 0, (size_t)(ne + 1) * 4, c->stream));
-        phi_launch_dp_counts(c->stream, c->d_a_e1.as<phi_ent_t>(), c->d_g_span.as<uint8_t>(), c->d_a_weight.as<uint8_t>(), n_dp,
-                             c->d_off_end.as<int32_t>(), c->d_off_start.as<int32_t>());
-        phi_launch_scan_i32(c->stream, c->d_off_end.as<int32_t>(), ne, c->d_off_end.as<int32_t>(), c->d_scan_blk.as<int32_t>(),
-                            c->d_scan_blkoff.as<int64_t>());
-        phi_launch_scan_i32(c->stream, c->d_off_start.as<int32_t>(), ne, c->d_off_start.as<int32_t>(), c->d_scan_blk.as<int32_t>(),
-                            c->d_scan_blkoff.as<int64_t>());
+        // per run: prefix sums of the anchor weights -> one record per event (phi_dp_event_fill_kernel)
+        {
+            const int64_t nb = phi_scan_i32_num_blocks(n_dp);
+            PHICHK(phi_dev_ensure(c, c->d_wpre, (size_t)(n_dp + 1) * 4));
+            PHICHK(phi_dev_ensure(c, c->d_scan_blk, (size_t)nb * 4));
+            PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
+            phi_launch_scan_u8(c->stream, c->d_a_weight.as<uint8_t>(), n_dp, c->d_wpre.as<int32_t>(), c->d_scan_blk.as<int32_t>(), c->d_scan_blkoff.as<int64_t>());
+        }
         PhiDpEventArgs A{};
         A.n_k = c->n_k; A.n_walks = c->n_walks; A.n_ev = c->n_ev;
         A.k_rec = c->d_k_rec.as<int32_t>(); A.k_in_packed = c->d_k_in.as<int32_t>();
@@ -226,7 +223,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         A.err = (uint32_t *)(c->d_scalars.as<uint64_t>() + S_ERR);
         A.q_limit = getenv("PHI_DP_QLIMIT") ? atoi(getenv("PHI_DP_QLIMIT")) : 0;      // tests: provoke the fallback
         phi_launch_dp_event_fill(c->stream, A, c->d_e_out.as<uint8_t>(), c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(),
-                                 c->d_a_e1.as<phi_ent_t>(), c->d_off_end.as<int32_t>(), c->d_off_start.as<int32_t>());
+                                 c->d_a_e1.as<phi_ent_t>(), c->d_wpre.as<int32_t>(), ne);
         if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("weights + per-run records"); }
         A.lane_stride = c->blk_ls;
         auto keep_whole_chain = [&](uint32_t kerr, uint32_t bit) -> int {
