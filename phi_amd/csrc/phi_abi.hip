@@ -61,10 +61,48 @@ int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes)
 
 static void dev_free(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
+// A large array from the caller's PAGEABLE memory (the walk entries of a chromosome-scale graph: 5 GB): the runtime stages such
+// a copy through its own pinned buffers with one thread, 7 GB/s -- most of phi_set_graph at that size.  Here: two pinned
+// buffers of the context, filled by four threads, each sent while the other is filled.
+static int upload_staged(phi_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    constexpr size_t PIECE = (size_t)64 << 20;
+    if (!c->h_stage[0]) {
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipHostMalloc(&c->h_stage[i], PIECE, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+        }
+    }
+    int k = 0;
+    for (size_t off = 0; off < bytes; off += PIECE, k ^= 1) {
+        const size_t n = std::min(PIECE, bytes - off);
+        HIPCHK(hipEventSynchronize(c->stage_ev[k]));          // (the copy that last read this buffer; a fresh event is complete)
+        {
+            const int nt = 4;
+            std::vector<std::thread> th;
+            char *d = static_cast<char *>(c->h_stage[k]);
+            const char *s = static_cast<const char *>(src) + off;
+            for (int t = 1; t < nt; t++) th.emplace_back([=]() { memcpy(d + n * t / nt, s + n * t / nt, n * (t + 1) / nt - n * t / nt); });
+            memcpy(d, s, n / nt);
+            for (auto &x : th) x.join();
+        }
+        HIPCHK(hipMemcpyAsync(static_cast<char *>(dst) + off, c->h_stage[k], n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(c->stage_ev[k], st));
+    }
+    return PHI_OK;
+}
+
 template <class T> static int upload(phi_ctx *c, DevBuf &b, const T *src, size_t n, hipStream_t st = nullptr)
 {
     PHICHK(phi_dev_ensure(c, b, (n ? n : 1) * sizeof(T)));
-    if (n) HIPCHK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, st ? st : c->stream));
+    if (!st) st = c->stream;
+    if (n * sizeof(T) >= ((size_t)256 << 20) && !getenv("PHI_NO_STAGED_UPLOAD")) {
+        hipPointerAttribute_t at{};
+        const bool pinned = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
+        (void)hipGetLastError();                               // (an unregistered pointer is an error of that call, not of ours)
+        if (!pinned) return upload_staged(c, b.p, src, n * sizeof(T), st);
+    }
+    if (n) HIPCHK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, st));
     return PHI_OK;
 }
 
@@ -253,6 +291,7 @@ void phi_ctx_destroy(phi_ctx *c)
     if (c && c->pin_future.valid()) c->pin_future.wait();
     if (c && c->dp_alloc_future.valid()) (void)c->dp_alloc_future.get();
     if (c && c->h_pin) { (void)hipSetDevice(c->device); (void)hipHostFree(c->h_pin); c->h_pin = nullptr; }
+    if (c) for (int i = 0; i < 2; i++) { if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); c->h_stage[i] = nullptr; c->stage_ev[i] = nullptr; }
     if (!c) return;
     (void)phi_comm_destroy(c);
     (void)hipSetDevice(c->device);
@@ -742,12 +781,15 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     // every early return below must first wait for that thread
     struct Joiner { std::future<int> &f; ~Joiner() { if (f.valid()) f.wait(); } } joiner{gpu_future};
     // ---- host copies of the graph, while the GPU thread uploads
-    c->h_seq.assign(seq_concat, seq_concat + seq_off[n_vtx]);
-    c->h_seq_off.assign(seq_off, seq_off + n_vtx + 1);
-    c->h_adj_off.assign(adj_off, adj_off + n_vtx + 1);
-    c->h_adj.assign(adj, adj + n_edges);
-    c->h_walk_off.assign(walk_off, walk_off + n_walks + 1);
-    c->h_topo_rank.assign(topo_rank, topo_rank + n_vtx);
+    // (each array on a thread of its own: at chromosome scale they are 0.45 GB of first-touched pages, 130 ms one after the other)
+    {
+        std::thread t1([&]() { c->h_seq.assign(seq_concat, seq_concat + seq_off[n_vtx]); });
+        std::thread t2([&]() { c->h_seq_off.assign(seq_off, seq_off + n_vtx + 1); });
+        std::thread t3([&]() { c->h_adj_off.assign(adj_off, adj_off + n_vtx + 1); c->h_adj.assign(adj, adj + n_edges); });
+        c->h_walk_off.assign(walk_off, walk_off + n_walks + 1);
+        c->h_topo_rank.assign(topo_rank, topo_rank + n_vtx);
+        t1.join(); t2.join(); t3.join();
+    }
     tm.lap("host copies");
     // ---- one parallel pass over the walk entries (host threads over fixed chunks of entries):
     //   * walks follow edges of forward vertices (ILP_index.cpp:104-107 exits on reverse strand; an

@@ -103,6 +103,8 @@ struct phi_ctx {
     int64_t n_rec = 0;
     DevBuf d_u_keys, d_u_rep, d_u_uid, d_u_replist;   // walk-minimiser table: keys, first record, dense id; dense id -> first record
     DevBuf d_u_kv;                                    // the same table as (key, id) pairs, for the read probes
+    void *h_stage[2] = {nullptr, nullptr};            // pinned staging buffers of large uploads from pageable memory (phi_abi.hip upload_staged)
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
     DevBuf d_wpre;                                    // per DP run: prefix sums of the anchor weights (dp_events.hip)
     DevBuf d_rowdiag;                                 // class-lane blocks: the rows' own columns (dp_events.hip)
     DevBuf d_in_s, d_last_walk;                       // solve on the device copy of the anchors: a flag / the last walk per minimiser
