@@ -268,8 +268,9 @@ static int split_tabs(const char *p, const char *e, Slice *f, int cap)
 {
     int n = 0;
     while (n < cap) {
-        const char *t = (const char *)memchr(p, '\t', (size_t)(e - p));
-        if (!t || n == cap - 1) { f[n++] = Slice{p, (size_t)(e - p)}; break; }
+        // (the last field asked for is the rest of the line, not searched: for a W-line that is the walk, megabytes long)
+        const char *t = n == cap - 1 ? nullptr : (const char *)memchr(p, '\t', (size_t)(e - p));
+        if (!t) { f[n++] = Slice{p, (size_t)(e - p)}; break; }
         f[n++] = Slice{p, (size_t)(t - p)};
         p = t + 1;
     }
@@ -300,7 +301,7 @@ void scan_slice(const char *p, const char *end, SliceOut &o)
         if (le > p && le[-1] == '\r') le--;
         if (le - p >= 3 && p[1] == '\t' && (p[0] == 'S' || p[0] == 'L' || p[0] == 'W')) {
             const char t = p[0];
-            const int nf = split_tabs(p, le, f, t == 'W' ? 8 : 6);
+            const int nf = split_tabs(p, le, f, t == 'W' ? 7 : 6);
             if (t == 'S' && nf >= 3) {
                 const bool has = f[2].n > 0 && f[2].p[0] != '*';
                 o.recs.push_back(Rec{f[1].p, has ? f[2].p : nullptr, (uint32_t)f[1].n, has ? (uint32_t)f[2].n : 0u, 'S', 0, 0});
@@ -314,8 +315,7 @@ void scan_slice(const char *p, const char *end, SliceOut &o)
                 WRec w;
                 w.sample = f[1];
                 w.hap = atoi(std::string(f[2].p, f[2].n).c_str());
-                w.text = f[6];
-                if (const char *tab = (const char *)memchr(w.text.p, '\t', w.text.n)) w.text.n = (size_t)(tab - w.text.p);   // optional tags follow
+                w.text = f[6];                                        // (optional tags may follow: cut off below, where the text is read anyway)
                 w.before = o.recs.size();
                 o.walks.push_back(w);
             }
@@ -326,7 +326,7 @@ void scan_slice(const char *p, const char *end, SliceOut &o)
 
 inline bool is_step(char c) { return c == '>' || c == '<'; }
 
-struct Piece { int32_t walk; const char *lo, *hi; int64_t n = 0, out = 0, dropped = 0; bool any_rev = false; };
+struct Piece { int32_t walk; const char *lo, *hi; int64_t n = 0, out = 0, dropped = 0; bool any_rev = false, has_tab = false; };
 }  // namespace
 
 extern "C" {
@@ -519,8 +519,12 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
 
     // ---- the walks' vertices: pieces of the W-lines, cut at steps, on all threads
     std::vector<Piece> pieces;
-    {
-        const size_t PIECE = getenv("PHI_GFA_PIECE") ? std::max<size_t>(16, (size_t)atoll(getenv("PHI_GFA_PIECE"))) : ((size_t)1 << 20);
+    const size_t PIECE = getenv("PHI_GFA_PIECE") ? std::max<size_t>(16, (size_t)atoll(getenv("PHI_GFA_PIECE"))) : ((size_t)1 << 20);
+    // (twice only when a W-line carries tags behind its walk: the pass that counts the steps reads every byte of the
+    //  walks anyway and looks for a tab while it does -- a search of its own was one more pass over 10 GB of text at
+    //  chromosome scale; a walk with a tab is cut off there and the pieces are made again)
+    for (int round = 0; round < 2; round++) {
+        pieces.clear();
         for (int64_t wi = 0; wi < n_walks; wi++) {
             const char *s = walks[(size_t)wi]->text.p, *const e = s + walks[(size_t)wi]->text.n;
             const char *lo = s;
@@ -532,13 +536,23 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
             }
             if (s == e) pieces.push_back(Piece{(int32_t)wi, s, e});
         }
+        parallel_for((int64_t)pieces.size(), [&](int64_t i) {
+            Piece &pc = pieces[(size_t)i];
+            int64_t n = 0;
+            int tab = 0;
+            for (const char *q = pc.lo; q < pc.hi; q++) { n += is_step(*q); tab |= *q == '\t'; }
+            pc.n = n;
+            pc.has_tab = tab != 0;
+        });
+        bool any_tab = false;
+        for (const Piece &pc : pieces)
+            if (pc.has_tab) {
+                any_tab = true;
+                WRec &w = *walks[(size_t)pc.walk];
+                if (const char *tab = (const char *)memchr(w.text.p, '\t', w.text.n)) w.text.n = (size_t)(tab - w.text.p);
+            }
+        if (!any_tab) break;
     }
-    parallel_for((int64_t)pieces.size(), [&](int64_t i) {
-        Piece &pc = pieces[(size_t)i];
-        int64_t n = 0;
-        for (const char *q = pc.lo; q < pc.hi; q++) n += is_step(*q);
-        pc.n = n;
-    });
     g->walk_off.assign((size_t)n_walks + 1, 0);
     {
         int64_t o = 0;

@@ -96,6 +96,28 @@ def test_host_gfa_reader_vs_reference_goldens(built, oracle):
     assert g.top_order_map.tolist() == og.top_rank
 
 
+def test_host_gfa_reader_w_line_tags(built, oracle, tmp_path, monkeypatch):
+    """Optional tags behind the walk of a W-line (gfa-io.cpp reads the walk up to the next tab).  The reader does not search
+    a walk for that tab on its own -- the pass that counts the steps looks for it, and a walk that has one is cut off there
+    and its pieces are made again: the graph must be the one of the same file without the tags (and the reference parser's),
+    with pieces of a few bytes as well as whole lines."""
+    from phi_amd import ilp_index as H
+    src = open(os.path.join(DATA, "test.gfa")).read().splitlines()
+    tagged = [l + "\tXX:Z:a<b>c\tYY:i:7" if l.startswith("W\t") and i % 2 == 0 else l for i, l in enumerate(src)]
+    assert tagged != src
+    (tmp_path / "plain.gfa").write_text("\n".join(src) + "\n")
+    (tmp_path / "tagged.gfa").write_text("\n".join(tagged) + "\n")
+    want = H.Graph(str(tmp_path / "plain.gfa"))
+    ref = oracle.parse_gfa(str(tmp_path / "tagged.gfa"))
+    for piece in (None, "16", "40"):
+        if piece: monkeypatch.setenv("PHI_GFA_PIECE", piece)
+        g = H.Graph(str(tmp_path / "tagged.gfa"))
+        assert g.hap_id2name == want.hap_id2name and g.seg_names == want.seg_names
+        assert g.walk_off.tolist() == want.walk_off.tolist() and g.walk_vtx.tolist() == want.walk_vtx.tolist()
+        assert g.adj_off.tolist() == want.adj_off.tolist() and g.adj.tolist() == want.adj.tolist()
+        assert [g.walk_vtx[g.walk_off[h]:g.walk_off[h + 1]].tolist() for h in range(g.num_walks)] == ref.paths
+
+
 def test_host_reader_over_memory_and_blocks_equals_kseq_vectors(built):
     """phi_reads_stream_open_blocks (the way a stream whose beginning the device has taken is finished on the exact state
     machine): the records of prefix + blocks are kseq's records of the whole text, however the text is cut."""
