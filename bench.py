@@ -97,12 +97,10 @@ def cpu_baseline(g_arrays, reads_concat, read_off, k, w, budget_s=6.0):
         out["stages"] = {"note": "skipped: this configuration's walks take the scalar port minutes (see the C2 line for the per-stage times)"}
         return out
     t0 = time.perf_counter()
-    h = L.orc_run(len(A["seq_off"]) - 1, A["seq_concat"].tobytes(), A["seq_off"].ctypes.data, len(A["walk_off"]) - 1,
-                  A["walk_off"].ctypes.data, A["walk_vtx"].ctypes.data, raw, off.ctypes.data, n_reads, k, w,
-                  ctypes.c_float(1.0))
+    stg = O.run_stage12_arrays(A, reads_concat, off, k, w, 1.0, threads=nt, want_minimizers=False)
     t_all = time.perf_counter() - t0
-    st = [L.orc_stage_seconds(h, i) for i in range(4)]
-    L.orc_free(h)
+    st = stg.stage_s
+    out["_stage12"] = stg                                   # main() compares its counters with the GPU's (parity_checked)
     walk_bases = int((A["seq_off"][A["walk_vtx"] + 1] - A["seq_off"][A["walk_vtx"]]).sum())
     out["stages"] = {"threads": nt, "walk_sketch_s": st[0], "read_sketch_spectrum_s": st[1], "anchors_s": st[2],
                      "filter_s": st[3], "total_s": t_all, "walk_gbases_per_s": walk_bases / max(st[0], 1e-9) / 1e9,
@@ -575,6 +573,26 @@ def main():
             out["end_to_end_s"] = out["file_to_fasta_s"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A, bases, off, K, W)
+        # the oracle's stages 1-2 over the WHOLE configuration (timed above as the CPU baseline's stage table) against what
+        # the GPU path just reported for the same graph and read set: every counter of the reference's log
+        # (ILP_index.cpp:563, 641, 725-743, 883).  A mismatch fails the run.
+        stg = out["cpu_baseline"].pop("_stage12", None)
+        if stg is not None and res is not None and args.scaling == "weak":      # (strong: the context holds the strong read set)
+            checks = {"n_minimizers_per_walk": np.array_equal(res["n_minimizers"], stg.n_minimizers),
+                      "spectrum_size": int(res["spectrum_size"]) == len(stg.spectrum),
+                      "filtered": int(res["filtered"]) == int(stg.filtered), "retained": int(res["retained"]) == int(stg.retained),
+                      "n_in_model": int(res["n_in_model"]) == int(stg.n_in_model),
+                      "n_anchors_per_walk": np.array_equal(res["n_anchors"], stg.n_anchors),
+                      "n_kept_anchors": int(res["n_anchors"].sum()) == len(stg.a_r)}
+            out["parity_checked"] = {"against": "oracle/phi_oracle.c orc_run, stages 1-2 of this configuration and read set on the host cores",
+                                     "ok": bool(all(checks.values())), "checks": {k_: bool(v) for k_, v in checks.items()},
+                                     "values": {"spectrum_size": len(stg.spectrum), "filtered": int(stg.filtered), "retained": int(stg.retained),
+                                                "n_in_model": int(stg.n_in_model), "n_walk_minimizers": int(stg.n_minimizers.sum()), "n_kept_anchors": len(stg.a_r)},
+                                     "note": "per-walk (hash, position) arrays, the spectrum as a set and the kept anchors as a multiset are compared in "
+                                             "tests/test_gpu_parity.py::test_full_size_vs_oracle on the same graph and reads"}
+            if not out["parity_checked"]["ok"]:
+                print(json.dumps(out["parity_checked"]), file=sys.stderr, flush=True)
+                raise SystemExit("bench.py: the GPU path's counters differ from the oracle's on this configuration")
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

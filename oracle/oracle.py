@@ -504,3 +504,39 @@ def run_stage12(g: Graph, reads, k=31, w=25, threshold=1.0) -> Stage12:
             m_off=m_off, m_hash=_arr(L.orc_m_hash(h), nm, np.uint64), m_pos=_arr(L.orc_m_pos(h), nm, np.int64))
     finally:
         L.orc_free(h)
+
+
+def run_stage12_arrays(A, bases, read_off, k=31, w=25, threshold=1.0, threads=None, want_minimizers=True) -> Stage12:
+    """Stages 1-2 on the flat arrays of the C ABI (a generator's graph: no per-vertex Python objects), reads as
+    (uint8 concat, int64 offsets): what the full-size parity tests and bench.py's parity check call.  The result also carries
+    `stage_s`: wall seconds of the walk sketch, read sketch + spectrum, anchors, filter."""
+    L = lib()
+    if threads:
+        L.orc_set_threads(int(threads))
+    seq_off = np.ascontiguousarray(A["seq_off"], np.int64)
+    walk_off = np.ascontiguousarray(A["walk_off"], np.int64)
+    walk_vtx = np.ascontiguousarray(A["walk_vtx"], np.int32)
+    read_off = np.ascontiguousarray(read_off, np.int64)
+    seq = A["seq_concat"]
+    seq = seq.tobytes() if isinstance(seq, np.ndarray) else bytes(seq)
+    raw = bases.tobytes() if isinstance(bases, np.ndarray) else bytes(bases)
+    nw = len(walk_off) - 1
+    h = L.orc_run(len(seq_off) - 1, seq, seq_off.ctypes.data, nw, walk_off.ctypes.data, walk_vtx.ctypes.data,
+                  raw, read_off.ctypes.data, len(read_off) - 1, k, w, C.c_float(threshold))
+    try:
+        nk = L.orc_n_kept(h)
+        m_off = _arr(L.orc_m_off(h), nw + 1, np.int64)
+        nm = int(m_off[-1]) if (nw and want_minimizers) else 0
+        st = Stage12(
+            n_minimizers=_arr(L.orc_n_minimizers(h), nw, np.int64),
+            n_anchors=_arr(L.orc_n_anchors(h), nw, np.int64),
+            spectrum=_arr(L.orc_spectrum(h), L.orc_spectrum_size(h), np.uint64),
+            filtered=L.orc_filtered(h), retained=L.orc_retained(h), n_in_model=L.orc_n_in_model(h),
+            a_r=_arr(L.orc_a_r(h), nk, np.int32), a_h=_arr(L.orc_a_h(h), nk, np.int32),
+            a_t0=_arr(L.orc_a_t0(h), nk, np.int32), a_t1=_arr(L.orc_a_t1(h), nk, np.int32),
+            a_pos=_arr(L.orc_a_pos(h), nk, np.int64),
+            m_off=m_off, m_hash=_arr(L.orc_m_hash(h), nm, np.uint64), m_pos=_arr(L.orc_m_pos(h), nm, np.int64))
+        st.stage_s = [L.orc_stage_seconds(h, i) for i in range(4)]
+        return st
+    finally:
+        L.orc_free(h)

@@ -187,14 +187,7 @@ static int64_t lower_bound_u64(const uint64_t *a, int64_t n, uint64_t key)
     return lo;
 }
 
-typedef struct { int32_t r, h, t0, t1; int64_t pos; int64_t seq_no; } anc_t;
-
-static int cmp_anc(const void *a, const void *b)
-{
-    const anc_t *x = (const anc_t *)a, *y = (const anc_t *)b;
-    if (x->r != y->r) return x->r < y->r ? -1 : 1;
-    return x->seq_no < y->seq_no ? -1 : x->seq_no > y->seq_no;
-}
+typedef struct { int32_t r, h, t0, t1; int64_t pos; } anc_t;
 
 /* vertex-list equality of two anchors == equality of the "v1_v2_..._" keys of :680-683 */
 static int same_vertex_list(const anc_t *a, const anc_t *b, const int32_t *walk_vtx,
@@ -294,13 +287,16 @@ orc_result_t *orc_run(int32_t n_vtx, const char *seq_concat, const int64_t *seq_
     R->spectrum = sp; R->spectrum_size = u;
 
     R->stage_s[1] = omp_get_wtime() - t_stage; t_stage = omp_get_wtime();
-    /* ---- stage 2a: anchors (compute_anchors, :495-526 + :645-655) */
-    int64_t a_cap = 1 << 16, a_n = 0;
-    anc_t *anc = (anc_t *)malloc(sizeof(anc_t) * (size_t)a_cap);
+    /* ---- stage 2a: anchors (compute_anchors, :495-526 + :645-655).  Walks in parallel (the reference: minimisers
+     *      of one walk in parallel, :499); Anchor_hits[r][h][k] order = by spectrum id, then walk, then position:
+     *      a stable counting sort by r of the walks' lists taken in walk order. */
+    anc_t **wa = (anc_t **)calloc((size_t)n_walks, sizeof(anc_t *));
+    int64_t *wa_n = (int64_t *)calloc((size_t)n_walks + 1, 8);
+#pragma omp parallel for schedule(dynamic, 1)
     for (int32_t h = 0; h < n_walks; h++) {
-        int64_t nv = walk_off[h + 1] - walk_off[h];
         const int64_t *base = wbase[h];
-        int64_t t = 0;
+        int64_t cap = 1 << 12, n = 0, t = 0;
+        anc_t *a = (anc_t *)malloc(sizeof(anc_t) * (size_t)cap);
         for (int64_t i = R->m_off[h]; i < R->m_off[h + 1]; i++) {
             uint64_t hash = R->m_hash[i];
             int64_t id = lower_bound_u64(sp, u, hash);
@@ -310,61 +306,92 @@ orc_result_t *orc_run(int32_t n_vtx, const char *seq_concat, const int64_t *seq_
             while (!(base[t] <= p && p < base[t + 1])) t++;
             int64_t t1 = t;
             while (!(base[t1] <= p + k - 1 && p + k - 1 < base[t1 + 1])) t1++;
-            if (a_n == a_cap) { a_cap *= 2; anc = (anc_t *)realloc(anc, sizeof(anc_t) * (size_t)a_cap); }
-            anc[a_n].r = (int32_t)id; anc[a_n].h = h; anc[a_n].t0 = (int32_t)t; anc[a_n].t1 = (int32_t)t1;
-            anc[a_n].pos = p; anc[a_n].seq_no = a_n;
-            a_n++;
+            if (n == cap) { cap *= 2; a = (anc_t *)realloc(a, sizeof(anc_t) * (size_t)cap); }
+            a[n].r = (int32_t)id; a[n].h = h; a[n].t0 = (int32_t)t; a[n].t1 = (int32_t)t1; a[n].pos = p;
+            n++;
         }
-        (void)nv;
+        wa[h] = a; wa_n[h] = n;
     }
-    qsort(anc, (size_t)a_n, sizeof(anc_t), cmp_anc);     /* Anchor_hits[r][h][k] order */
+    int64_t a_n = 0;
+    for (int32_t h = 0; h < n_walks; h++) a_n += wa_n[h];
+    /* g_off[r] .. g_off[r + 1]: the anchors of spectrum id r */
+    int64_t *g_off = (int64_t *)calloc((size_t)u + 2, 8);
+    for (int32_t h = 0; h < n_walks; h++)
+        for (int64_t i = 0; i < wa_n[h]; i++) g_off[wa[h][i].r + 1]++;
+    for (int64_t r = 0; r < u; r++) g_off[r + 1] += g_off[r];
+    anc_t *anc = (anc_t *)malloc(sizeof(anc_t) * (size_t)(a_n + 1));
+#pragma omp parallel
+    {
+        /* every thread places the ids of its own range, scanning the walks in order: stable */
+        int nt = omp_get_num_threads(), me = omp_get_thread_num();
+        int64_t r_lo = u * me / nt, r_hi = u * (me + 1) / nt;
+        int64_t *cur = (int64_t *)malloc(8 * (size_t)(r_hi - r_lo + 1));
+        for (int64_t r = r_lo; r < r_hi; r++) cur[r - r_lo] = g_off[r];
+        for (int32_t h = 0; h < n_walks; h++)
+            for (int64_t i = 0; i < wa_n[h]; i++) {
+                int64_t r = wa[h][i].r;
+                if (r >= r_lo && r < r_hi) anc[cur[r - r_lo]++] = wa[h][i];
+            }
+        free(cur);
+    }
+    for (int32_t h = 0; h < n_walks; h++) free(wa[h]);
+    free(wa); free(wa_n);
 
     R->stage_s[2] = omp_get_wtime() - t_stage; t_stage = omp_get_wtime();
-    /* ---- stage 2b: filter (:670-722) */
+    /* ---- stage 2b: filter (:670-722), spectrum ids in parallel as :674: per id "dropped" and "has an anchor over
+     *      two vertices or more"; the kept anchors are then copied out in id order */
     R->a_r = (int32_t *)malloc(4 * (size_t)(a_n + 1)); R->a_h = (int32_t *)malloc(4 * (size_t)(a_n + 1));
     R->a_t0 = (int32_t *)malloc(4 * (size_t)(a_n + 1)); R->a_t1 = (int32_t *)malloc(4 * (size_t)(a_n + 1));
     R->a_pos = (int64_t *)malloc(8 * (size_t)(a_n + 1));
     int64_t kept = 0, filtered = 0, in_model = 0;
     const float limit = threshold * (float)(uint32_t)n_walks;     /* threshold * num_walks, :698 */
-    int32_t *grp = 0; int64_t grp_cap = 0;
-    for (int64_t s = 0; s < a_n;) {
-        int64_t e = s;
-        while (e < a_n && anc[e].r == anc[s].r) e++;
-        int64_t m = e - s;
-        if (m > grp_cap) { grp_cap = m * 2; grp = (int32_t *)realloc(grp, 4 * (size_t)grp_cap); }
-        /* group by vertex list, quadratic in the (small) anchors-per-minimiser count */
-        int drop = 0;
-        for (int64_t i = 0; i < m; i++) grp[i] = -1;
-        for (int64_t i = 0; i < m && !drop; i++) {
-            if (grp[i] >= 0) continue;
-            int32_t c = 0;
-            for (int64_t j = i; j < m; j++)
-                if (grp[j] < 0 && same_vertex_list(&anc[s + i], &anc[s + j], walk_vtx, walk_off, node_len)) {
-                    grp[j] = (int32_t)i; c++;
-                }
-            if ((float)c >= limit) drop = 1;
-        }
-        if (drop) filtered++;
-        else {
-            int has_multi = 0;
-            for (int64_t i = s; i < e; i++) {
-                R->a_r[kept] = anc[i].r; R->a_h[kept] = anc[i].h;
-                R->a_t0[kept] = anc[i].t0; R->a_t1[kept] = anc[i].t1; R->a_pos[kept] = anc[i].pos;
-                kept++;
-                R->n_anchors[anc[i].h]++;
-                if (n_vertices(&anc[i], walk_vtx, walk_off, node_len) >= 2) has_multi = 1;  /* :795/:846 */
+    uint8_t *verdict = (uint8_t *)calloc((size_t)u + 1, 1);      /* bit 0: dropped, bit 1: in the model */
+#pragma omp parallel
+    {
+        int32_t *grp = 0; int64_t grp_cap = 0;
+#pragma omp for schedule(dynamic, 1024) reduction(+ : filtered, in_model)
+        for (int64_t r = 0; r < u; r++) {
+            int64_t s = g_off[r], e = g_off[r + 1], m = e - s;
+            if (m == 0) continue;
+            if (m > grp_cap) { grp_cap = m * 2; grp = (int32_t *)realloc(grp, 4 * (size_t)grp_cap); }
+            /* group by vertex list, quadratic in the (small) anchors-per-minimiser count */
+            int drop = 0;
+            for (int64_t i = 0; i < m; i++) grp[i] = -1;
+            for (int64_t i = 0; i < m && !drop; i++) {
+                if (grp[i] >= 0) continue;
+                int32_t c = 0;
+                for (int64_t j = i; j < m; j++)
+                    if (grp[j] < 0 && same_vertex_list(&anc[s + i], &anc[s + j], walk_vtx, walk_off, node_len)) {
+                        grp[j] = (int32_t)i; c++;
+                    }
+                if ((float)c >= limit) drop = 1;
             }
-            in_model += has_multi;                                                           /* :822/:868 */
+            if (drop) { filtered++; verdict[r] = 1; continue; }
+            int has_multi = 0;
+            for (int64_t i = s; i < e && !has_multi; i++)
+                if (n_vertices(&anc[i], walk_vtx, walk_off, node_len) >= 2) has_multi = 1;      /* :795/:846 */
+            in_model += has_multi;                                                               /* :822/:868 */
+            verdict[r] = (uint8_t)(has_multi << 1);
         }
-        s = e;
+        free(grp);
     }
+    for (int64_t r = 0; r < u; r++) {
+        if (verdict[r] & 1) continue;
+        for (int64_t i = g_off[r]; i < g_off[r + 1]; i++) {
+            R->a_r[kept] = anc[i].r; R->a_h[kept] = anc[i].h;
+            R->a_t0[kept] = anc[i].t0; R->a_t1[kept] = anc[i].t1; R->a_pos[kept] = anc[i].pos;
+            kept++;
+            R->n_anchors[anc[i].h]++;
+        }
+    }
+    free(verdict); free(g_off);
     R->stage_s[3] = omp_get_wtime() - t_stage;
     R->n_kept = kept;
     R->filtered = filtered;
     R->retained = u - filtered;           /* ids without anchors count as retained, :721 */
     R->n_in_model = in_model;
 
-    free(grp); free(anc); free(node_len);
+    free(anc); free(node_len);
     for (int32_t h = 0; h < n_walks; h++) free(wbase[h]);
     free(wbase);
     return R;

@@ -1118,11 +1118,76 @@ def _evaluate_path_numpy(A, res, kept, cost):
     return n_cov - cost * len(brk), n_cov, len(brk)
 
 
+def _sorted_anchor_table(h, wk, t0, t1):
+    """Kept anchors as a (n, 4) table in canonical order: a multiset comparison is then array equality."""
+    o = np.lexsort((t1, t0, wk, h))
+    return np.stack([h[o].astype(np.uint64), wk[o].astype(np.uint64), t0[o].astype(np.uint64), t1[o].astype(np.uint64)], axis=1)
+
+
+@pytest.mark.parametrize("config", ["C2", "C3", "C4", "C5s"])
+def test_full_size_vs_oracle(oracle, ctx_factory, monkeypatch, config):
+    """The CPU oracle at the sizes of BASELINE.json's configurations (its anchor and filter stages run over walks /
+    spectrum ids in parallel: the whole of C2 takes it ~2 s on the GPU box's 16 threads, C5s ~15 s), on the exact
+    read sets bench.py scores.  Everything stages 1-2 produce, against the reference's loops ILP_index.cpp:559-573
+    (walk minimisers), :617-655 (read spectrum, anchors), :670-743 (filter, counters):
+      * the (hash, position) arrays of EVERY walk, and the per-walk counts;
+      * |Sp_R|, and the read hashes that are not walk minimisers as a set (the others are the hit flags);
+      * filtered / retained / minimisers in the model, anchors per walk;
+      * the kept anchors (hash, walk, first entry, last entry) as a multiset;
+    with the reads scored by the one-chunk kernel AND by the pooled kernel (PHI_SKETCH_POOL_MIN picks; the default is
+    the one-chunk kernel below 12.6 Mbases per batch), handed over whole and in three batches."""
+    import torch
+    from phi_amd import dist as pdist
+    from phi_amd import synth
+    gk, rk = synth.CONFIGS[config]
+    g = synth.make_graph(**gk)
+    bases, off, truth = synth.make_reads(g, **rk)
+    A = g.arrays()
+    st = oracle.run_stage12_arrays(A, bases, off, 31, 25, 1.0)
+    all_walk_hashes = np.unique(st.m_hash)
+    want_missing = st.spectrum[~np.isin(st.spectrum, all_walk_hashes)]
+    want_kept = _sorted_anchor_table(st.spectrum[st.a_r], st.a_h, st.a_t0, st.a_t1)
+    n = len(off) - 1
+    cuts = [0, n // 3, 2 * n // 3, n]
+    parts = [(bases[off[a]:off[b]], off[a:b + 1] - off[a]) for a, b in zip(cuts[:-1], cuts[1:])]
+    for leg, (pool_min, batches) in enumerate((("1", [(bases, off)]), (str(1 << 40), parts))):
+        monkeypatch.setenv("PHI_SKETCH_POOL_MIN", pool_min)                 # "1": every batch pooled; 2^40 chunks: never
+        ctx = ctx_factory(k=31, w=25, threshold=1.0, recombination=100)
+        ctx.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
+        for b, o in batches:
+            ctx.add_reads((b, o))
+        res = ctx.solve()
+        monkeypatch.delenv("PHI_SKETCH_POOL_MIN")
+        assert np.array_equal(res["n_minimizers"], st.n_minimizers)
+        assert res["spectrum_size"] == len(st.spectrum)
+        assert (res["filtered"], res["retained"], res["n_in_model"]) == (st.filtered, st.retained, st.n_in_model)
+        assert np.array_equal(res["n_anchors"], st.n_anchors)
+        assert ctx.reads_stats()["n_distinct"] == len(st.spectrum)
+        p, m = ctx.spectrum_export()
+        got_missing = np.sort(torch.as_tensor(pdist.DevArray(p, m, "<i8"), device="cuda").clone().cpu().numpy().view(np.uint64))
+        assert np.array_equal(got_missing, want_missing)
+        p, nu = ctx.hits_buffer()
+        hits = torch.as_tensor(pdist.DevArray(p, nu), device="cuda").cpu().numpy()
+        assert nu == len(all_walk_hashes) and int(hits.sum()) == len(st.spectrum) - len(want_missing)
+        kh, kw, k0, k1 = ctx.kept_anchors()
+        assert len(kh) == len(st.a_r)
+        assert np.array_equal(_sorted_anchor_table(kh, kw, k0, k1), want_kept)
+        if leg == 0:
+            for h in range(g.n_walks):
+                gh, gp = ctx.walk_minimizers(h)
+                lo, hi = st.m_off[h], st.m_off[h + 1]
+                assert np.array_equal(gh, st.m_hash[lo:hi]), f"walk {h} hashes"
+                assert np.array_equal(gp, st.m_pos[lo:hi]), f"walk {h} positions"
+        assert res["optimal"] == 1
+        ctx.close()
+
+
 @pytest.mark.parametrize("config", ["C2", "C3", "C4", "C5s"])
 def test_full_size_properties(ctx_factory, config):
     """At the sizes of BASELINE.json's configurations (synMHC-49: 49 walks x 5.2 Mbp with 1x / 10x short reads
-    and 5x long noisy reads; 200 walks with 30x reads at the MHC's length) no CPU checker finishes in seconds;
-    the domain's size-independent properties stand in: the read set is a SET of canonical k-mers (order,
+    and 5x long noisy reads; 200 walks with 30x reads at the MHC's length) the CPU oracle checks stages 1-2
+    (test_full_size_vs_oracle); no CPU solver finishes the exact solve at these sizes, and
+    the domain's size-independent properties stand in for it: the read set is a SET of canonical k-mers (order,
     strand, batching and repetition of reads change nothing), the solve carries its own certificate
     (objective == proven bound), the path's objective is recounted in numpy from the kept anchors, the
     per-walk minimisers of the index equal a direct sketch of the walk's sequence, and the generator's truth
