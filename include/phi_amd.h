@@ -302,6 +302,10 @@ int phi_host_unregister(phi_ctx *ctx, void *p);
 int phi_prof_enable(phi_ctx *ctx, int on);
 int phi_prof_read(phi_ctx *ctx, int64_t *n_launches, double *total_ms, int64_t *total_bases);
 
+/* Wait for everything this process has put on the context's device, on every stream, and report the device's error
+ * state: a fault raised by an earlier asynchronous launch surfaces here (diagnostics; no reference counterpart). */
+int phi_device_synchronize(phi_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

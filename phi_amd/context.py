@@ -270,6 +270,9 @@ class Context:
             self._chk(self._L.phi_kept_anchors(self._h, _ptr(h), _ptr(wk), _ptr(t0), _ptr(t1), n.value, C.byref(n)))
         return h, wk, t0, t1
 
+    def device_synchronize(self):
+        self._chk(self._L.phi_device_synchronize(self._h))
+
     def prof_enable(self, on=True):
         self._chk(self._L.phi_prof_enable(self._h, int(on)))
 

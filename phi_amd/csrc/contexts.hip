@@ -350,9 +350,17 @@ __global__ void __launch_bounds__(256) phi_class_rec_kernel(const int64_t *__res
         const int64_t cb = cls_base[c];
         const int left = cls_left[c];
         const bool first = i == 0 || raw_pos[i - 1] < cb;
-        keep[i] = !(left && first);
+        const bool kept = !(left && first);
+        keep[i] = kept;
         const int32_t rel = (int32_t)(p - cb) - left;            // >= 0 for every kept record (its window starts inside the vertex)
         int64_t e = cls_rep[c];
+        if (!kept) {
+            // the left base's own window: dropped, and its k-mer may reach past the bases the class's entries own (the
+            // walk's last vertex shorter than k - 1: the entries below would be looked for beyond the end of the walks --
+            // found by a fuzz case, k = 4 on a last vertex of 3 bases, once the allocation order had changed)
+            r_cls[i] = (int32_t)c; r_rel[i] = rel; r_e0[i] = (phi_ent_t)e; r_e1[i] = (phi_ent_t)e;
+            continue;
+        }
         int32_t cum = 0;
         int32_t rl = rel < 0 ? 0 : rel;
         while (cum + vlen[walk_vtx[e]] <= rl) { cum += vlen[walk_vtx[e]]; e++; }

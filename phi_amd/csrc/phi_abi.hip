@@ -14,7 +14,7 @@
 
 // scalar slots in d_scalars (8 bytes each)
 enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_BATCHBAD2 = 7,
-       S_SPDIRTY = 8 /* .. 10: three rotating flags, see sp_dirty in phi_ctx.h */, S_N = 11 };
+       S_OVCNT = 8 /* .. 10: three rotating counters of the overflow list, generation g uses g % 3 (phi_ctx.h) */, S_N = 11 };
 
 int phi_fail(phi_ctx *c, int code, const char *fmt, ...)
 {
@@ -61,6 +61,16 @@ int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes)
 
 static void dev_free(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
+// (the pinned staging buffers serve phi_set_graph's uploads only: given back when it is done)
+static void stage_release(phi_ctx *c)
+{
+    for (int i = 0; i < 2; i++) {
+        if (c->stage_ev[i]) { (void)hipEventSynchronize(c->stage_ev[i]); (void)hipEventDestroy(c->stage_ev[i]); }
+        if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
+        c->h_stage[i] = nullptr; c->stage_ev[i] = nullptr;
+    }
+}
+
 // A large array from the caller's PAGEABLE memory (the walk entries of a chromosome-scale graph: 5 GB): the runtime stages such
 // a copy through its own pinned buffers with one thread, 7 GB/s -- most of phi_set_graph at that size.  Here: two pinned
 // buffers of the context, filled by four threads, each sent while the other is filled.
@@ -68,10 +78,19 @@ static int upload_staged(phi_ctx *c, void *dst, const void *src, size_t bytes, h
 {
     constexpr size_t PIECE = (size_t)64 << 20;
     if (!c->h_stage[0]) {
-        for (int i = 0; i < 2; i++) {
-            HIPCHK(hipHostMalloc(&c->h_stage[i], PIECE, hipHostMallocDefault));
-            HIPCHK(hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+        // both buffers and both events, or none: a context never holds half of them
+        void *b[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < 2 && e == hipSuccess; i++) {
+            e = hipHostMalloc(&b[i], PIECE, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
         }
+        if (e != hipSuccess) {
+            for (int i = 0; i < 2; i++) { if (b[i]) (void)hipHostFree(b[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+            return phi_hip_check(c, e, "pinned staging buffers");
+        }
+        for (int i = 0; i < 2; i++) { c->h_stage[i] = b[i]; c->stage_ev[i] = ev[i]; }
     }
     int k = 0;
     for (size_t off = 0; off < bytes; off += PIECE, k ^= 1) {
@@ -107,7 +126,7 @@ template <class T> static int upload(phi_ctx *c, DevBuf &b, const T *src, size_t
 }
 
 static uint64_t *scalar(phi_ctx *c, int i) { return c->d_scalars.as<uint64_t>() + i; }
-static unsigned long long *sp_stripes(phi_ctx *c) { return c->d_stripes.as<unsigned long long>(); }
+static unsigned long long *logged_stripes(phi_ctx *c) { return c->d_stripes.as<unsigned long long>(); }
 static unsigned long long *emit_stripes(phi_ctx *c) { return c->d_stripes.as<unsigned long long>() + PHI_STRIPES * 8; }
 #define STRIPE_BYTES ((size_t)PHI_STRIPES * 8 * 8)
 
@@ -128,24 +147,128 @@ int phi_flush_reset(phi_ctx *) { return PHI_OK; }
 
 static void swap_read_bufs(phi_ctx *c)
 {
-    std::swap(c->d_sp_keys, c->alt.sp_keys); std::swap(c->sp_cap, c->alt.sp_cap);
     std::swap(c->d_hit, c->alt.hit); std::swap(c->d_stripes, c->alt.stripes);
-    std::swap(c->d_splog, c->alt.splog); std::swap(c->d_splog_cnt, c->alt.splog_cnt);
-    std::swap(c->log_chunks, c->alt.log_chunks); std::swap(c->sp_full, c->alt.sp_full);
 }
 
-int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted)
+static int sum_stripes(phi_ctx *c, const void *d, int n_sets, uint64_t *out)
+{
+    std::vector<uint64_t> h((size_t)n_sets * PHI_STRIPES * 8);
+    int rc = phi_hip_check(c, phi_copy_sync(c, h.data(), d, (size_t)n_sets * STRIPE_BYTES, hipMemcpyDeviceToHost), "D2H counters");
+    if (rc) return rc;
+    for (int s_ = 0; s_ < n_sets; s_++) {
+        uint64_t a = 0;
+        for (int i = 0; i < PHI_STRIPES; i++) a += h[((size_t)s_ * PHI_STRIPES + i) * 8];
+        out[s_] = a;
+    }
+    return PHI_OK;
+}
+
+int phi_read_counts(phi_ctx *c, uint64_t *n_logged, uint64_t *n_emitted)
 {
     int frc = phi_flush_reset(c);
     if (frc) return frc;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return phi_fail(c, PHI_ERR_DEVICE, "stream synchronize failed");
-    std::vector<uint64_t> h(2 * PHI_STRIPES * 8);
-    int rc = phi_hip_check(c, phi_copy_sync(c, h.data(), c->d_stripes.p, 2 * STRIPE_BYTES, hipMemcpyDeviceToHost), "D2H counters");
+    uint64_t v[2];
+    int rc = sum_stripes(c, c->d_stripes.p, 2, v);
     if (rc) return rc;
-    uint64_t a = 0, b = 0;
-    for (int i = 0; i < PHI_STRIPES; i++) { a += h[(size_t)i * 8]; b += h[(size_t)(PHI_STRIPES + i) * 8]; }
-    if (n_distinct) *n_distinct = a;
-    if (n_emitted) *n_emitted = b;
+    if (n_logged) *n_logged = v[0];
+    if (n_emitted) *n_emitted = v[1];
+    return PHI_OK;
+}
+
+static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
+static void dev_free(DevBuf &b);
+
+// a device buffer that grows and KEEPS its first `keep` bytes
+static int dev_grow_keep(phi_ctx *c, DevBuf &b, size_t bytes, size_t keep)
+{
+    if (bytes <= b.cap && b.p) return PHI_OK;
+    DevBuf nb;
+    int rc = phi_dev_ensure(c, nb, bytes);
+    if (rc) return rc;
+    if (b.p && keep) {
+        rc = phi_hip_check(c, phi_copy_sync(c, nb.p, b.p, std::min(keep, b.cap), hipMemcpyDeviceToDevice), "copy into the grown buffer");
+        if (rc) { dev_free(nb); return rc; }
+    } else if (b.p) {
+        rc = phi_hip_check(c, hipStreamSynchronize(c->stream), "stream synchronize");      // an earlier launch may still write the old buffer
+        if (rc) { dev_free(nb); return rc; }
+    }
+    dev_free(b);
+    b = nb;
+    return PHI_OK;
+}
+
+static int sp_set_size(phi_ctx *c, uint64_t *n)
+{
+    *n = 0;
+    if (c->sp_cap == 0 || c->sp_set_gen != c->sp_gen) return PHI_OK;
+    return sum_stripes(c, c->d_sp_cnt.p, 1, n);
+}
+
+static int sp_clear(phi_ctx *c, uint64_t cap)
+{
+    if (cap != c->sp_cap || !c->d_sp_keys.p) {
+        dev_free(c->d_sp_keys);
+        c->sp_cap = 0;
+        PHICHK(phi_dev_ensure(c, c->d_sp_keys, cap * 8));
+        c->sp_cap = cap;
+    }
+    PHICHK(phi_dev_ensure(c, c->d_sp_cnt, STRIPE_BYTES));
+    phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)cap, PHI_EMPTY_KEY);
+    HIPCHK(hipMemsetAsync(c->d_sp_cnt.p, 0, STRIPE_BYTES, c->stream));
+    return PHI_OK;
+}
+
+// room in the set for `more` further keys (load factor <= 0.5): a set that has to grow is listed, emptied at its new
+// size and filled again
+static int sp_reserve(phi_ctx *c, uint64_t in_set, uint64_t more)
+{
+    const uint64_t need = pow2_at_least(std::max<uint64_t>(1u << 16, 2 * (in_set + more)));
+    if (c->sp_set_gen != c->sp_gen) {                         // the set of another generation of reads: nothing of it is kept
+        PHICHK(sp_clear(c, (c->sp_cap >= need && c->sp_cap <= 4 * need) ? c->sp_cap : need));
+        c->sp_set_gen = c->sp_gen;
+        return PHI_OK;
+    }
+    if (need <= c->sp_cap) return PHI_OK;
+    PHICHK(phi_dev_ensure(c, c->d_export, (size_t)std::max<uint64_t>(in_set, 1) * 8));
+    HIPCHK(hipMemsetAsync(scalar(c, S_EXPORT), 0, 8, c->stream));
+    phi_launch_spectrum_export(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_export.as<uint64_t>(),
+                               (unsigned long long *)scalar(c, S_EXPORT));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    PHICHK(sp_clear(c, need));
+    phi_launch_spectrum_insert(c->stream, c->d_export.as<uint64_t>(), (int64_t)in_set, c->d_sp_keys.as<uint64_t>(), c->sp_cap - 1,
+                               c->d_sp_cnt.as<unsigned long long>(), nullptr, 0, nullptr, nullptr, (uint32_t *)scalar(c, S_ERR));
+    return PHI_OK;
+}
+
+// The set made current: every novel hash this generation of reads has logged so far is entered (the log's chunks since
+// the last flush, the overflow list's entries since then).  Waits for the stream.  *n_in_set (optional) = the set's size.
+int phi_sp_flush(phi_ctx *c, uint64_t *n_in_set)
+{
+    PHICHK(phi_sync_check(c));                                // (also: an overflow list that ran full under an unwaited batch)
+    c->async_batches = false;
+    uint64_t logged = 0, in_set = 0;
+    PHICHK(phi_read_counts(c, &logged, nullptr));
+    unsigned long long ov_now = 0;
+    HIPCHK(phi_copy_sync(c, &ov_now, scalar(c, S_OVCNT + (int)(c->sp_gen % 3)), 8, hipMemcpyDeviceToHost));
+    if ((int64_t)ov_now > c->ov_cap) ov_now = (unsigned long long)c->ov_cap;
+    const bool pending = c->log_chunks > c->log_done || (int64_t)ov_now > c->ov_done;
+    PHICHK(sp_set_size(c, &in_set));
+    if (pending) {
+        const uint64_t more = logged > (uint64_t)c->logged_done ? logged - (uint64_t)c->logged_done : 0;
+        PHICHK(sp_reserve(c, in_set, more));
+        if (c->log_chunks > c->log_done)
+            phi_launch_spectrum_flush(c->stream, c->d_novlog.as<uint64_t>(), c->d_novcnt.as<uint16_t>(), c->log_done, c->log_chunks, c->nov_shift,
+                                      c->d_sp_keys.as<uint64_t>(), c->sp_cap - 1, c->d_sp_cnt.as<unsigned long long>(), (uint32_t *)scalar(c, S_ERR));
+        if ((int64_t)ov_now > c->ov_done)
+            phi_launch_spectrum_insert(c->stream, c->d_ovlist.as<uint64_t>() + c->ov_done, (int64_t)ov_now - c->ov_done, c->d_sp_keys.as<uint64_t>(),
+                                       c->sp_cap - 1, c->d_sp_cnt.as<unsigned long long>(), nullptr, 0, nullptr, nullptr, (uint32_t *)scalar(c, S_ERR));
+        HIPCHK(hipGetLastError());
+        c->log_done = c->log_chunks; c->ov_done = (int64_t)ov_now; c->logged_done = (int64_t)logged;
+        PHICHK(phi_sync_check(c));
+        PHICHK(sp_set_size(c, &in_set));
+    }
+    if (n_in_set) *n_in_set = in_set;
     return PHI_OK;
 }
 
@@ -153,7 +276,7 @@ int phi_read_counts(phi_ctx *c, uint64_t *n_distinct, uint64_t *n_emitted)
 int phi_spectrum_count(phi_ctx *c, uint64_t *n_distinct)
 {
     uint64_t in_set = 0, flagged = 0;
-    PHICHK(phi_read_counts(c, &in_set, nullptr));
+    PHICHK(phi_sp_flush(c, &in_set));
     if (c->n_unique > 0) {
         HIPCHK(hipMemsetAsync(scalar(c, S_EXPORT), 0, 8, c->stream));
         phi_launch_count_flags(c->stream, c->d_hit.as<uint8_t>(), c->n_unique, (unsigned long long *)scalar(c, S_EXPORT));
@@ -185,12 +308,10 @@ int phi_sync_check(phi_ctx *c)
     uint64_t s[S_N];
     HIPCHK(phi_copy_sync(c, s, c->d_scalars.p, sizeof s, hipMemcpyDeviceToHost));
     const uint32_t err = (uint32_t)s[S_ERR];
-    if (err & PHI_KERR_TABLE_FULL) return phi_fail(c, PHI_ERR_OVERFLOW, "open-addressed table overflow (probe bound %d)", PHI_MAX_PROBE);
+    if (err & PHI_KERR_TABLE_FULL) return phi_fail(c, PHI_ERR_OVERFLOW, "open-addressed table overflow (probe bound %d), or the overflow list of novel read hashes ran full under a batch handed over with phi_add_reads_device", PHI_MAX_PROBE);
     if (err & PHI_KERR_SENTINEL) return phi_fail(c, PHI_ERR_UNSUPPORTED, "a minimiser hashes to UINT64_MAX (table sentinel)");
     return PHI_OK;
 }
-
-static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
 extern "C" {
 
@@ -291,12 +412,12 @@ void phi_ctx_destroy(phi_ctx *c)
     if (c && c->pin_future.valid()) c->pin_future.wait();
     if (c && c->dp_alloc_future.valid()) (void)c->dp_alloc_future.get();
     if (c && c->h_pin) { (void)hipSetDevice(c->device); (void)hipHostFree(c->h_pin); c->h_pin = nullptr; }
-    if (c) for (int i = 0; i < 2; i++) { if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); c->h_stage[i] = nullptr; c->stage_ev[i] = nullptr; }
+    if (c) { (void)hipSetDevice(c->device); stage_release(c); }
     if (!c) return;
     (void)phi_comm_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->d_anchors, &c->d_cov_all, &c->d_cov_w, &c->d_slots, &c->d_slots2, &c->d_segs, &c->d_ctr, &c->d_vmax, &c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.sp_keys, &c->alt.hit, &c->alt.stripes, &c->alt.splog, &c->alt.splog_cnt, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_splog, &c->d_splog_cnt, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->d_anchors, &c->d_cov_all, &c->d_cov_w, &c->d_slots, &c->d_slots2, &c->d_segs, &c->d_ctr, &c->d_vmax, &c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.hit, &c->alt.stripes, &c->d_sp_cnt, &c->d_novlog, &c->d_novcnt, &c->d_ovlist, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_in_s, &c->d_last_walk, &c->d_rowdiag, &c->d_wpre, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
@@ -969,10 +1090,13 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     if (tm.on) fprintf(stderr, "[phi timing] set_graph: %d vertices, %d compact steps, %lld entries, %lld events\n", n_vtx, c->n_k, (long long)n_entries, (long long)c->n_ev);
     tm.lap("late uploads + event list");
 
-    c->sp_cap = 0; c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
-    c->log_chunks = 0; c->sp_full = true;
-    c->alt.sp_cap = 0; c->alt.log_chunks = 0; c->alt.sp_full = true; c->alt.needs_clean = false;
-    c->next_flag_zeroed = false;                               // (set_graph zeroed all scalars, the dirty flags among them)
+    c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
+    c->sp_set_gen = -1; c->log_chunks = c->log_done = 0; c->logged_done = 0; c->ov_done = 0; c->ov_bound = 0; c->async_batches = false;
+    c->nov_shift = phi_nov_shift(c->w);
+    if (const char *e = getenv("PHI_NOV_SHIFT")) c->nov_shift = std::max(0, std::min(9, atoi(e)));   // tests: chunk logs of a few entries, so that ordinary reads spill into the overflow list
+    c->alt.needs_clean = false;
+    c->next_flag_zeroed = false;                               // (set_graph zeroed all scalars, the overflow counters among them)
+    stage_release(c);
     if (c->dp_alloc_future.valid()) {
         const int rc = c->dp_alloc_future.get();
         if (rc) return rc;
@@ -982,57 +1106,22 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     return PHI_OK;
 }
 
-// make room in the read-spectrum set for est more distinct hashes (load factor <= 0.5; measured at C2:
-// half the capacity slows the probes by 19 %, twice the capacity slows the per-reset clear by more than it gains)
-static int sp_ensure(phi_ctx *c, int64_t est)
-{
-    uint64_t need = pow2_at_least(std::max<uint64_t>(1u << 16, 2 * (uint64_t)(c->sp_bound + est)));
-    if (c->sp_cap == 0) {
-        PHICHK(phi_dev_ensure(c, c->d_sp_keys, need * 8));
-        c->sp_cap = need;
-        c->sp_full = true;
-        phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)need, PHI_EMPTY_KEY);
-        HIPCHK(hipMemsetAsync(sp_stripes(c), 0, STRIPE_BYTES, c->stream));
-    } else if (need > c->sp_cap) {
-        // the bound is pessimistic: look at the real size before growing
-        uint64_t cnt = 0;
-        PHICHK(phi_read_counts(c, &cnt, nullptr));
-        c->sp_bound = (int64_t)cnt;
-        need = pow2_at_least(std::max<uint64_t>(1u << 16, 2 * (uint64_t)(c->sp_bound + est)));
-        if (need > c->sp_cap) {
-            PHICHK(phi_dev_ensure(c, c->d_export, (size_t)std::max<uint64_t>(cnt, 1) * 8));
-            HIPCHK(hipMemsetAsync(scalar(c, S_EXPORT), 0, 8, c->stream));
-            phi_launch_spectrum_export(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap,
-                                       c->d_export.as<uint64_t>(), (unsigned long long *)scalar(c, S_EXPORT));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            dev_free(c->d_sp_keys);
-            PHICHK(phi_dev_ensure(c, c->d_sp_keys, need * 8));
-            c->sp_cap = need;
-            c->sp_full = true;                               // the re-inserted keys are in no log
-            phi_launch_fill_u64(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)need, PHI_EMPTY_KEY);
-            HIPCHK(hipMemsetAsync(sp_stripes(c), 0, STRIPE_BYTES, c->stream));
-            phi_launch_spectrum_insert(c->stream, c->d_export.as<uint64_t>(), (int64_t)cnt, c->d_sp_keys.as<uint64_t>(),
-                                       c->sp_cap - 1, sp_stripes(c), nullptr, 0, nullptr, nullptr,
-                                       (uint32_t *)scalar(c, S_ERR));
-        }
-    }
-    c->sp_bound += est;
-    return PHI_OK;
-}
-
 }  // extern "C"
 
 extern "C" {
 
 int phi_add_reads_device(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases)
 {
-    return phi_add_reads_device_impl(c, d_bases, d_read_off, n_reads, n_bases, false);
+    const int rc = phi_add_reads_device_impl(c, d_bases, d_read_off, n_reads, n_bases, false);
+    if (c && rc == PHI_OK) c->async_batches = true;            // nobody waits behind this batch: an overflow list that ran full shows at the next check
+    return rc;
 }
 
 }  // extern "C"
 
-// replay: the same batch again after the spectrum set was regrown (its first pass overflowed the set): everything a
-// batch does is idempotent (hit flags, set inserts) except the count of emitted minimisers, which is not repeated
+// replay: the same batch again after the overflow list of novel hashes was grown (its first pass filled the list):
+// everything a batch does is idempotent (hit flags, the log's entries: the replay rewrites the same ones) except the
+// counts of emitted minimisers and of logged hashes, which are not repeated
 int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_read_off, int64_t n_reads, int64_t n_bases, bool replay)
 {
     if (!c) return PHI_ERR_INVALID;
@@ -1054,21 +1143,47 @@ int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_rea
     if (n_reads == 0 || n_bases == 0) { if (!replay) c->reads_count += n_reads; return PHI_OK; }
     HIPCHK(hipSetDevice(c->device));
     c->solved = false;
-    // distinct minimisers of this batch: the emitted density of random sequence is 2/(w+1) (0.077 at
-    // w = 25); room for 1.5x that.  Denser input (low-complexity reads at large w: at most one per base) runs into
-    // the probe bound: phi_add_reads then regrows the set and replays the batch; a caller of phi_add_reads_device
-    // sees PHI_ERR_OVERFLOW at its next synchronising call.
-    int64_t est = replay ? (int64_t)(2 * c->sp_cap) : (int64_t)((double)n_bases * std::min(1.0, 3.0 / (c->w + 1))) + 16;
-    if (!replay && getenv("PHI_SP_EST_DIV")) est = est / std::max(1, atoi(getenv("PHI_SP_EST_DIV"))) + 16;   // tests: provoke the regrow
-    PHICHK(sp_ensure(c, est));
-    if (replay) c->sp_full = true;                            // what the replay inserts is in no log
-    // this batch's part of the insert log (a buffer that has to grow loses what it held)
+    // this batch's part of the log of novel hashes: 1 << nov_shift entries per chunk, behind the chunks logged so far.
+    // A log that has no room grows -- keeping what it holds -- up to 1 GB; beyond that what it holds is entered into
+    // the set (sp_flush) and the log starts over.  (A batch larger than the log has it made as large as the batch.)
     const int64_t n_log_chunks = phi_sketch_num_blocks(n_bases);
-    if ((size_t)(c->log_chunks + n_log_chunks) * PHI_SPLOG * 4 > c->d_splog.cap || (size_t)(c->log_chunks + n_log_chunks) > c->d_splog_cnt.cap) {
-        if (c->log_chunks > 0) c->sp_full = true;
-        HIPCHK(hipStreamSynchronize(c->stream));             // an earlier launch may still write the old buffers
-        PHICHK(phi_dev_ensure(c, c->d_splog, (size_t)(c->log_chunks + n_log_chunks) * 2 * PHI_SPLOG * 4));
-        PHICHK(phi_dev_ensure(c, c->d_splog_cnt, (size_t)(c->log_chunks + n_log_chunks) * 2));
+    if (replay) c->log_chunks -= c->last_log_chunks;          // the same entries again
+    {
+        const size_t ent = (size_t)8 << c->nov_shift;
+        size_t need = (size_t)(c->log_chunks + n_log_chunks) * ent;
+        if (need > c->d_novlog.cap || (size_t)(c->log_chunks + n_log_chunks) * 2 > c->d_novcnt.cap) {
+            size_t budget = (size_t)1 << 30;
+            if (const char *e = getenv("PHI_NOVLOG_BUDGET")) budget = (size_t)std::max<long long>(atoll(e), 1);      // tests: a log that starts over
+            if (c->log_chunks > 0 && need > budget) {
+                PHICHK(phi_sp_flush(c, nullptr));
+                c->log_chunks = c->log_done = 0;
+                need = (size_t)n_log_chunks * ent;
+                // (the overflow list starts over with the log: what it held is in the set)
+                HIPCHK(hipMemsetAsync(scalar(c, S_OVCNT + (int)(c->sp_gen % 3)), 0, 8, c->stream));
+                c->ov_done = 0; c->ov_bound = 0;
+            }
+            if (need > c->d_novlog.cap || (size_t)(c->log_chunks + n_log_chunks) * 2 > c->d_novcnt.cap) {
+                const size_t want = std::max(need, std::min(2 * c->d_novlog.cap, budget));
+                PHICHK(dev_grow_keep(c, c->d_novlog, want, (size_t)c->log_chunks * ent));
+                PHICHK(dev_grow_keep(c, c->d_novcnt, want / ent * 2 + 64, (size_t)c->log_chunks * 2));
+            }
+        }
+        // The overflow list: room for everything this batch can emit at 1.5x the density of random sequence (2 / (w + 1) per
+        // base) -- reads full of N, or k > 32, send ALL their novel hashes there, and a batch handed over with
+        // phi_add_reads_device has nobody behind it to grow the list and replay (phi_add_reads and the text path do:
+        // replay_if_full).  Memory that is reserved, not touched: 0.9 bytes per base at w = 25.
+        if (!replay) {
+            c->ov_bound += (int64_t)((double)n_bases * std::min(1.0, 3.0 / (c->w + 1))) + 16;
+            const char *e = getenv("PHI_OVLIST_CAP");                                                                     // tests: a list that runs full (provokes the replay)
+            if (e && !c->d_ovlist.p) {
+                c->ov_cap = std::max<long long>(atoll(e), 1);
+                PHICHK(phi_dev_ensure(c, c->d_ovlist, (size_t)c->ov_cap * 8));
+            } else if (!e && c->ov_bound > c->ov_cap) {
+                const int64_t cap = std::max<int64_t>(std::max<int64_t>(c->ov_bound, 2 * c->ov_cap), 1 << 16);
+                PHICHK(dev_grow_keep(c, c->d_ovlist, (size_t)cap * 8, (size_t)c->ov_cap * 8));
+                c->ov_cap = cap;
+            }
+        }
     }
     // ONE launch per batch: every wave stages its chunk straight from the ASCII bases (2-bit pack, bases outside
     // ACGTacgt, read starts from the offsets), sketches, hashes and probes; windows touching a base outside ACGT
@@ -1084,28 +1199,23 @@ int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_rea
     }
     A.allslow = c->k > PHI_MAX_K_PACKED;                       // longer k-mers: the byte-wise routine for every window
     A.n_bases = n_bases; A.k = c->k; A.w = c->w;
-    A.sp_keys = c->d_sp_keys.as<uint64_t>(); A.sp_mask = c->sp_cap - 1;
-    A.sp_count = sp_stripes(c);
+    A.n_logged = replay ? nullptr : logged_stripes(c);
     A.n_emitted = replay ? nullptr : emit_stripes(c);
     A.u_kv = c->d_u_kv.as<uint64_t>(); A.u_mask = c->u_cap - 1;
     A.hit = c->d_hit.as<uint8_t>();
     A.err = (uint32_t *)scalar(c, S_ERR);
-    A.sp_log = c->d_splog.as<uint32_t>(); A.sp_log_cnt = c->d_splog_cnt.as<uint8_t>(); A.log_base = c->log_chunks;
-    A.sp_dirty = (uint32_t *)scalar(c, S_SPDIRTY + (int)(c->sp_gen % 3));
-    if (c->sp_cap > 0xFFFFFFFFull) { A.sp_log = nullptr; c->sp_full = true; }   // the log holds 32-bit slots
-    c->log_chunks += n_log_chunks;
+    A.nov_log = c->d_novlog.as<uint64_t>(); A.nov_cnt = c->d_novcnt.as<uint16_t>(); A.log_base = c->log_chunks; A.nov_shift = c->nov_shift;
+    A.ov_list = c->d_ovlist.as<uint64_t>(); A.ov_cap = c->ov_cap;
+    A.ov_count = (unsigned long long *)scalar(c, S_OVCNT + (int)(c->sp_gen % 3));
+    c->log_chunks += n_log_chunks; c->last_log_chunks = n_log_chunks;
     if (c->alt.needs_clean) {
-        // the first launch since the reset: its waves empty what the ended generation filled (the other half of the
-        // double buffers) for the generation after this one, and zero that generation's dirty flag
+        // the first launch since the reset: its waves zero what the ended generation filled (the other half of the
+        // double buffers) for the generation after this one, and that generation's overflow counter
         A.q_clean = 1;
-        A.q_full = c->alt.sp_full || !c->alt.splog.p || c->alt.sp_cap > 0xFFFFFFFFull;
-        A.q_sp_keys = c->alt.sp_cap ? c->alt.sp_keys.as<uint64_t>() : nullptr; A.q_sp_cap = (int64_t)c->alt.sp_cap;
-        A.q_log = c->alt.splog.as<uint32_t>(); A.q_log_cnt = c->alt.splog_cnt.as<uint8_t>(); A.q_log_chunks = c->alt.log_chunks;
-        A.q_dirty = (const uint32_t *)scalar(c, S_SPDIRTY + (int)(c->alt.gen % 3));
-        A.dirty_zero = (uint32_t *)scalar(c, S_SPDIRTY + (int)((c->sp_gen + 1) % 3));
+        A.ov_zero = (unsigned long long *)scalar(c, S_OVCNT + (int)((c->sp_gen + 1) % 3));
         A.q_hit_words = c->alt.hit.as<uint64_t>(); A.q_n_hit_words = c->n_unique / 8 + 1;
         A.q_stripes = c->alt.stripes.as<uint64_t>(); A.q_n_stripe_words = 2 * PHI_STRIPES * 8;
-        c->alt.needs_clean = false; c->alt.log_chunks = 0; c->alt.sp_full = false;
+        c->alt.needs_clean = false;
         c->next_flag_zeroed = true;
     }
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1127,12 +1237,21 @@ int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_rea
 }
 
 
-// After the stream has been waited for: if the spectrum set overflowed under the batch whose data still sits at
-// (d_bases, d_off) -- denser input than the set was sized for; the reference's std::map has no such limit,
-// ILP_index.cpp:622-635 -- regrow the set and replay that batch.  err = the device error word as read behind the batch.
+// After the stream has been waited for: if the overflow list of novel hashes ran full under the batch whose data still
+// sits at (d_bases, d_off) -- chunks that emit far more than random sequence does; the reference's std::map has no such
+// limit, ILP_index.cpp:622-635 -- grow the list (keeping what it holds: everything below its old capacity is valid) and
+// replay that batch.  err = the device error word as read behind the batch.
 static int replay_if_full(phi_ctx *c, uint32_t err, const void *d_bases, const void *d_off, int64_t n_reads, int64_t n_bases)
 {
-    for (int attempt = 0; attempt < 6 && (err & PHI_KERR_TABLE_FULL); attempt++) {
+    for (int attempt = 0; attempt < 8 && (err & PHI_KERR_TABLE_FULL); attempt++) {
+        unsigned long long *cnt = (unsigned long long *)scalar(c, S_OVCNT + (int)(c->sp_gen % 3));
+        unsigned long long wanted = 0;
+        HIPCHK(phi_copy_sync(c, &wanted, cnt, 8, hipMemcpyDeviceToHost));
+        const unsigned long long valid = std::min<unsigned long long>(wanted, (unsigned long long)c->ov_cap);
+        const int64_t cap = (int64_t)std::max<unsigned long long>(4ull * (unsigned long long)c->ov_cap, 2 * wanted);
+        PHICHK(dev_grow_keep(c, c->d_ovlist, (size_t)cap * 8, (size_t)valid * 8));
+        c->ov_cap = cap;
+        HIPCHK(phi_copy_sync(c, cnt, &valid, 8, hipMemcpyHostToDevice));
         err &= ~PHI_KERR_TABLE_FULL;
         HIPCHK(phi_copy_sync(c, scalar(c, S_ERR), &err, 4, hipMemcpyHostToDevice));
         PHICHK(phi_add_reads_device_impl(c, d_bases, d_off, n_reads, n_bases, true));
@@ -1181,6 +1300,7 @@ int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_
     HIPCHK(hipSetDevice(c->device));
     PhiStageTimer tm("add_reads");
     // (every call ends with a wait for the stream: nothing of an earlier batch still reads the staging buffers)
+    if (c->async_batches) { PHICHK(phi_sync_check(c)); c->async_batches = false; }   // (a replay below must only ever concern THIS batch)
     PHICHK(phi_dev_ensure(c, c->d_roff, (size_t)(n_reads + 1) * 8));
     if (!c->h_err) HIPCHK(hipHostMalloc((void **)&c->h_err, 64, hipHostMallocDefault));
     tm.lap("buffers");
@@ -1201,7 +1321,7 @@ int phi_add_reads(phi_ctx *c, const char *bases, const int64_t *read_off, int64_
     tm.lap("H2D + sketch + probe");
     if (*c->h_err & PHI_KERR_TABLE_FULL) {
         PHICHK(replay_if_full(c, *c->h_err, c->d_rbases.p, uniform ? nullptr : c->d_roff.p, n_reads, n_bases));
-        tm.lap("spectrum set regrown, batch replayed");
+        tm.lap("overflow list grown, batch replayed");
     }
     return PHI_OK;
 }
@@ -1214,7 +1334,8 @@ int phi_reads_text_begin(phi_ctx *c, int64_t max_chunk_bytes)
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reads_text_begin before phi_set_graph");
     if (max_chunk_bytes <= 0) return phi_fail(c, PHI_ERR_INVALID, "phi_reads_text_begin: bad chunk size");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    PHICHK(phi_sync_check(c));                                // (batches handed over without a wait: their overflow shows here, not in a replay of ours)
+    c->async_batches = false;
     auto &T = c->text;
     const uint32_t chunk = (uint32_t)std::min<int64_t>(std::max<int64_t>(max_chunk_bytes, 64), (int64_t)1 << 28);
     // the carry holds what a chunk leaves unfinished: a record at most (the longest reads are a few Mbases, twice that as FASTQ)
@@ -1241,7 +1362,7 @@ int phi_reads_text_begin(phi_ctx *c, int64_t max_chunk_bytes)
 
 }  // extern "C"
 
-// the sketch of the chunk before may have overflowed the spectrum set: its bases and offsets are still in their slot
+// the sketch of the chunk before may have filled the overflow list of novel hashes: its bases and offsets are still in their slot
 static int text_replay_last(phi_ctx *c, uint32_t err)
 {
     auto &T = c->text;
@@ -1384,23 +1505,22 @@ int phi_reset_reads(phi_ctx *c)
     if (!c) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_reset_reads before phi_set_graph");
     HIPCHK(hipSetDevice(c->device));
-    // The buffers this generation filled go to the back (the next read launch empties them), the other half
-    // comes to the front: no launch, no wait.
+    // The buffers this generation filled go to the back (the next read launch zeroes them), the other half
+    // comes to the front: no launch, no wait.  The log of novel hashes starts over; the set made from it belongs to the
+    // ended generation (sp_set_gen) and is emptied when the new one first needs it.
     const bool front_dirty = c->alt.needs_clean;               // two resets with no read launch in between
     swap_read_bufs(c);
-    c->alt.needs_clean = true; c->alt.gen = c->sp_gen;
+    c->alt.needs_clean = true;
     if (front_dirty) {
-        // nothing emptied the half that comes to the front: do it now, the whole of it
-        if (c->sp_cap || c->n_unique)
-            phi_launch_reset_reads(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_hit.as<uint64_t>(),
-                                   c->n_unique / 8 + 1, c->d_stripes.as<uint64_t>(), 2 * PHI_STRIPES * 8);
-        c->log_chunks = 0; c->sp_full = false;
+        // nothing zeroed the half that comes to the front: do it now
+        phi_launch_reset_reads(c->stream, c->d_hit.as<uint64_t>(), c->d_hit.p ? c->n_unique / 8 + 1 : 0, c->d_stripes.as<uint64_t>(), 2 * PHI_STRIPES * 8);
         HIPCHK(hipGetLastError());
     }
     c->sp_gen++;
-    if (!c->next_flag_zeroed) HIPCHK(hipMemsetAsync(scalar(c, S_SPDIRTY + (int)(c->sp_gen % 3)), 0, 8, c->stream));   // the new generation's dirty flag
+    if (!c->next_flag_zeroed) HIPCHK(hipMemsetAsync(scalar(c, S_OVCNT + (int)(c->sp_gen % 3)), 0, 8, c->stream));   // the new generation's overflow counter
     c->next_flag_zeroed = false;
-    c->sp_bound = 0; c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
+    c->log_chunks = c->log_done = 0; c->logged_done = 0; c->ov_done = 0; c->ov_bound = 0; c->last_log_chunks = 0;
+    c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
     c->solved = false;
     return PHI_OK;
 }
@@ -1417,7 +1537,7 @@ int phi_reads_stats(phi_ctx *c, int64_t *n_reads, int64_t *n_bases, int64_t *n_e
     if (n_reads) *n_reads = c->reads_count;
     if (n_bases) *n_bases = c->reads_bases;
     if (n_emitted) *n_emitted = (int64_t)ne;
-    if (n_distinct) *n_distinct = c->sp_cap ? (int64_t)nd : 0;
+    if (n_distinct) *n_distinct = (int64_t)nd;
     return PHI_OK;
 }
 
@@ -1438,15 +1558,15 @@ int phi_spectrum_export(phi_ctx *c, void **d_hashes, int64_t *n)
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_spectrum_export before phi_set_graph");
     HIPCHK(hipSetDevice(c->device));
     *d_hashes = nullptr; *n = 0;
-    if (c->sp_cap == 0) return PHI_OK;
-    PHICHK(phi_sync_check(c));
     uint64_t cnt = 0;
-    PHICHK(phi_read_counts(c, &cnt, nullptr));
-    PHICHK(phi_dev_ensure(c, c->d_export, (size_t)std::max<uint64_t>(cnt, 1) * 8));
-    HIPCHK(hipMemsetAsync(scalar(c, S_EXPORT), 0, 8, c->stream));
-    phi_launch_spectrum_export(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_export.as<uint64_t>(),
-                               (unsigned long long *)scalar(c, S_EXPORT));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    PHICHK(phi_sp_flush(c, &cnt));                            // waits for the stream
+    PHICHK(phi_dev_ensure(c, c->d_export, (size_t)std::max<uint64_t>(cnt, 1) * 8));      // (an empty list still has an address)
+    if (cnt) {
+        HIPCHK(hipMemsetAsync(scalar(c, S_EXPORT), 0, 8, c->stream));
+        phi_launch_spectrum_export(c->stream, c->d_sp_keys.as<uint64_t>(), (int64_t)c->sp_cap, c->d_export.as<uint64_t>(),
+                                   (unsigned long long *)scalar(c, S_EXPORT));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     *d_hashes = c->d_export.p;
     *n = (int64_t)cnt;
     return PHI_OK;
@@ -1459,11 +1579,11 @@ int phi_spectrum_import(phi_ctx *c, const void *d_hashes, int64_t n)
     if (n == 0) return PHI_OK;
     HIPCHK(hipSetDevice(c->device));
     if (d_hashes == c->d_export.p) return phi_fail(c, PHI_ERR_INVALID, "phi_spectrum_import: pass a copy, not the export buffer");
-    PHICHK(phi_flush_reset(c));
-    PHICHK(sp_ensure(c, n));
-    c->sp_full = true;                                       // imported keys are in no log
+    uint64_t in_set = 0;
+    PHICHK(phi_sp_flush(c, &in_set));                         // the set made current first: what is imported goes straight into it
+    PHICHK(sp_reserve(c, in_set, (uint64_t)n));
     phi_launch_spectrum_insert(c->stream, (const uint64_t *)d_hashes, n, c->d_sp_keys.as<uint64_t>(), c->sp_cap - 1,
-                               sp_stripes(c), c->d_u_keys.as<uint64_t>(), c->u_cap - 1, c->d_u_uid.as<uint32_t>(),
+                               c->d_sp_cnt.as<unsigned long long>(), c->d_u_keys.as<uint64_t>(), c->u_cap - 1, c->d_u_uid.as<uint32_t>(),
                                c->d_hit.as<uint8_t>(), (uint32_t *)scalar(c, S_ERR));
     HIPCHK(hipGetLastError());
     c->solved = false;
@@ -1725,6 +1845,15 @@ int phi_host_unregister(phi_ctx *c, void *p)
     if (!c || !p) return PHI_ERR_INVALID;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipHostUnregister(p));
+    return PHI_OK;
+}
+
+int phi_device_synchronize(phi_ctx *c)
+{
+    if (!c) return PHI_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipGetLastError());
     return PHI_OK;
 }
 

@@ -113,35 +113,39 @@ struct phi_ctx {
     DevBuf d_hit;                                     // uint8 per distinct walk minimiser
 
     // ---- reads
-    DevBuf d_sp_keys;                                 // read spectrum set
+    // The reference's read spectrum Sp_R (ILP_index.cpp:622-635) = the hit flags (read hashes that are walk minimisers, d_hit)
+    // + the NOVEL read hashes.  The read kernels only LOG the novel ones, coalesced: d_novlog holds 1 << nov_shift entries per
+    // 512-window chunk of every batch since the last flush (d_novcnt of them valid), d_ovlist what those entries could not
+    // hold and what the byte-wise routine found.  sp_flush (phi_abi.hip) enters what has been logged into the set d_sp_keys
+    // when something asks for |Sp_R| or for the list (phi_reads_stats, phi_solve, phi_spectrum_export / _import): once per
+    // read set, with every lane of the launch an insert, instead of a dependent atomic behind each probe of the scoring wave.
+    DevBuf d_sp_keys;                                 // the set (open addressing), valid for generation sp_set_gen
     uint64_t sp_cap = 0;
-    int64_t sp_bound = 0;                             // host-side upper bound of the set size
+    DevBuf d_sp_cnt;                                  // [PHI_STRIPES][8] u64: keys in the set
+    int64_t sp_set_gen = -1;                          // the generation of reads whose hashes the set holds (another one: emptied before use)
+    DevBuf d_novlog, d_novcnt;
+    int32_t nov_shift = 6;
+    int64_t log_chunks = 0, log_done = 0;             // chunks in the log; of those, already in the set
+    int64_t logged_done = 0;                          // the n_logged stripes' sum at the last flush
+    DevBuf d_ovlist;
+    int64_t ov_cap = 0, ov_done = 0, ov_bound = 0;    // overflow list: capacity; entries already in the set; what the batches so far may have sent there at most
+    bool async_batches = false;                       // batches went in without a wait behind them (phi_add_reads_device): their overflow shows at the next check
+    int64_t last_log_chunks = 0;                      // log chunks of the last batch (a replay rewinds the log by them)
     int64_t reads_bases = 0, reads_count = 0;
     int64_t spectrum_override = -1;
     DevBuf d_rbases, d_roff, d_roff_made, d_export, d_peer_send;
-    // device scalars: [0] err(u32 in low half) [1] n_bad [2] sp_count [3] n_emitted [4..] scratch
+    // device scalars: [0] err(u32 in low half) [1] n_bad ... [8..10] three rotating overflow counters (generation g: g % 3)
     DevBuf d_scalars;
-    DevBuf d_stripes;                                 // [2][PHI_STRIPES][8] u64: distinct read hashes, emitted records
-    // Log of the spectrum slots filled since the last reset (PHI_SPLOG per chunk): the next reset empties
-    // those instead of the whole set.  A generation of reads (between two resets) raises "its" dirty flag
-    // -- scalar S_SPDIRTY + sp_gen % 3 -- when something filled a slot without logging it; the reset that
-    // ends generation g reads flag g % 3 and zeroes flag (g + 2) % 3 for the generation after the next.
-    DevBuf d_splog, d_splog_cnt;
-    int64_t log_chunks = 0;                           // chunks logged in this generation
+    DevBuf d_stripes;                                 // [2][PHI_STRIPES][8] u64: novel hashes logged (with duplicates), emitted records
     int64_t sp_gen = 0;
-    bool sp_full = true;                              // the next reset must empty the whole set (import, regrow, log too small)
-    // Double buffers: everything a generation of reads writes (d_sp_keys / sp_cap, d_hit, d_stripes, d_splog*, log_chunks,
-    // sp_full) exists twice.  phi_reset_reads swaps the two sets on the host; the set the ended generation filled is emptied
-    // by the waves of the next read launch (sketch.hip clean_previous), ready for the generation after: no reset launch.
+    // Double buffers: what a generation of reads accumulates in place (d_hit, d_stripes) exists twice.  phi_reset_reads swaps
+    // the two on the host; what the ended generation filled is zeroed by the waves of the next read launch (sketch.hip
+    // clean_finish), ready for the generation after: no reset launch.  The log needs none of it: a generation starts it over.
     struct PhiReadBufs {
-        DevBuf sp_keys, hit, stripes, splog, splog_cnt;
-        uint64_t sp_cap = 0;
-        int64_t log_chunks = 0;
-        bool sp_full = true;
-        bool needs_clean = false;                     // filled by generation `gen`, not emptied yet
-        int64_t gen = 0;
+        DevBuf hit, stripes;
+        bool needs_clean = false;                     // filled by the ended generation, not zeroed yet
     } alt;
-    bool next_flag_zeroed = false;                    // a launch of this generation has zeroed the dirty flag of the next one
+    bool next_flag_zeroed = false;                    // a launch of this generation has zeroed the overflow counter of the next one
 
     uint32_t *h_err = nullptr;                        // pinned copy of the device error word, fetched behind a batch's last kernel
     // ---- reads as raw text (phi_add_reads_text, reads_text.hip): the device finds the records
@@ -323,8 +327,8 @@ int phi_sync_check(phi_ctx *c);
 // pinned host buffer of at least `bytes` (contents are not kept)
 int phi_pin_ensure(phi_ctx *c, size_t bytes);
 int phi_host_anchors(phi_ctx *c);                      // the host copy of the kept anchors, fetched if it is not there
-// sums of the striped counters (waits for the stream)
-int phi_read_counts(phi_ctx *c, uint64_t *n_in_set, uint64_t *n_emitted);
+// sums of the striped counters (waits for the stream): novel hashes logged (with duplicates), emitted records
+int phi_read_counts(phi_ctx *c, uint64_t *n_logged, uint64_t *n_emitted);
 int phi_spectrum_count(phi_ctx *c, uint64_t *n_distinct);
 int phi_scan_counts_wide(phi_ctx *c, const int32_t *cnt, int64_t n, int64_t *off);
 // flags[n] (0/1) -> ascending list of flagged indices (int32) in out

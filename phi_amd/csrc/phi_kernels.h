@@ -12,7 +12,16 @@
 #define PHI_MAX_K 64              // k-mers of up to 32 bases are 2-bit values in 64 bits (the fast kernels); 33 .. 64 take the
 #define PHI_MAX_K_PACKED 32       // exact byte-wise routine for every window (slow, exact: the reference is string based, any k)
 #define PHI_MAX_PROBE 4096     // linear-probe bound of the open-addressed tables
-#define PHI_SPLOG 32            // logged spectrum inserts per chunk of 512 windows (31 hashes are emitted per chunk of short reads)
+// log of the read hashes that are not walk minimisers: 1 << shift entries per chunk of 512 windows, 1.5x what random
+// sequence emits at this w (2 / (w + 1) per window), a power of two in [16, 512]; what a chunk has beyond goes to the
+// generation's overflow list
+static inline int phi_nov_shift(int w)
+{
+    const int want = (3 * 2 * PHI_WCH) / (2 * (w + 1));
+    int sh = 4;
+    while ((1 << sh) < want && sh < 9) sh++;
+    return sh;
+}
 #define PHI_STRIPES 256          // counters are striped over 256 cache lines: one hot address
                                  // serialises at ~12 ns per atomic (MI355X_MICROARCH.md "fanin")
 #define PHI_RCAP 32            // DP run-length states 0..31 (an anchor spans <= k-1 <= 31 edges)
@@ -49,16 +58,18 @@ struct PhiSketchArgs {
     uint64_t *out_hash;
     int64_t *out_pos;
     // PHI_MODE_PROBE
-    uint64_t *sp_keys; uint64_t sp_mask;   // read spectrum set
-    unsigned long long *sp_count;          // [PHI_STRIPES][8] striped counter of new spectrum entries
+    unsigned long long *n_logged;          // [PHI_STRIPES][8] striped counter of novel hashes logged (with duplicates: an upper bound of the set's growth)
     unsigned long long *n_emitted;         // [PHI_STRIPES][8] striped counter of emitted records
     const uint64_t *u_kv; uint64_t u_mask; // walk-minimiser table as (key, dense id) pairs: one 16-byte load per probe
     uint8_t *hit;                          // per distinct walk minimiser (dense id)
     uint32_t *err;
-    // PHI_MODE_PROBE: log of the spectrum slots this batch fills (PHI_SPLOG entries per chunk, chunk
-    // log_base + i of the reads since the last reset) so that the next reset empties those slots instead
-    // of the whole table; *sp_dirty is raised when a chunk fills more, or the byte-wise path inserts
-    uint32_t *sp_log; uint8_t *sp_log_cnt; int64_t log_base; uint32_t *sp_dirty;
+    // PHI_MODE_PROBE: log of the NOVEL read hashes (emitted, not walk minimisers): 1 << nov_shift entries per chunk,
+    // chunk log_base + i of the log, written in order by the wave that owns the chunk (coalesced); nov_cnt = how many.
+    // What a chunk (pooled kernel: a wave) has beyond its entries, and what the byte-wise routine finds, goes to
+    // ov_list[atomicAdd(ov_count)]; a full list raises PHI_KERR_TABLE_FULL (the host grows it and replays the batch).
+    // The read-spectrum set is made from these when |Sp_R| is asked for (phi_abi.hip sp_flush, table.hip).
+    uint64_t *nov_log; uint16_t *nov_cnt; int64_t log_base; int32_t nov_shift;
+    uint64_t *ov_list; unsigned long long *ov_count; int64_t ov_cap;
     // PHI_MODE_PROBE reads ASCII: the 2-bit pack, the bases outside ACGTacgt and the read-start bitmap of a chunk
     // are made by the wave that sketches it (no preparation launch): `ascii` + read offsets
     const int64_t *read_off; int64_t n_reads;
@@ -69,9 +80,8 @@ struct PhiSketchArgs {
     int32_t wave_stride;                   // reads, k <= 32: wave g takes the chunks g, g + wave_stride, ... (set by the launcher)
     // ... and, in the first launch after a reset, every wave also empties its share of the buffers the PREVIOUS
     // generation of reads filled (the other half of the context's double buffers), for the generation after this one
-    int32_t q_clean, q_full;
-    uint64_t *q_sp_keys; int64_t q_sp_cap; const uint32_t *q_log; const uint8_t *q_log_cnt; int64_t q_log_chunks;
-    const uint32_t *q_dirty; uint32_t *dirty_zero;
+    int32_t q_clean;
+    unsigned long long *ov_zero;           // the overflow counter of the generation after this one (three rotate)
     uint64_t *q_hit_words; int64_t q_n_hit_words; uint64_t *q_stripes; int64_t q_n_stripe_words;
 };
 
@@ -81,8 +91,7 @@ void phi_launch_pack_ascii(hipStream_t st, const uint8_t *bases, int64_t n, uint
 void phi_launch_mark_starts(hipStream_t st, const int64_t *seq_off, int64_t n_seq, unsigned long long *starts);
 
 void phi_launch_sketch_bytes(hipStream_t st, int mode, const PhiSketchArgs &A, const unsigned long long *batch_bad);
-void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, uint64_t *hit_words, int64_t n_hit_words,
-                            uint64_t *stripes, int64_t n_stripe_words);
+void phi_launch_reset_reads(hipStream_t st, uint64_t *hit_words, int64_t n_hit_words, uint64_t *stripes, int64_t n_stripe_words);
 int64_t phi_sketch_num_blocks(int64_t n_bases);
 void phi_launch_sketch(hipStream_t st, int mode, const PhiSketchArgs &A, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void phi_launch_scan_counts(hipStream_t st, const int32_t *cnt, int64_t n, int64_t *off);
@@ -108,6 +117,9 @@ void phi_launch_iota_i64(hipStream_t st, int64_t *p, int64_t n, int64_t step);  
 void phi_launch_spectrum_insert(hipStream_t st, const uint64_t *hashes, int64_t n, uint64_t *sp_keys,
                                 uint64_t sp_mask, unsigned long long *sp_count, const uint64_t *u_keys, uint64_t u_mask,
                                 const uint32_t *u_uid, uint8_t *hit, uint32_t *err);
+// the logged novel hashes of chunks [c_lo, c_hi) (1 << shift entries each, cnt[c] of them valid) into the spectrum set
+void phi_launch_spectrum_flush(hipStream_t st, const uint64_t *nov_log, const uint16_t *nov_cnt, int64_t c_lo, int64_t c_hi, int32_t shift,
+                               uint64_t *sp_keys, uint64_t sp_mask, unsigned long long *sp_count, uint32_t *err);
 // *n_out += number of non-zero bytes of flags[0..n)
 void phi_launch_count_flags(hipStream_t st, const uint8_t *flags, int64_t n, unsigned long long *n_out);
 // compact the occupied slots of the spectrum set into a list; *n_out receives the count

@@ -27,7 +27,7 @@
 #define PHICHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
 enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_BATCHBAD2 = 7,
-       S_SPDIRTY = 8 /* .. 10: three rotating flags, see sp_dirty in phi_ctx.h */, S_N = 11 };
+       S_OVCNT = 8 /* .. 10: three rotating overflow counters (phi_ctx.h) */, S_N = 11 };
 static uint64_t *scalar(phi_ctx *c, int i) { return c->d_scalars.as<uint64_t>() + i; }
 static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
@@ -483,8 +483,9 @@ int phi_solve_impl(phi_ctx *c)
     uint64_t sc[S_N];
     HIPCHK(phi_copy_sync(c, sc, c->d_scalars.p, sizeof sc, hipMemcpyDeviceToHost));
     uint64_t n_distinct = 0;
-    PHICHK(phi_spectrum_count(c, &n_distinct));
-    const int64_t spectrum = c->spectrum_override >= 0 ? c->spectrum_override : (c->sp_cap ? (int64_t)n_distinct : 0);
+    PHICHK(phi_spectrum_count(c, &n_distinct));                   // (enters the logged novel read hashes into the set: the read set's one de-duplication)
+    tm.lap("read spectrum (set from the log)");
+    const int64_t spectrum = c->spectrum_override >= 0 ? c->spectrum_override : (int64_t)n_distinct;
     const int64_t n_rec = c->n_rec;
     const int32_t nw = c->n_walks;
 

@@ -19,7 +19,7 @@
 //            into LDS with a wave scan so that the hash runs on dense lanes only
 //   phase 4  murmur3 of each candidate, hash-change test against its predecessor
 //   phase 5  ballot/prefix-sum compaction of the emitted records and, by mode,
-//            count | ordered write | open-addressed spectrum insert + table probe
+//            count | ordered write | table probe + coalesced log of the read hashes that are not walk minimisers
 //
 // Bases outside ACGTacgt (the reference keeps them as bytes: N sorts between G and T and is its
 // own complement, ILP_index.cpp:350-353) cannot live in 2 bits.  The pack kernels set one bit per
@@ -150,32 +150,15 @@ static __device__ __forceinline__ void start_bitmap_word(int64_t j, const int64_
     starts[j] = word;
 }
 
-// one launch that forgets all reads: empty spectrum set, zero hit vector, zero striped counters
-static __device__ __forceinline__ void reset_reads_part(int64_t t, int64_t stride, uint64_t *__restrict__ sp_keys,
-                                                        int64_t sp_cap, uint64_t *__restrict__ hit_words,
-                                                        int64_t n_hit_words, uint64_t *__restrict__ stripes,
-                                                        int64_t n_stripe_words, const uint32_t *__restrict__ sp_log = nullptr,
-                                                        const uint8_t *__restrict__ sp_log_cnt = nullptr, int64_t log_chunks = 0,
-                                                        bool sparse = false)
-{
-    if (sparse) {
-        // the set holds what the logged chunks put there and nothing else: empty those slots only
-        for (int64_t i = t; i < log_chunks * PHI_SPLOG; i += stride)
-            if ((int)(i & (PHI_SPLOG - 1)) < (int)sp_log_cnt[i / PHI_SPLOG]) sp_keys[sp_log[i]] = PHI_EMPTY_KEY;
-    } else {
-        for (int64_t i = t; i < sp_cap; i += stride) sp_keys[i] = PHI_EMPTY_KEY;
-    }
-    for (int64_t i = t; i < n_hit_words; i += stride) hit_words[i] = 0;
-    for (int64_t i = t; i < n_stripe_words; i += stride) stripes[i] = 0;
-}
-
+// one launch that forgets all reads: zero hit vector, zero striped counters (only when two resets follow each other with
+// no read launch in between: otherwise the waves of the next read launch do it, see clean_finish)
 #ifndef PHI_SKETCH_POOLED_TU
-__global__ void __launch_bounds__(256) phi_reset_reads_kernel(uint64_t *__restrict__ sp_keys, int64_t sp_cap,
-                                                              uint64_t *__restrict__ hit_words, int64_t n_hit_words,
+__global__ void __launch_bounds__(256) phi_reset_reads_kernel(uint64_t *__restrict__ hit_words, int64_t n_hit_words,
                                                               uint64_t *__restrict__ stripes, int64_t n_stripe_words)
 {
-    reset_reads_part((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, sp_keys, sp_cap,
-                     hit_words, n_hit_words, stripes, n_stripe_words);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = t; i < n_hit_words; i += stride) hit_words[i] = 0;
+    for (int64_t i = t; i < n_stripe_words; i += stride) stripes[i] = 0;
 }
 
 #endif
@@ -218,16 +201,17 @@ struct MinEnt { uint64_t v; int i; };
 // b lies to the right of a: ties go right (the reference's deque pops on >=, ILP_index.cpp:397)
 __device__ __forceinline__ MinEnt take_right(MinEnt a, MinEnt b) { return (b.v <= a.v) ? b : a; }
 
-// walk-minimiser table probe + read spectrum insert of one emitted read hash.  A hash found in the
-// walk table is recorded by its hit flag alone; the spectrum set (ILP_index.cpp:622-635) keeps only
-// the hashes absent from the table, so |Sp_R| = set flags + set size and most reads of a sample
-// that resembles the graph never pay the atomic.
-// returns the spectrum slot it filled, or PHI_NO_SLOT (the set has fewer than 2^32 slots)
-#define PHI_NO_SLOT 0xFFFFFFFFu
-struct ProbeArgs { const uint64_t *u_kv; uint64_t u_mask; uint8_t *hit; uint64_t *sp_keys; uint64_t sp_mask; uint32_t *err; };
-__device__ __forceinline__ uint32_t probe_tables(const ProbeArgs &A, uint64_t h, int &n_new)
+// Walk-minimiser table probe of one emitted read hash.  A hash found in the walk table is recorded by its hit flag
+// alone; the others -- NOVEL hashes: sequencing errors, alleles no walk carries -- only feed |Sp_R| and the log counters
+// that derive from it (ILP_index.cpp:622-641, 738-743, 883).  They are not entered into a set here (round 3: an atomicCAS
+// per novel hash into a 64-MB table, a second dependent round trip behind the probe and ~100 bytes of write traffic per
+// 8-byte key: 45 % of the launch on long noisy reads): the wave appends them to its LOG, coalesced, and the set is made
+// from the log once, when somebody asks for |Sp_R| (phi_abi.hip sp_flush).
+// returns true when h is NOT a walk minimiser
+struct ProbeArgs { const uint64_t *u_kv; uint64_t u_mask; uint8_t *hit; uint32_t *err; };
+__device__ __forceinline__ bool probe_table(const ProbeArgs &A, uint64_t h)
 {
-    if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return PHI_NO_SLOT; }
+    if (h == PHI_EMPTY_KEY) { atomicOr(A.err, PHI_KERR_SENTINEL); return false; }
     uint64_t su = h & A.u_mask;
     const ulonglong2 *kv = reinterpret_cast<const ulonglong2 *>(A.u_kv);
     ulonglong2 e0 = kv[su];                            // key and dense id in one round trip
@@ -235,37 +219,43 @@ __device__ __forceinline__ uint32_t probe_tables(const ProbeArgs &A, uint64_t h,
     //  inside the branch of a match -- 85 % of the probes)
     asm volatile("" : "+v"(e0.x), "+v"(e0.y));
     // walk-minimiser table: lookup, mark the minimiser as hit
-    if (e0.x == h) { A.hit[(uint32_t)e0.y] = 1; return PHI_NO_SLOT; }
+    if (e0.x == h) { A.hit[(uint32_t)e0.y] = 1; return false; }
     if (e0.x != PHI_EMPTY_KEY) {
         for (int probes = 1; probes <= PHI_MAX_PROBE; probes++) {
             su = (su + 1) & A.u_mask;
             const ulonglong2 e = kv[su];
-            if (e.x == h) { A.hit[(uint32_t)e.y] = 1; return PHI_NO_SLOT; }
+            if (e.x == h) { A.hit[(uint32_t)e.y] = 1; return false; }
             if (e.x == PHI_EMPTY_KEY) break;
         }
     }
-    // not a walk minimiser: open-addressed insert into the spectrum set
-#if PHI_ABL == 21
-    return PHI_NO_SLOT;                                   // (experiment: no insert)
-#endif
-    uint64_t ss = h & A.sp_mask;
-#if PHI_ABL == 22
-    { const uint64_t v = __builtin_nontemporal_load(&A.sp_keys[ss]); if (v == h) return PHI_NO_SLOT; if (v == PHI_EMPTY_KEY) { A.sp_keys[ss] = h; n_new++; return (uint32_t)ss; } return PHI_NO_SLOT; }   // (experiment: load + plain store instead of the CAS)
-#endif
-    for (int probes = 0;; probes++) {
-        const unsigned long long prev = atomicCAS((unsigned long long *)&A.sp_keys[ss], PHI_EMPTY_KEY, h);
-        if (prev == PHI_EMPTY_KEY) { n_new++; return (uint32_t)ss; }
-        if (prev == h) break;
-        if (probes > PHI_MAX_PROBE) { atomicOr(A.err, PHI_KERR_TABLE_FULL); break; }
-        ss = (ss + 1) & A.sp_mask;
-    }
-    return PHI_NO_SLOT;
+    return true;
 }
 
-__device__ __forceinline__ uint32_t probe_tables(const PhiSketchArgs &A, uint64_t h, int &n_new)
+__device__ __forceinline__ bool probe_table(const PhiSketchArgs &A, uint64_t h)
 {
-    const ProbeArgs P{A.u_kv, A.u_mask, A.hit, A.sp_keys, A.sp_mask, A.err};
-    return probe_tables(P, h, n_new);
+    const ProbeArgs P{A.u_kv, A.u_mask, A.hit, A.err};
+    return probe_table(P, h);
+}
+
+// Novel hashes a wave's log has no room for (a chunk that emits more than 1.5x what random sequence does; the byte-wise
+// routine's windows): one atomic per round for all of them, then a coalesced store into the generation's overflow list.
+// A full list raises PHI_KERR_TABLE_FULL: phi_add_reads grows it and replays the batch.  Wave-uniform call.
+// returns how many the round sent there
+struct OverflowArgs { uint64_t *list; unsigned long long *count; int64_t cap; uint32_t *err; };
+__device__ __forceinline__ int overflow_novel(const OverflowArgs &O, bool ov, uint64_t h, int lane)
+{
+    const unsigned long long ob = __ballot(ov);
+    if (!ob) return 0;
+    const int first = __ffsll((long long)ob) - 1, n = __popcll(ob);
+    unsigned long long base = 0;
+    if (lane == first) base = atomicAdd(O.count, (unsigned long long)n);
+    base = __shfl(base, first, 64);
+    if (ov) {
+        const unsigned long long idx = base + (unsigned long long)__popcll(ob & ((1ull << lane) - 1));
+        if ((int64_t)idx < O.cap) O.list[idx] = h;
+        else atomicOr(O.err, PHI_KERR_TABLE_FULL);
+    }
+    return n;
 }
 // The kernel's arguments where the launch put them (the kernarg segment; the one struct parameter sits at its start), through
 // a pointer the compiler cannot see through: what is read this way is loaded (scalar loads) where it is used instead of
@@ -277,14 +267,6 @@ __device__ __forceinline__ KArgs kargs_now()
     KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return p;
-}
-
-// "something filled a spectrum slot without logging it": a flag thousands of waves may want to raise at
-// once (long noisy reads fill more slots per chunk than a chunk logs) -- look first, then a plain store:
-// atomics on one address serialise at ~12 ns each
-__device__ __forceinline__ void raise_sp_dirty(uint32_t *flag)
-{
-    if (__builtin_nontemporal_load(flag) == 0u) __builtin_nontemporal_store(1u, flag);
 }
 
 // ---------------------------------------------------------------------------------- byte-wise routine
@@ -352,7 +334,7 @@ __device__ __forceinline__ bool range_has_bit(const unsigned long long *s_bits, 
 template <int MODE, bool LONGK = false>
 __device__ __forceinline__ void slow_windows(const PhiSketchArgs &A, int64_t c0, int64_t chunk, int lane, int k, int w,
                                           const unsigned long long *s_bits, const unsigned long long *s_bad,
-                                          bool allslow, int64_t out_base, int &n_emit, int &n_new)
+                                          bool allslow, int64_t out_base, int &n_emit, int &n_nov)
 {
     const int64_t N = A.n_bases;
     const int span = w + k - 1;
@@ -377,14 +359,19 @@ __device__ __forceinline__ void slow_windows(const PhiSketchArgs &A, int64_t c0,
             }
         }
         const unsigned long long bal = __ballot(emit);
+        bool novel = false;
         if (emit) {
             const int rank = n_emit + __popcll(bal & ((1ull << lane) - 1));
             if (MODE == PHI_MODE_WRITE) {
                 A.out_hash[out_base + rank] = h;
                 A.out_pos[out_base + rank] = pos;
             } else if (MODE == PHI_MODE_PROBE) {
-                if (probe_tables(A, h, n_new) != PHI_NO_SLOT && A.sp_dirty) raise_sp_dirty(A.sp_dirty);   // not logged: the next reset empties the whole set
+                novel = probe_table(A, h);
             }
+        }
+        if (MODE == PHI_MODE_PROBE) {
+            const OverflowArgs O{A.ov_list, A.ov_count, A.ov_cap, A.err};
+            n_nov += overflow_novel(O, novel, h, lane);               // (the byte-wise routine's novel hashes: straight to the overflow list)
         }
         n_emit += __popcll(bal);
     }
@@ -484,22 +471,14 @@ static __device__ __forceinline__ void bytes_role(const PhiSketchArgs &A, const 
         }
         const bool chunk_bad = __ballot(my_bad != 0) != 0ull;
         wave_sync();
-        int n_emit = 0, n_new = 0;
+        int n_emit = 0, n_nov = 0;
         if (A.allslow || chunk_bad) {
             const int64_t out_base = (MODE == PHI_MODE_WRITE) ? A.block_off[chunk] : 0;
-            if (A.k > PHI_MAX_K_PACKED) slow_windows<MODE, true>(A, c0, chunk, lane, A.k, A.w, s_bits, s_bad, A.allslow != 0, out_base, n_emit, n_new);
-            else slow_windows<MODE>(A, c0, chunk, lane, A.k, A.w, s_bits, s_bad, A.allslow != 0, out_base, n_emit, n_new);
+            if (A.k > PHI_MAX_K_PACKED) slow_windows<MODE, true>(A, c0, chunk, lane, A.k, A.w, s_bits, s_bad, A.allslow != 0, out_base, n_emit, n_nov);
+            else slow_windows<MODE>(A, c0, chunk, lane, A.k, A.w, s_bits, s_bad, A.allslow != 0, out_base, n_emit, n_nov);
         }
         if (MODE == PHI_MODE_COUNT) {
             if (lane == 0) A.block_cnt[chunk] = n_emit;
-        } else if (MODE == PHI_MODE_PROBE) {
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) n_new += __shfl_xor(n_new, d, 64);
-            if (lane == 0) {
-                const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
-                if (n_new) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new);
-                if (n_emit && A.n_emitted) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
-            }
         }
     }
 }
@@ -508,37 +487,14 @@ static __device__ __forceinline__ void bytes_role(const PhiSketchArgs &A, const 
 // ---- read batches: what used to be a preparation launch, done by the waves of the sketch launch
 
 // This wave's share of emptying the buffers of the previous generation of reads (phi_reset_reads swaps the
-// context's double buffers; the generation after this one will fill them again): the spectrum slots that
-// generation logged -- or the whole set when something filled a slot without logging it --, its hit vector
-// and its striped counters.  The three loads it needs (dirty flag, the wave's log count, its logged slots)
-// are independent and are issued when the wave starts, beside the loads of its chunk; the stores come last.
-struct CleanLoad { uint32_t dirty; uint32_t cnt; uint32_t slot; };
-__device__ __forceinline__ CleanLoad clean_issue(const PhiSketchArgs &A, int64_t gw, int lane)
-{
-    CleanLoad c{1u, 0u, 0u};
-    if (A.q_sp_keys && !A.q_full && A.q_log) {
-        c.dirty = *A.q_dirty;
-        if (gw < A.q_log_chunks) {
-            c.cnt = A.q_log_cnt[gw];
-            if (lane < PHI_SPLOG) c.slot = A.q_log[gw * PHI_SPLOG + lane];
-        }
-    }
-    return c;
-}
+// context's double buffers; the generation after this one will fill them again): its hit vector and its striped
+// counters -- stores into buffers nothing in this launch reads.  (Until round 3 also the slots that generation had
+// filled in a spectrum set, from a log of slots: the set is now made from the log of novel hashes when it is asked
+// for, and nothing of it lives across a reset.)
 template <class AT>
-__device__ __forceinline__ void clean_finish(const AT &A, int64_t gw, int64_t n_waves, int lane, const CleanLoad &c)
+__device__ __forceinline__ void clean_finish(const AT &A, int64_t gw, int64_t n_waves, int lane)
 {
-    if (gw == 0 && lane == 0 && A.dirty_zero) *A.dirty_zero = 0;        // the flag of the generation after this one
-    if (A.q_sp_keys) {
-        const bool sparse = !A.q_full && A.q_log && c.dirty == 0;
-        if (sparse) {
-            if (lane < PHI_SPLOG && lane < (int)c.cnt) A.q_sp_keys[c.slot] = PHI_EMPTY_KEY;
-            for (int64_t lc = gw + n_waves; lc < A.q_log_chunks; lc += n_waves)      // a smaller launch than the one that filled the log
-                if (lane < PHI_SPLOG && lane < (int)A.q_log_cnt[lc]) A.q_sp_keys[A.q_log[lc * PHI_SPLOG + lane]] = PHI_EMPTY_KEY;
-        } else {
-            for (int64_t i = gw * 64 + lane; i < A.q_sp_cap; i += n_waves * 64) A.q_sp_keys[i] = PHI_EMPTY_KEY;
-        }
-    }
+    if (gw == 0 && lane == 0 && A.ov_zero) *A.ov_zero = 0;              // the overflow counter of the generation after this one
     // (wave-uniform guards: most waves of a large launch have nothing to empty and skip on scalar compares)
     if (gw * 64 < A.q_n_hit_words)
         for (int64_t i = gw * 64 + lane; i < A.q_n_hit_words; i += n_waves * 64) A.q_hit_words[i] = 0;
@@ -688,12 +644,10 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     const int64_t N = A.n_bases;
     const int64_t chunk = (int64_t)blockIdx.x * (TPB / 64) + wid;
     const int64_t c0 = chunk * WCH;                       // first window start of this chunk
-    // read batches, first launch after a reset: this wave's share of the buffers the previous generation of
-    // reads filled (stores into buffers nothing in this launch reads: no ordering needed)
-    CleanLoad cl{};
-    if (FUSED && A.q_clean) cl = clean_issue(A, chunk, lane);
     if (c0 >= N) {                                        // wave-uniform
-        if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
+        // read batches, first launch after a reset: this wave's share of the buffers the previous generation of
+        // reads filled (stores into buffers nothing in this launch reads: no ordering needed)
+        if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane);
         return;
     }
     const uint64_t kmask = phi_kmask(k);
@@ -714,7 +668,7 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     // (names the shared phases use; the last four only matter in the pooled kernel)
     constexpr bool POOL = false;
     bool chunk_bad = false;
-    int ncand = 0, n_emit = 0, n_new = 0, n_log = 0, n_new_slow = 0;
+    int ncand = 0, n_emit = 0, n_log = 0, n_nov_slow = 0;
     int64_t out_base = 0;
     uint4 xn = make_uint4(0, 0, 0, 0);
     const int ci = 0, mine = 1;
@@ -746,24 +700,27 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, 63);
             const bool emit = valid && !(meta & ITEM_NOEMIT) && ((meta & ITEM_FIRST) || h != hp);
             const unsigned long long bal = __ballot(emit);
-            uint32_t filled = PHI_NO_SLOT;
+            bool novel = false;
             if (emit) {
                 const int rank = n_emit + __popcll(bal & ((1ull << lane) - 1));
                 if (MODE == PHI_MODE_WRITE) {
                     A.out_hash[out_base + rank] = h;
                     A.out_pos[out_base + rank] = c0 - 1 + (int64_t)((meta >> 10) & 0x3FFu);
                 } else if (MODE == PHI_MODE_PROBE) {
-                    filled = probe_tables(A, h, n_new);
+                    novel = probe_table(A, h);
                 }
             }
             if (MODE == PHI_MODE_PROBE) {
-                // the slots this chunk fills (= its new spectrum entries, counted for the whole wave), for the next reset
-                const unsigned long long ib = __ballot(filled != PHI_NO_SLOT);
-                if (A.sp_log && filled != PHI_NO_SLOT) {
-                    const int pos = n_log + __popcll(ib & ((1ull << lane) - 1));
-                    if (pos < PHI_SPLOG) A.sp_log[(A.log_base + chunk) * PHI_SPLOG + pos] = filled;
-                }
+                // the round's novel hashes, appended to the chunk's log in lane order: one coalesced store
+                const unsigned long long ib = __ballot(novel);
+                const int pos = n_log + __popcll(ib & ((1ull << lane) - 1));
+                const int cap = 1 << A.nov_shift;
+                if (novel && pos < cap) A.nov_log[((A.log_base + chunk) << A.nov_shift) + pos] = h;
                 n_log += __popcll(ib);
+                if (n_log > cap) {                            // (wave-uniform, rare) past the chunk's log: the overflow list
+                    const OverflowArgs O{A.ov_list, A.ov_count, A.ov_cap, A.err};
+                    overflow_novel(O, novel && pos >= cap, h, lane);
+                }
             }
             n_emit += __popcll(bal);
         }
@@ -771,27 +728,23 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
 
     if (FUSED && chunk_bad) {
         // (rare) windows over a base outside ACGTacgt, or right after one: the exact byte-wise routine, by the wave
-        // that owns the chunk (its inserts are not logged: slow_windows raises the dirty flag)
-        int n_emit_slow = 0, n_new_lane = 0;
-        slow_windows<MODE>(A, c0, chunk, lane, k, w, s_bits, s_bad, false, 0, n_emit_slow, n_new_lane);
+        // that owns the chunk (its novel hashes go to the overflow list)
+        int n_emit_slow = 0;
+        slow_windows<MODE>(A, c0, chunk, lane, k, w, s_bits, s_bad, false, 0, n_emit_slow, n_nov_slow);
         n_emit += n_emit_slow;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) n_new_lane += __shfl_xor(n_new_lane, d, 64);
-        n_new_slow = n_new_lane;
     }
-    if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane, cl);
+    if (FUSED && A.q_clean) clean_finish(A, chunk, (int64_t)gridDim.x * (TPB / 64), lane);
     if (MODE == PHI_MODE_COUNT) {
         if (lane == 0) A.block_cnt[chunk] = n_emit;
     } else if (MODE == PHI_MODE_PROBE) {
-        if (A.sp_log && lane == 0) {
-            A.sp_log_cnt[A.log_base + chunk] = (uint8_t)(n_log < PHI_SPLOG ? n_log : PHI_SPLOG);
-            if (n_log > PHI_SPLOG) raise_sp_dirty(A.sp_dirty);
-        }
-        // one atomic per wave for the number of new spectrum entries (n_log counts them: wave-uniform) and emitted records
-        const int n_new_wave = n_log + n_new_slow;
+        // one atomic per wave for the number of novel hashes logged (n_log counts them: wave-uniform; an upper bound of what
+        // the set will grow by) and of emitted records
         if (lane == 0) {
+            const int cap = 1 << A.nov_shift;
+            A.nov_cnt[A.log_base + chunk] = (uint16_t)(n_log < cap ? n_log : cap);
+            const int n_nov_wave = n_log + n_nov_slow;
             const int stripe = (int)(chunk & (PHI_STRIPES - 1)) * 8;
-            if (n_new_wave) atomicAdd(A.sp_count + stripe, (unsigned long long)n_new_wave);
+            if (n_nov_wave && A.n_logged) atomicAdd(A.n_logged + stripe, (unsigned long long)n_nov_wave);
             if (n_emit && A.n_emitted) atomicAdd(A.n_emitted + stripe, (unsigned long long)n_emit);
         }
     }
@@ -817,17 +770,14 @@ __global__ void __launch_bounds__(TPB, 6) phi_sketch_pool_kernel(PhiSketchArgs A
     const int64_t N = A.n_bases;
     const int64_t n_chunks_all = (N + WCH - 1) / WCH;
     const int64_t stride = (int64_t)A.wave_stride;
-    // read batches, first launch after a reset: this wave's share of the buffers the previous generation of
-    // reads filled (stores into buffers nothing in this launch reads: no ordering needed).  Its loads are issued when
-    // the wave starts
-    CleanLoad cl{};
     int mine;                                             // chunks of this wave (wave-uniform)
     {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
         const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + wid;      // this wave's job
-        if (A.q_clean) cl = clean_issue(A, gw, lane);
         if (gw >= n_chunks_all || gw >= stride) {         // wave-uniform
-            if (A.q_clean) clean_finish(A, gw, (int64_t)gridDim.x * (TPB / 64), lane, cl);
+            // read batches, first launch after a reset: this wave's share of the buffers the previous generation of
+            // reads filled (stores into buffers nothing in this launch reads: no ordering needed)
+            if (A.q_clean) clean_finish(A, gw, (int64_t)gridDim.x * (TPB / 64), lane);
             return;
         }
         mine = __builtin_amdgcn_readfirstlane((int)((n_chunks_all - gw + stride - 1) / stride));
@@ -840,7 +790,7 @@ __global__ void __launch_bounds__(TPB, 6) phi_sketch_pool_kernel(PhiSketchArgs A
     using MetaT = uint16_t;
     constexpr uint32_t ITEM_FIRST = 1u << 15;            // the first window of its sequence
     constexpr uint32_t ITEM_NOEMIT = 1u << 14;           // only its hash is needed (the window before a candidate)
-    int n_emit = 0, n_log = 0, n_new_slow = 0;
+    int n_emit = 0, n_log = 0, n_nov_slow = 0;
     // the items waiting for a full round -- lane j < pend holds item j: its minimum and its flags (for k <= 31 in
     // the two bits a value leaves free) -- and the hash of the last item hashed
     uint64_t pv = 0;
@@ -863,7 +813,7 @@ __global__ void __launch_bounds__(TPB, 6) phi_sketch_pool_kernel(PhiSketchArgs A
     const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + wid;
     const int64_t chunk = gw + ci * stride;
     const int64_t c0 = chunk * WCH;                       // first window start of this chunk
-    int ncand = 0, n_new = 0;                             // (n_new: per-lane count kept by probe_tables, unused here)
+    int ncand = 0;
     bool chunk_bad = false;
     int64_t out_base = 0;                                 // (a name of the shared phases: the ordered write of the walks)
     (void)out_base;
@@ -913,26 +863,27 @@ __global__ void __launch_bounds__(TPB, 6) phi_sketch_pool_kernel(PhiSketchArgs A
                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, 63);
             const bool emit = valid && !(flg & 1u) && ((flg & 2u) || h != hp);
             const unsigned long long bal = __ballot(emit);
-            uint32_t filled = PHI_NO_SLOT;
+            bool novel = false;
             const KArgs R = kargs_now();
 #if PHI_ABL == 5
             asm volatile("" :: "v"(h));                   // (experiment: hash, no probe)
 #else
             if (emit) {
-                const ProbeArgs P{R->u_kv, R->u_mask, R->hit, R->sp_keys, R->sp_mask, R->err};
-                filled = probe_tables(P, h, n_new);
+                const ProbeArgs P{R->u_kv, R->u_mask, R->hit, R->err};
+                novel = probe_table(P, h);
             }
 #endif
-            // the slots this wave fills (= its new spectrum entries, counted for the whole wave), for the next reset:
-            // logged in the entries of the wave's chunks, one after the other
-            const unsigned long long ib = __ballot(filled != PHI_NO_SLOT);
-            uint32_t *const sp_log = R->sp_log;
-            if (sp_log && filled != PHI_NO_SLOT) {
-                const int pos = n_log + __popcll(ib & ((1ull << lane) - 1));
-                // (entry pos of the wave's log: entry pos % PHI_SPLOG of its chunk number pos / PHI_SPLOG)
-                if (pos < mine * PHI_SPLOG) sp_log[(R->log_base + gw + (pos / PHI_SPLOG) * stride) * PHI_SPLOG + (pos & (PHI_SPLOG - 1))] = filled;
-            }
+            // the round's novel hashes, appended to the wave's log in lane order (coalesced): the log entries of the wave's
+            // chunks, one after the other -- entry pos of the wave is entry pos % cap of its chunk number pos / cap
+            const unsigned long long ib = __ballot(novel);
+            const int pos = n_log + __popcll(ib & ((1ull << lane) - 1));
+            const int sh = R->nov_shift, room = mine << sh;
+            if (novel && pos < room) R->nov_log[((R->log_base + gw + (int64_t)(pos >> sh) * stride) << sh) + (pos & ((1 << sh) - 1))] = h;
             n_log += __popcll(ib);
+            if (n_log > room) {                           // (wave-uniform, rare) past the wave's log: the overflow list
+                const OverflowArgs O{R->ov_list, R->ov_count, R->ov_cap, R->err};
+                overflow_novel(O, novel && pos >= room, h, lane);
+            }
             n_emit += __popcll(bal);
         }
         const int rem = flush ? 0 : n_items - taken;      // < 64 - pend
@@ -947,13 +898,10 @@ __global__ void __launch_bounds__(TPB, 6) phi_sketch_pool_kernel(PhiSketchArgs A
 
     if (chunk_bad) {
         // (rare) windows over a base outside ACGTacgt, or right after one: the exact byte-wise routine, by the wave
-        // that owns the chunk (its inserts are not logged: slow_windows raises the dirty flag)
-        int n_emit_slow = 0, n_new_lane = 0;
-        slow_windows<MODE>(A, c0, chunk, lane, k, w, s_bits, s_bad, false, 0, n_emit_slow, n_new_lane);
+        // that owns the chunk (its novel hashes go to the overflow list)
+        int n_emit_slow = 0;
+        slow_windows<MODE>(A, c0, chunk, lane, k, w, s_bits, s_bad, false, 0, n_emit_slow, n_nov_slow);
         n_emit += n_emit_slow;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) n_new_lane += __shfl_xor(n_new_lane, d, 64);
-        n_new_slow += n_new_lane;
     }
     }   // chunks of this wave
     uint32_t tid_end = threadIdx.x;
@@ -963,20 +911,20 @@ __global__ void __launch_bounds__(TPB, 6) phi_sketch_pool_kernel(PhiSketchArgs A
     {
         // (the arguments of this part are loaded now, not kept in scalar registers through the loop)
         const KArgs R = kargs_now();
-        if (R->q_clean) clean_finish(*R, gw, (int64_t)gridDim.x * (TPB / 64), lane, cl);
-        if (R->sp_log) {
-            // entries of the log: PHI_SPLOG per chunk of this wave, filled in order
+        if (R->q_clean) clean_finish(*R, gw, (int64_t)gridDim.x * (TPB / 64), lane);
+        {
+            // entries of the log: 1 << nov_shift per chunk of this wave, filled in order
+            const int sh = R->nov_shift, cap = 1 << sh;
             for (int j = lane; j < mine; j += 64) {
-                const int left = n_log - j * PHI_SPLOG;
-                R->sp_log_cnt[R->log_base + gw + j * stride] = (uint8_t)(left < 0 ? 0 : left < PHI_SPLOG ? left : PHI_SPLOG);
+                const int left = n_log - (j << sh);
+                R->nov_cnt[R->log_base + gw + j * stride] = (uint16_t)(left < 0 ? 0 : left < cap ? left : cap);
             }
-            if (lane == 0 && n_log > mine * PHI_SPLOG) raise_sp_dirty(R->sp_dirty);
         }
-        // one atomic per wave for the number of new spectrum entries (n_log counts them: wave-uniform) and emitted records
-        const int n_new_wave = n_log + n_new_slow;
+        // one atomic per wave for the number of novel hashes logged (n_log counts them: wave-uniform) and emitted records
+        const int n_nov_wave = n_log + n_nov_slow;
         if (lane == 0) {
             const int stripe = (int)(gw & (PHI_STRIPES - 1)) * 8;
-            if (n_new_wave) atomicAdd(R->sp_count + stripe, (unsigned long long)n_new_wave);
+            if (n_nov_wave && R->n_logged) atomicAdd(R->n_logged + stripe, (unsigned long long)n_nov_wave);
             if (n_emit && R->n_emitted) atomicAdd(R->n_emitted + stripe, (unsigned long long)n_emit);
         }
     }
@@ -1072,24 +1020,20 @@ void phi_launch_sketch_bytes(hipStream_t st, int mode, const PhiSketchArgs &A, c
     if (nchunks <= 0) return;
     int64_t nb = (nchunks + TPB / 64 - 1) / (TPB / 64);
     if (!A.allslow && nb > 1024) nb = 1024;           // usually leaves at once: keep the launch small
+    // (count / ordered write of sequences with bases outside ACGT; the read kernel does such windows itself)
     if (mode == PHI_MODE_COUNT)
         hipLaunchKernelGGL(phi_sketch_bytes_kernel<PHI_MODE_COUNT>, dim3((unsigned)nb), dim3(TPB), 0, st, A, batch_bad);
-    else if (mode == PHI_MODE_WRITE)
-        hipLaunchKernelGGL(phi_sketch_bytes_kernel<PHI_MODE_WRITE>, dim3((unsigned)nb), dim3(TPB), 0, st, A, batch_bad);
     else
-        hipLaunchKernelGGL(phi_sketch_bytes_kernel<PHI_MODE_PROBE>, dim3((unsigned)nb), dim3(TPB), 0, st, A, batch_bad);
+        hipLaunchKernelGGL(phi_sketch_bytes_kernel<PHI_MODE_WRITE>, dim3((unsigned)nb), dim3(TPB), 0, st, A, batch_bad);
 }
 
-void phi_launch_reset_reads(hipStream_t st, uint64_t *sp_keys, int64_t sp_cap, uint64_t *hit_words, int64_t n_hit_words,
-                            uint64_t *stripes, int64_t n_stripe_words)
+void phi_launch_reset_reads(hipStream_t st, uint64_t *hit_words, int64_t n_hit_words, uint64_t *stripes, int64_t n_stripe_words)
 {
-    int64_t n = sp_cap > n_hit_words ? sp_cap : n_hit_words;
-    if (n_stripe_words > n) n = n_stripe_words;
+    int64_t n = n_hit_words > n_stripe_words ? n_hit_words : n_stripe_words;
     int64_t nb = (n + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(phi_reset_reads_kernel, dim3((unsigned)nb), dim3(256), 0, st, sp_keys, sp_cap, hit_words,
-                       n_hit_words, stripes, n_stripe_words);
+    hipLaunchKernelGGL(phi_reset_reads_kernel, dim3((unsigned)nb), dim3(256), 0, st, hit_words, n_hit_words, stripes, n_stripe_words);
 }
 
 // number of per-wave chunks (= entries of block_cnt / block_off)

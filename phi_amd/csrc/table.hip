@@ -243,6 +243,45 @@ void phi_launch_spectrum_insert(hipStream_t st, const uint64_t *hashes, int64_t 
                            sp_mask, sp_count, u_keys, u_mask, u_uid, hit, err);
 }
 
+// The read-spectrum set from the log of novel hashes (sketch.hip): thread -> entry (chunk, i); every lane of a wave
+// that holds a logged hash inserts it, the wave adds its new entries to a striped counter.  All lanes of the launch are
+// inserts (in the sketch kernel an insert was a lane's second dependent round trip behind its table probe).
+__global__ void __launch_bounds__(256) phi_spectrum_flush_kernel(const uint64_t *__restrict__ nov_log, const uint16_t *__restrict__ nov_cnt,
+                                                                 int64_t c_lo, int64_t n_ent, int32_t shift,
+                                                                 uint64_t *__restrict__ sp_keys, uint64_t sp_mask,
+                                                                 unsigned long long *__restrict__ sp_count, uint32_t *__restrict__ err)
+{
+    int n_new = 0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_ent; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = c_lo + (t >> shift);
+        const int i = (int)(t & ((1 << shift) - 1));
+        if (i >= (int)nov_cnt[c]) continue;
+        const uint64_t h = __builtin_nontemporal_load(&nov_log[(c << shift) + i]);
+        uint64_t slot = h & sp_mask;
+        int probes = 0;
+        for (;;) {
+            const unsigned long long prev = atomicCAS((unsigned long long *)&sp_keys[slot], PHI_EMPTY_KEY, h);
+            if (prev == PHI_EMPTY_KEY) { n_new++; break; }
+            if (prev == h) break;
+            slot = (slot + 1) & sp_mask;
+            if (++probes > PHI_MAX_PROBE) { atomicOr(err, PHI_KERR_TABLE_FULL); break; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n_new += __shfl_xor(n_new, d, 64);
+    if ((threadIdx.x & 63) == 0 && n_new)
+        atomicAdd(sp_count + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) & (PHI_STRIPES - 1)) * 8, (unsigned long long)n_new);
+}
+
+void phi_launch_spectrum_flush(hipStream_t st, const uint64_t *nov_log, const uint16_t *nov_cnt, int64_t c_lo, int64_t c_hi, int32_t shift,
+                               uint64_t *sp_keys, uint64_t sp_mask, unsigned long long *sp_count, uint32_t *err)
+{
+    const int64_t n_ent = (c_hi - c_lo) << shift;
+    if (n_ent > 0)
+        hipLaunchKernelGGL(phi_spectrum_flush_kernel, dim3(grid_for(n_ent, 256)), dim3(256), 0, st, nov_log, nov_cnt, c_lo, n_ent, shift,
+                           sp_keys, sp_mask, sp_count, err);
+}
+
 // number of set hit flags (bytes != 0), added to *n_out
 __global__ void __launch_bounds__(256) phi_count_flags_kernel(const uint8_t *__restrict__ flags, int64_t n,
                                                               unsigned long long *__restrict__ n_out)

@@ -12,9 +12,11 @@ from oracle import solve_oracle as S
 import test_gpu_parity as T
 seed0 = int(sys.argv[1]); t_end = time.time() + float(sys.argv[2])
 n = 0; nbf = 0; ncap = 0
-s = seed0 * 100000
+s = seed0 * 100000 + (int(sys.argv[3]) if len(sys.argv) > 3 else 0)      # (a third argument: cases to skip -- to come back to one case)
+verbose = os.environ.get("PHI_FUZZ_VERBOSE")
 while time.time() < t_end:
     s += 1
+    if verbose: print("case", s, file=sys.stderr, flush=True)
     rng = np.random.default_rng(s)
     k, w = int(rng.integers(2, 10)), int(rng.integers(1, 7))
     if rng.random() < 0.2: k, w = int(rng.integers(10, 33)), int(rng.integers(1, 40))

@@ -207,6 +207,29 @@ def test_random_small_graphs_vs_brute_force(oracle, ctx_factory, seed):
     assert res["objective"] == best, (seed, k, w, R, T)
 
 
+@pytest.mark.parametrize("k,w", [(4, 1), (6, 2), (9, 1), (31, 25)])
+def test_walks_that_end_on_a_vertex_shorter_than_a_kmer(oracle, ctx_factory, k, w):
+    """The class of a walk's LAST entry is [left base][its vertex]: when the vertex has k - 1 bases the class space holds
+    exactly one k-mer, the left base's own window, whose record is dropped -- and whose bases reach past everything the
+    class's entries own.  phi_class_rec_kernel used to look for the entry under that k-mer's last base anyway and ran off
+    the end of the walk entries (a read of whatever lay behind the array: a GPU memory fault in one fuzz case, k = 4 on a
+    last vertex of 3 bases, once the order of the allocations had changed).  Last vertices of 1 .. k + 1 bases, one and
+    several walks, against the oracle."""
+    rng = np.random.default_rng(40 * k + w)
+    for last_len in list(range(1, min(k + 2, 12))) + [k - 1]:
+        g = random_graph(rng, n_sites=4, n_walks=int(rng.integers(1, 4)), seg_len=(k, k + 20), alt_len=(1, 6))
+        # the common last segment cut down to last_len bases
+        sink = g.paths[0][-1]
+        assert all(p[-1] == sink for p in g.paths)
+        g.node_seq[sink] = g.node_seq[sink][:last_len] if len(g.node_seq[sink]) >= last_len else (g.node_seq[sink] * k)[:last_len]
+        reads = mosaic_reads(rng, g, n_reads=30, read_len=k + w + 12, n_seg=2)
+        ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=3)
+        _set_graph(ctx, g)
+        ctx.add_reads(reads)
+        _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 3)
+        ctx.close()
+
+
 @pytest.mark.parametrize("k,w", [(15, 12), (11, 30), (31, 25)])
 def test_full_path_wide_windows(oracle, ctx_factory, k, w):
     """w > 8 takes the suffix/core/prefix kernel instances (generic and the (31,25) one) in all
@@ -1350,27 +1373,50 @@ def test_chromosome_scale_properties(ctx_factory, config):
     assert solve([2, 0, 1], False) == base                            # the reads in another order of batches
 
 
-def test_spectrum_set_regrows_on_dense_input(oracle, ctx_factory, monkeypatch):
-    """The read-spectrum set is sized for 1.5x the minimiser density of random sequence; denser input (low-complexity or
-    adversarial reads at large w) overflows it.  The reference's std::map has no limit (ILP_index.cpp:622-635):
-    phi_add_reads regrows the set and replays the batch.  PHI_SP_EST_DIV=1000 shrinks the estimate so that ordinary
-    random reads provoke it (65536 slots for ~10^5 distinct hashes)."""
+@pytest.mark.parametrize("pooled", [False, True])
+def test_novel_hash_log_spills_grows_and_starts_over(oracle, ctx_factory, monkeypatch, pooled):
+    """The read kernels LOG the read hashes that are not walk minimisers (a fixed number of entries per 512-window chunk,
+    1.5x what random sequence emits); what a chunk has beyond goes to the generation's overflow list, a full list makes
+    phi_add_reads grow it and replay the batch, and a log past its budget is entered into the set and starts over.  The
+    reference's std::map has no limit (ILP_index.cpp:622-635).  PHI_NOV_SHIFT=2 gives chunk logs of four entries, so that
+    ordinary random reads (~39 novel hashes per chunk) spill; PHI_OVLIST_CAP=50 makes the list run full at once (replays:
+    the list grows to twice what the batch wanted); PHI_NOVLOG_BUDGET=4096 makes the log start over with every batch.
+    Reads with N take the byte-wise routine, whose novel hashes all go to the list.  |Sp_R|, the emitted count (a replay
+    must not count twice), the exported list and the whole solve against the oracle; then a second generation on the
+    same context."""
+    import torch
+    from phi_amd import dist as pdist
     rng = np.random.default_rng(606)
     g = random_graph(rng, n_sites=10, n_walks=3, seg_len=(30, 60), alt_len=(2, 8))
     k, w = 15, 10
     reads = [bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(60, 140))).tolist()) for _ in range(9000)]
     reads += mosaic_reads(rng, g, n_reads=40, read_len=60, n_seg=2)
-    monkeypatch.setenv("PHI_SP_EST_DIV", "1000")
+    reads += [bytes(rng.choice(list(b"ACGTN"), size=300, p=[0.24, 0.24, 0.24, 0.24, 0.04]).tolist()) for _ in range(200)]
+    monkeypatch.setenv("PHI_NOV_SHIFT", "2")
+    monkeypatch.setenv("PHI_OVLIST_CAP", "50")
+    monkeypatch.setenv("PHI_NOVLOG_BUDGET", "4096")
+    if pooled:
+        monkeypatch.setenv("PHI_SKETCH_POOL_MIN", "1")
+        monkeypatch.setenv("PHI_SKETCH_WAVES", "7")
     ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=3)
     _set_graph(ctx, g)
     ctx.add_reads(reads[:10])
-    ctx.add_reads(reads[10:])                                    # overflows the 65536-slot set: regrown, replayed
-    monkeypatch.delenv("PHI_SP_EST_DIV")
+    ctx.add_reads(reads[10:5000])                                # spills, fills the list: grown, replayed
+    ctx.add_reads(reads[5000:])                                  # the log starts over (what it held went into the set first)
     sk = [oracle.sketch(r, k, w)[0] for r in reads]
     st = ctx.reads_stats()
     assert st["n_distinct"] == len(np.unique(np.concatenate(sk))) > 65536
-    assert st["n_emitted"] == sum(len(x) for x in sk)            # the replay does not count twice
-    _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 3)
+    assert st["n_emitted"] == sum(len(x) for x in sk)            # the replays do not count twice
+    st12, res, m = _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 3)
+    walk_h = np.unique(st12.m_hash)
+    p, n = ctx.spectrum_export()
+    got = np.sort(torch.as_tensor(pdist.DevArray(p, n, "<i8"), device="cuda").clone().cpu().numpy().view(np.uint64))
+    assert np.array_equal(got, st12.spectrum[~np.isin(st12.spectrum, walk_h)])
+    # the next generation: a log and a list that start empty, a set that forgets the old one
+    ctx.reset_reads()
+    ctx.add_reads(reads[8000:])
+    want = len(np.unique(np.concatenate(sk[8000:])))
+    assert ctx.reads_stats()["n_distinct"] == want and ctx.solve()["spectrum_size"] == want
 
 
 @pytest.mark.parametrize("block_steps", ["1", "3", "16", None])

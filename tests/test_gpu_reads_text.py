@@ -154,7 +154,8 @@ def test_large_regular_files_score_like_host_parsed_reads(ctx_factory, oracle, t
     """The reference's own read set (test/CHM13_reads.fq.gz, 16 401 x 150 bp) and a wrapped FASTA of long reads: the
     text path (chunks of 1 MB and of 50 kB, then whatever the device hands back through the host reader) leaves the
     context in the state that adding the host-parsed reads leaves it in -- counters, hit vector, spectrum -- and the
-    solve gives the same result.  Also: a spectrum set sized too small is regrown and the chunk replayed."""
+    solve gives the same result.  Also: chunk logs of novel hashes that spill into an overflow list too small for them -- the
+    list is grown and the chunk replayed -- and a log that starts over with every chunk."""
     from phi_amd import ilp_index as H
     g = oracle.parse_gfa(os.path.join(DATA, "MHC_4.gfa.gz"))
     A = g.arrays()
@@ -171,7 +172,7 @@ def test_large_regular_files_score_like_host_parsed_reads(ctx_factory, oracle, t
         long_reads.append(b">long%d\n" % i + b"\n".join(hap[s + j:s + j + 80] for j in range(0, L, 80)) + b"\n")
     fa = b"".join(long_reads)
 
-    def state():
+    def state(c):
         import torch
         from phi_amd import dist as pdist
         st = c.reads_stats()
@@ -182,23 +183,34 @@ def test_large_regular_files_score_like_host_parsed_reads(ctx_factory, oracle, t
         res = c.solve()
         return st, hits, sp, {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in res.items()}
 
+    # a context whose chunk logs hold four novel hashes and whose overflow list starts at 40 entries (read at phi_set_graph / at
+    # the list's first use): every chunk of text spills, fills the list, has it grown and is replayed; the log starts over with every chunk
+    tight_env = {"PHI_NOV_SHIFT": "2", "PHI_OVLIST_CAP": "40", "PHI_NOVLOG_BUDGET": "65536"}
+    os.environ.update(tight_env)
+    try:
+        c_tight = ctx_factory(k=31, w=25, threshold=1.0, recombination=100)
+        c_tight.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
+    finally:
+        for k_ in tight_env:
+            del os.environ[k_]
+
     for text in (fq, fa):
         c.reset_reads()
         c.add_reads(H.reads_of_text(text))
-        want = state()
-        for chunk, env in ((1 << 20, {}), (50_000, {}), (1 << 20, {"PHI_SP_EST_DIV": "64"})):
+        want = state(c)
+        for chunk, env, cc in ((1 << 20, {}, c), (50_000, {}, c), (1 << 20, tight_env, c_tight)):
             for k_, v_ in env.items():
                 os.environ[k_] = v_
             try:
-                c.reset_reads()
-                c.reads_text_begin(chunk)
+                cc.reset_reads()
+                cc.reads_text_begin(chunk)
                 for i in range(0, len(text), chunk):
-                    assert not c.add_reads_text(text[i:i + chunk])
-                pending, taken = c.reads_text_end()
+                    assert not cc.add_reads_text(text[i:i + chunk])
+                pending, taken = cc.reads_text_end()
                 # (FASTQ: every whole group of four lines is taken; FASTA: the last record waits for the end of the file)
                 assert (0 < len(pending) < 70_000 if text is fa else pending == b"") and taken + len(pending) == len(text)
-                c.add_reads(H.reads_of_text(pending))
-                got = state()
+                cc.add_reads(H.reads_of_text(pending))
+                got = state(cc)
             finally:
                 for k_ in env:
                     del os.environ[k_]
