@@ -408,7 +408,12 @@ def main():
         value_with_offsets = n_bases * world * g_steps / el_g / 1e9
         primary_step()                                         # leave the context holding the primary read set
         torch.cuda.synchronize()
+    # |Sp_R| is made from the log of novel read hashes when it is first asked for (once per read set, not once per step):
+    # phi_reads_stats here, phi_solve in a job -- timed as its own leg, and inside solve_s / gpu_path_s of the job below
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     stats = ctx.reads_stats()
+    spectrum_dedupe_ms = (time.perf_counter() - t0) * 1e3
     density = stats["n_emitted"] / max(1, stats["n_bases"])
     ms_per_step = elapsed / args.steps * 1e3
     step_bases = n_bases * world if args.scaling == "weak" else strong["total_bases"]
@@ -528,6 +533,11 @@ def main():
                      "note": "achieved/frac price the sketch kernel's time against the SURVEY 8d bytes of a base (1.5 + 24 d); kernel_own_frac prices it against "
                              "the bytes the fused kernel itself moves (1 + 24 d); step_frac = SURVEY bytes / whole step time (the step is this one launch)",
                      "kernel_gbases_per_s": launch_bases / (kern_avg_ms * 1e-3) / 1e9 if n_launch else 0.0},
+        "spectrum_dedupe_ms": spectrum_dedupe_ms,
+        "step_accounting": "a step = phi_reset_reads + phi_add_reads_device: sketch, hash, table probe (hit flags) and the coalesced LOG of the read hashes that are not walk "
+                           "minimisers, one launch.  The set of those hashes (it only feeds |Sp_R| and the log counters derived from it, ILP_index.cpp:641, 738-743, 883) is "
+                           "made from the log ONCE per read set, when |Sp_R| is first asked for: spectrum_dedupe_ms = that call (phi_reads_stats: set from the log + flag count, "
+                           "host wall clock with its waits), outside the step, INSIDE solve_s / gpu_path_s / end_to_end_s of a job (phi_solve asks first there)",
         "reads_handed_over": "without offsets (one length: the kernel computes the read starts)" if not primary_step.uses_offsets else "with an offsets array",
         "value_with_offsets": value_with_offsets,
         "index_build_s": repeats["index_build_s"] if repeats else t_index, "index_build_s_cold": t_index,

@@ -196,6 +196,29 @@ int phi_peers_allreduce_hits(phi_ctx *ctx);
 int phi_peers_exchange(phi_ctx *ctx);
 int phi_peers_destroy(void *group);
 
+/*
+ * The same exchange between PROCESSES of one node -- one process and one context per GPU, as bench.py runs under
+ * torch.distributed.run -- without RCCL: every rank maps the other ranks' hit vectors (hipIpcGetMemHandle /
+ * hipIpcOpenMemHandle; the loads travel over xGMI) and ORs them into its own with one kernel per read set.  The ranks
+ * order themselves through flags in device memory; no host call takes part in an exchange, and the gather of read set i
+ * runs on a stream of its own beside the scoring of read set i + 1 (the context keeps four hit vectors for that).  For hit
+ * vectors of a few MB, where an 8-rank ncclAllReduce is all latency.  One exchange per read set (per phi_reset_reads), the
+ * same sequence of calls on every rank.  HSA_ENABLE_IPC_MODE_LEGACY=0 where the host driver only shares memory by dmabuf.
+ *   phi_ipc_unique_id        128 bytes (the name of a small shared-memory block) made by one rank, handed to the others out of band
+ *   phi_ipc_init             collective, after phi_set_graph: handles published and mapped; phi_set_graph is refused from here on
+ *   phi_ipc_allreduce_hits   step 1 alone, asynchronous; whatever observes the hit vector afterwards waits for it by itself
+ *   phi_ipc_exchange         steps 1 + 2 (the lists of novel read hashes, through mapped buffers and a host barrier), once per job
+ *   phi_ipc_check            waits for the gathers issued so far; PHI_ERR_DEVICE when one gave up on a peer (PHI_IPC_TIMEOUT_S, 20 s)
+ *   phi_ipc_destroy          collective; also done by phi_ctx_destroy
+ */
+int phi_ipc_unique_id(void *id_out, size_t cap);
+int phi_ipc_init(phi_ctx *ctx, const void *id, int32_t rank, int32_t n_ranks);
+int phi_ipc_info(const phi_ctx *ctx, int32_t *rank, int32_t *n_ranks);
+int phi_ipc_allreduce_hits(phi_ctx *ctx);
+int phi_ipc_exchange(phi_ctx *ctx);
+int phi_ipc_check(phi_ctx *ctx);
+int phi_ipc_destroy(phi_ctx *ctx);
+
 typedef struct {
     /* ---- solve (ILP_index.cpp:776-1418) */
     int64_t objective;          /* max  #covered minimisers - 2*(R/2)*#recombinations          */

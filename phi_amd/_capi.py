@@ -25,6 +25,7 @@ SYMBOLS = [
     "phi_index_stats", "phi_solve_stats", "phi_comm_unique_id", "phi_comm_init", "phi_comm_info", "phi_comm_allreduce_hits", "phi_comm_exchange", "phi_comm_destroy",
     "phi_reads_text_begin", "phi_add_reads_text", "phi_reads_text_end", "phi_reads_text_detach_carry", "phi_reads_text_last_batch",
     "phi_peers_create", "phi_peers_join", "phi_peers_allreduce_hits", "phi_peers_exchange", "phi_peers_destroy",
+    "phi_ipc_unique_id", "phi_ipc_init", "phi_ipc_info", "phi_ipc_allreduce_hits", "phi_ipc_exchange", "phi_ipc_check", "phi_ipc_destroy",
 ]
 
 
@@ -100,6 +101,13 @@ def load():
     L.phi_peers_allreduce_hits.argtypes = [vp]
     L.phi_peers_exchange.argtypes = [vp]
     L.phi_peers_destroy.argtypes = [vp]
+    L.phi_ipc_unique_id.argtypes = [vp, C.c_size_t]
+    L.phi_ipc_init.argtypes = [vp, C.c_char_p, i32, i32]
+    L.phi_ipc_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.phi_ipc_allreduce_hits.argtypes = [vp]
+    L.phi_ipc_exchange.argtypes = [vp]
+    L.phi_ipc_check.argtypes = [vp]
+    L.phi_ipc_destroy.argtypes = [vp]
     L.phi_path_sequence.argtypes = [vp, vp, i64]
     L.phi_sketch.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i64, C.POINTER(i64)]
     L.phi_walk_minimizers.argtypes = [vp, i32, vp, vp, i64, C.POINTER(i64)]

@@ -201,6 +201,38 @@ class Context:
     def peers_exchange(self):
         self._chk(self._L.phi_peers_exchange(self._h))
 
+    # ------------------------------------------------------------------ processes of one node exchanging through mapped hit vectors
+    @staticmethod
+    def ipc_unique_id():
+        """128 bytes (the name of a shared-memory block) made by one rank; the others receive them out of band."""
+        L = _capi.load()
+        buf = C.create_string_buffer(_capi.PHI_COMM_ID_BYTES)
+        rc = L.phi_ipc_unique_id(buf, _capi.PHI_COMM_ID_BYTES)
+        if rc:
+            raise PhiError(rc, "phi_ipc_unique_id failed")
+        return buf.raw
+
+    def ipc_init(self, uid, rank, n_ranks):
+        assert len(uid) == _capi.PHI_COMM_ID_BYTES
+        self._chk(self._L.phi_ipc_init(self._h, C.c_char_p(uid), rank, n_ranks))
+
+    def ipc_info(self):
+        r, n = C.c_int32(), C.c_int32()
+        self._chk(self._L.phi_ipc_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def ipc_allreduce_hits(self):
+        self._chk(self._L.phi_ipc_allreduce_hits(self._h))
+
+    def ipc_exchange(self):
+        self._chk(self._L.phi_ipc_exchange(self._h))
+
+    def ipc_check(self):
+        self._chk(self._L.phi_ipc_check(self._h))
+
+    def ipc_destroy(self):
+        self._chk(self._L.phi_ipc_destroy(self._h))
+
     def comm_destroy(self):
         self._chk(self._L.phi_comm_destroy(self._h))
 

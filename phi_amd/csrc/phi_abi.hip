@@ -142,12 +142,22 @@ int phi_scan_counts_wide(phi_ctx *c, const int32_t *cnt, int64_t n, int64_t *off
     return PHI_OK;
 }
 
-// (a reset leaves nothing pending: phi_reset_reads swaps the context's double buffers, see phi_ctx.h)
-int phi_flush_reset(phi_ctx *) { return PHI_OK; }
+// Called by everything that observes the read state.  A reset leaves nothing pending (phi_reset_reads swaps the context's
+// double buffers, see phi_ctx.h); in a group of processes the last gather of the hit vectors runs on a stream of its own
+// (phi_ipc.hip): the context's stream waits for it here.
+int phi_flush_reset(phi_ctx *c) { return c && c->ipc ? phi_ipc_wait_pending(c) : PHI_OK; }
 
 static void swap_read_bufs(phi_ctx *c)
 {
-    std::swap(c->d_hit, c->alt.hit); std::swap(c->d_stripes, c->alt.stripes);
+    if (c->hit_n == PHI_HIT_RING) {
+        // a group of processes: the ended read set's vector stays readable for the peers (it is zeroed two read sets later)
+        const DevBuf old = c->d_hit;
+        c->d_hit = c->alt.hit; c->alt.hit = c->hit_extra[0]; c->hit_extra[0] = c->hit_extra[1]; c->hit_extra[1] = old;
+        c->hit_idx = (c->hit_idx + 1) % PHI_HIT_RING;
+    } else {
+        std::swap(c->d_hit, c->alt.hit);
+    }
+    std::swap(c->d_stripes, c->alt.stripes);
 }
 
 static int sum_stripes(phi_ctx *c, const void *d, int n_sets, uint64_t *out)
@@ -415,9 +425,10 @@ void phi_ctx_destroy(phi_ctx *c)
     if (c) { (void)hipSetDevice(c->device); stage_release(c); }
     if (!c) return;
     (void)phi_comm_destroy(c);
+    (void)phi_ipc_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->d_anchors, &c->d_cov_all, &c->d_cov_w, &c->d_slots, &c->d_slots2, &c->d_segs, &c->d_ctr, &c->d_vmax, &c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.hit, &c->alt.stripes, &c->d_sp_cnt, &c->d_novlog, &c->d_novcnt, &c->d_ovlist, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->d_anchors, &c->d_cov_all, &c->d_cov_w, &c->d_slots, &c->d_slots2, &c->d_segs, &c->d_ctr, &c->d_vmax, &c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.hit, &c->hit_extra[0], &c->hit_extra[1], &c->alt.stripes, &c->d_sp_cnt, &c->d_novlog, &c->d_novcnt, &c->d_ovlist, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_in_s, &c->d_last_walk, &c->d_rowdiag, &c->d_wpre, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
@@ -674,6 +685,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         return phi_fail(c, PHI_ERR_INVALID, "phi_set_graph: null pointer or empty graph");
     if (adj_off[n_vtx] > 0 && !adj) return phi_fail(c, PHI_ERR_INVALID, "phi_set_graph: adj is null");
     HIPCHK(hipSetDevice(c->device));
+    if (c->ipc) return phi_fail(c, PHI_ERR_STATE, "phi_set_graph on a context in a group of processes: phi_ipc_destroy first (the peers have this context's hit vectors mapped)");
     c->have_graph = false;
     c->solved = false;
 
@@ -1511,6 +1523,7 @@ int phi_reset_reads(phi_ctx *c)
     const bool front_dirty = c->alt.needs_clean;               // two resets with no read launch in between
     swap_read_bufs(c);
     c->alt.needs_clean = true;
+    PHICHK(phi_ipc_before_generation(c, c->sp_gen + 1));       // (a group of processes: the peers are done with what is about to be zeroed)
     if (front_dirty) {
         // nothing zeroed the half that comes to the front: do it now
         phi_launch_reset_reads(c->stream, c->d_hit.as<uint64_t>(), c->d_hit.p ? c->n_unique / 8 + 1 : 0, c->d_stripes.as<uint64_t>(), 2 * PHI_STRIPES * 8);

@@ -60,6 +60,8 @@ struct PhiAnchorSpan {
 };
 
 struct PhiComm;               // phi_comm.hip: the RCCL communicator of a multi-GPU job
+struct PhiIpc;                // phi_ipc.hip: a group of PROCESSES of one node that map each other's hit vectors
+#define PHI_HIT_RING 4        // hit buffers of a context in such a group (two otherwise)
 struct PhiPeers;              // phi_comm.hip: the contexts of one process that exchange through peer-mapped memory
 
 struct phi_ctx {
@@ -67,6 +69,7 @@ struct phi_ctx {
     PhiComm *comm = nullptr;
     PhiPeers *peers = nullptr;
     int peer_rank = 0;
+    PhiIpc *ipc = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t aux_stream = nullptr;    // the host thread's copies inside phi_set_graph, while the GPU thread works on `stream`
     std::string last_error;
@@ -111,6 +114,11 @@ struct phi_ctx {
     int64_t n_unique = 0;                             // distinct walk minimisers
     uint64_t u_cap = 0;
     DevBuf d_hit;                                     // uint8 per distinct walk minimiser
+    // In a group of processes (phi_ipc.hip) the hit vector exists FOUR times and phi_reset_reads rotates d_hit <- alt.hit <-
+    // hit_extra[0] <- hit_extra[1] <- d_hit: the peers read the vector of read set g while this rank scores read set g + 1,
+    // and it is zeroed two read sets later.  hit_idx = which buffer of the ring (in the order the peers mapped them) d_hit is.
+    DevBuf hit_extra[PHI_HIT_RING - 2];
+    int hit_n = 2, hit_idx = 0;
 
     // ---- reads
     // The reference's read spectrum Sp_R (ILP_index.cpp:622-635) = the hit flags (read hashes that are walk minimisers, d_hit)
@@ -327,6 +335,9 @@ int phi_sync_check(phi_ctx *c);
 // pinned host buffer of at least `bytes` (contents are not kept)
 int phi_pin_ensure(phi_ctx *c, size_t bytes);
 int phi_host_anchors(phi_ctx *c);                      // the host copy of the kept anchors, fetched if it is not there
+// phi_ipc.hip
+int phi_ipc_wait_pending(phi_ctx *c);                  // the context's stream waits for the last gather (every observer of the hit vector: phi_flush_reset)
+int phi_ipc_before_generation(phi_ctx *c, int64_t gen); // phi_reset_reads: before the hit buffer of read set gen - 3 may be zeroed
 // sums of the striped counters (waits for the stream): novel hashes logged (with duplicates), emitted records
 int phi_read_counts(phi_ctx *c, uint64_t *n_logged, uint64_t *n_emitted);
 int phi_spectrum_count(phi_ctx *c, uint64_t *n_distinct);
