@@ -189,6 +189,13 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the second scaling mode, the H2D-inclusive rate and the command-line run")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N > 1 on ONE GPU for testing: every rank uses cuda:0 and the exchange goes through gloo on the host")
+    ap.add_argument("--rehearse-ipc", action="store_true",
+                    help="N > 1 on ONE GPU for testing: every rank uses cuda:0, the exchange is the library's mapped hit vectors (phi_ipc_*), "
+                         "torch.distributed (gloo) only carries the group's id and the timing reductions")
+    ap.add_argument("--exchange", choices=("auto", "ipc", "rccl"), default="auto",
+                    help="N > 1: the per-read-set exchange of the hit vectors.  ipc: every rank maps the others' vectors and ORs them with one kernel on a "
+                         "stream of its own, beside the next read set's scoring (phi_ipc_*); rccl: ncclAllReduce inside the library (phi_comm_*); "
+                         "auto: ipc for hit vectors of up to 4 M flags (every MHC-sized graph), rccl beyond, and rccl when the ipc group cannot be set up or fails its check")
     args = ap.parse_args()
 
     import torch
@@ -217,14 +224,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.rehearse_gloo:
+        rehearsal = args.rehearse_gloo or args.rehearse_ipc
+        if rehearsal:
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("gloo" if args.rehearse_gloo else "nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    ctl_dev = "cpu" if (world > 1 and args.rehearse_gloo) else dev      # where control-plane tensors of torch.distributed live
+    ctl_dev = "cpu" if (world > 1 and (args.rehearse_gloo or args.rehearse_ipc)) else dev      # where control-plane tensors of torch.distributed live
 
     K, W = 31, 25
     t0 = time.perf_counter()
@@ -275,16 +283,72 @@ def main():
     index_info["sketch_gbases_per_s"] = walk_bases / max(index_info["sketch_gpu_ms"], 1e-6) / 1e6
     index_info["dedup_factor_bases"] = walk_bases / max(1, index_info["class_bases"])
 
-    # the library's own RCCL communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes
-    use_lib_comm = world > 1 and not args.rehearse_gloo
+    # The exchange of a read set's hit vectors, inside the library; torch.distributed only carries the 128 bytes of the group's id.
+    #   ipc : every rank maps the others' hit vectors (hipIpc*) and ORs them with ONE kernel on a stream of its own -- ordered by
+    #         flags in device memory, no host call per exchange, beside the next read set's scoring (phi_amd/csrc/phi_ipc.hip);
+    #   rccl: ncclAllReduce(MAX, uint8) on the context's stream (phi_comm.hip): 25-40 us of latency for 0.5 MB, more than C2's step.
+    # No multi-GPU node has been available to any round: the ipc group is CHECKED here before it is used (one exchange of known
+    # vectors, the ranks compare what came out) and the run falls back to RCCL if it cannot be set up or the check fails.
+    use_ipc = False
+    exchange_note = None
+    if world > 1 and not args.rehearse_gloo:
+        want_ipc = args.rehearse_ipc or args.exchange == "ipc" or (args.exchange == "auto" and index_info["n_distinct_minimizers"] <= (4 << 20))
+        if want_ipc:
+            ok = 1
+            try:
+                box = [phi_amd.Context.ipc_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ctx.ipc_init(box[0], rank, world)
+                # the check: rank r scores a read set of its own (the generator's seed + r), the exchanged vector must hold at least the
+                # rank's own flags and the SAME number of flags on every rank
+                cb, co, _ = (g.reads(7000 + rank, 0, 2000) + (None,)) if native else synth.make_reads(g, **dict(rk, coverage=0.02, seed=7000 + rank, sample_seed=7000 + rank))
+                d_cb, d_co = torch.from_numpy(np.ascontiguousarray(cb)).to(dev), torch.from_numpy(np.ascontiguousarray(co)).to(dev)
+                ctx.reset_reads()
+                ctx.add_reads_device(d_cb.data_ptr(), d_co.data_ptr(), len(co) - 1, int(co[-1]))
+                p_, n_ = ctx.hits_buffer()
+                stream.synchronize()
+                own = int(torch.as_tensor(pdist.DevArray(p_, n_), device=dev).sum().item())
+                ctx.ipc_allreduce_hits()
+                ctx.ipc_check()
+                p_, n_ = ctx.hits_buffer()
+                stream.synchronize()
+                got = int(torch.as_tensor(pdist.DevArray(p_, n_), device=dev).sum().item())
+                t = torch.tensor([got, -got, own], dtype=torch.int64, device=ctl_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                if int(t[0]) != -int(t[1]) or got < own or (world > 1 and got < int(t[2])):
+                    ok = 0
+                    exchange_note = f"ipc check failed: {got} flags here, max {int(t[0])} / min {-int(t[1])} over ranks, own {own}"
+                ctx.reset_reads()
+            except Exception as e:                                      # noqa: BLE001 -- whatever went wrong, the run goes on over RCCL
+                ok = 0
+                exchange_note = f"ipc group not usable: {e}"
+            t = torch.tensor([ok], dtype=torch.int64, device=ctl_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            use_ipc = bool(int(t[0]))
+            if not use_ipc:
+                try:
+                    ctx.ipc_destroy()
+                except Exception:                                       # noqa: BLE001
+                    pass
+                if args.rehearse_ipc or args.exchange == "ipc":
+                    raise SystemExit(f"bench.py: the ipc exchange was asked for and is not usable ({exchange_note})")
+    use_lib_comm = world > 1 and not args.rehearse_gloo and not use_ipc
     if use_lib_comm:
         box = [phi_amd.Context.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         ctx.comm_init(box[0], rank, world)
 
+    def dev_sync():
+        # (a group of processes: the gather of the LAST exchange starts with the next read launch -- or with this flush)
+        if use_ipc:
+            ctx.ipc_flush()
+        torch.cuda.synchronize()
+
     def allreduce_hits():
-        # the one data-path collective of a read set: all-reduce (MAX) of the hit vector, in place
-        if use_lib_comm:
+        # the one data-path collective of a read set: OR (= MAX) of the hit vectors, in place
+        if use_ipc:
+            ctx.ipc_allreduce_hits()
+        elif use_lib_comm:
             ctx.comm_allreduce_hits()
         elif world > 1:
             hit_ptr, n_unique = ctx.hits_buffer()
@@ -314,11 +378,11 @@ def main():
             step()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-        torch.cuda.synchronize()
+        dev_sync()
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -361,7 +425,7 @@ def main():
         for _ in range(50 if n_bases < 5e7 else 1):
             ctx.reset_reads()
             ctx.add_reads_device(d_bases.data_ptr(), ramp_off, n_reads, n_bases)
-        torch.cuda.synchronize()
+        dev_sync()
 
     for _ in range(args.warmup):
         primary_step()
@@ -373,7 +437,7 @@ def main():
     n_prof = max(24, args.prof_launches) if n_bases < 5e8 else max(3, min(args.prof_launches, args.steps))
     for _ in range(n_prof):
         primary_step()
-    torch.cuda.synchronize()
+    dev_sync()
     ctx.prof_enable(False)
     n_launch, kern_ms, kern_bases = ctx.prof_read()
     # several GPUs: where a step's time goes -- the rank's own scoring, and the exchange (which also absorbs the wait for the slowest rank)
@@ -383,6 +447,8 @@ def main():
         sc, ar = [], []
         d_b, d_o, nr, nb = (d_bases, d_off, n_reads, n_bases) if args.scaling == "weak" else (strong["d_b"], strong["d_o"], strong["n_reads"], strong["n_bases"])
         for _ in range(20):
+            if use_ipc:
+                ctx.ipc_flush()
             ctx.reset_reads()
             ev[0].record(stream)
             ctx.add_reads_device(d_b.data_ptr(), d_o.data_ptr(), nr, nb)
@@ -396,9 +462,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         step_split = {"score_ms_median_this_rank": float(t[0]), "allreduce_ms_median_this_rank": float(t[1]),
                       "score_ms_max_over_ranks": float(tmax[0]), "allreduce_ms_max_over_ranks": float(tmax[1]),
-                      "hit_vector_bytes": int(index_info["n_distinct_minimizers"]), "rccl_ranks": ctx.comm_info()[1] if use_lib_comm else world,
-                      "note": "GPU time between events on the stream, 20 steps: reset + sketch launch, then ncclAllReduce(MAX, uint8) of the hit vector; "
-                              "the all-reduce figure includes waiting for the slowest rank's sketch"}
+                      "hit_vector_bytes": int(index_info["n_distinct_minimizers"]), "ranks": ctx.ipc_info()[1] if use_ipc else (ctx.comm_info()[1] if use_lib_comm else world),
+                      "step_ms": elapsed / args.steps * 1e3,
+                      "exchange_exposed_ms": max(0.0, elapsed / args.steps * 1e3 - float(tmax[0])),
+                      "note": ("GPU time between events on the context's stream, 20 steps: reset + sketch launch = score; the exchange (ipc) runs on a stream of its own beside "
+                               "the NEXT read set's scoring, so allreduce_ms here is only what the context's stream sees of it (the issue of the gather: ~0); "
+                               "exchange_exposed_ms = timed step - score = what the exchange adds to a step (waiting for the slowest rank included)") if use_ipc else
+                              ("GPU time between events on the stream, 20 steps: reset + sketch launch, then ncclAllReduce(MAX, uint8) of the hit vector; "
+                               "the all-reduce figure includes waiting for the slowest rank's sketch; exchange_exposed_ms = timed step - score")}
     # the same read set handed over WITH its offsets array (reads of uneven lengths always are): the general path, beside `value`
     value_with_offsets = None
     if args.scaling == "weak" and not primary_step.uses_offsets and not args.no_extra_legs:
@@ -407,10 +478,10 @@ def main():
         el_g = timed(gstep, g_steps, max(2, args.warmup))
         value_with_offsets = n_bases * world * g_steps / el_g / 1e9
         primary_step()                                         # leave the context holding the primary read set
-        torch.cuda.synchronize()
+        dev_sync()
     # |Sp_R| is made from the log of novel read hashes when it is first asked for (once per read set, not once per step):
     # phi_reads_stats here, phi_solve in a job -- timed as its own leg, and inside solve_s / gpu_path_s of the job below
-    torch.cuda.synchronize()
+    dev_sync()
     t0 = time.perf_counter()
     stats = ctx.reads_stats()
     spectrum_dedupe_ms = (time.perf_counter() - t0) * 1e3
@@ -435,21 +506,23 @@ def main():
                                       "workload": f"{args.config} reads: every rank its own set of {n_bases / 1e6:.2f} Mbases per step + hit all-reduce"})
         # leave the context holding the primary read set for the solve below
         primary_step()
-        torch.cuda.synchronize()
+        dev_sync()
 
     # ---- the rest of the job, once: spectrum merge (N > 1), filter + exact solve
     t_solve = None
     res = None
     solve_info = None
     if not args.no_solve:
-        torch.cuda.synchronize()
+        dev_sync()
         t0 = time.perf_counter()
-        if use_lib_comm:
+        if use_ipc:
+            ctx.ipc_exchange()                                 # hit gather (idempotent) + the lists of novel read hashes through mapped buffers
+        elif use_lib_comm:
             ctx.comm_exchange()                                # hit all-reduce (idempotent) + spectrum all-gather / import
         else:
             pdist.merge_spectrum_into(ctx, dev)
         res = ctx.solve()
-        torch.cuda.synchronize()
+        dev_sync()
         t_solve = time.perf_counter() - t0
         solve_info = ctx.solve_stats()
         solve_info["dp_mode_name"] = ("every vertex a step", "event chain", "blocks in parallel, walk lanes", "blocks in parallel, rows on class lanes")[solve_info["dp_mode"]]
@@ -470,16 +543,16 @@ def main():
             c2 = phi_amd.Context(local_rank)
             c2.set_params(k=K, w=W, threshold=1.0, recombination=100)
             c2.set_stream(stream.cuda_stream)
-            torch.cuda.synchronize()
+            dev_sync()
             t0 = time.perf_counter()
             c2.set_graph(A["seq_concat"], A["seq_off"], A["adj_off"], A["adj"], A["walk_off"], A["walk_vtx"], A["top_rank"])
-            torch.cuda.synchronize()
+            dev_sync()
             t1 = time.perf_counter()
             c2.add_reads_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases)
-            torch.cuda.synchronize()
+            dev_sync()
             t2 = time.perf_counter()
             r2 = c2.solve()
-            torch.cuda.synchronize()
+            dev_sync()
             t3 = time.perf_counter()
             assert r2["objective"] == res["objective"] and np.array_equal(r2["path_vtx"], res["path_vtx"]) and np.array_equal(r2["path_hap"], res["path_hap"]), "a fresh context gave another result"
             reps.append((t1 - t0, t2 - t1, t3 - t2))
@@ -521,7 +594,10 @@ def main():
                                (f"{n_reads} reads of mean {n_bases / max(1, n_reads):.0f} bp per GPU (seed {rk['seed']}, {n_bases / 1e6:.2f} Mbases)" if args.scaling == "weak" else
                                 f"ONE set of {strong['total_reads']} reads ({args.strong_config}, {strong['total_bases'] / 1e6:.2f} Mbases) in {world} shard(s)"),
                    "k": K, "w": W, "R": 100, "reads_per_gpu_bases": per_rank_bases, "parallelism": f"read-shard x{world}",
-                   "exchange": "none (1 GPU)" if world == 1 else ("gloo through the host (rehearsal)" if args.rehearse_gloo else "RCCL all-reduce(MAX, uint8) of the hit vector per step, inside libphi_amd.so")},
+                   "exchange": "none (1 GPU)" if world == 1 else ("gloo through the host (rehearsal)" if args.rehearse_gloo else
+                                ("mapped hit vectors (hipIpc*), one OR-gather kernel per read set on a stream of its own beside the next read set's scoring, inside libphi_amd.so (phi_ipc_*)"
+                                 + (" -- rehearsal: all ranks on ONE GPU" if args.rehearse_ipc else "") if use_ipc else
+                                 "RCCL all-reduce(MAX, uint8) of the hit vector per step, inside libphi_amd.so" + (f" ({exchange_note})" if exchange_note else "")))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "phi_sketch_pool_kernel (batches of 12 Mbases and more)" if per_rank_bases >= 4 * 6144 * 512 else "phi_sketch_kernel<PHI_MODE_PROBE>", "kernel_avg_ms": kern_avg_ms,
@@ -570,11 +646,11 @@ def main():
         reps = max(3, min(20, int(2e8 // max(n_bases, 1))))
         for _ in range(2):
             ctx.reset_reads(); ctx.add_reads((hb, off))
-        torch.cuda.synchronize()
+        dev_sync()
         t0 = time.perf_counter()
         for _ in range(reps):
             ctx.reset_reads(); ctx.add_reads((hb, off))
-        torch.cuda.synchronize()
+        dev_sync()
         out["h2d_inclusive_gbases_per_s"] = n_bases * reps / (time.perf_counter() - t0) / 1e9
         ctx._chk(ctx._L.phi_host_unregister(ctx._h, hb.ctypes.data))
         if walk_bases < 2e9:

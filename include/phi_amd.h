@@ -206,7 +206,11 @@ int phi_peers_destroy(void *group);
  * same sequence of calls on every rank.  HSA_ENABLE_IPC_MODE_LEGACY=0 where the host driver only shares memory by dmabuf.
  *   phi_ipc_unique_id        128 bytes (the name of a small shared-memory block) made by one rank, handed to the others out of band
  *   phi_ipc_init             collective, after phi_set_graph: handles published and mapped; phi_set_graph is refused from here on
- *   phi_ipc_allreduce_hits   step 1 alone, asynchronous; whatever observes the hit vector afterwards waits for it by itself
+ *   phi_ipc_allreduce_hits   step 1 alone, asynchronous: the gather starts once the read set is scored, which the context's NEXT
+ *                            read launch tells it (no launch, event or host call in between); whatever observes the hit vector
+ *                            through this library afterwards waits for it by itself
+ *   phi_ipc_flush            behind a LAST exchange, before waiting on the device by other means (hipDeviceSynchronize,
+ *                            torch.cuda.synchronize): lets the gather start without a further read launch.  Asynchronous
  *   phi_ipc_exchange         steps 1 + 2 (the lists of novel read hashes, through mapped buffers and a host barrier), once per job
  *   phi_ipc_check            waits for the gathers issued so far; PHI_ERR_DEVICE when one gave up on a peer (PHI_IPC_TIMEOUT_S, 20 s)
  *   phi_ipc_destroy          collective; also done by phi_ctx_destroy
@@ -215,6 +219,7 @@ int phi_ipc_unique_id(void *id_out, size_t cap);
 int phi_ipc_init(phi_ctx *ctx, const void *id, int32_t rank, int32_t n_ranks);
 int phi_ipc_info(const phi_ctx *ctx, int32_t *rank, int32_t *n_ranks);
 int phi_ipc_allreduce_hits(phi_ctx *ctx);
+int phi_ipc_flush(phi_ctx *ctx);
 int phi_ipc_exchange(phi_ctx *ctx);
 int phi_ipc_check(phi_ctx *ctx);
 int phi_ipc_destroy(phi_ctx *ctx);

@@ -25,7 +25,7 @@ SYMBOLS = [
     "phi_index_stats", "phi_solve_stats", "phi_comm_unique_id", "phi_comm_init", "phi_comm_info", "phi_comm_allreduce_hits", "phi_comm_exchange", "phi_comm_destroy",
     "phi_reads_text_begin", "phi_add_reads_text", "phi_reads_text_end", "phi_reads_text_detach_carry", "phi_reads_text_last_batch",
     "phi_peers_create", "phi_peers_join", "phi_peers_allreduce_hits", "phi_peers_exchange", "phi_peers_destroy",
-    "phi_ipc_unique_id", "phi_ipc_init", "phi_ipc_info", "phi_ipc_allreduce_hits", "phi_ipc_exchange", "phi_ipc_check", "phi_ipc_destroy",
+    "phi_ipc_unique_id", "phi_ipc_init", "phi_ipc_info", "phi_ipc_allreduce_hits", "phi_ipc_flush", "phi_ipc_exchange", "phi_ipc_check", "phi_ipc_destroy",
 ]
 
 
@@ -106,6 +106,7 @@ def load():
     L.phi_ipc_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.phi_ipc_allreduce_hits.argtypes = [vp]
     L.phi_ipc_exchange.argtypes = [vp]
+    L.phi_ipc_flush.argtypes = [vp]
     L.phi_ipc_check.argtypes = [vp]
     L.phi_ipc_destroy.argtypes = [vp]
     L.phi_path_sequence.argtypes = [vp, vp, i64]

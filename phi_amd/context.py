@@ -224,6 +224,9 @@ class Context:
     def ipc_allreduce_hits(self):
         self._chk(self._L.phi_ipc_allreduce_hits(self._h))
 
+    def ipc_flush(self):
+        self._chk(self._L.phi_ipc_flush(self._h))
+
     def ipc_exchange(self):
         self._chk(self._L.phi_ipc_exchange(self._h))
 

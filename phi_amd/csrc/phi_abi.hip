@@ -1230,6 +1230,7 @@ int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_rea
         c->alt.needs_clean = false;
         c->next_flag_zeroed = true;
     }
+    phi_ipc_launch_args(c, A);                                 // (a context in a group of processes: the flags of its exchanges)
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (c->prof && c->prof_period > 0 && (c->prof_seq++ % c->prof_period) == 0) {
         if (c->prof_used == c->prof_events.size()) {
@@ -1523,8 +1524,8 @@ int phi_reset_reads(phi_ctx *c)
     const bool front_dirty = c->alt.needs_clean;               // two resets with no read launch in between
     swap_read_bufs(c);
     c->alt.needs_clean = true;
-    PHICHK(phi_ipc_before_generation(c, c->sp_gen + 1));       // (a group of processes: the peers are done with what is about to be zeroed)
     if (front_dirty) {
+        PHICHK(phi_ipc_before_generation(c, c->sp_gen + 1));   // (a group of processes: the peers are done with what is about to be zeroed)
         // nothing zeroed the half that comes to the front: do it now
         phi_launch_reset_reads(c->stream, c->d_hit.as<uint64_t>(), c->d_hit.p ? c->n_unique / 8 + 1 : 0, c->d_stripes.as<uint64_t>(), 2 * PHI_STRIPES * 8);
         HIPCHK(hipGetLastError());

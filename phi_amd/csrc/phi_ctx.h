@@ -337,7 +337,8 @@ int phi_pin_ensure(phi_ctx *c, size_t bytes);
 int phi_host_anchors(phi_ctx *c);                      // the host copy of the kept anchors, fetched if it is not there
 // phi_ipc.hip
 int phi_ipc_wait_pending(phi_ctx *c);                  // the context's stream waits for the last gather (every observer of the hit vector: phi_flush_reset)
-int phi_ipc_before_generation(phi_ctx *c, int64_t gen); // phi_reset_reads: before the hit buffer of read set gen - 3 may be zeroed
+int phi_ipc_before_generation(phi_ctx *c, int64_t gen); // phi_reset_reads, two resets in a row: before a hit buffer is zeroed by a launch of its own
+void phi_ipc_launch_args(phi_ctx *c, PhiSketchArgs &A);  // every read launch: the flags its waves publish / look at
 // sums of the striped counters (waits for the stream): novel hashes logged (with duplicates), emitted records
 int phi_read_counts(phi_ctx *c, uint64_t *n_logged, uint64_t *n_emitted);
 int phi_spectrum_count(phi_ctx *c, uint64_t *n_distinct);

@@ -34,6 +34,13 @@ typedef uint32_t phi_ent_t;
 
 enum { PHI_MODE_COUNT = 0, PHI_MODE_WRITE = 1, PHI_MODE_PROBE = 2 };
 
+// words (u64) of a rank's flag block in a group of processes (phi_ipc.hip): 0 .. 3 the flags the peers read; the error word;
+// local: last exchange whose read set is scored, last exchange gathered, workgroups of the gathers that have ended
+#define PHI_MB_ERR 8
+#define PHI_MB_SCORED 16
+#define PHI_MB_GATHERED 17
+#define PHI_MB_BLOCKS 18
+
 // bits of the device error word
 #define PHI_KERR_SENTINEL 1u    // a minimiser hashed to the empty-slot sentinel
 #define PHI_KERR_TABLE_FULL 2u  // probe bound exceeded
@@ -82,6 +89,12 @@ struct PhiSketchArgs {
     // generation of reads filled (the other half of the context's double buffers), for the generation after this one
     int32_t q_clean;
     unsigned long long *ov_zero;           // the overflow counter of the generation after this one (three rotate)
+    // a context in a group of processes (phi_ipc.hip): this rank's flag block.  The launch's first wave publishes "the
+    // exchanges issued before this launch have their read sets scored" (ipc_scored: the stream is in order, so every
+    // earlier scoring launch has ended) -- the gather kernels on the group's stream wait for that flag, no launch or event
+    // on this stream in between --; and before a wave zeroes its share of a retired hit vector it makes sure this rank's
+    // gather ipc_need has ended (by then every peer has read that vector; true long before, except when a peer lags)
+    unsigned long long *ipc_mb; unsigned long long ipc_scored, ipc_need;
     uint64_t *q_hit_words; int64_t q_n_hit_words; uint64_t *q_stripes; int64_t q_n_stripe_words;
 };
 

@@ -495,6 +495,12 @@ template <class AT>
 __device__ __forceinline__ void clean_finish(const AT &A, int64_t gw, int64_t n_waves, int lane)
 {
     if (gw == 0 && lane == 0 && A.ov_zero) *A.ov_zero = 0;              // the overflow counter of the generation after this one
+    if (A.ipc_mb && A.ipc_need) {
+        // a group of processes: the hit vector about to be zeroed may still be read by a peer until this rank's gather
+        // ipc_need has ended (phi_ipc.hip) -- it has, long ago, unless a peer lags: then wait (bounded: the gather itself gives up)
+        // (relaxed polls: an acquire load would invalidate the XCD's L2 with every poll; the stores below depend on the loop's exit)
+        while (__hip_atomic_load(A.ipc_mb + PHI_MB_GATHERED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.ipc_need) __builtin_amdgcn_s_sleep(32);
+    }
     // (wave-uniform guards: most waves of a large launch have nothing to empty and skip on scalar compares)
     if (gw * 64 < A.q_n_hit_words)
         for (int64_t i = gw * 64 + lane; i < A.q_n_hit_words; i += n_waves * 64) A.q_hit_words[i] = 0;
@@ -644,6 +650,8 @@ __global__ void __launch_bounds__(TPB, MODE == PHI_MODE_PROBE ? 6 : 1) phi_sketc
     const int64_t N = A.n_bases;
     const int64_t chunk = (int64_t)blockIdx.x * (TPB / 64) + wid;
     const int64_t c0 = chunk * WCH;                       // first window start of this chunk
+    if (FUSED && A.ipc_mb && chunk == 0 && lane == 0)      // (a group of processes: see PhiSketchArgs)
+        __hip_atomic_store(A.ipc_mb + PHI_MB_SCORED, A.ipc_scored, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (c0 >= N) {                                        // wave-uniform
         // read batches, first launch after a reset: this wave's share of the buffers the previous generation of
         // reads filled (stores into buffers nothing in this launch reads: no ordering needed)
@@ -774,6 +782,8 @@ __global__ void __launch_bounds__(TPB, 6) phi_sketch_pool_kernel(PhiSketchArgs A
     {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
         const int64_t gw = (int64_t)blockIdx.x * (TPB / 64) + wid;      // this wave's job
+        if (A.ipc_mb && gw == 0 && lane == 0)             // (a group of processes: see PhiSketchArgs)
+            __hip_atomic_store(A.ipc_mb + PHI_MB_SCORED, A.ipc_scored, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (gw >= n_chunks_all || gw >= stride) {         // wave-uniform
             // read batches, first launch after a reset: this wave's share of the buffers the previous generation of
             // reads filled (stores into buffers nothing in this launch reads: no ordering needed)

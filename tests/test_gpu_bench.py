@@ -1,8 +1,8 @@
 """bench.py's own N > 1 branch under the driver's launcher, on ONE GPU: two ranks started by
-torch.distributed.run, both on cuda:0, the exchange staged through gloo on the host (--rehearse-gloo) -- the
-same sharding, step, barrier / max-over-ranks timing and solve agreement code as the multi-GPU run, whose only
-difference is the collective behind the exchange (the library's RCCL communicator, covered for one rank by
-test_rccl_communicator_inside_the_library)."""
+torch.distributed.run, both on cuda:0 -- the same sharding, step, barrier / max-over-ranks timing and solve agreement
+code as the multi-GPU run.  The exchange: --rehearse-ipc = the library's mapped hit vectors (phi_ipc_*: what a multi-GPU
+run of an MHC-sized graph takes by default, here with both processes on one device), --rehearse-gloo = staged through
+gloo on the host (the library's RCCL communicator is covered for one rank by test_rccl_communicator_inside_the_library)."""
 import json
 import os
 import socket
@@ -24,14 +24,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_two_ranks_rehearsed_on_one_gpu(scaling):
+@pytest.mark.parametrize("scaling,exchange", [("weak", "gloo"), ("strong", "gloo"), ("weak", "ipc"), ("strong", "ipc")])
+def test_bench_two_ranks_rehearsed_on_one_gpu(scaling, exchange):
     import __graft_entry__
     __graft_entry__.ensure_built()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--rehearse-gloo", "--config", "small", "--strong-config", "small", "--scaling", scaling, "--no-cpu-baseline"]
+           "--rehearse-" + exchange, "--config", "small", "--strong-config", "small", "--scaling", scaling, "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -39,6 +39,8 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(scaling):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == scaling and d["value"] > 0
     assert d["result"]["optimal"] == 1
+    if exchange == "ipc":
+        assert "mapped hit vectors" in d["config"]["exchange"] and d["step_split"]["ranks"] == 2
     other = "strong_scaling" if scaling == "weak" else "weak_scaling"
     assert d[other]["value"] > 0
     if scaling == "strong":
