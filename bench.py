@@ -131,9 +131,15 @@ def _phi_stage_table(stderr):
 
 def file_to_fasta(g, bases, off, k, w, runs=5, fastq=False):
     """The drop-in command line on this configuration's files (GFA 1.1 + FASTA / FASTQ in a temp dir, page cache warm):
-    `PHI -g -r -o` from process start to the closed FASTA, parse and H2D included.  Several runs,
-    a pause between them (the driver takes a finished process's GPU state down for ~0.1 s, which the next start would
-    otherwise wait for); the median run's stage table is reported."""
+    `PHI -g -r -o` from process start to the closed FASTA, parse and H2D included.  Three ways,
+    none of whose definitions relies on a pause:
+      back to back   `runs` consecutive commands, nothing between them, each ONE process (the default: when the command
+                     returns its memory and its GPU state are given back, as the reference's does): the median command =
+                     end_to_end_s, the wall clock of all of them / runs = back_to_back_s (what a harness that loops PHI over
+                     samples sees, data/run_batch_4_miqp.py:31-46);
+      detached       PHI_DETACH=1: the command returns when the FASTA is closed, its teardown runs on behind it (round 3's
+                     end_to_end_s; here with 0.4 s between two runs, because the NEXT start would otherwise wait for that teardown);
+      several jobs   ONE command with `runs` read sets against the graph (-r .. -o .. -r .. -o ..): graph parsed and indexed once."""
     from phi_amd import synth
     phi = os.path.join(ROOT, "phi_amd", "PHI")
     if not os.path.exists(phi):
@@ -143,30 +149,49 @@ def file_to_fasta(g, bases, off, k, w, runs=5, fastq=False):
         synth.write_gfa(g, gfa)
         synth.write_reads(bases, off, rd, fastq=fastq)
         env = dict(os.environ, PHI_TIMING="1")
-        recs = []
-        for i in range(runs + 1):
-            time.sleep(0.4)
-            e = dict(env, PHI_DETACH="0") if i == runs else env       # the last run: one process, teardown inside the wall clock
+        env.pop("PHI_DETACH", None)
+
+        def one(e, extra=()):
             t_spawn = time.time()
             t0 = time.perf_counter()
-            r = subprocess.run([phi, "-g", gfa, "-r", rd, "-o", fa, "-k", str(k), "-w", str(w)], capture_output=True, text=True, env=e)
+            r = subprocess.run([phi, "-g", gfa, "-r", rd, "-o", fa, "-k", str(k), "-w", str(w)] + list(extra), capture_output=True, text=True, env=e)
             dt = time.perf_counter() - t0
             if r.returncode != 0:
                 return {"error": r.stderr[-300:]}
             stages, info = _phi_stage_table(r.stderr)
-            recs.append({"wall_s": dt, "spawn_to_main_s": info.get("main_entered_epoch", t_spawn) - t_spawn,
-                         "spawn_to_fasta_closed_s": info.get("fasta_closed_epoch", t_spawn + dt) - t_spawn, "stages": stages})
-        one_process = recs.pop()
-        walls = sorted(x["wall_s"] for x in recs)
+            return {"wall_s": dt, "spawn_to_main_s": info.get("main_entered_epoch", t_spawn) - t_spawn,
+                    "spawn_to_fasta_closed_s": info.get("fasta_closed_epoch", t_spawn + dt) - t_spawn, "stages": stages}
+        first = one(env)                                        # (the page cache, and a first run right behind the bench's own allocations)
+        if "error" in first:
+            return first
+        t0 = time.perf_counter()
+        recs = [one(env) for _ in range(runs)]
+        back_to_back = (time.perf_counter() - t0) / runs
+        if any("error" in x for x in recs):
+            return [x for x in recs if "error" in x][0]
+        det = []
+        for _ in range(runs):
+            time.sleep(0.4)
+            det.append(one(dict(env, PHI_DETACH="1")))
+        extra = []
+        for i in range(1, runs):
+            extra += ["-r", rd, "-o", os.path.join(d, f"out{i}.fa")]
+        t0 = time.perf_counter()
+        multi = one(env, extra)
+        multi_wall = time.perf_counter() - t0
         med = sorted(recs, key=lambda x: x["wall_s"])[len(recs) // 2]
-        return {"seconds": med["wall_s"], "seconds_all_runs": [x["wall_s"] for x in recs], "seconds_min": walls[0], "seconds_first_run": recs[0]["wall_s"],
+        det_ok = [x["wall_s"] for x in det if "error" not in x]
+        return {"seconds": med["wall_s"], "seconds_all_runs": [x["wall_s"] for x in recs], "seconds_min": min(x["wall_s"] for x in recs), "seconds_first_run": first["wall_s"],
+                "back_to_back_s": back_to_back,
+                "detached_seconds": float(np.median(det_ok)) if det_ok else None, "detached_all_runs": det_ok,
+                "several_jobs_per_read_set_s": None if "error" in multi else multi_wall / runs, "several_jobs_command_s": None if "error" in multi else multi_wall,
                 "spawn_to_fasta_closed_s": med["spawn_to_fasta_closed_s"], "spawn_to_main_s": med["spawn_to_main_s"],
                 "stages_s": {k_: v for k_, v in med["stages"].items() if k_ != "detail"}, "detail_ms": med["stages"].get("detail", {}),
-                "one_process_wall_s": one_process["wall_s"],
                 "gfa_mb": os.path.getsize(gfa) / 1e6, "reads_mb": os.path.getsize(rd) / 1e6,
-                "note": f"median of {runs} runs of phi_amd/PHI on uncompressed files (page cache warm, 0.4 s apart): wall clock of the command as its caller sees it "
-                        "= process start -> FASTA closed and log written; the worker's teardown (free of the arrays, the driver taking the GPU state down, ~0.1 s) runs "
-                        "detached behind it -- one_process_wall_s is the same command with PHI_DETACH=0, teardown included; stages_s = [begin, end] on the process's clock"}
+                "note": f"phi_amd/PHI on uncompressed files (page cache warm).  seconds = the median of {runs} consecutive commands with nothing between them, each one process "
+                        "(teardown inside the wall clock); back_to_back_s = the wall clock of all of them / their number; detached_seconds = the same command with PHI_DETACH=1 "
+                        "(it returns when the FASTA is closed, the teardown runs on behind it; 0.4 s between two runs); several_jobs_per_read_set_s = ONE command with "
+                        f"{runs} read sets against the graph, its wall clock / {runs}; stages_s = [begin, end] on the process's clock (median run)"}
 
 
 def main():
@@ -624,7 +649,7 @@ def main():
         "gpu_path_s_cold": (t_index + ms_per_step * 1e-3 + t_solve) if t_solve is not None else None,
         "job_repeats": repeats,
         # process start -> FASTA closed, from files, with the command line (filled in below)
-        "end_to_end_s": None,
+        "end_to_end_s": None, "end_to_end_one_process_s": None, "back_to_back_s": None, "end_to_end_detached_s": None, "several_jobs_per_read_set_s": None,
         "synthetic_gen_s": t_gen,
     }
     if step_split is not None:
@@ -655,8 +680,16 @@ def main():
         ctx._chk(ctx._L.phi_host_unregister(ctx._h, hb.ctypes.data))
         if walk_bases < 2e9:
             out["file_to_fasta"] = file_to_fasta(g, bases, off, K, W)
-            out["file_to_fasta_s"] = (out["file_to_fasta"] or {}).get("seconds")
-            out["end_to_end_s"] = out["file_to_fasta_s"]
+            f2f = out["file_to_fasta"] or {}
+            out["file_to_fasta_s"] = f2f.get("seconds")
+            # process start -> FASTA closed, from files.  end_to_end_s: ONE process, teardown inside, the median of
+            # consecutive commands (= end_to_end_one_process_s: the key the review asked for); back_to_back_s: their total / their number;
+            # end_to_end_detached_s: round 3's definition (the command returns at the closed FASTA, teardown behind it)
+            out["end_to_end_s"] = f2f.get("seconds")
+            out["end_to_end_one_process_s"] = f2f.get("seconds")
+            out["back_to_back_s"] = f2f.get("back_to_back_s")
+            out["end_to_end_detached_s"] = f2f.get("detached_seconds")
+            out["several_jobs_per_read_set_s"] = f2f.get("several_jobs_per_read_set_s")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A, bases, off, K, W)
         # the oracle's stages 1-2 over the WHOLE configuration (timed above as the CPU baseline's stage table) against what

@@ -4,6 +4,9 @@
 //
 //   ./PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta> [-k -w -R -q -m -T -t -d -N -c]
 //         [--device N | --devices 0,1,..] [--dp-budget RUNS]
+//   ./PHI -g <target.gfa> -r a.fq -o a.fa -r b.fq -o b.fa ...      several read sets against ONE graph: the graph is parsed and
+//         indexed once (the reference's harness runs PHI once per sample x coverage on the same graph,
+//         data/run_batch_4_miqp.py:31-46), every job prints the log of a run of its own and writes its own FASTA
 //
 // --devices: one context and one host thread per GPU; every GPU builds the full index, the chunks of the reads file are
 // handed out in turn, the library's RCCL exchange (phi_comm_*) merges hit vectors and spectra once, and the first
@@ -19,8 +22,10 @@
 // path: ~60-180 ms to start it, ~20 ms per hardware queue, and ~100 ms for the driver to take the process's GPU state
 // down again when it ends.  So: the device context is made by a thread of its own while the graph is parsed; the reads
 // file goes to the device as raw text (the records are found there: phi_add_reads_text); and the process that does
-// the work is a CHILD -- the parent returns the child's status the moment the FASTA is closed and the log written, the
-// child's teardown (free of the arrays, the driver's cleanup) goes on behind it.  PHI_DETACH=0 keeps one process.
+// the work can be a CHILD (PHI_DETACH=1) -- the parent returns the child's status the moment the FASTA is closed and the log
+// written, the child's teardown (free of the arrays, the driver's cleanup: ~0.1 s at MHC size, ~1 s and 65 GB of HBM at
+// chromosome scale) goes on behind it.  Off by default: when the reference's command returns its resources are free, and a
+// harness that starts the next GPU job at once would find them still held.
 // Exit status: 0; 1 on any error; 3 when --dp-budget was given and ran out before the path was proven optimal.
 #include <errno.h>
 #include <getopt.h>
@@ -49,7 +54,7 @@
 
 #define PHI_VERSION "1.0-mi355x"
 
-static double t0_real;
+static double t0_real, cpu0;
 static double realtime()
 {
     struct timeval tp;
@@ -60,7 +65,7 @@ static double cputime()
 {
     struct rusage r;
     getrusage(RUSAGE_SELF, &r);
-    return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+    return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec) - cpu0;
 }
 static long peakrss()
 {
@@ -126,7 +131,8 @@ struct Options {
     long long dp_budget = -1;                                 // --dp-budget: DP runs of the exact search; not given: no limit, as model.optimize()
     long long shard_min_bases = 50000000;                     // --shard-min-bases: text bytes of reads a further GPU must be worth
     float threshold = 1.0f;
-    std::string gfa_file, reads_file, hap_file;
+    std::string gfa_file, reads_file, hap_file;               // (reads_file / hap_file: the first job's, for the usage text)
+    std::vector<std::string> reads_files, hap_files;          // one entry per job: -r a -o a.fa -r b -o b.fa ...
     int argc = 0;
     char **argv = nullptr;
     bool detached = false;
@@ -172,7 +178,9 @@ static int64_t next_block_from_queue(void *user, const char **block)
 static int run(const Options &o)
 {
     const int k = o.k, w = o.w, recombination = o.recombination, is_qclp = o.is_qclp, is_mixed = o.is_mixed, debug = o.debug;
-    const std::string &gfa_file = o.gfa_file, &reads_file = o.reads_file, &hap_file = o.hap_file;
+    const std::string &gfa_file = o.gfa_file;
+    const int n_jobs = (int)o.reads_files.size();
+    std::string reads_file = o.reads_files[0], hap_file = o.hap_files[0];      // the job at hand
     char err[512] = "";
 
     // The device context (HIP initialisation) and the reads file are prepared by two host threads
@@ -214,15 +222,22 @@ static int run(const Options &o)
     // finds the records on the device -- chunk i + 1 crosses the link while chunk i is sketched, and no byte of a
     // regular file is looked at by a host core.  Host memory stays bounded: 2 + GPUs buffers.
     int64_t chunk_bytes = getenv("PHI_READ_CHUNK") ? std::max<int64_t>(256, atoll(getenv("PHI_READ_CHUNK"))) : ((int64_t)64 << 20);
-    {
-        struct stat st;
-        if (stat(reads_file.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && !getenv("PHI_READ_CHUNK")) {
-            FILE *fp = fopen(reads_file.c_str(), "rb");
-            unsigned char m2[2] = {0, 0};
-            const bool gz = fp && fread(m2, 1, 2, fp) == 2 && m2[0] == 0x1f && m2[1] == 0x8b;
-            if (fp) fclose(fp);
-            if (!gz) chunk_bytes = std::min<int64_t>(chunk_bytes, ((int64_t)st.st_size + 4095) & ~(int64_t)4095);   // a small file: one chunk of its size
+    if (!getenv("PHI_READ_CHUNK")) {
+        // small plain files: one chunk of the file's size (of the largest file, when there are several jobs)
+        int64_t need = 0;
+        for (const std::string &rf : o.reads_files) {
+            struct stat st;
+            int64_t want = chunk_bytes;
+            if (stat(rf.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+                FILE *fp = fopen(rf.c_str(), "rb");
+                unsigned char m2[2] = {0, 0};
+                const bool gz = fp && fread(m2, 1, 2, fp) == 2 && m2[0] == 0x1f && m2[1] == 0x8b;
+                if (fp) fclose(fp);
+                if (!gz) want = std::min<int64_t>(chunk_bytes, ((int64_t)st.st_size + 4095) & ~(int64_t)4095);
+            }
+            need = std::max(need, want);
         }
+        chunk_bytes = need;
     }
     ChunkQueue Q;
     const int N_CHUNK_BUF = 2 + n_dev;                        // one in flight per GPU, two with the reader
@@ -233,10 +248,12 @@ static int run(const Options &o)
         Q.q_free.push_back(i);
     }
     char rerr[512] = "";
-    std::future<int> f_reads = std::async(std::launch::async, [&]() {
+    std::future<int> f_reads;
+    auto start_reads = [&]() {
+      f_reads = std::async(std::launch::async, [&, rf = reads_file]() {
         Stage st("reads file -> text chunks [thread]");
         phi_text_stream *ts = nullptr;
-        int r = phi_text_stream_open(reads_file.c_str(), &ts, rerr, sizeof rerr);
+        int r = phi_text_stream_open(rf.c_str(), &ts, rerr, sizeof rerr);
         for (;;) {
             int slot;
             {
@@ -260,7 +277,9 @@ static int run(const Options &o)
         }
         if (ts) phi_text_stream_close(ts);
         return r;
-    });
+      });
+    };
+    start_reads();
     auto stop_reads = [&]() {
         { std::lock_guard<std::mutex> lk(Q.mu); Q.stop = true; }
         Q.cv.notify_all();
@@ -332,15 +351,14 @@ static int run(const Options &o)
                 return r;
             })) return 1;
     }
-    // The exchange of a multi-GPU run: hit vectors of a few MB (every MHC-sized graph) go through peer-mapped memory -- one
-    // OR-gather kernel per GPU, no RCCL --; longer ones (chromosome scale: ~100 MB) through the library's RCCL all-reduce,
-    // which is bandwidth-bound there.  PHI_EXCHANGE=rccl|peers overrides.
+    // The exchange of a multi-GPU run: the library's RCCL all-reduce.  PHI_EXCHANGE=peers takes the peer-mapped OR-gather
+    // instead (one kernel per GPU, no RCCL: made for hit vectors of a few MB, every MHC-sized graph) -- opt-in until a run on
+    // two or more GPUs has compared the two bit for bit: its cross-GPU loads have only ever run between contexts on ONE GPU.
     bool use_peers = false;
     void *peer_group = nullptr;
     if (n_dev > 1) {
         phi_index_info info;
         if ((rc = phi_index_stats(ctx, &info))) return die("index", rc);
-        use_peers = info.n_distinct_minimizers <= (int64_t)4 << 20;
         if (const char *e = getenv("PHI_EXCHANGE")) use_peers = strcmp(e, "peers") == 0;
         if (use_peers && (rc = phi_peers_create(n_dev, &peer_group))) return die("peer group", rc);
         Stage st(use_peers ? "peer group (xGMI peer access)" : "RCCL communicator");
@@ -349,12 +367,36 @@ static int run(const Options &o)
         fprintf(stderr, "[M::main] %d GPUs; hit vector of %lld flags merged through %s\n", n_dev, (long long)info.n_distinct_minimizers, use_peers ? "peer-mapped memory (one OR-gather kernel per GPU)" : "RCCL all-reduce");
     }
 
+    // ---- one job per read set (-r a -o a.fa -r b -o b.fa ...): the graph, its index and the communicator are made once
+    int status = 0;
+    std::atomic<bool> pinned{true};
+    std::once_flag pin_once;
+    bool registered = false;
+    for (int job = 0; job < n_jobs; job++) {
+    if (job > 0) {
+        // the next read set: clocks, names, the chunk queue and the reader thread start over; the contexts forget the reads
+        fflush(nullptr);
+        const double now = realtime();
+        cpu0 += cputime();
+        t0_real = now;
+        { std::lock_guard<std::mutex> lk(g_marks.mu); g_marks.marks.clear(); }
+        reads_file = o.reads_files[(size_t)job]; hap_file = o.hap_files[(size_t)job];
+        if (phi_hap_name(gfa_file.c_str(), reads_file.c_str(), hap_name, sizeof hap_name) < 0) { fprintf(stderr, "[E::%s] output name too long\n", "main"); return 1; }
+        {
+            std::lock_guard<std::mutex> lk(Q.mu);
+            Q.q_free.clear(); Q.q_full.clear(); Q.stop = false;
+            for (int i = 0; i < N_CHUNK_BUF; i++) { Q.buf[(size_t)i].n = 0; Q.q_free.push_back(i); }
+        }
+        rerr[0] = 0;
+        start_reads();
+        if (run_on_all("reset", [&](int, phi_ctx *cx) -> int { return phi_reset_reads(cx); })) return 1;
+        stamp("main");
+        fprintf(stderr, "Loaded graph from: %s\n", gfa_file.c_str());
+    }
     // ---- reads (main.cpp:136-137) and stage 1b/2a (:615-655), chunk by chunk.  The chunks are taken in stream order,
     //      one GPU at a time (a chunk needs the unfinished rest of the one before); the sketch of a chunk runs on
     //      behind the turn.  Text that is not laid out regularly goes through the host reader from that byte on.
     std::atomic<int> n_chunks{0};
-    std::atomic<bool> pinned{true};
-    std::once_flag pin_once;
     std::mutex turn_mu;
     std::vector<char> carry;                                  // several GPUs: the bytes the last turn left unfinished
     bool stream_done = false;                                 // under turn_mu
@@ -409,6 +451,7 @@ static int run(const Options &o)
                         // a file of more than one chunk: pin the buffers, so that the device copy of every further
                         // chunk is a direct DMA (pinning takes milliseconds: not worth it for a single chunk)
                         std::call_once(pin_once, [&]() {
+                            registered = true;
                             for (auto &b : Q.buf) if (phi_host_register(cx, b.text, (size_t)chunk_bytes) != PHI_OK) pinned = false;
                         });
                     stream_fed += cb.n;
@@ -552,7 +595,6 @@ static int run(const Options &o)
                 o.detached ? "; teardown detached" : "");
         g_marks.print();
     }
-    int status = 0;
     if (!res.optimal) {
         // the reference returns only what model.optimize() proved (ILP_index.cpp:1418); here that can only fall short when
         // --dp-budget set a limit: the path written is feasible and within the printed bound, the exit status says so
@@ -561,10 +603,11 @@ static int run(const Options &o)
                 res.n_dp_runs, (long long)res.objective, (long long)res.upper_bound);
         status = 3;
     }
+    }   // jobs
     if (getenv("PHI_FULL_TEARDOWN")) {                        // (leak checks: give everything back in order)
         stop_reads();
         for (auto &cb : Q.buf) {
-            if (n_chunks >= 2) (void)phi_host_unregister(ctx, cb.text);
+            if (registered) (void)phi_host_unregister(ctx, cb.text);
             free(cb.text);
         }
         phi_graph_free(g);
@@ -591,8 +634,8 @@ int main(int argc, char *argv[])
         else if (c == 'q') o.is_qclp = atoi(optarg);
         else if (c == 'N') o.is_naive = atoi(optarg);
         else if (c == 'T') o.threshold = (float)atof(optarg);
-        else if (c == 'r') o.reads_file = optarg;
-        else if (c == 'o') o.hap_file = optarg;
+        else if (c == 'r') { o.reads_file = optarg; o.reads_files.push_back(optarg); }
+        else if (c == 'o') { o.hap_file = optarg; o.hap_files.push_back(optarg); }
         else if (c == 'c') o.max_occ = atoi(optarg);
         else if (c == 'd') o.debug = atoi(optarg);
         else if (c == 'h' || c == '?') help = 1;
@@ -616,13 +659,14 @@ int main(int argc, char *argv[])
         usage(stderr, o.k, o.w, o.recombination, o.is_qclp, o.is_mixed, o.threshold, o.n_threads, o.gfa_file.c_str(), o.reads_file.c_str(), o.hap_file.c_str(), o.debug);
         return 1;
     }
+    if (o.reads_files.size() != o.hap_files.size()) { fprintf(stderr, "[E::main] %zu -r but %zu -o: several read sets against one graph are given as -r a.fq -o a.fa -r b.fq -o b.fa ...\n", o.reads_files.size(), o.hap_files.size()); return 1; }
     o.argc = argc; o.argv = argv;
     t0_real = realtime();
 
     // The work is done by a child; this process returns the child's status as soon as the child reports it -- after the
     // FASTA is closed and the log written, before the teardown.  Not under a profiler or any other preloaded library that
     // may have started the GPU runtime in this process already (a runtime does not survive a fork), and not when asked.
-    bool detach = true;
+    bool detach = false;                                      // (opt-in: see the head of this file)
     if (const char *e = getenv("PHI_DETACH")) detach = atoi(e) != 0;
     if (getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("HSA_TOOLS_LIB") || getenv("ROCPROF_OUTPUT_PATH")) detach = false;
     if (const char *pl = getenv("LD_PRELOAD"))
@@ -647,7 +691,9 @@ int main(int argc, char *argv[])
                 close(pfd[0]);
                 report_fd = pfd[1];
                 o.detached = true;
-                (void)prctl(PR_SET_PDEATHSIG, SIGTERM);        // a killed parent takes the child with it
+                // (the parent's death ends the child: a killed parent takes it along -- and so does the parent's ordinary exit
+                //  right after the status arrived: the child is then inside its teardown, which the signal merely cuts short)
+                (void)prctl(PR_SET_PDEATHSIG, SIGTERM);
             } else { close(pfd[0]); close(pfd[1]); }           // no fork: one process
         }
     }

@@ -15,6 +15,7 @@
 // never pays for it (it is the largest shared object of the ROCm stack).
 #include <dlfcn.h>
 #include <string.h>
+#include <chrono>
 #include <condition_variable>
 #include <rccl/rccl.h>
 #include "phi_ctx.h"
@@ -213,13 +214,15 @@ struct PhiPeers {
     uint64_t phase = 0;
     int failed = 0;
     // all n threads meet; returns nonzero when some rank raised `fail` before or at this barrier
+    // (a rank that returned early, died or hangs must not leave the others waiting for ever: the wait is timed, and a barrier
+    //  that timed out -- like a failure any rank reports -- fails every later barrier of the group: make a new group)
     int barrier(int fail)
     {
         std::unique_lock<std::mutex> lk(mu);
         if (fail) failed = fail;
         const uint64_t p = phase;
         if (++arrived == n) { arrived = 0; phase++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return phase != p; });
+        else if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return phase != p; })) { failed = PHI_ERR_STATE; arrived = 0; phase++; cv.notify_all(); }
         return failed;
     }
 };
@@ -271,8 +274,8 @@ int phi_peers_join(phi_ctx *c, void *group, int32_t rank)
     // every GPU may load from every other (the same device twice -- two contexts on one GPU, as the tests run it -- needs nothing)
     for (int r = 0; r < g->n && !rc; r++) {
         const int dev = g->ctx[(size_t)r]->device;
-        if (dev == c->device) continue;
         if (g->n_unique[(size_t)r] != c->n_unique) { rc = phi_fail(c, PHI_ERR_INVALID, "the ranks of a peer group hold different graphs"); break; }
+        if (dev == c->device) continue;
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, c->device, dev) != hipSuccess || !can) { rc = phi_fail(c, PHI_ERR_DEVICE, "GPU %d cannot address GPU %d", c->device, dev); break; }
         const hipError_t e = hipDeviceEnablePeerAccess(dev, 0);
@@ -303,31 +306,32 @@ static int peers_exchange(phi_ctx *c, bool hits_only)
         rc = phi_hip_check(c, hipEventRecord(g->ready[(size_t)me], c->stream), "hipEventRecord");
     }
     if (g->barrier(rc)) return rc ? rc : phi_fail(c, PHI_ERR_STATE, "a peer failed before the exchange");
-    // ---- step 1: OR of the hit vectors
+    // ---- step 1: OR of the hit vectors.  From here to the phase's last barrier nothing returns: whatever fails is carried in
+    //      rc to the next barrier, which every rank reaches (a rank that left between two barriers would leave the others waiting)
     PeerPtrs pp{};
     int np = 0;
     for (int r = 0; r < g->n; r++) {
         if (r == me) continue;
-        HIPCHK(hipStreamWaitEvent(c->stream, g->ready[(size_t)r], 0));
+        if (!rc) rc = phi_hip_check(c, hipStreamWaitEvent(c->stream, g->ready[(size_t)r], 0), "hipStreamWaitEvent");
         pp.p[np++] = (const unsigned long long *)g->hits[(size_t)r];
     }
     const int64_t n_words = n / 8 + 1;                         // (the vectors are allocated in whole words)
-    if (np && n > 0) {
+    if (!rc && np && n > 0) {
         const unsigned nb = (unsigned)std::min<int64_t>((n_words + 255) / 256, 2048);
         hipLaunchKernelGGL(phi_or_gather_kernel, dim3(nb), dim3(256), 0, c->stream, (unsigned long long *)d_hit, pp, np, n_words);
-        HIPCHK(hipGetLastError());
+        rc = phi_hip_check(c, hipGetLastError(), "phi_or_gather_kernel");
     }
     c->solved = false;
     if (hits_only) {
-        HIPCHK(hipEventRecord(g->done[(size_t)me], c->stream));
-        if (g->barrier(0)) return phi_fail(c, PHI_ERR_STATE, "a peer failed in the exchange");
-        for (int r = 0; r < g->n; r++) if (r != me) HIPCHK(hipStreamWaitEvent(c->stream, g->done[(size_t)r], 0));   // nobody resets a vector a peer still reads
+        if (!rc) rc = phi_hip_check(c, hipEventRecord(g->done[(size_t)me], c->stream), "hipEventRecord");
+        if (g->barrier(rc)) return rc ? rc : phi_fail(c, PHI_ERR_STATE, "a peer failed in the exchange");
+        for (int r = 0; r < g->n; r++) if (r != me) HIPCHK(hipStreamWaitEvent(c->stream, g->done[(size_t)r], 0));   // nobody resets a vector a peer still reads (no barrier follows: returning is safe)
         return PHI_OK;
     }
     // ---- step 2: the union of the read hashes that are not walk minimisers
     void *d_mine = nullptr;
     int64_t n_mine = 0;
-    rc = phi_spectrum_export(c, &d_mine, &n_mine);             // waits for the stream
+    if (!rc) rc = phi_spectrum_export(c, &d_mine, &n_mine);    // waits for the stream
     if (!rc && n_mine) {
         // a copy the peers read: importing THEIR lists may regrow this context's set, which goes through the export buffer
         rc = phi_dev_ensure(c, c->d_peer_send, (size_t)n_mine * 8);
@@ -335,7 +339,7 @@ static int peers_exchange(phi_ctx *c, bool hits_only)
         if (!rc) rc = phi_hip_check(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
         d_mine = c->d_peer_send.p;
     }
-    g->sp_list[(size_t)me] = d_mine; g->sp_n[(size_t)me] = n_mine;
+    g->sp_list[(size_t)me] = d_mine; g->sp_n[(size_t)me] = rc ? 0 : n_mine;
     if (g->barrier(rc)) return rc ? rc : phi_fail(c, PHI_ERR_STATE, "a peer failed in the exchange");
     for (int r = 0; r < g->n && !rc; r++)
         if (r != me && g->sp_n[(size_t)r] > 0) rc = phi_spectrum_import(c, g->sp_list[(size_t)r], g->sp_n[(size_t)r]);

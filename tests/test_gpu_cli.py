@@ -262,3 +262,47 @@ def test_cli_through_the_vcf_route_and_the_log_scrape(tmp_path):
     assert ">(REF.0,[0," in r.stderr
     truth, query = eval_log.read_fasta(os.path.join(DATA, "MHC-CHM13.0.fa.gz")), eval_log.read_fasta(str(out))
     assert query == truth and eval_log.edit_distance(truth[:20000], query[:20000]) == 0
+
+
+def test_cli_several_read_sets_against_one_graph(tmp_path):
+    """`PHI -g G -r a -o a.fa -r b -o b.fa -r c -o c.fa`: the graph is parsed and indexed once, every job prints the log
+    of a run of its own and writes its own FASTA -- line for line and byte for byte what three separate commands give (the
+    reference's harness runs PHI once per sample x coverage against the same graph, data/run_batch_4_miqp.py:31-46).
+    Read sets of different sizes and layouts: the whole FASTQ, its first 2 000 records as FASTA, its last 500 as FASTQ."""
+    import gzip
+    gfa = os.path.join(DATA, "MHC_4.gfa.gz")
+    fq = gzip.open(os.path.join(DATA, "CHM13_reads.fq.gz"), "rt").read().split("\n")
+    recs = [fq[i:i + 4] for i in range(0, len(fq) - 1, 4)]
+    a = os.path.join(DATA, "CHM13_reads.fq.gz")
+    b = tmp_path / "first.fa"
+    b.write_text("".join(f">{r[0][1:]}\n{r[1]}\n" for r in recs[:2000]))
+    c = tmp_path / "last.fq"
+    c.write_text("".join("\n".join(r) + "\n" for r in recs[-500:]))
+    sets = [(a, tmp_path / "a.fa"), (str(b), tmp_path / "b.fa"), (str(c), tmp_path / "c.fa")]
+
+    def keep(log):
+        out = []
+        for l in log.splitlines():
+            if l.startswith("[phi timing]") or "Real time" in l or "CMD:" in l:
+                continue
+            out.append(re.sub(r"^\[M::[^\]]*\] ", "", l))
+        return out
+    singles = []
+    for rd, out in sets:
+        single = tmp_path / ("single_" + out.name)
+        r = _run_cli(["-g", gfa, "-r", rd, "-o", str(single)], tmp_path)
+        assert r.returncode == 0, r.stderr
+        singles.append((keep(r.stderr.replace(str(single), str(out))), single.read_text()))
+    args = ["-g", gfa]
+    for rd, out in sets:
+        args += ["-r", rd, "-o", str(out)]
+    r = _run_cli(args, tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("Loaded graph from") == 3 and r.stderr.count("PHI Version") == 3
+    want = [l for lines, _ in singles for l in lines]
+    assert keep(r.stderr) == want
+    for (rd, out), (_, fa) in zip(sets, singles):
+        assert out.read_text() == fa
+    # -r and -o come in pairs
+    bad = _run_cli(["-g", gfa, "-r", a, "-r", str(b), "-o", str(tmp_path / "x.fa")], tmp_path)
+    assert bad.returncode == 1 and "-r but" in bad.stderr

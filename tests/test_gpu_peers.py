@@ -106,13 +106,13 @@ def test_cli_two_contexts_take_the_chunks_in_turn(tmp_path):
     one = run(["-o", str(tmp_path / "one.fa")], {})
     assert one.returncode == 0, one.stderr
     two = run(["-o", str(tmp_path / "two.fa"), "--devices", "0,0", "--shard-min-bases", "100000"],
-              {"PHI_ALLOW_SAME_DEVICE": "1", "PHI_READ_CHUNK": "300001", "PHI_TIMING": "1"})
+              {"PHI_ALLOW_SAME_DEVICE": "1", "PHI_EXCHANGE": "peers", "PHI_READ_CHUNK": "300001", "PHI_TIMING": "1"})      # (peers: opt-in -- and RCCL takes no two ranks on one GPU)
     assert two.returncode == 0, two.stderr
     assert "2 GPUs; hit vector of" in two.stderr and "peer-mapped memory" in two.stderr
     assert re.search(r"main: (\d+) text chunk\(s\)", two.stderr) and int(re.search(r"main: (\d+) text chunk\(s\)", two.stderr).group(1)) >= 15
     assert lines(one.stderr) == lines(two.stderr)
     assert (tmp_path / "one.fa").read_text() == (tmp_path / "two.fa").read_text()
     # a reads file not worth a second GPU: one is used, and the log says so
-    few = run(["-o", str(tmp_path / "few.fa"), "--devices", "0,0"], {"PHI_ALLOW_SAME_DEVICE": "1"})
+    few = run(["-o", str(tmp_path / "few.fa"), "--devices", "0,0"], {"PHI_ALLOW_SAME_DEVICE": "1", "PHI_EXCHANGE": "peers"})
     assert few.returncode == 0 and "using 1 of the 2 GPUs given" in few.stderr
     assert (tmp_path / "one.fa").read_text() == (tmp_path / "few.fa").read_text()
