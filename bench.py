@@ -614,7 +614,7 @@ def main():
         "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {'reference graph' if args.config == 'C1syn' else (f'native syn-{g.n_walks} graph' if native else f'synMHC-{g.n_walks} graph')} (seed {gk['seed']}, {g.n_walks} walks, {g.n_vtx} vertices{'' if args.config == 'C1syn' else ' <=30 bp'}, "
+        "config": {"workload": f"{args.config}: {'reference graph' if args.config == 'C1syn' else (f'native syn-{g.n_walks} graph' if native else f'synMHC-{g.n_walks} graph')} (seed {gk['seed']}{', backbone = ' + os.path.basename(gk['backbone_fasta']) if isinstance(gk, dict) and gk.get('backbone_fasta') else ''}, {g.n_walks} walks, {g.n_vtx} vertices{'' if args.config == 'C1syn' else ' <=30 bp'}, "
                                f"{walk_bases / 1e6:.1f} Mbases of walks) + " +
                                (f"{n_reads} reads of mean {n_bases / max(1, n_reads):.0f} bp per GPU (seed {rk['seed']}, {n_bases / 1e6:.2f} Mbases)" if args.scaling == "weak" else
                                 f"ONE set of {strong['total_reads']} reads ({args.strong_config}, {strong['total_bases'] / 1e6:.2f} Mbases) in {world} shard(s)"),

@@ -53,10 +53,31 @@ class SynGraph:
         return self.seq_concat[idx]
 
 
+def load_backbone(path):
+    """The first record of a FASTA (gz or plain) as upper-case bytes; bases outside ACGT become A (the generator's allele
+    arithmetic is over ACGT)."""
+    import gzip
+    import os
+    if not os.path.isabs(path):
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
+    raw = (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")).read()
+    recs = raw.split(b">")
+    body = recs[1].split(b"\n", 1)[1] if len(recs) > 1 else raw
+    a = np.frombuffer(body.replace(b"\n", b"").replace(b"\r", b"").upper(), np.uint8).copy()
+    a[~np.isin(a, _ACGT)] = ord("A")
+    return a
+
+
 def make_graph(backbone_len=5_000_000, n_walks=49, seed=4901, site_spacing=250, chop=30, block_len=20_000,
-               n_founders=6, max_sv=5000):
+               n_founders=6, max_sv=5000, backbone_fasta=None):
+    """backbone_fasta: a REAL sequence as the backbone (low complexity, tandem repeats, segmental duplications: what
+    uniform-random bases have none of) instead of backbone_len random bases; everything else is the same model."""
     rng = np.random.default_rng(seed)
-    backbone = _rand_seq(rng, backbone_len)
+    if backbone_fasta is not None:
+        backbone = load_backbone(backbone_fasta)
+        backbone_len = len(backbone)
+    else:
+        backbone = _rand_seq(rng, backbone_len)
     # variant sites: position on the backbone, type, alleles
     n_sites = max(1, backbone_len // site_spacing)
     pos = np.sort(rng.choice(np.arange(chop + 1, backbone_len - max_sv - chop - 1), size=n_sites, replace=False))
@@ -304,6 +325,10 @@ CONFIGS = {
     # generates and holds in minutes; the DP takes the dense path of > 128 walks)
     "C5s": (dict(backbone_len=5_000_000, n_walks=200, seed=20001), dict(coverage=30.0, seed=20002)),
     "C2w100": (dict(backbone_len=5_000_000, n_walks=100, seed=4901), dict(coverage=1.0, seed=4902)),
+    # C2 over REAL sequence: the backbone is the CHM13 MHC contig of the reference's own test data (4.92 Mbp; the
+    # reference's test/MHC-CHM13.0.fa.gz), same variant / block-coalescent model, same read generator, 49 walks, 1x reads
+    "C2r": (dict(backbone_fasta="tests/golden/data/MHC-CHM13.0.fa.gz", n_walks=49, seed=4901), dict(coverage=1.0, seed=4902)),
+    "C3r": (dict(backbone_fasta="tests/golden/data/MHC-CHM13.0.fa.gz", n_walks=49, seed=4901), dict(coverage=10.0, seed=4903)),
     # small variants for tests and smoke runs
     "tiny": (dict(backbone_len=60_000, n_walks=7, seed=11, max_sv=800), dict(coverage=2.0, seed=12)),
     "small": (dict(backbone_len=400_000, n_walks=16, seed=21, max_sv=2000), dict(coverage=1.0, seed=22)),

@@ -1147,7 +1147,7 @@ def _sorted_anchor_table(h, wk, t0, t1):
     return np.stack([h[o].astype(np.uint64), wk[o].astype(np.uint64), t0[o].astype(np.uint64), t1[o].astype(np.uint64)], axis=1)
 
 
-@pytest.mark.parametrize("config", ["C2", "C3", "C4", "C5s"])
+@pytest.mark.parametrize("config", ["C2", "C3", "C4", "C5s", "C2r"])
 def test_full_size_vs_oracle(oracle, ctx_factory, monkeypatch, config):
     """The CPU oracle at the sizes of BASELINE.json's configurations (its anchor and filter stages run over walks /
     spectrum ids in parallel: the whole of C2 takes it ~2 s on the GPU box's 16 threads, C5s ~15 s), on the exact
@@ -1158,7 +1158,8 @@ def test_full_size_vs_oracle(oracle, ctx_factory, monkeypatch, config):
       * filtered / retained / minimisers in the model, anchors per walk;
       * the kept anchors (hash, walk, first entry, last entry) as a multiset;
     with the reads scored by the one-chunk kernel AND by the pooled kernel (PHI_SKETCH_POOL_MIN picks; the default is
-    the one-chunk kernel below 12.6 Mbases per batch), handed over whole and in three batches."""
+    the one-chunk kernel below 12.6 Mbases per batch), handed over whole and in three batches.  C2r = C2's model over REAL
+    sequence (the CHM13 MHC contig of the reference's test data as the backbone: low complexity, tandem repeats)."""
     import torch
     from phi_amd import dist as pdist
     from phi_amd import synth
@@ -1205,7 +1206,7 @@ def test_full_size_vs_oracle(oracle, ctx_factory, monkeypatch, config):
         ctx.close()
 
 
-@pytest.mark.parametrize("config", ["C2", "C3", "C4", "C5s"])
+@pytest.mark.parametrize("config", ["C2", "C3", "C4", "C5s", "C2r"])
 def test_full_size_properties(ctx_factory, config):
     """At the sizes of BASELINE.json's configurations (synMHC-49: 49 walks x 5.2 Mbp with 1x / 10x short reads
     and 5x long noisy reads; 200 walks with 30x reads at the MHC's length) the CPU oracle checks stages 1-2
