@@ -1182,8 +1182,18 @@ __global__ void __launch_bounds__(256) phi_blk_classes_kernel(PhiBlkClassArgs G)
 // lane alone, so the four waves split the classes and leave four partial maxima per lane in LDS.  Rows and tables
 // of block b + DEPTH are on their way while block b is chained.  All sums stay far inside int32: keys and offsets are
 // bounded by the anchors of one walk (< 2^27, phi_solve.hip).
+//
+// The chain is a sequence of max-plus AFFINE maps of the walks' keys (S' = M_b (x) S (+) T_b: every term above is a maximum of
+// sums, T_b the walk starts inside the block), so it can be cut: MODE 1 runs the blocks of one SEGMENT from a unit vector
+// ("key 0 on walk u", walk starts switched off: column u of the segment's matrix) or from no key at all with the starts on
+// (its constant term) -- segments x (walks + 1) independent workgroups --, phi_seg_chain_kernel chains the segments'
+// matrices (one workgroup, segments x walks rows), and MODE 2 replays every segment from its true entry keys, in
+// parallel, writing what MODE 0 (the whole chain by one workgroup) writes.  C5: 94 671 blocks in 64 segments.
+template <int MODE>
 __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, const int32_t *__restrict__ rows, const int32_t *__restrict__ rownew,
-                                                            const int32_t *__restrict__ rowdiag, int32_t *__restrict__ blk_S)
+                                                            const int32_t *__restrict__ rowdiag, int32_t *__restrict__ blk_S,
+                                                            const int32_t *__restrict__ seg_lo, int32_t *__restrict__ seg_row,
+                                                            const int32_t *__restrict__ seg_S)
 {
     constexpr int NR = 65 * 64;
     constexpr int DEPTH = 4;
@@ -1195,9 +1205,16 @@ __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, c
     __shared__ int32_t s_diag[2][64], s_start[2][64], s_new[2][64];
     __shared__ int32_t s_part[2][4][64];
     const int x = threadIdx.x, lane = x & 63, wid = __builtin_amdgcn_readfirstlane(x >> 6);
-    const int32_t LS = G.lane_stride, nb = G.n_blk;
+    const int32_t LS = G.lane_stride;
     const bool has_walk = x < G.n_walks;
+    // the blocks this workgroup chains, the keys it starts from, whether walks may start inside
+    const int32_t seg = MODE == 0 ? 0 : MODE == 1 ? (int32_t)blockIdx.x / (G.n_walks + 1) : (int32_t)blockIdx.x;
+    const int32_t unit = MODE == 1 ? (int32_t)blockIdx.x % (G.n_walks + 1) : -1;
+    const int32_t b_lo = MODE == 0 ? 0 : seg_lo[seg], nb = MODE == 0 ? G.n_blk : seg_lo[seg + 1];
+    const bool with_starts = MODE != 1 || unit == G.n_walks;
     int32_t S = NEGK;
+    if (MODE == 1 && x == unit) S = 0;
+    if (MODE == 2 && has_walk) S = seg_S[(int64_t)seg * LS + x];
     int32_t st_row[DEPTH][16], st_x[DEPTH], st_lx[DEPTH], st_dx[DEPTH];
     const int32_t *p_row = rows + wid * 64 + lane;   // + b * NR + 256 * i
     const int32_t *p_x = wid == 0 ? rows + 64 * 64 + lane : wid == 1 ? rownew + lane : rowdiag + lane;   // + b * (NR | 65 | 64): walk starts (wave 0), new-run keys (wave 1), the rows' own columns (wave 2)
@@ -1216,10 +1233,10 @@ __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, c
         constexpr int j = decltype(J)::value;
         const int p = b & 1;
         const int32_t lx = st_lx[j], dx = st_dx[j];
-        if (wid == 0) s_start[p][lane] = st_x[j];               // (lanes past the block's classes are never read)
+        if (wid == 0) s_start[p][lane] = with_starts ? st_x[j] : NEGK;   // (lanes past the block's classes are never read)
         if (wid == 1) s_new[p][lane] = st_x[j];
         if (wid == 2) s_diag[p][lane] = st_x[j];
-        if (has_walk) blk_S[(int64_t)b * LS + x] = S;
+        if (MODE != 1 && has_walk) blk_S[(int64_t)b * LS + x] = S;
         const bool live = has_walk && S > NEGK / 2;
         const int32_t v = S + dx;
         if (live) atomicMax(&s_b1[p][lx], v);                   // (reset in the previous iteration, a barrier ago)
@@ -1257,15 +1274,15 @@ __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, c
         // (no barrier here: the next iteration writes the other parity only, and what it reads of it was settled
         //  before this iteration's second barrier)
     };
-    if (x < 64) { s_b1[0][x] = NONE; s_b2[0][x] = NONE; s_n1[0][x] = 0; }
+    if (x < 64) { s_b1[b_lo & 1][x] = NONE; s_b2[b_lo & 1][x] = NONE; s_n1[b_lo & 1][x] = 0; }
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    issue(I0{}, 0);
-    issue(I1{}, min(1, nb - 1));
-    issue(I2{}, min(2, nb - 1));
-    issue(I3{}, min(3, nb - 1));
+    issue(I0{}, min(b_lo, nb - 1));
+    issue(I1{}, min(b_lo + 1, nb - 1));
+    issue(I2{}, min(b_lo + 2, nb - 1));
+    issue(I3{}, min(b_lo + 3, nb - 1));
     __syncthreads();
-    int32_t b = 0;
+    int32_t b = b_lo;
     for (; b + DEPTH <= nb; b += DEPTH) {
         step(I0{}, b);
         step(I1{}, b + 1);
@@ -1275,6 +1292,28 @@ __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, c
     if (b < nb) step(I0{}, b);
     if (b + 1 < nb) step(I1{}, b + 1);
     if (b + 2 < nb) step(I2{}, b + 2);
+    if (MODE == 1 && has_walk) seg_row[(int64_t)blockIdx.x * LS + x] = S;      // what leaves the segment
+}
+
+// The segments' matrices chained: seg_S[g] = the keys entering segment g.  seg_row[(g * (walks + 1) + u) * LS + x] = the key
+// leaving segment g on walk x when key 0 entered on walk u (u = walks: when nothing entered -- the walk starts inside).
+__global__ void __launch_bounds__(256) phi_seg_chain_kernel(int32_t n_seg, int32_t n_walks, int32_t LS, const int32_t *__restrict__ seg_row,
+                                                            int32_t *__restrict__ seg_S)
+{
+    __shared__ int32_t s_S[256];
+    const int x = threadIdx.x;
+    int32_t S = NEGK;
+    for (int32_t g = 0; g < n_seg; g++) {
+        seg_S[(int64_t)g * LS + x] = S;
+        s_S[x] = S;
+        __syncthreads();
+        const int32_t *R = seg_row + (int64_t)g * (n_walks + 1) * LS + x;
+        int32_t best = R[(int64_t)n_walks * LS];
+#pragma unroll 8
+        for (int32_t u = 0; u < n_walks; u++) best = max(best, s_S[u] + R[(int64_t)u * LS]);   // (NEGK + anything stays "no value")
+        S = best > NEGK / 2 ? best : NEGK;
+        __syncthreads();
+    }
 }
 
 // the two passes must agree on what leaves every block: keys_out[b] (DP_PATH) against S[b + 1] (the chain)
@@ -1319,7 +1358,15 @@ void phi_launch_blk_classes(hipStream_t st, const PhiBlkClassArgs &G)
 }
 void phi_launch_blk_chain(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, const int32_t *rowdiag, int32_t *blk_S)
 {
-    hipLaunchKernelGGL(phi_blk_chain_kernel, dim3(1), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S);
+    hipLaunchKernelGGL(phi_blk_chain_kernel<0>, dim3(1), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S, nullptr, nullptr, nullptr);
+}
+// the same chain cut into n_seg segments (d_seg_lo[n_seg + 1]: first block of each): unit rows, segment chain, replay
+void phi_launch_blk_chain_segments(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, const int32_t *rowdiag, int32_t *blk_S,
+                                   int32_t n_seg, const int32_t *d_seg_lo, int32_t *seg_row, int32_t *seg_S)
+{
+    hipLaunchKernelGGL(phi_blk_chain_kernel<1>, dim3((unsigned)n_seg * (unsigned)(G.n_walks + 1)), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S, d_seg_lo, seg_row, seg_S);
+    hipLaunchKernelGGL(phi_seg_chain_kernel, dim3(1), dim3(256), 0, st, n_seg, G.n_walks, G.lane_stride, seg_row, seg_S);
+    hipLaunchKernelGGL(phi_blk_chain_kernel<2>, dim3((unsigned)n_seg), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S, d_seg_lo, seg_row, seg_S);
 }
 void phi_launch_blk_check(hipStream_t st, const int32_t *keys, const int32_t *S, int32_t n_blk, int32_t LS, int32_t n_walks, int32_t *bad)
 {

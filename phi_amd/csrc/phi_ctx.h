@@ -204,6 +204,7 @@ struct phi_ctx {
     bool blk_no_small = false;          // this solve met a block task with more than 8 live runs on a lane: no 256-step blocks
     int32_t blk_ls = 64;                // row length of the per-(block, walk) tables
     DevBuf d_lane_walk, d_walk_lane, d_coff, d_blk_ncls, d_rownew, d_blk_bad;
+    DevBuf d_seg_lo, d_seg_row, d_seg_S;  // the chain over the blocks cut into segments (dp_events.hip)
     DevBuf d_k_rec, d_k_in, d_cvtx, d_ev_e, d_ev_off, d_ev, d_off_end, d_off_start, d_scan_blk, d_scan_blk64, d_scan_blkoff;
     // The kept anchors as triples (minimiser id, first entry, last entry) in HBM, and whether the host has its copy:
     // a large model whose anchors all span an edge is solved on the device copy (solve_dev.hip); h_kept / h_dp are then

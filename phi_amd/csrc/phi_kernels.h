@@ -320,6 +320,8 @@ struct PhiBlkClassArgs {
 };
 void phi_launch_blk_classes(hipStream_t st, const PhiBlkClassArgs &G);
 void phi_launch_blk_chain(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, const int32_t *rowdiag, int32_t *blk_S);
+void phi_launch_blk_chain_segments(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, const int32_t *rowdiag, int32_t *blk_S,
+                                   int32_t n_seg, const int32_t *d_seg_lo, int32_t *seg_row, int32_t *seg_S);
 void phi_launch_blk_check(hipStream_t st, const int32_t *keys, const int32_t *S, int32_t n_blk, int32_t LS, int32_t n_walks, int32_t *bad);
 void phi_launch_carry_resolve(hipStream_t st, const int32_t *carry, int32_t LS, int32_t b_from, int32_t h, int32_t *out);
 void phi_launch_dp_block_paths_wide(hipStream_t st, const PhiDpEventArgs &A);

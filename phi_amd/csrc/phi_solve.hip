@@ -160,7 +160,16 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
     PHICHK(phi_dev_ensure(c, c->d_blk_S, nbk * ls * 4));
     PHICHK(phi_dev_ensure(c, c->d_blk_keys, nbk * ls * 4));
     PHICHK(phi_dev_ensure(c, c->d_blk_carry, nbk * ls * 4));
-    PHICHK(phi_dev_ensure(c, c->d_row_out, nbk * nrow * 64 * 4));
+    {
+        // The chain over class-lane blocks adds "no value" (NEGK) to whatever lies in the rows of class lanes a block does not
+        // use, without looking: that must be a value NEGK can be added to -- not what an earlier owner of the memory left there
+        // (found when a freed buffer of segment rows, holding sums of two NEGK, came back as this table: NEGK + INT32_MIN wraps
+        // into a valid key).  A table allocated anew is filled with 0xC0C0C0C0 (below NEGK / 2, and NEGK plus it stays inside
+        // int32); afterwards only keys and NEGK are written into it.
+        const void *before = c->d_row_out.p;
+        PHICHK(phi_dev_ensure(c, c->d_row_out, nbk * nrow * 64 * 4));
+        if (c->d_row_out.p != before) HIPCHK(hipMemsetAsync(c->d_row_out.p, 0xC0, c->d_row_out.cap, c->stream));
+    }
     PHICHK(phi_dev_ensure(c, c->d_rowend, nbk * nrow * 4));
     if (cls) {
         PHICHK(phi_dev_ensure(c, c->d_lane_walk, nbk * 64 * 4));
@@ -273,7 +282,25 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
             }
             phi_launch_dp_block_rows(c->stream, A);
             if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("block rows"); }
-            phi_launch_blk_chain(c->stream, G, A.row_out, A.rownew_out, A.rowdiag_out, c->d_blk_S.as<int32_t>());
+            {
+                // the chain over the blocks: one workgroup, 1.1 us per block -- or, from a few thousand blocks on, cut into segments
+                // whose matrices are made in parallel, chained, and replayed in parallel (dp_events.hip; PHI_DP_CHAIN_SEGMENTS: tests)
+                int32_t n_seg = nb >= 4096 ? std::min<int32_t>(64, nb / 1024) : 0;
+                if (const char *e = getenv("PHI_DP_CHAIN_SEGMENTS")) n_seg = std::max(0, std::min(atoi(e), nb));
+                if (n_seg >= 2) {
+                    std::vector<int32_t> seg_lo((size_t)n_seg + 1);
+                    for (int32_t g_ = 0; g_ <= n_seg; g_++) seg_lo[(size_t)g_] = (int32_t)((int64_t)nb * g_ / n_seg);
+                    PHICHK(phi_dev_ensure(c, c->d_seg_lo, ((size_t)n_seg + 1) * 4));
+                    PHICHK(phi_dev_ensure(c, c->d_seg_row, (size_t)n_seg * (size_t)(c->n_walks + 1) * (size_t)c->blk_ls * 4));
+                    PHICHK(phi_dev_ensure(c, c->d_seg_S, (size_t)n_seg * (size_t)c->blk_ls * 4));
+                    HIPCHK(phi_copy_sync(c, c->d_seg_lo.p, seg_lo.data(), seg_lo.size() * 4, hipMemcpyHostToDevice));
+                    phi_launch_blk_chain_segments(c->stream, G, A.row_out, A.rownew_out, A.rowdiag_out, c->d_blk_S.as<int32_t>(), n_seg,
+                                                  c->d_seg_lo.as<int32_t>(), c->d_seg_row.as<int32_t>(), c->d_seg_S.as<int32_t>());
+                } else {
+                    phi_launch_blk_chain(c->stream, G, A.row_out, A.rownew_out, A.rowdiag_out, c->d_blk_S.as<int32_t>());
+                }
+                HIPCHK(hipGetLastError());
+            }
             if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.lap("block chain"); }
             A.lane_walk = nullptr;
             phi_launch_dp_block_paths_wide(c->stream, A);

@@ -1502,7 +1502,10 @@ def test_dp_blocks_on_class_lanes_equal_the_whole_chain(oracle, ctx_factory, mon
             ctx.set_solve_budget(32)
             _set_graph(ctx, g)
             ctx.add_reads(reads)
-            res = ctx.solve()
+            try:
+                res = ctx.solve()
+            except Exception as e:
+                raise AssertionError(f"seed {seed} mode {mode} walks {n_walks} k {k} w {w} R {R}: {e}")
             info = ctx.solve_stats()
             if mode == "whole":
                 assert info["dp_mode"] == 1 and info["n_blocks"] == 0
@@ -1512,6 +1515,26 @@ def test_dp_blocks_on_class_lanes_equal_the_whole_chain(oracle, ctx_factory, mon
                 monkeypatch.delenv(name, raising=False)
             out[mode] = res
         a, b = out["blocks"], out["whole"]
+        # the chain over the blocks cut into segments (unit rows in parallel, segment chain, replay): 3 segments, and as many as
+        # there are blocks -- field for field what the one-workgroup chain gives
+        for n_seg in ("3", "100000"):
+            monkeypatch.setenv("PHI_DP_CHAIN_SEGMENTS", n_seg)
+            if block_steps is not None:
+                monkeypatch.setenv("PHI_DP_BLOCK_STEPS", block_steps)
+            ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=R)
+            ctx.set_solve_budget(32)
+            _set_graph(ctx, g)
+            ctx.add_reads(reads)
+            sres = ctx.solve()
+            sinfo = ctx.solve_stats()
+            monkeypatch.delenv("PHI_DP_CHAIN_SEGMENTS")
+            monkeypatch.delenv("PHI_DP_BLOCK_STEPS", raising=False)
+            for key in a:
+                if isinstance(a[key], np.ndarray):
+                    assert np.array_equal(a[key], sres[key]), (seed, n_seg, key)
+                else:
+                    assert a[key] == sres[key], (seed, n_seg, key, a[key], sres[key])
+            ctx.close()
         for key in ("spectrum_size", "filtered", "n_in_model"):
             assert a[key] == b[key]
         if a["optimal"] and b["optimal"]:
