@@ -775,10 +775,16 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     if (n_walks > PHI_DP_MAX_WALKS) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than %d walks", PHI_DP_MAX_WALKS);
     c->dp_nw = phi_dp_num_waves(n_walks);
     const int nw64 = c->dp_nw;
-    if (!c->h_walk_vtx.resize(n_entries)) return phi_fail(c, PHI_ERR_NOMEM, "host allocation failed");
-    // host copy of the walk entries for the solve (38 MB at C2, 4 ms of page faults): a few threads of
-    // their own, joined before this call returns
+    // host copy of the walk entries for the solve (38 MB at C2, 4 ms of page faults): a few threads of their own, joined
+    // before this call returns.  NOT for a chromosome-scale graph (5.3 GB at 1.3 G entries, beside the caller's own copy):
+    // what the solve looks up there -- a few entries per recombination of the backtrack, the stretches of the decoded path --
+    // it reads from the device copy (phi_solve.hip walk_vtx_*); the branch and bound proper fetches the array if it ever starts.
+    int64_t host_walks_max = (int64_t)1 << 26;
+    if (const char *e = getenv("PHI_HOST_WALKS_MAX")) host_walks_max = atoll(e);                     // tests: no host copy at any size
+    const bool keep_host_walks = n_entries <= host_walks_max;
+    if (!c->h_walk_vtx.resize(keep_host_walks ? n_entries : 0)) return phi_fail(c, PHI_ERR_NOMEM, "host allocation failed");
     std::future<void> wv_copy = std::async(std::launch::async, [&]() {
+        if (!keep_host_walks) return;
         int32_t *dst = c->h_walk_vtx.data();
         const int nt = 4;
         std::vector<std::thread> th;

@@ -29,6 +29,27 @@
 enum { S_ERR = 0, S_NBAD = 1, S_BATCHBAD = 2, S_NEMIT = 3, S_FILTERED = 4, S_INMODEL = 5, S_EXPORT = 6, S_BATCHBAD2 = 7,
        S_OVCNT = 8 /* .. 10: three rotating overflow counters (phi_ctx.h) */, S_N = 11 };
 static uint64_t *scalar(phi_ctx *c, int i) { return c->d_scalars.as<uint64_t>() + i; }
+
+// The walk entries as the solve's host code reads them: from the context's host copy, or -- a chromosome-scale graph keeps none
+// (phi_set_graph) -- from the device copy: single entries for the backtrack, whole stretches for the decoded path.
+static bool have_host_walks(const phi_ctx *c) { return (int64_t)c->h_walk_vtx.size() == c->n_entries; }
+static int walk_vtx_at(phi_ctx *c, int64_t e, int32_t *v)
+{
+    if (have_host_walks(c)) { *v = c->h_walk_vtx[(size_t)e]; return PHI_OK; }
+    return phi_hip_check(c, phi_copy_sync(c, v, c->d_walk_vtx.as<int32_t>() + e, 4, hipMemcpyDeviceToHost), "walk entry D2H");
+}
+static int walk_vtx_range(phi_ctx *c, int64_t es, int64_t n, int32_t *dst)
+{
+    if (have_host_walks(c)) { memcpy(dst, c->h_walk_vtx.data() + es, (size_t)n * 4); return PHI_OK; }
+    return phi_hip_check(c, phi_copy_sync(c, dst, c->d_walk_vtx.as<int32_t>() + es, (size_t)n * 4, hipMemcpyDeviceToHost), "walk entries D2H");
+}
+// (the branch and bound proper and the host-side score bound index the array freely: fetched whole, once)
+static int ensure_host_walks(phi_ctx *c)
+{
+    if (have_host_walks(c)) return PHI_OK;
+    if (!c->h_walk_vtx.resize((size_t)c->n_entries)) return phi_fail(c, PHI_ERR_NOMEM, "host allocation failed");
+    return phi_hip_check(c, phi_copy_sync(c, c->h_walk_vtx.data(), c->d_walk_vtx.p, (size_t)c->n_entries * 4, hipMemcpyDeviceToHost), "walk entries D2H");
+}
 static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
 struct Seg { int32_t h; int64_t es, ee; };     // path segment: walk h, entries es..ee (inclusive)
@@ -436,7 +457,8 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         else HIPCHK(phi_copy_sync(c, &bs, d_bstart + e, 4, hipMemcpyDeviceToHost));
         if (bs < 0 && c->dp_blocks && events) {
             // the run crossed into its block: follow it back through the blocks it was carried over
-            const int32_t vq = c->h_walk_vtx[e];
+            int32_t vq = 0;
+            PHICHK(walk_vtx_at(c, e, &vq));
             const int32_t kq = c->h_cstep[c->h_topo_rank[vq]];
             int32_t b = (int32_t)(std::upper_bound(c->h_blk_lo.begin(), c->h_blk_lo.end(), kq) - c->h_blk_lo.begin()) - 1;
             if (c->dp_cls) {
@@ -454,7 +476,8 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         if (es < c->h_walk_off[h] || es > e) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack left the walk (internal error)");
         segs->push_back(Seg{h, es, e});
         if (es == c->h_walk_off[h]) break;                     // reached s_{first(h),h}
-        const int32_t v = c->h_walk_vtx[es];
+        int32_t v = 0;
+        PHICHK(walk_vtx_at(c, es, &v));
         const int32_t step = events ? c->h_cstep[c->h_topo_rank[v]] : c->h_topo_rank[v];
         if (step < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack: run begins on a vertex without events (internal error)");
         int32_t src, h2;
@@ -472,9 +495,15 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
             int64_t lo = c->h_walk_off[h2], hi = c->h_walk_off[h2 + 1];
             while (lo < hi) {
                 const int64_t mid = (lo + hi) >> 1;
-                if (c->h_topo_rank[c->h_walk_vtx[mid]] < src) lo = mid + 1; else hi = mid;
+                int32_t vm = 0;
+                PHICHK(walk_vtx_at(c, mid, &vm));
+                if (c->h_topo_rank[vm] < src) lo = mid + 1; else hi = mid;
             }
-            if (lo < c->h_walk_off[h2 + 1] && c->h_walk_vtx[lo] == u) e2 = lo;
+            if (lo < c->h_walk_off[h2 + 1]) {
+                int32_t vl = 0;
+                PHICHK(walk_vtx_at(c, lo, &vl));
+                if (vl == u) e2 = lo;
+            }
         }
         if (e2 < 0) return phi_fail(c, PHI_ERR_DEVICE, "DP backtrack: walk %d is not on vertex %d (internal error)", h2, u);
         h = h2; e = e2;
@@ -708,6 +737,7 @@ int phi_solve_impl(phi_ctx *c)
         // a path is on one walk at every vertex, so it scores at most sum over vertices of the most anchors that
         // end there on one walk: that sum, not the number of anchors, has to stay inside the DP's score range
         std::vector<int32_t> vmax((size_t)c->n_vtx, 0);
+        PHICHK(ensure_host_walks(c));
         for (int64_t i = 0; i < n_dp;) {
             int64_t j = i;
             while (j < n_dp && a_e1[j] == a_e1[i]) j++;
@@ -917,6 +947,7 @@ int phi_solve_impl(phi_ctx *c)
     } else { cov_all.assign((size_t)n_ids, 0); cov_w.assign((size_t)n_ids, 0); }
     // device mode ends where the branch and bound proper begins: the host copies arrive, the search goes on unchanged
     auto to_host = [&]() -> int {
+        PHICHK(ensure_host_walks(c));                           // (clusters_of indexes the walk entries freely)
         if (!dev) return PHI_OK;
         PhiStageTimer th("solve");
         PHICHK(phi_host_anchors(c));
@@ -1093,9 +1124,9 @@ int phi_solve_impl(phi_ctx *c)
     {
         int64_t o = 0;
         for (const Seg &s : best_segs) {
-            memcpy(c->h_path_vtx.data() + o, c->h_walk_vtx.data() + s.es, (size_t)(s.ee - s.es + 1) * 4);
+            PHICHK(walk_vtx_range(c, s.es, s.ee - s.es + 1, c->h_path_vtx.data() + o));
             std::fill(c->h_path_hap.begin() + o, c->h_path_hap.begin() + o + (s.ee - s.es + 1), s.h);
-            for (int64_t e = s.es; e <= s.ee; e++) { const int32_t v = c->h_walk_vtx[e]; hap_len += c->h_seq_off[v + 1] - c->h_seq_off[v]; }
+            for (int64_t i = 0; i <= s.ee - s.es; i++) { const int32_t v = c->h_path_vtx[(size_t)(o + i)]; hap_len += c->h_seq_off[v + 1] - c->h_seq_off[v]; }
             o += s.ee - s.es + 1;
         }
     }

@@ -55,7 +55,7 @@ def main():
         phi = os.path.join(ROOT, "phi_amd", "PHI")
         runs = []
         for i in range(args.runs):
-            time.sleep(6.0)                                    # (the run before is still giving back 65 GB of HBM behind its detached exit)
+            time.sleep(1.0)                                    # (one process per run since round 4: when the command returns its 65 GB of HBM are free)
             t_spawn = time.time()
             t0 = time.perf_counter()
             r = subprocess.run([phi, "-g", gfa, "-r", rd, "-o", fa], capture_output=True, text=True, env=dict(os.environ, PHI_TIMING="1"))
@@ -71,7 +71,7 @@ def main():
                 if l.startswith("Recombined haplotypes"):
                     rec["recombined"] = l[:300]
             runs.append(rec)
-            print(json.dumps({k: rec[k] for k in ("rc", "wall_s", "spawn_to_fasta_closed_s", "stages_s")}), flush=True)
+            print(json.dumps({k: rec.get(k) for k in ("rc", "wall_s", "spawn_to_fasta_closed_s", "phi_line", "stages_s")}), flush=True)
             if r.returncode != 0:
                 print(r.stderr[-3000:])
                 break

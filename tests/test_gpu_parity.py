@@ -1588,6 +1588,43 @@ def test_solve_on_device_resident_anchors_equals_the_host_solve(oracle, ctx_fact
     assert n_branching >= 1                                      # some case went past the root node
 
 
+def test_solve_without_a_host_copy_of_the_walk_entries(oracle, ctx_factory, monkeypatch):
+    """A chromosome-scale graph keeps no host copy of its walk entries inside the context (5.3 GB at config 5, beside the
+    caller's own): the backtrack reads single entries and the decode whole stretches from the device copy, the branch and
+    bound proper fetches the array when it starts.  PHI_HOST_WALKS_MAX=0 makes every graph such a graph: the same results
+    field by field, on instances that close at the root, that switch walks (R = 0 .. 3), and that branch."""
+    cases = []
+    for seed in range(8):
+        rng = np.random.default_rng(6600 + seed)
+        k, w = int(rng.integers(5, 12)), int(rng.integers(1, 7))
+        rep = bytes(rng.choice(list(b"ACGT"), size=k + 4).tolist()) if seed % 2 else None
+        g = random_graph(rng, n_sites=int(rng.integers(25, 100)), n_walks=int(rng.choice([3, 8, 30, 70])), seg_len=(3, 14), alt_len=(1, 8), p_del=0.25, repeat=rep)
+        reads = mosaic_reads(rng, g, n_reads=200, read_len=k + w + 25, n_seg=int(rng.integers(2, 5)), err=0.01)
+        cases.append((g, reads, k, w, int(rng.choice([0, 1, 2, 3])), 200))
+    n_branching = 0
+    for g, reads, k, w, R, budget in cases:
+        out = {}
+        for mode in ("0", None):
+            if mode is not None:
+                monkeypatch.setenv("PHI_HOST_WALKS_MAX", mode)
+            ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=R)
+            ctx.set_solve_budget(budget)
+            _set_graph(ctx, g)
+            monkeypatch.delenv("PHI_HOST_WALKS_MAX", raising=False)
+            ctx.add_reads(reads)
+            out[mode] = (ctx.solve(), ctx.path_sequence(ctx.solve()["hap_len"]))
+            ctx.close()
+        (a, sa), (b, sb) = out["0"], out[None]
+        for key in a:
+            if isinstance(a[key], np.ndarray):
+                assert np.array_equal(a[key], b[key]), key
+            else:
+                assert a[key] == b[key], (key, a[key], b[key])
+        assert sa == sb
+        n_branching += a["n_dp_runs"] > 4
+    assert n_branching >= 1
+
+
 def test_read_state_double_buffers_through_awkward_sequences(oracle, ctx_factory):
     """phi_reset_reads swaps the context's two sets of read buffers; the next read launch empties the set left behind.
     Sequences that stress the bookkeeping: resets with nothing in between (the half that comes to the front was never
