@@ -30,7 +30,9 @@ enum {
     PHI_HOST_ERR_IO = -1,       /* file cannot be opened / read (main.cpp:102-105 returns 1) */
     PHI_HOST_ERR_WALK = -2,     /* a walk holds a reverse-strand vertex (ILP_index.cpp:104-107 exits) */
     PHI_HOST_ERR_CYCLE = -3,    /* Kahn's algorithm did not reach every vertex: graph is not acyclic */
-    PHI_HOST_ERR_INVALID = -4
+    PHI_HOST_ERR_INVALID = -4,
+    PHI_HOST_ERR_UNSUPPORTED = -5 /* a link onto the reverse strand of its target: the reference's own adjacency for it depends on
+                                     the line's place in the file (gfa-base.cpp:269-303): refused, not guessed */
 };
 
 /* Parse S/L/W lines (plain or gzip), flip walks as gfa_walk_flip does, complete arcs with their

@@ -448,7 +448,7 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
     // ---- nothing of the walks is needed for the sequences, the names, the adjacency and the topological order: one thread
     //      makes them while the others resolve the W-lines (99 % of a pangenome GFA's bytes)
     phi_graph *g = new phi_graph();
-    int side_rc = 0;                                               // 1: out of memory, 2: cycle
+    int side_rc = 0;                                               // 1: out of memory, 2: cycle, 3: a link onto a reverse strand
     int32_t side_sorted = 0;
     bool side_joined = false;
     std::thread side([&]() {
@@ -472,6 +472,14 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
         // arcs: those touching a segment without sequence are dropped; an arc v -> w and its complement w' -> v' give the
         // forward-strand adjacency (target orientation dropped): u -> w when v = u+, and w -> v when w is a reverse strand
         {
+            // A link onto the REVERSE strand of its target (L a + b -, L a - b -) is refused: the forward arc it implies is the
+            // COMPLEMENT b+ -> a(-/+), which the reference appends behind its sorted arc array and whose arc index shows it only
+            // when the appended arcs happen to break the array's sort order (gfa-base.cpp:269-303 re-sorts on a vertex-count
+            // test that never fires) -- the reference's own adjacency for such a file depends on where the line stands.  Rounds
+            // 1-3 kept the arc silently; a graph whose meaning the reference itself does not fix is an error here.
+            // (L a - b +: neither the arc nor its complement leaves a forward strand: nothing to add, as in the reference.)
+            for (const auto &a : arcs)
+                if ((a.second & 1) && seqs[a.first >> 1].n && seqs[a.second >> 1].n) { side_rc = 3; side_sorted = (int32_t)(a.second >> 1); return; }
             std::vector<int64_t> cnt((size_t)n_seg + 1, 0);
             auto each = [&](auto fn) {
                 for (const auto &a : arcs) {
@@ -652,6 +660,12 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
     side.join();
     side_joined = true;
     if (side_rc == 1) { delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory"); }
+    if (side_rc == 3) {
+        const std::string nm(g->name_arena.data() + g->name_off[(size_t)side_sorted]);
+        delete g;
+        return fail(err, err_cap, PHI_HOST_ERR_UNSUPPORTED, "a link onto the reverse strand of segment %s: the reference's arc index shows the forward arc such a link implies "
+                    "only sometimes (gfa-base.cpp:269-303); write the link from the forward strand", nm.c_str());
+    }
     if (side_rc == 2) {
         const int code = fail(err, err_cap, PHI_HOST_ERR_CYCLE, "graph is not acyclic: %d of %d vertices sorted", side_sorted, n_seg);
         delete g;

@@ -1062,6 +1062,14 @@ int phi_solve_impl(phi_ctx *c)
             const int64_t ub = val + (int64_t)S.size();
             node_ub = std::min(node_ub, ub);
             if (n_runs == 1) global_ub = ub;
+            // a search that goes on says so (the reference's model.optimize() prints Gurobi's log; the command line runs without a
+            // budget unless --dp-budget gives one): every 64 DP runs, and the 16th (PHI_PROGRESS=0: never; =n: every n runs)
+            {
+                static const int every = getenv("PHI_PROGRESS") ? atoi(getenv("PHI_PROGRESS")) : 64;
+                if (every > 0 && (n_runs % every == 0 || (every == 64 && n_runs == 16)))
+                    fprintf(stderr, "[M::solve] exact search: %d DP runs, best path %lld, proven bound %lld, %zu open node(s)%s\n", n_runs,
+                            (long long)incumbent, (long long)global_ub, stack.size() + 1, max_runs > 0 ? "" : " (no budget: --dp-budget N limits it)");
+            }
             if (node_ub <= incumbent) { closed = true; break; }
             // tighten: bound doubly-counted minimisers by the constant 1, release unused constants
             if (!dev) for (uint32_t s : touched) if (cov_w[s] >= 2) D.insert(s);

@@ -83,6 +83,17 @@ def main():
             # edge check: compare fully on forward links only.
             complemented = rng.random() < 0.25
             write_random_gfa(rng, g, path, complemented)
+            raw_txt = (gzip.open(path).read() if path.endswith(".gz") else open(path, "rb").read()).decode()
+            if any(l.startswith("L\t") and l.split("\t")[4].strip() == "-" for l in raw_txt.splitlines()):
+                # a link onto the reverse strand of its target: what the reference makes of it depends on where the line stands
+                # (see above) -- the reader refuses the file (PHI_HOST_ERR_UNSUPPORTED = -5), it does not guess
+                try:
+                    H.Graph(path)
+                except H.HostError as e:
+                    assert e.args[0] == -5 or "-5" in str(e) or "reverse strand" in str(e), str(e)
+                    n += 1
+                    continue
+                raise AssertionError(("a link onto a reverse strand was accepted", raw_txt[:2000]))
             try:
                 ref = O.ref_parse_gfa(path)
             except Exception as e:                 # the reference rejects it: so must the reader

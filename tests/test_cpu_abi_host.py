@@ -198,6 +198,20 @@ def test_host_gfa_reader_errors(built, tmp_path):
     with pytest.raises(H.HostError) as e:
         H.Graph(str(p))
     assert e.value.status == -3
+    # a link onto the REVERSE strand of its target (L b - a -: the link a -> b written from the other strand): the forward arc it
+    # implies is the complement, which the reference appends behind its sorted arc array and finds again only sometimes
+    # (gfa-base.cpp:269-303) -- refused (-5), not guessed; L a - b + adds nothing on either side and is accepted
+    segs = "S\ts1\tACGT\nS\ts2\tGGA\nS\ts3\tTT\n"
+    for links in ("L\ts1\t+\ts2\t+\t0M\nL\ts3\t-\ts2\t-\t0M\n", "L\ts3\t-\ts2\t-\t0M\nL\ts1\t+\ts2\t+\t0M\n", "L\ts1\t+\ts2\t+\t0M\nL\ts2\t+\ts3\t-\t0M\n"):
+        p = tmp_path / "revlink.gfa"
+        p.write_text(segs + links + "W\ta\t0\tc\t0\t1\t>s1>s2\n")
+        with pytest.raises(H.HostError) as e:
+            H.Graph(str(p))
+        assert e.value.status == -5 and "reverse strand" in str(e.value)
+    p = tmp_path / "revsrc.gfa"
+    p.write_text(segs + "L\ts1\t+\ts2\t+\t0M\nL\ts2\t+\ts3\t+\t0M\nL\ts3\t-\ts1\t+\t0M\nW\ta\t0\tc\t0\t1\t>s1>s2>s3\n")
+    g = H.Graph(str(p))
+    assert [g.adj[g.adj_off[v]:g.adj_off[v + 1]].tolist() for v in range(3)] == [[1], [2], []]
     # a fully reversed walk is flipped to the forward strand (gfa_walk_flip), CRLF and no final newline
     p = tmp_path / "flip.gfa"
     p.write_bytes(b"S\ts1\tACGT\r\nS\ts2\tGGA\r\nL\ts1\t+\ts2\t+\t0M\r\nW\ta\t0\tc\t0\t1\t>s1>s2\r\nW\tb\t1\tc\t0\t1\t<s2<s1")
