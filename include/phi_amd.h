@@ -330,6 +330,25 @@ int phi_host_unregister(phi_ctx *ctx, void *p);
 int phi_prof_enable(phi_ctx *ctx, int on);
 int phi_prof_read(phi_ctx *ctx, int64_t *n_launches, double *total_ms, int64_t *total_bases);
 
+/*
+ * The walks resolved ON THE DEVICE from the text of the GFA's W-lines (the reference: gfa-io.cpp:367-432 on one core, then
+ * ILP_index.cpp:96-113).  At chromosome scale the walk text is the file (10.5 of config 5's 10.9 GB).
+ *   phi_walk_text_upload    the walk field of every W-line (">s17>s18...", optional tags may follow), as it stands in the (mapped)
+ *                           file, to the device through pinned staging; returns when the last piece is on its way -- call it
+ *                           on a thread of its own while the host still reads the S- and L-lines
+ *   phi_walk_text_resolve   names <prefix><canonical decimal> -> num2id[number] (the direct index of the host reader's name table,
+ *                           include/phi_host.h phi_graph_name_index); walk_off_out[n_walks + 1].  *irregular != 0 (a reverse step:
+ *                           the reference flips such walks by majority strand; a name of another form, or naming no segment: the
+ *                           reference leaves such steps out): nothing was resolved, fall back to the host reader
+ *   phi_set_graph(..., walk_vtx = NULL, ...)  then takes the walk entries from where phi_walk_text_resolve left them
+ *   phi_walk_entries        (tests) a host copy of the walk entries on the device
+ */
+typedef struct { const char *text; int64_t n; } phi_walk_text;
+int phi_walk_text_upload(phi_ctx *ctx, const phi_walk_text *walks, int32_t n_walks);
+int phi_walk_text_resolve(phi_ctx *ctx, const char *prefix, int32_t prefix_n, const int32_t *num2id, int64_t n_num, int32_t n_seg,
+                          int64_t *walk_off_out, uint32_t *irregular);
+int phi_walk_entries(phi_ctx *ctx, int32_t *out, int64_t cap, int64_t *n);
+
 /* Wait for everything this process has put on the context's device, on every stream, and report the device's error
  * state: a fault raised by an earlier asynchronous launch surfaces here (diagnostics; no reference counterpart). */
 int phi_device_synchronize(phi_ctx *ctx);

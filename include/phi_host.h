@@ -38,6 +38,27 @@ enum {
 /* Parse S/L/W lines (plain or gzip), flip walks as gfa_walk_flip does, complete arcs with their
  * complements, keep forward-strand arcs, build walks / names / Kahn topological order. */
 int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap);
+/* The same with the walks left as TEXT, for a caller that resolves them on the device (include/phi_amd.h phi_walk_text_*: at
+ * chromosome scale the W-lines are 96 % of the file and resolving them was the reader's largest stage).  on_text (optional) is
+ * called on a thread of the reader's own as soon as the walk fields are known -- before the segment names are --, with slices
+ * of the mapped file (valid until the walks are resolved either way); it is joined before the call returns.
+ *   phi_graph_walks_deferred   1 while the walks are text
+ *   phi_graph_walk_texts       the walk fields again (optional tags may follow a walk); returns their number
+ *   phi_graph_name_index       the name table's direct index: names are <prefix><canonical decimal> -> num2id[number];
+ *                              PHI_HOST_ERR_UNSUPPORTED when some name is of another form or a W-line stands before an S-line
+ *                              (the device path does not take such a file: phi_graph_resolve_walks)
+ *   phi_graph_resolve_walks    the host path after all, with the reference's rules (steps naming no segment left out, walks
+ *                              flipped by majority strand, a reverse vertex left over is PHI_HOST_ERR_WALK)
+ *   phi_graph_set_walk_off     the device resolved them: their offsets [n_walks + 1]; the text is let go
+ * phi_graph_walk_vtx stays NULL for walks resolved on the device. */
+typedef struct { const char *text; int64_t n; } phi_host_walk_text;
+typedef void (*phi_walk_text_fn)(void *user, const phi_host_walk_text *walks, int32_t n_walks);
+int phi_gfa_read_deferred(const char *path, phi_graph **out, phi_walk_text_fn on_text, void *user, char *err, int err_cap);
+int phi_graph_walks_deferred(const phi_graph *g);
+int phi_graph_walk_texts(const phi_graph *g, phi_host_walk_text *out, int32_t cap);
+int phi_graph_name_index(const phi_graph *g, const char **prefix, int32_t *prefix_n, const int32_t **num2id, int64_t *n_num);
+int phi_graph_resolve_walks(phi_graph *g, char *err, int err_cap);
+int phi_graph_set_walk_off(phi_graph *g, const int64_t *walk_off);
 void phi_graph_free(phi_graph *g);
 
 int32_t phi_graph_n_vtx(const phi_graph *g);

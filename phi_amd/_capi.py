@@ -21,7 +21,7 @@ SYMBOLS = [
     "phi_set_graph", "phi_add_reads", "phi_add_reads_device", "phi_reset_reads", "phi_reads_stats", "phi_hits_buffer",
     "phi_spectrum_export", "phi_spectrum_import", "phi_spectrum_set_size", "phi_solve", "phi_path_sequence",
     "phi_sketch", "phi_walk_minimizers", "phi_walk_sharing", "phi_kept_anchors", "phi_prof_enable", "phi_prof_read",
-    "phi_host_register", "phi_host_unregister", "phi_set_solve_budget", "phi_device_synchronize",
+    "phi_host_register", "phi_host_unregister", "phi_set_solve_budget", "phi_device_synchronize", "phi_walk_text_upload", "phi_walk_text_resolve", "phi_walk_entries",
     "phi_index_stats", "phi_solve_stats", "phi_comm_unique_id", "phi_comm_init", "phi_comm_info", "phi_comm_allreduce_hits", "phi_comm_exchange", "phi_comm_destroy",
     "phi_reads_text_begin", "phi_add_reads_text", "phi_reads_text_end", "phi_reads_text_detach_carry", "phi_reads_text_last_batch",
     "phi_peers_create", "phi_peers_join", "phi_peers_allreduce_hits", "phi_peers_exchange", "phi_peers_destroy",
@@ -119,6 +119,9 @@ def load():
     L.phi_host_unregister.argtypes = [vp, vp]
     L.phi_prof_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64)]
     L.phi_device_synchronize.argtypes = [vp]
+    L.phi_walk_text_upload.argtypes = [vp, vp, i32]
+    L.phi_walk_text_resolve.argtypes = [vp, C.c_char_p, i32, vp, i64, i32, vp, C.POINTER(C.c_uint32)]
+    L.phi_walk_entries.argtypes = [vp, vp, i64, C.POINTER(i64)]
     for name in SYMBOLS:
         f = getattr(L, name)          # AttributeError here = the library does not export the ABI
         if f.restype is C.c_int and name not in ("phi_strerror", "phi_last_error", "phi_ctx_destroy"):

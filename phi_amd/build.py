@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, "phi_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["sketch.hip", "sketch_pooled.hip", "table.hip", "anchors.hip", "contexts.hip", "dp.hip", "dp_events.hip", "phi_abi.hip", "phi_solve.hip", "solve_dev.hip", "phi_comm.hip", "phi_ipc.hip", "reads_text.hip"]
+HIP_SOURCES = ["sketch.hip", "sketch_pooled.hip", "table.hip", "anchors.hip", "contexts.hip", "dp.hip", "dp_events.hip", "phi_abi.hip", "phi_solve.hip", "solve_dev.hip", "phi_comm.hip", "phi_ipc.hip", "reads_text.hip", "walk_text.hip"]
 HIP_HEADERS = ["phi_dev.h", "phi_kernels.h", "phi_ctx.h", "sketch.hip", "sketch_phases.inc", os.path.join("..", "..", "include", "phi_amd.h")]
 
 

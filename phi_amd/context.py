@@ -61,7 +61,7 @@ class Context:
         adj_off = np.ascontiguousarray(adj_off, np.int64)
         adj = np.ascontiguousarray(adj, np.int32)
         walk_off = np.ascontiguousarray(walk_off, np.int64)
-        walk_vtx = np.ascontiguousarray(walk_vtx, np.int32)
+        walk_vtx = np.ascontiguousarray(walk_vtx, np.int32) if walk_vtx is not None else None     # (None: resolved on the device, phi_walk_text_resolve)
         top_rank = np.ascontiguousarray(top_rank, np.int32)
         buf = np.frombuffer(seq_concat, np.uint8) if not isinstance(seq_concat, np.ndarray) else seq_concat
         self.n_vtx, self.n_walks = len(seq_off) - 1, len(walk_off) - 1
@@ -304,6 +304,15 @@ class Context:
         if n.value:
             self._chk(self._L.phi_kept_anchors(self._h, _ptr(h), _ptr(wk), _ptr(t0), _ptr(t1), n.value, C.byref(n)))
         return h, wk, t0, t1
+
+    def walk_entries(self):
+        """(tests) host copy of the walk entries on the device."""
+        n = C.c_int64()
+        self._chk(self._L.phi_walk_entries(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        if n.value:
+            self._chk(self._L.phi_walk_entries(self._h, _ptr(out), n.value, C.byref(n)))
+        return out
 
     def device_synchronize(self):
         self._chk(self._L.phi_device_synchronize(self._h))

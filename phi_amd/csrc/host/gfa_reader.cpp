@@ -46,7 +46,12 @@
 #include <vector>
 #include "../../../include/phi_host.h"
 
+struct GfaState;                                       // the text, its slices and the name table, while the walks are still text
 struct phi_graph {
+    GfaState *state = nullptr;
+    bool name_index_ok = false;                        // every name is <prefix><number> and every W-line stands behind all S-lines
+    std::vector<int32_t> num2id;                       // the name table's direct index (number -> segment id, -1: none)
+    std::string prefix;
     std::vector<char> name_arena;                      // segment names, NUL-terminated, back to back
     std::vector<int64_t> name_off;
     std::vector<std::string> hap_names;
@@ -55,7 +60,7 @@ struct phi_graph {
     std::vector<int64_t> seq_off, adj_off, walk_off;
     std::vector<int32_t> adj, topo_rank;
     int32_t n_seg = 0;
-    ~phi_graph() { free(seq_concat); free(walk_vtx); }
+    ~phi_graph();
 };
 
 static int fail(char *err, int cap, int code, const char *fmt, ...)
@@ -172,6 +177,9 @@ public:
     bool all_direct() const { return n_hashed_ == 0 && prefix_n_ == 0 && !keys_.empty(); }
     int32_t by_number(uint64_t num) const { return num < direct_.size() ? direct_[(size_t)num] : -1; }
     const std::vector<Slice> &keys() const { return keys_; }
+    bool no_hashed_names() const { return n_hashed_ == 0; }
+    std::string prefix() const { return std::string(prefix_, prefix_n_); }
+    const std::vector<int32_t> &direct() const { return direct_; }
 
     int32_t find(const char *p, size_t n) const
     {
@@ -329,14 +337,25 @@ inline bool is_step(char c) { return c == '>' || c == '<'; }
 struct Piece { int32_t walk; const char *lo, *hi; int64_t n = 0, out = 0, dropped = 0; bool any_rev = false, has_tab = false; };
 }  // namespace
 
-extern "C" {
+struct GfaState {
+    Text text;
+    std::vector<SliceOut> so;                          // (the W-line records live in here)
+    NameTable table;
+    std::vector<WRec *> walks;                         // in file order
+    int32_t n_seg = 0;
+};
+phi_graph::~phi_graph() { free(seq_concat); free(walk_vtx); delete state; }
 
-int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
+static int resolve_walks(GfaState &st, phi_graph *g, StageTimer &tm, char *err, int err_cap);
+
+static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk_text_fn on_text, void *user, char *err, int err_cap)
 {
     if (!path || !out) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "null argument");
     *out = nullptr;
     StageTimer tm;
-    Text text;
+    GfaState *stp = new GfaState();
+    struct StateGuard { GfaState *&p; ~StateGuard() { delete p; } } state_guard{stp};      // (handed to the graph when the walks stay text)
+    Text &text = stp->text;
     if (const int lr = text.load(path))
         return fail(err, err_cap, PHI_HOST_ERR_IO, lr == -2 ? "gzip stream corrupt in the GFA file %s" : "failed to load the GFA file %s", path);
     tm.lap(text.map ? "map" : "read / inflate");
@@ -352,19 +371,29 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
         const char *nl = q < tend ? (const char *)memchr(q, '\n', (size_t)(tend - q)) : nullptr;
         cut[(size_t)i] = nl ? nl + 1 : tend;
     }
-    std::vector<SliceOut> so((size_t)n_slices);
+    std::vector<SliceOut> &so = stp->so;
+    so.resize((size_t)n_slices);
     parallel_for(n_slices, [&](int64_t i) { scan_slice(cut[(size_t)i], cut[(size_t)i + 1], so[(size_t)i]); });
     tm.lap("lines + fields (threads)");
+    // the walk fields are known now, long before their names can be resolved: a caller that resolves them on the device
+    // starts sending the text there (a thread of its own, joined before this call returns)
+    std::vector<phi_host_walk_text> wtexts;
+    std::thread text_thread;
+    struct TextJoin { std::thread &t; ~TextJoin() { if (t.joinable()) t.join(); } } text_join{text_thread};
+    if (defer && on_text) {
+        for (SliceOut &s_ : so) for (WRec &w_ : s_.walks) wtexts.push_back(phi_host_walk_text{w_.text.p, (int64_t)w_.text.n});
+        text_thread = std::thread([&]() { on_text(user, wtexts.data(), (int32_t)wtexts.size()); });
+    }
 
     // ---- segment ids in first-seen order over S- and L-lines.  In every graph a tool writes, an L-line names segments whose
     //      S-lines stand before it, so the ids are the order of the S-lines: one thread enters the S-line names (and fixes what
     //      each W-line may name), then all threads resolve the L-lines against the finished table, checking for each name that
     //      its S-line does come first.  A file where that does not hold (an L-line that introduces a segment) is done again
     //      by one thread, record by record.
-    NameTable table;
+    NameTable &table = stp->table;
     std::vector<Slice> seqs;                                         // per segment; n = 0: no sequence
     std::vector<std::pair<uint32_t, uint32_t>> arcs;                 // oriented vertices v = seg<<1 | strand
-    std::vector<WRec *> walks;
+    std::vector<WRec *> &walks = stp->walks;
     size_t n_rec = 0;
     std::vector<size_t> rec_base((size_t)n_slices + 1, 0);
     for (int i = 0; i < n_slices; i++) { n_rec += so[(size_t)i].recs.size(); rec_base[(size_t)i + 1] = n_rec; }
@@ -443,6 +472,7 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
     for (SliceOut &s : so) std::vector<Rec>().swap(s.recs);
     const int32_t n_seg = table.size();
     const int64_t n_walks = (int64_t)walks.size();
+    stp->n_seg = n_seg;
     tm.lap("segment ids, links");
 
     // ---- nothing of the walks is needed for the sequences, the names, the adjacency and the topological order: one thread
@@ -525,6 +555,55 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
     });
     struct Joiner { std::thread &t; bool &done; ~Joiner() { if (!done && t.joinable()) t.join(); } } joiner{side, side_joined};
 
+    // ---- the walks' vertices: resolved here by all threads (resolve_walks below) -- or left as text for the caller, who
+    //      resolves them on the device (phi_gfa_read_deferred) and comes back for the host path only if the text is not of
+    //      the kind the device takes
+    g->prefix = table.prefix();
+    g->name_index_ok = table.no_hashed_names();
+    for (int64_t wi = 0; wi < n_walks && g->name_index_ok; wi++) g->name_index_ok = walks[(size_t)wi]->n_known == n_seg;
+    if (defer) {
+        if (g->name_index_ok) g->num2id = table.direct();
+    } else if (const int wrc = resolve_walks(*stp, g, tm, err, err_cap)) {
+        side.join();
+        delete g;
+        return wrc;
+    }
+
+    // ---- what the side thread made meanwhile
+    side.join();
+    side_joined = true;
+    if (side_rc == 1) { delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory"); }
+    if (side_rc == 3) {
+        const std::string nm(g->name_arena.data() + g->name_off[(size_t)side_sorted]);
+        delete g;
+        return fail(err, err_cap, PHI_HOST_ERR_UNSUPPORTED, "a link onto the reverse strand of segment %s: the reference's arc index shows the forward arc such a link implies "
+                    "only sometimes (gfa-base.cpp:269-303); write the link from the forward strand", nm.c_str());
+    }
+    if (side_rc == 2) {
+        const int code = fail(err, err_cap, PHI_HOST_ERR_CYCLE, "graph is not acyclic: %d of %d vertices sorted", side_sorted, n_seg);
+        delete g;
+        return code;
+    }
+    tm.lap("wait for arrays + topological order (side thread)");
+    if (defer) {
+        if (text_thread.joinable()) text_thread.join();
+        tm.lap("wait for the walk text's consumer");
+        g->state = stp;
+        stp = nullptr;
+    }
+    *out = g;
+    return PHI_HOST_OK;
+}
+
+// The walks' vertices from the text of the W-lines, on all host threads: the reference's rules (names resolved against the
+// segments seen so far, unknown names left out, walks flipped by majority strand, a reverse vertex left over is an error).
+static int resolve_walks(GfaState &st, phi_graph *g, StageTimer &tm, char *err, int err_cap)
+{
+    Text &text = st.text;
+    NameTable &table = st.table;
+    std::vector<WRec *> &walks = st.walks;
+    const int32_t n_seg = st.n_seg;
+    const int64_t n_walks = (int64_t)walks.size();
     // ---- the walks' vertices: pieces of the W-lines, cut at steps, on all threads
     std::vector<Piece> pieces;
     const size_t PIECE = getenv("PHI_GFA_PIECE") ? std::max<size_t>(16, (size_t)atoll(getenv("PHI_GFA_PIECE"))) : ((size_t)1 << 20);
@@ -573,7 +652,7 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
     }
     const int64_t n_entries = g->walk_off[(size_t)n_walks];
     uint32_t *wv = (uint32_t *)malloc(std::max<size_t>(1, (size_t)n_entries) * 4);
-    if (!wv) { side.join(); side_joined = true; delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory for %lld walk entries", (long long)n_entries); }
+    if (!wv) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory for %lld walk entries", (long long)n_entries);
     g->walk_vtx = (int32_t *)wv;
     const uint32_t DROP = 0xFFFFFFFFu;
     parallel_for((int64_t)pieces.size(), [&](int64_t i) {
@@ -648,31 +727,59 @@ int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap)
             const int64_t x = first_bad.load();
             const int64_t w = (int64_t)(std::upper_bound(g->walk_off.begin(), g->walk_off.end(), x) - g->walk_off.begin()) - 1;
             // (entries before x in other chunks may already be converted; x itself is not)
-            const int code = fail(err, err_cap, PHI_HOST_ERR_WALK, "Error: Walk %d has reverse strand vertices %u", (int)w, wv[x]);
-            side.join(); side_joined = true;
-            delete g;
-            return code;
+            return fail(err, err_cap, PHI_HOST_ERR_WALK, "Error: Walk %d has reverse strand vertices %u", (int)w, wv[x]);
         }
     }
     tm.lap("walk flips, vertex ids");
 
-    // ---- what the side thread made meanwhile
-    side.join();
-    side_joined = true;
-    if (side_rc == 1) { delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory"); }
-    if (side_rc == 3) {
-        const std::string nm(g->name_arena.data() + g->name_off[(size_t)side_sorted]);
-        delete g;
-        return fail(err, err_cap, PHI_HOST_ERR_UNSUPPORTED, "a link onto the reverse strand of segment %s: the reference's arc index shows the forward arc such a link implies "
-                    "only sometimes (gfa-base.cpp:269-303); write the link from the forward strand", nm.c_str());
-    }
-    if (side_rc == 2) {
-        const int code = fail(err, err_cap, PHI_HOST_ERR_CYCLE, "graph is not acyclic: %d of %d vertices sorted", side_sorted, n_seg);
-        delete g;
-        return code;
-    }
-    tm.lap("wait for arrays + topological order (side thread)");
-    *out = g;
+    return PHI_HOST_OK;
+}
+
+extern "C" {
+
+int phi_gfa_read(const char *path, phi_graph **out, char *err, int err_cap) { return gfa_read_impl(path, out, false, nullptr, nullptr, err, err_cap); }
+
+/* The same, but the walks stay TEXT: on_text (optional) is called on a thread of its own as soon as the walk fields are known
+ * -- long before the names are --, and the graph comes back without walk_off / walk_vtx.  The caller resolves the walks on the
+ * device (include/phi_amd.h phi_walk_text_*) with phi_graph_name_index and reports their offsets with phi_graph_set_walk_off,
+ * or has them resolved here after all: phi_graph_resolve_walks. */
+int phi_gfa_read_deferred(const char *path, phi_graph **out, phi_walk_text_fn on_text, void *user, char *err, int err_cap)
+{
+    return gfa_read_impl(path, out, true, on_text, user, err, err_cap);
+}
+int phi_graph_walks_deferred(const phi_graph *g) { return g && g->state != nullptr; }
+int phi_graph_walk_texts(const phi_graph *g, phi_host_walk_text *out, int32_t cap)
+{
+    if (!g || !g->state) return PHI_HOST_ERR_INVALID;
+    const int32_t n = (int32_t)g->state->walks.size();
+    if (out) for (int32_t i = 0; i < n && i < cap; i++) out[i] = phi_host_walk_text{g->state->walks[(size_t)i]->text.p, (int64_t)g->state->walks[(size_t)i]->text.n};
+    return n;
+}
+int phi_graph_name_index(const phi_graph *g, const char **prefix, int32_t *prefix_n, const int32_t **num2id, int64_t *n_num)
+{
+    if (!g || !g->state || !g->name_index_ok) return PHI_HOST_ERR_UNSUPPORTED;
+    if (prefix) *prefix = g->prefix.data();
+    if (prefix_n) *prefix_n = (int32_t)g->prefix.size();
+    if (num2id) *num2id = g->num2id.data();
+    if (n_num) *n_num = (int64_t)g->num2id.size();
+    return PHI_HOST_OK;
+}
+int phi_graph_resolve_walks(phi_graph *g, char *err, int err_cap)
+{
+    if (!g || !g->state) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "the walks of this graph are resolved already");
+    StageTimer tm;
+    const int rc = resolve_walks(*g->state, g, tm, err, err_cap);
+    delete g->state;
+    g->state = nullptr;
+    return rc;
+}
+int phi_graph_set_walk_off(phi_graph *g, const int64_t *walk_off)
+{
+    if (!g || !g->state || !walk_off) return PHI_HOST_ERR_INVALID;
+    const size_t n = g->state->walks.size();
+    g->walk_off.assign(walk_off, walk_off + n + 1);
+    delete g->state;                                   // (the mapping of the file goes with it)
+    g->state = nullptr;
     return PHI_HOST_OK;
 }
 

@@ -206,7 +206,7 @@ static int run(const Options &o)
     const int n_dev = (int)devices.size();
     std::vector<phi_ctx *> ctxs((size_t)n_dev, nullptr);
     const bool timing = g_marks.on;
-    std::future<int> f_ctx = std::async(std::launch::async, [&]() {
+    std::shared_future<int> f_ctx = std::async(std::launch::async, [&]() {
         Stage st("device context(s) [thread]");
         // one host thread per GPU (each context initialises its own device)
         std::vector<std::future<int>> fs;
@@ -215,7 +215,7 @@ static int run(const Options &o)
         int r = 0;
         for (auto &f : fs) { const int ri = f.get(); if (ri && !r) r = ri; }
         return r;
-    });
+    }).share();
 
     // The reads file is streamed as TEXT: a host thread fills chunk buffers with the file's (inflated)
     // bytes while this thread parses the graph and builds the index; every chunk then goes to phi_add_reads_text, which
@@ -287,16 +287,57 @@ static int run(const Options &o)
     };
 
     // ---- graph (main.cpp:101-115)
+    // One GPU: the walks stay TEXT in the reader (include/phi_host.h phi_gfa_read_deferred) and go to HBM as soon as the reader
+    // knows where they are -- while it still enters the segment names --, and the device resolves them (phi_walk_text_*): at
+    // chromosome scale the walks are 96% of the file.  Text the device path does not take (reverse steps, names of another form:
+    // walk_text.hip) is resolved by the host after all, with the reference's rules.  Small files (PHI_WALK_TEXT_MIN bytes of
+    // walk text, default 32 MB) and multi-GPU runs (every GPU needs the walks) stay with the host.
     phi_graph *g = nullptr;
+    struct WalkText { std::shared_future<int> *ctx_ready; std::vector<phi_ctx *> *ctxs; int64_t min_bytes; int64_t bytes = 0; int rc = 0; bool sent = false; } wt{&f_ctx, &ctxs, 0};
+    wt.min_bytes = getenv("PHI_WALK_TEXT_MIN") ? atoll(getenv("PHI_WALK_TEXT_MIN")) : ((int64_t)32 << 20);
+    const bool defer_walks = n_dev == 1 && !(getenv("PHI_WALKS") && !strcmp(getenv("PHI_WALKS"), "host"));
+    auto gfa_failed = [&]() {
+        if (err[0] == 'E') fprintf(stderr, "%s\n", err);            // walk error text of ILP_index.cpp:105
+        else fprintf(stderr, "[E::%s] failed to load the GFA file\n", "main");
+        if (err[0] && err[0] != 'E') fprintf(stderr, "[E::%s] %s\n", "main", err);
+        f_ctx.wait(); stop_reads();
+        return 1;
+    };
     {
         Stage st("GFA read + parse");
-        if (phi_gfa_read(gfa_file.c_str(), &g, err, sizeof err) != PHI_HOST_OK) {
-            if (err[0] == 'E') fprintf(stderr, "%s\n", err);            // walk error text of ILP_index.cpp:105
-            else fprintf(stderr, "[E::%s] failed to load the GFA file\n", "main");
-            if (err[0] && err[0] != 'E') fprintf(stderr, "[E::%s] %s\n", "main", err);
-            f_ctx.wait(); stop_reads();
-            return 1;
+        int r;
+        if (defer_walks)
+            r = phi_gfa_read_deferred(gfa_file.c_str(), &g, [](void *user, const phi_host_walk_text *walks, int32_t n) {
+                    WalkText &t = *static_cast<WalkText *>(user);
+                    for (int32_t i = 0; i < n; i++) t.bytes += walks[i].n;
+                    if (t.bytes < t.min_bytes) return;
+                    if (t.ctx_ready->get()) return;                              // (no device: main reports it)
+                    static_assert(sizeof(phi_host_walk_text) == sizeof(phi_walk_text), "the two libraries' walk text records");
+                    t.rc = phi_walk_text_upload((*t.ctxs)[0], reinterpret_cast<const phi_walk_text *>(walks), n);
+                    t.sent = t.rc == 0;
+                }, &wt, err, sizeof err);
+        else
+            r = phi_gfa_read(gfa_file.c_str(), &g, err, sizeof err);
+        if (r != PHI_HOST_OK) return gfa_failed();
+    }
+    if (defer_walks) {
+        Stage st("walks");
+        bool on_device = false;
+        if (wt.rc) { fprintf(stderr, "[E::%s] walk text to the device: %s: %s\n", "main", phi_strerror(wt.rc), phi_last_error(ctxs[0])); stop_reads(); return 1; }
+        if (wt.sent) {
+            const char *prefix = nullptr; int32_t prefix_n = 0; const int32_t *num2id = nullptr; int64_t n_num = 0;
+            uint32_t irregular = 0;
+            if (phi_graph_name_index(g, &prefix, &prefix_n, &num2id, &n_num) == PHI_HOST_OK) {
+                std::vector<int64_t> woff((size_t)phi_graph_n_walks(g) + 1, 0);
+                const int r = phi_walk_text_resolve(ctxs[0], prefix, prefix_n, num2id, n_num, phi_graph_n_vtx(g), woff.data(), &irregular);
+                if (r) { fprintf(stderr, "[E::%s] walks on the device: %s: %s\n", "main", phi_strerror(r), phi_last_error(ctxs[0])); stop_reads(); return 1; }
+                if (!irregular) { phi_graph_set_walk_off(g, woff.data()); on_device = true; }
+            } else {
+                (void)phi_walk_text_upload(ctxs[0], nullptr, 0);                 // (lets the text on the device go)
+            }
+            if (timing) fprintf(stderr, "[phi] walks: %lld bytes of text %s\n", (long long)wt.bytes, on_device ? "resolved on the device" : irregular ? "irregular for the device: host" : "names not <prefix><number>: host");
         }
+        if (!on_device && phi_graph_resolve_walks(g, err, sizeof err) != PHI_HOST_OK) return gfa_failed();
     }
     stamp("main");
     fprintf(stderr, "Loaded graph from: %s\n", gfa_file.c_str());

@@ -408,6 +408,7 @@ int phi_ctx_create(int device_id, phi_ctx **out)
     }
     phi_warm_sketch(c->stream); phi_warm_table(c->stream); phi_warm_anchors(c->stream); phi_warm_contexts(c->stream);
     phi_warm_dp(c->stream); phi_warm_dp_events(c->stream); phi_warm_solve_dev(c->stream); phi_warm_reads_text(c->stream);
+    phi_warm_walk_text(c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(PHI_ERR_DEVICE);
     tm.lap("scalars + code objects");
     if (aux.get() != hipSuccess) { c->aux_stream = nullptr; return bail(PHI_ERR_DEVICE); }
@@ -428,7 +429,7 @@ void phi_ctx_destroy(phi_ctx *c)
     (void)phi_ipc_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->d_anchors, &c->d_cov_all, &c->d_cov_w, &c->d_slots, &c->d_slots2, &c->d_segs, &c->d_ctr, &c->d_vmax, &c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_seg_lo, &c->d_seg_row, &c->d_seg_S, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.hit, &c->hit_extra[0], &c->hit_extra[1], &c->alt.stripes, &c->d_sp_cnt, &c->d_novlog, &c->d_novcnt, &c->d_ovlist, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->d_anchors, &c->d_cov_all, &c->d_cov_w, &c->d_slots, &c->d_slots2, &c->d_segs, &c->d_ctr, &c->d_vmax, &c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_seg_lo, &c->d_seg_row, &c->d_seg_S, &c->wtext.d_text, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.hit, &c->hit_extra[0], &c->hit_extra[1], &c->alt.stripes, &c->d_sp_cnt, &c->d_novlog, &c->d_novcnt, &c->d_ovlist, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_in_s, &c->d_last_walk, &c->d_rowdiag, &c->d_wpre, &c->d_hit, &c->d_sp_keys, &c->d_rbases,
@@ -681,7 +682,11 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
                   const int32_t *topo_rank)
 {
     if (!c) return PHI_ERR_INVALID;
-    if (n_vtx <= 0 || n_walks <= 0 || !seq_concat || !seq_off || !adj_off || !walk_off || !walk_vtx || !topo_rank)
+    // walk_vtx == NULL: the entries are on the device already, resolved there from the W-lines' text (phi_walk_text_resolve)
+    const bool dev_walks = walk_vtx == nullptr;
+    if (dev_walks && c && walk_off && n_walks > 0 && !(c->walks_on_device && c->walks_on_device_n == walk_off[n_walks] && (int32_t)(c->wtext.ends.size() / 2) == n_walks))
+        return phi_fail(c, PHI_ERR_STATE, "phi_set_graph without walk_vtx: phi_walk_text_resolve must have resolved exactly these walks on this context");
+    if (n_vtx <= 0 || n_walks <= 0 || !seq_concat || !seq_off || !adj_off || !walk_off || !topo_rank)
         return phi_fail(c, PHI_ERR_INVALID, "phi_set_graph: null pointer or empty graph");
     if (adj_off[n_vtx] > 0 && !adj) return phi_fail(c, PHI_ERR_INVALID, "phi_set_graph: adj is null");
     HIPCHK(hipSetDevice(c->device));
@@ -717,6 +722,9 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     for (int32_t h = 0; h < n_walks; h++)
         if (walk_off[h + 1] <= walk_off[h]) return phi_fail(c, PHI_ERR_INVALID, "walk %d is empty", h);
     const int64_t n_edges = adj_off[n_vtx], n_entries = walk_off[n_walks];
+    // (the first and the last vertex of a walk are all the host pass looks at of the walk entries)
+    auto walk_first = [&](int32_t h) -> int32_t { return dev_walks ? c->wtext.ends[(size_t)h * 2] : walk_vtx[walk_off[h]]; };
+    auto walk_last = [&](int32_t h) -> int32_t { return dev_walks ? c->wtext.ends[(size_t)h * 2 + 1] : walk_vtx[walk_off[h + 1] - 1]; };
     if (n_entries > PHI_MAX_ENTRIES) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^32 - 64 walk entries");
     // The DP's per-entry buffers of a chromosome-scale graph (5 x 4-8 bytes per walk entry: 26 GB at 1.3 G entries) are
     // allocated now, on a thread of their own: the driver clears device memory as it hands it out (tens of GB/s), which
@@ -742,7 +750,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         HIPCHK(hipSetDevice(c->device));
         PHICHK(upload(c, c->d_seq, seq_concat, (size_t)seq_off[n_vtx]));
         PHICHK(upload(c, c->d_seq_off, seq_off, (size_t)n_vtx + 1));
-        PHICHK(upload(c, c->d_walk_vtx, walk_vtx, (size_t)n_entries));
+        if (!dev_walks) PHICHK(upload(c, c->d_walk_vtx, walk_vtx, (size_t)n_entries));
         PHICHK(upload(c, c->d_walk_off, walk_off, (size_t)n_walks + 1));
         PHICHK(upload(c, c->d_adj_off, adj_off, (size_t)n_vtx + 1));
         if (n_edges == 0) PHICHK(phi_dev_ensure(c, c->d_adj, 4));
@@ -786,12 +794,18 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     std::future<void> wv_copy = std::async(std::launch::async, [&]() {
         if (!keep_host_walks) return;
         int32_t *dst = c->h_walk_vtx.data();
+        if (dev_walks) {                                       // (resolved on the device: the host copy comes from there)
+            (void)hipSetDevice(c->device);
+            if (n_entries && hipMemcpyAsync(dst, c->d_walk_vtx.p, (size_t)n_entries * 4, hipMemcpyDeviceToHost, c->aux_stream) == hipSuccess)
+                (void)hipStreamSynchronize(c->aux_stream);
+            return;
+        }
         const int nt = 4;
         std::vector<std::thread> th;
         for (int t = 0; t < nt; t++)
             th.emplace_back([=]() {
                 const int64_t lo = n_entries * t / nt, hi = n_entries * (t + 1) / nt;
-                memcpy(dst + lo, walk_vtx + lo, (size_t)(hi - lo) * 4);
+                if (!dev_walks) memcpy(dst + lo, walk_vtx + lo, (size_t)(hi - lo) * 4);
             });
         for (auto &x : th) x.join();
     });
@@ -946,8 +960,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     tm.lap("walk entries: pass on the GPU");
     bool start_interior = false, end_interior = false;
     for (int32_t h = 0; h < n_walks; h++) {
-        if (indeg[walk_vtx[walk_off[h]]] > 0) start_interior = true;
-        const int32_t last = walk_vtx[walk_off[h + 1] - 1];
+        if (indeg[walk_first(h)] > 0) start_interior = true;
+        const int32_t last = walk_last(h);
         if (adj_off[last + 1] > adj_off[last]) end_interior = true;
     }
     if (start_interior && end_interior)
@@ -1002,8 +1016,8 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     if (c->dp_events) {
         std::vector<uint8_t> lane_only(n_vtx, 0);
         for (int32_t h = 0; h < n_walks; h++) {
-            lane_only[walk_vtx[walk_off[h]]] = 1;
-            lane_only[walk_vtx[walk_off[h + 1] - 1]] = 1;
+            lane_only[walk_first(h)] = 1;
+            lane_only[walk_last(h)] = 1;
         }
         c->h_cstep.assign(n_vtx, -1);
         c->h_kstep.clear();
@@ -1110,6 +1124,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
 
     c->reads_bases = 0; c->reads_count = 0; c->spectrum_override = -1;
     c->sp_set_gen = -1; c->log_chunks = c->log_done = 0; c->logged_done = 0; c->ov_done = 0; c->ov_bound = 0; c->async_batches = false;
+    c->walks_on_device = false;                                // (consumed: a later phi_set_graph brings its own walks)
     c->nov_shift = phi_nov_shift(c->w);
     if (const char *e = getenv("PHI_NOV_SHIFT")) c->nov_shift = std::max(0, std::min(9, atoi(e)));   // tests: chunk logs of a few entries, so that ordinary reads spill into the overflow list
     c->alt.needs_clean = false;

@@ -90,6 +90,18 @@ struct phi_ctx {
     PhiRawBuf<int32_t> h_walk_vtx;                    // host copy of the walk entries
     int64_t n_entries = 0, walk_bases = 0;
 
+    // ---- the walks resolved on the device from the text of the W-lines (walk_text.hip): the text while it is being uploaded and
+    //      resolved; afterwards d_walk_vtx holds the entries and phi_set_graph(walk_vtx = NULL) takes them from there
+    struct PhiWalkText {
+        bool ready = false;
+        int32_t n_walks = 0;
+        std::vector<int64_t> tile0, t_len;            // first 4-KB tile and bytes of every walk's text in d_text
+        std::vector<int32_t> ends;                    // first and last vertex of every walk (what phi_set_graph's host pass looks at)
+        DevBuf d_text;
+    } wtext;
+    bool walks_on_device = false;
+    int64_t walks_on_device_n = 0;
+
     // ---- graph, device side
     DevBuf d_seq, d_seq_off, d_walk_vtx, d_walk_off, d_topo, d_in_off, d_in_src;
     DevBuf d_e_out, d_st_rec, d_st_mask, d_in_packed;  // DP step stream (dp.hip)

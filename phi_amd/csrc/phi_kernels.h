@@ -387,3 +387,4 @@ void phi_warm_dp(hipStream_t st);
 void phi_warm_dp_events(hipStream_t st);
 void phi_warm_solve_dev(hipStream_t st);
 void phi_warm_reads_text(hipStream_t st);
+void phi_warm_walk_text(hipStream_t st);

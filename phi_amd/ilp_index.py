@@ -28,7 +28,11 @@ HOST_SYMBOLS = [
     "phi_write_fasta", "phi_reads_stream_open", "phi_reads_stream_next", "phi_reads_stream_reads",
     "phi_reads_stream_bases", "phi_reads_stream_close", "phi_reads_stream_open_blocks",
     "phi_text_stream_open", "phi_text_stream_read", "phi_text_stream_close",
+    "phi_gfa_read_deferred", "phi_graph_walks_deferred", "phi_graph_walk_texts", "phi_graph_name_index", "phi_graph_resolve_walks",
+    "phi_graph_set_walk_off",
 ]
+
+WALK_TEXT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int32)
 
 TEXT_BLOCK_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.POINTER(C.c_void_p))
 
@@ -85,6 +89,12 @@ def host_lib():
     L.phi_text_stream_close.argtypes = [vp]
     L.phi_reads_stream_close.restype = None
     L.phi_reads_stream_close.argtypes = [vp]
+    L.phi_gfa_read_deferred.argtypes = [C.c_char_p, C.POINTER(vp), vp, vp, C.c_char_p, C.c_int]
+    L.phi_graph_walks_deferred.argtypes = [vp]
+    L.phi_graph_walk_texts.argtypes = [vp, vp, C.c_int32]
+    L.phi_graph_name_index.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.phi_graph_resolve_walks.argtypes = [vp, C.c_char_p, C.c_int]
+    L.phi_graph_set_walk_off.argtypes = [vp, vp]
     L.phi_hap_name.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
     L.phi_write_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64]
     for n in HOST_SYMBOLS:
@@ -225,6 +235,86 @@ class Graph:
             self.seg_names = [L.phi_graph_seg_name(h, v).decode() for v in range(self.n_vtx)]
         finally:
             L.phi_graph_free(h)
+
+
+class DeferredGraph:
+    """A GFA read with its walks left as TEXT (phi_gfa_read_deferred): resolve_on_device(ctx) sends the W-lines' walk fields
+    to the context's GPU and resolves them there (include/phi_amd.h phi_walk_text_*); when the text is not of the kind
+    the device takes -- or on request -- resolve_on_host() does what Graph does.  set_graph(ctx) hands the graph over."""
+
+    def __init__(self, path, on_text=None):
+        L = host_lib()
+        self._L = L
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        self._cb = WALK_TEXT_FN(on_text) if on_text else None
+        rc = L.phi_gfa_read_deferred(os.fsencode(path), C.byref(self._h), C.cast(self._cb, C.c_void_p) if self._cb else None, None, err, 512)
+        if rc:
+            raise HostError(rc, err.value.decode())
+        h = self._h
+        self.n_vtx = L.phi_graph_n_vtx(h)
+        self.num_walks = L.phi_graph_n_walks(h)
+        ne = L.phi_graph_n_edges(h)
+        self.seq_off = _view(L.phi_graph_seq_off(h), self.n_vtx + 1, C.c_int64, np.int64).copy()
+        self.seq_concat = _view(L.phi_graph_seq_concat(h), int(self.seq_off[-1]), C.c_uint8, np.uint8).copy()
+        self.adj_off = _view(L.phi_graph_adj_off(h), self.n_vtx + 1, C.c_int64, np.int64).copy()
+        self.adj = _view(L.phi_graph_adj(h), ne, C.c_int32, np.int32).copy()
+        self.top_order_map = _view(L.phi_graph_topo_rank(h), self.n_vtx, C.c_int32, np.int32).copy()
+        self.hap_id2name = [L.phi_graph_hap_name(h, w).decode() for w in range(self.num_walks)]
+        self.walk_off = None
+        self.walk_vtx = None                          # stays None when the device resolved the walks
+        self.on_device = False
+
+    def close(self):
+        if self._h:
+            self._L.phi_graph_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def walk_texts(self):
+        """(address, bytes) of every walk field in the mapped file."""
+        n = self._L.phi_graph_walk_texts(self._h, None, 0)
+        buf = (C.c_int64 * (2 * max(n, 1)))()
+        self._L.phi_graph_walk_texts(self._h, buf, n)
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
+
+    def resolve_on_device(self, ctx, upload=True):
+        """True when the device resolved the walks; False when the text is irregular (then: resolve_on_host)."""
+        L = self._L
+        prefix, pn, tbl, nn = C.c_void_p(), C.c_int32(), C.c_void_p(), C.c_int64()
+        if L.phi_graph_name_index(self._h, C.byref(prefix), C.byref(pn), C.byref(tbl), C.byref(nn)) != 0:
+            return False
+        n = self.num_walks
+        if upload:
+            buf = (C.c_int64 * (2 * max(n, 1)))()
+            L.phi_graph_walk_texts(self._h, buf, n)
+            ctx._chk(ctx._L.phi_walk_text_upload(ctx._h, buf, n))
+        woff = np.zeros(n + 1, np.int64)
+        irr = C.c_uint32()
+        ctx._chk(ctx._L.phi_walk_text_resolve(ctx._h, C.cast(prefix, C.c_char_p), pn.value, tbl, nn.value, self.n_vtx, woff.ctypes.data, C.byref(irr)))
+        self.irregular = irr.value
+        if irr.value:
+            return False
+        self.walk_off = woff
+        L.phi_graph_set_walk_off(self._h, woff.ctypes.data)
+        self.on_device = True
+        return True
+
+    def resolve_on_host(self):
+        err = C.create_string_buffer(512)
+        rc = self._L.phi_graph_resolve_walks(self._h, err, 512)
+        if rc:
+            raise HostError(rc, err.value.decode())
+        self.walk_off = _view(self._L.phi_graph_walk_off(self._h), self.num_walks + 1, C.c_int64, np.int64).copy()
+        self.walk_vtx = _view(self._L.phi_graph_walk_vtx(self._h), int(self.walk_off[-1]) if self.num_walks else 0, C.c_int32, np.int32).copy()
+
+    def set_graph(self, ctx):
+        ctx.set_graph(self.seq_concat, self.seq_off, self.adj_off, self.adj, self.walk_off, self.walk_vtx, self.top_order_map)
 
 
 def read_reads(path):
