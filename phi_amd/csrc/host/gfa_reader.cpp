@@ -60,6 +60,9 @@ struct phi_graph {
     std::vector<int64_t> seq_off, adj_off, walk_off;
     std::vector<int32_t> adj, topo_rank;
     int32_t n_seg = 0;
+    GfaState *retired = nullptr;                       // the reader's state after the walks are resolved: only its mapping of the file is left
+    std::thread reaper;                                // frees the line tables once the walks are resolved
+    void let_state_go();
     ~phi_graph();
 };
 
@@ -180,6 +183,16 @@ public:
     bool no_hashed_names() const { return n_hashed_ == 0; }
     std::string prefix() const { return std::string(prefix_, prefix_n_); }
     const std::vector<int32_t> &direct() const { return direct_; }
+    // (the reader's all-at-once entry of names <prefix><number>: the prefix as add() takes it from the first name, then the
+    //  finished key list and direct index)
+    void set_prefix_of(const char *p, size_t n)
+    {
+        size_t l = 0;
+        while (l < n && !(p[l] >= '0' && p[l] <= '9')) l++;
+        prefix_n_ = 0;
+        if (l <= sizeof prefix_) { memcpy(prefix_, p, l); prefix_n_ = l; }
+    }
+    void adopt(std::vector<Slice> &&keys, std::vector<int32_t> &&direct) { keys_ = std::move(keys); direct_ = std::move(direct); n_hashed_ = 0; }
 
     int32_t find(const char *p, size_t n) const
     {
@@ -222,6 +235,7 @@ public:
     }
 private:
     struct Slot { int32_t id; uint32_t tag; };       // tag 0 = empty
+public:
     // the number behind the prefix when the name is <prefix><decimal without leading zeros, at most 9 digits>, else -1
     int64_t number(const char *p, size_t n) const
     {
@@ -238,6 +252,7 @@ private:
         }
         return v;
     }
+private:
     static uint64_t hash(const char *p, size_t n)
     {
         uint64_t h = 0xcbf29ce484222325ull ^ (n * 0x9E3779B97F4A7C15ull);
@@ -297,7 +312,7 @@ struct WRec {
     size_t before;                                    // index of the next S/L record of its slice: what the line can name
     int32_t n_known = 0;
 };
-struct SliceOut { std::vector<Rec> recs; std::vector<WRec> walks; };
+struct SliceOut { std::vector<Rec> recs; std::vector<WRec> walks; size_t n_S = 0, n_L = 0; };
 
 void scan_slice(const char *p, const char *end, SliceOut &o)
 {
@@ -313,11 +328,14 @@ void scan_slice(const char *p, const char *end, SliceOut &o)
             if (t == 'S' && nf >= 3) {
                 const bool has = f[2].n > 0 && f[2].p[0] != '*';
                 o.recs.push_back(Rec{f[1].p, has ? f[2].p : nullptr, (uint32_t)f[1].n, has ? (uint32_t)f[2].n : 0u, 'S', 0, 0});
+                o.n_S++;
             } else if (t == 'L' && nf >= 5) {
                 if (f[2].n == 1 && f[4].n == 1) {
                     const char ov = f[2].p[0], ow = f[4].p[0];
-                    if ((ov == '+' || ov == '-') && (ow == '+' || ow == '-'))
+                    if ((ov == '+' || ov == '-') && (ow == '+' || ow == '-')) {
                         o.recs.push_back(Rec{f[1].p, f[3].p, (uint32_t)f[1].n, (uint32_t)f[3].n, 'L', ov, ow});
+                        o.n_L++;
+                    }
                 }
             } else if (t == 'W' && nf >= 7) {
                 WRec w;
@@ -344,7 +362,26 @@ struct GfaState {
     std::vector<WRec *> walks;                         // in file order
     int32_t n_seg = 0;
 };
-phi_graph::~phi_graph() { free(seq_concat); free(walk_vtx); delete state; }
+// The reader's tables are freed on a thread of their own once the walks are resolved; the MAPPING of the file stays until the
+// graph itself goes: unmapping the 11 GB of a chromosome-scale GFA takes 0.2-0.5 s (measured at config 5, as the "walks" stage
+// of the command line) and holds the address-space lock against every allocation and page fault of the other threads while it
+// does.  The pages are the file's own, clean and shared: they cost nothing to keep.
+void phi_graph::let_state_go()
+{
+    GfaState *st = state;
+    state = nullptr;
+    if (!st) return;
+    if (reaper.joinable()) reaper.join();
+    delete retired;
+    retired = st;
+    reaper = std::thread([st]() {
+        std::vector<SliceOut>().swap(st->so);
+        std::vector<WRec *>().swap(st->walks);
+        st->table = NameTable();
+        if (!st->text.map) { std::vector<char>().swap(st->text.own); st->text.p = nullptr; st->text.n = 0; }
+    });
+}
+phi_graph::~phi_graph() { if (reaper.joinable()) reaper.join(); free(seq_concat); free(walk_vtx); delete state; delete retired; }
 
 static int resolve_walks(GfaState &st, phi_graph *g, StageTimer &tm, char *err, int err_cap);
 
@@ -362,18 +399,37 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
 
     // ---- lines and fields, on all threads over slices of the text cut at line ends
     const char *const t0 = text.p, *const tend = text.p + text.n;
-    const int n_slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads() * 4, text.n / ((size_t)1 << 20) + 1));
-    std::vector<const char *> cut((size_t)n_slices + 1, tend);
-    cut[0] = t0;
-    for (int i = 1; i < n_slices; i++) {
-        const char *q = t0 + text.n / (size_t)n_slices * (size_t)i;
-        if (q < cut[(size_t)i - 1]) q = cut[(size_t)i - 1];
-        const char *nl = q < tend ? (const char *)memchr(q, '\n', (size_t)(tend - q)) : nullptr;
-        cut[(size_t)i] = nl ? nl + 1 : tend;
-    }
+    // Cuts: a pangenome GFA is a few hundred MB of short S- and L-lines (millions of records) followed by W-lines of tens of MB
+    // each.  Equal slices by bytes would leave all the records to the two or three threads whose slices hold the short lines, so
+    // the text is cut FINE (a few MB) wherever a line ends within 64 KB of the nominal cut -- everywhere among short lines,
+    // almost nowhere inside the W-lines -- and every 32nd cut is COARSE: moved on to the next line end however far that is,
+    // so that the long lines are still shared out.  All cuts are looked for at once, by all threads.
+    const size_t fine_bytes = getenv("PHI_GFA_SLICE") ? std::max<size_t>(64, (size_t)atoll(getenv("PHI_GFA_SLICE"))) : ((size_t)4 << 20);
+    const size_t n_nominal = std::max<size_t>(1, std::min<size_t>((size_t)1 << 16, text.n / fine_bytes + 1));
+    const size_t coarse_every = std::max<size_t>(1, n_nominal / ((size_t)host_threads() * 4));
+    std::vector<const char *> cand(n_nominal, nullptr);
+    parallel_for((int64_t)n_nominal - 1, [&](int64_t j) {
+        const size_t i = (size_t)j + 1;
+        const char *q = t0 + text.n / n_nominal * i;
+        if (q[-1] == '\n') { cand[i] = q; return; }
+        const size_t room = (size_t)(tend - q), window = i % coarse_every == 0 ? room : std::min<size_t>(room, (size_t)64 << 10);
+        const char *nl = (const char *)memchr(q, '\n', window);
+        if (nl && nl + 1 < tend) cand[i] = nl + 1;
+    });
+    std::vector<const char *> cut{t0};
+    for (size_t i = 1; i < n_nominal; i++) if (cand[i] && cand[i] > cut.back()) cut.push_back(cand[i]);
+    const int n_slices = (int)cut.size();
+    cut.push_back(tend);
     std::vector<SliceOut> &so = stp->so;
     so.resize((size_t)n_slices);
-    parallel_for(n_slices, [&](int64_t i) { scan_slice(cut[(size_t)i], cut[(size_t)i + 1], so[(size_t)i]); });
+    const bool populate = text.map && getenv("PHI_GFA_POPULATE") && atoi(getenv("PHI_GFA_POPULATE")) != 0;   // (experiment: page tables filled slice by slice by the thread about to read it)
+    parallel_for(n_slices, [&](int64_t i) {
+        if (populate) {
+            const uintptr_t a = (uintptr_t)cut[(size_t)i] & ~(uintptr_t)4095, b = ((uintptr_t)cut[(size_t)i + 1] + 4095) & ~(uintptr_t)4095;
+            (void)madvise((void *)a, b - a, 22 /* MADV_POPULATE_READ */);
+        }
+        scan_slice(cut[(size_t)i], cut[(size_t)i + 1], so[(size_t)i]);
+    });
     tm.lap("lines + fields (threads)");
     // the walk fields are known now, long before their names can be resolved: a caller that resolves them on the device
     // starts sending the text there (a thread of its own, joined before this call returns)
@@ -427,48 +483,99 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
         }
     };
     {
-        // S-lines and W-lines, in file order
         std::vector<size_t> first_rec;                               // per segment: the record that introduced it
-        seqs.reserve(n_rec);
-        for (int si = 0; si < n_slices; si++) {
-            SliceOut &s = so[(size_t)si];
-            size_t wi = 0;
-            for (size_t i = 0; i <= s.recs.size(); i++) {
-                while (wi < s.walks.size() && s.walks[wi].before == i) {
-                    s.walks[wi].n_known = table.size();
-                    walks.push_back(&s.walks[wi++]);
+        // S-lines and W-lines.  Every tool names its segments <prefix><number>, each once: then the ids are simply the order of
+        // the S-lines and all threads enter them at once (a compare-and-swap on the number's slot finds a name given twice).
+        // Anything else -- a name of another form, a name twice, a number far beyond the count -- goes in file order on one thread.
+        std::vector<size_t> s_base((size_t)n_slices + 1, 0), l_base((size_t)n_slices + 1, 0);
+        for (int i = 0; i < n_slices; i++) { s_base[(size_t)i + 1] = s_base[(size_t)i] + so[(size_t)i].n_S; l_base[(size_t)i + 1] = l_base[(size_t)i] + so[(size_t)i].n_L; }
+        const size_t n_S = s_base[(size_t)n_slices], n_L = l_base[(size_t)n_slices];
+        auto bulk = [&]() -> bool {
+            if (n_S == 0 || n_S >= (size_t)INT32_MAX || getenv("PHI_GFA_NAMES_SERIAL")) return false;
+            const Rec *first = nullptr;
+            for (int i = 0; i < n_slices && !first; i++) for (const Rec &r : so[(size_t)i].recs) if (r.type == 'S') { first = &r; break; }
+            table.set_prefix_of(first->a, first->an);
+            std::vector<int64_t> mx((size_t)n_slices, -1);
+            std::atomic<int> bad{0};
+            parallel_for(n_slices, [&](int64_t si) {
+                size_t k = s_base[(size_t)si];
+                int64_t m = -1;
+                for (const Rec &r : so[(size_t)si].recs) {
+                    if (r.type != 'S') continue;
+                    const int64_t num = table.number(r.a, r.an);
+                    if (num < 0 || num >= std::max<int64_t>(1 << 20, 16 * (int64_t)(k + 1))) { bad.store(1); return; }
+                    m = std::max(m, num);
+                    k++;
                 }
-                if (i == s.recs.size()) break;
-                const Rec &r = s.recs[i];
-                if (r.type != 'S') continue;
-                const int32_t id = add_seg(r.a, r.an);
-                if ((size_t)id == first_rec.size()) first_rec.push_back(rec_base[(size_t)si] + i);
-                seqs[(size_t)id] = Slice{r.b, r.bn};
+                mx[(size_t)si] = m;
+            });
+            if (bad.load()) return false;
+            std::vector<int32_t> direct((size_t)(*std::max_element(mx.begin(), mx.end()) + 1), -1);
+            std::vector<Slice> keys(n_S);
+            seqs.assign(n_S, Slice{nullptr, 0});
+            first_rec.assign(n_S, 0);
+            parallel_for(n_slices, [&](int64_t si) {
+                SliceOut &s_ = so[(size_t)si];
+                size_t k = s_base[(size_t)si], wi = 0;
+                for (size_t i = 0; i <= s_.recs.size(); i++) {
+                    while (wi < s_.walks.size() && s_.walks[wi].before == i) s_.walks[wi++].n_known = (int32_t)k;
+                    if (i == s_.recs.size()) break;
+                    const Rec &r = s_.recs[i];
+                    if (r.type != 'S') continue;
+                    int32_t none = -1;
+                    if (!__atomic_compare_exchange_n(&direct[(size_t)table.number(r.a, r.an)], &none, (int32_t)k, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { bad.store(1); return; }
+                    keys[k] = Slice{r.a, r.an};
+                    seqs[k] = Slice{r.b, r.bn};
+                    first_rec[k] = rec_base[(size_t)si] + i;
+                    k++;
+                }
+            });
+            if (bad.load()) return false;
+            table.adopt(std::move(keys), std::move(direct));
+            for (SliceOut &s_ : so) for (WRec &w_ : s_.walks) walks.push_back(&w_);
+            return true;
+        };
+        if (!bulk()) {
+            table = NameTable();
+            seqs.clear(); walks.clear(); first_rec.clear();
+            seqs.reserve(n_rec);
+            for (int si = 0; si < n_slices; si++) {
+                SliceOut &s = so[(size_t)si];
+                size_t wi = 0;
+                for (size_t i = 0; i <= s.recs.size(); i++) {
+                    while (wi < s.walks.size() && s.walks[wi].before == i) {
+                        s.walks[wi].n_known = table.size();
+                        walks.push_back(&s.walks[wi++]);
+                    }
+                    if (i == s.recs.size()) break;
+                    const Rec &r = s.recs[i];
+                    if (r.type != 'S') continue;
+                    const int32_t id = add_seg(r.a, r.an);
+                    if ((size_t)id == first_rec.size()) first_rec.push_back(rec_base[(size_t)si] + i);
+                    seqs[(size_t)id] = Slice{r.b, r.bn};
+                }
             }
         }
-        // L-lines, all threads: both names known, and known BEFORE the line
-        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> part((size_t)n_slices);
+        tm.lap("  S-line names");
+        // L-lines, all threads: both names known, and known BEFORE the line; every line writes its arc where it stands
+        arcs.resize(n_L);
         std::atomic<int> hazard{0};
         parallel_for(n_slices, [&](int64_t si) {
             const SliceOut &s = so[(size_t)si];
-            auto &out = part[(size_t)si];
+            size_t k = l_base[(size_t)si];
             for (size_t i = 0; i < s.recs.size(); i++) {
                 const Rec &r = s.recs[i];
                 if (r.type != 'L') continue;
                 const int32_t a = table.find(r.a, r.an), b2 = table.find(r.b, r.bn);
                 const size_t at = rec_base[(size_t)si] + i;
                 if (a < 0 || b2 < 0 || first_rec[(size_t)a] > at || first_rec[(size_t)b2] > at) { hazard.store(1); return; }
-                out.emplace_back((uint32_t)a << 1 | (r.ov != '+'), (uint32_t)b2 << 1 | (r.ow != '+'));
+                arcs[k++] = std::make_pair((uint32_t)a << 1 | (r.ov != '+'), (uint32_t)b2 << 1 | (r.ow != '+'));
             }
         });
+        tm.lap("  L-line names (threads)");
         if (hazard.load()) one_thread();
-        else {
-            size_t n_arc = 0;
-            for (auto &p : part) n_arc += p.size();
-            arcs.reserve(n_arc);
-            for (auto &p : part) arcs.insert(arcs.end(), p.begin(), p.end());
-        }
     }
+    tm.lap("  arcs together");
     for (SliceOut &s : so) std::vector<Rec>().swap(s.recs);
     const int32_t n_seg = table.size();
     const int64_t n_walks = (int64_t)walks.size();
@@ -480,9 +587,13 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
     phi_graph *g = new phi_graph();
     int side_rc = 0;                                               // 1: out of memory, 2: cycle, 3: a link onto a reverse strand
     int32_t side_sorted = 0;
+    int copy_rc = 0;
     bool side_joined = false;
-    std::thread side([&]() {
-            g->n_seg = n_seg;
+    // (side thread 2: the sequences and the names, copied together -- by all threads when the walks stay text and nobody else
+    //  needs them)
+    std::thread side_copy([&]() {
+        StageTimer tc;
+        g->n_seg = n_seg;
         const std::vector<Slice> &names = table.keys();
         g->name_off.assign((size_t)n_seg + 1, 0);
         for (int32_t i = 0; i < n_seg; i++) g->name_off[(size_t)i + 1] = g->name_off[(size_t)i] + (int64_t)names[(size_t)i].n + 1;
@@ -490,15 +601,25 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
         g->seq_off.assign((size_t)n_seg + 1, 0);
         for (int32_t i = 0; i < n_seg; i++) g->seq_off[(size_t)i + 1] = g->seq_off[(size_t)i] + (int64_t)seqs[(size_t)i].n;
         g->seq_concat = (char *)malloc(std::max<size_t>(1, (size_t)g->seq_off[(size_t)n_seg]));
-        if (!g->seq_concat) { side_rc = 1; return; }
-        for (int64_t i = 0; i < n_seg; i++) {                          // (one thread: the others are on the W-lines)
-            if (seqs[(size_t)i].n) memcpy(g->seq_concat + g->seq_off[(size_t)i], seqs[(size_t)i].p, seqs[(size_t)i].n);
-            char *d = g->name_arena.data() + g->name_off[(size_t)i];
-            memcpy(d, names[(size_t)i].p, names[(size_t)i].n);
-            d[names[(size_t)i].n] = '\0';
-        }
+        if (!g->seq_concat) { copy_rc = 1; return; }
+        auto copy = [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) {
+                if (seqs[(size_t)i].n) memcpy(g->seq_concat + g->seq_off[(size_t)i], seqs[(size_t)i].p, seqs[(size_t)i].n);
+                char *d = g->name_arena.data() + g->name_off[(size_t)i];
+                memcpy(d, names[(size_t)i].p, names[(size_t)i].n);
+                d[names[(size_t)i].n] = '\0';
+            }
+        };
+        const int64_t CH = 1 << 16, n_ch = ((int64_t)n_seg + CH - 1) / CH;
+        if (defer) parallel_for(n_ch, [&](int64_t c) { copy(c * CH, std::min<int64_t>(n_seg, (c + 1) * CH)); });
+        else copy(0, n_seg);                                         // (one thread: the others are on the W-lines)
         for (int64_t w = 0; w < n_walks; w++)
             g->hap_names.push_back(std::string(walks[(size_t)w]->sample.p, walks[(size_t)w]->sample.n) + "." + std::to_string(walks[(size_t)w]->hap));
+        tc.lap("  [copy thread] sequences, names");
+    });
+    struct CopyJoiner { std::thread &t; ~CopyJoiner() { if (t.joinable()) t.join(); } } copy_joiner{side_copy};
+    std::thread side([&]() {
+        StageTimer ts;
         // arcs: those touching a segment without sequence are dropped; an arc v -> w and its complement w' -> v' give the
         // forward-strand adjacency (target orientation dropped): u -> w when v = u+, and w -> v when w is a reverse strand
         {
@@ -508,35 +629,58 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
             // test that never fires) -- the reference's own adjacency for such a file depends on where the line stands.  Rounds
             // 1-3 kept the arc silently; a graph whose meaning the reference itself does not fix is an error here.
             // (L a - b +: neither the arc nor its complement leaves a forward strand: nothing to add, as in the reference.)
-            for (const auto &a : arcs)
-                if ((a.second & 1) && seqs[a.first >> 1].n && seqs[a.second >> 1].n) { side_rc = 3; side_sorted = (int32_t)(a.second >> 1); return; }
+            // (all threads, in pieces of the arc list: the targets of a vertex arrive in any order and are sorted below)
+            const int64_t n_arcs = (int64_t)arcs.size(), ACH = 1 << 16, n_ach = (n_arcs + ACH - 1) / ACH;
+            std::atomic<int64_t> first_rev{INT64_MAX};
             std::vector<int64_t> cnt((size_t)n_seg + 1, 0);
-            auto each = [&](auto fn) {
-                for (const auto &a : arcs) {
-                    const uint32_t v = a.first, w = a.second;
+            auto each = [&](int64_t lo, int64_t hi, auto fn) {
+                for (int64_t i = lo; i < hi; i++) {
+                    const uint32_t v = arcs[(size_t)i].first, w = arcs[(size_t)i].second;
                     if (seqs[v >> 1].n == 0 || seqs[w >> 1].n == 0) continue;
                     if (!(v & 1)) fn(v >> 1, w >> 1);
                     if (w & 1) fn(w >> 1, v >> 1);
                 }
             };
-            each([&](uint32_t u, uint32_t) { cnt[(size_t)u + 1]++; });
+            parallel_for(n_ach, [&](int64_t c) {
+                const int64_t lo = c * ACH, hi = std::min(n_arcs, lo + ACH);
+                for (int64_t i = lo; i < hi; i++) {
+                    const auto &a = arcs[(size_t)i];
+                    if ((a.second & 1) && seqs[a.first >> 1].n && seqs[a.second >> 1].n) {
+                        int64_t cur = first_rev.load();
+                        while (i < cur && !first_rev.compare_exchange_weak(cur, i)) {}
+                        return;
+                    }
+                }
+                each(lo, hi, [&](uint32_t u, uint32_t) { __atomic_fetch_add(&cnt[(size_t)u + 1], 1, __ATOMIC_RELAXED); });
+            });
+            if (first_rev.load() != INT64_MAX) { side_rc = 3; side_sorted = (int32_t)(arcs[(size_t)first_rev.load()].second >> 1); return; }
             for (int32_t i = 0; i < n_seg; i++) cnt[(size_t)i + 1] += cnt[(size_t)i];
             std::vector<int32_t> tgt((size_t)cnt[(size_t)n_seg]);
-            std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
-            each([&](uint32_t u, uint32_t x) { tgt[(size_t)cur[u]++] = (int32_t)x; });
-            // duplicate links, and oriented targets that collapse onto one segment, are merged
-            g->adj_off.assign((size_t)n_seg + 1, 0);
-            int64_t o = 0;
-            for (int32_t u = 0; u < n_seg; u++) {
-                int32_t *b = tgt.data() + cnt[(size_t)u], *e = tgt.data() + cnt[(size_t)u + 1];
-                if (e - b > 1) { std::sort(b, e); e = std::unique(b, e); }
-                g->adj_off[(size_t)u] = o;
-                for (; b < e; b++) tgt[(size_t)o++] = *b;             // (o never passes the read position)
+            {
+                std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+                parallel_for(n_ach, [&](int64_t c) {
+                    each(c * ACH, std::min(n_arcs, (c + 1) * ACH), [&](uint32_t u, uint32_t x) { tgt[(size_t)__atomic_fetch_add(&cur[u], 1, __ATOMIC_RELAXED)] = (int32_t)x; });
+                });
             }
-            g->adj_off[(size_t)n_seg] = o;
-            tgt.resize((size_t)o);
-            g->adj.swap(tgt);
+            // duplicate links, and oriented targets that collapse onto one segment, are merged
+            const int64_t VCH = 1 << 16, n_vch = ((int64_t)n_seg + VCH - 1) / VCH;
+            std::vector<int32_t> deg((size_t)n_seg, 0);
+            parallel_for(n_vch, [&](int64_t c) {
+                for (int64_t u = c * VCH, ue = std::min<int64_t>(n_seg, u + VCH); u < ue; u++) {
+                    int32_t *b = tgt.data() + cnt[(size_t)u], *e = tgt.data() + cnt[(size_t)u + 1];
+                    if (e - b > 1) { std::sort(b, e); e = std::unique(b, e); }
+                    deg[(size_t)u] = (int32_t)(e - b);
+                }
+            });
+            g->adj_off.assign((size_t)n_seg + 1, 0);
+            for (int32_t u = 0; u < n_seg; u++) g->adj_off[(size_t)u + 1] = g->adj_off[(size_t)u] + deg[(size_t)u];
+            g->adj.resize((size_t)g->adj_off[(size_t)n_seg]);
+            parallel_for(n_vch, [&](int64_t c) {
+                for (int64_t u = c * VCH, ue = std::min<int64_t>(n_seg, u + VCH); u < ue; u++)
+                    if (deg[(size_t)u]) memcpy(g->adj.data() + g->adj_off[(size_t)u], tgt.data() + cnt[(size_t)u], (size_t)deg[(size_t)u] * 4);
+            });
         }
+        ts.lap("  [side thread] adjacency");
         // Kahn's algorithm, FIFO
         {
             std::vector<int32_t> indeg((size_t)n_seg, 0), q((size_t)n_seg);
@@ -552,6 +696,7 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
             }
             if (head != n_seg) { side_rc = 2; side_sorted = head; return; }
         }
+        ts.lap("  [side thread] topological order");
     });
     struct Joiner { std::thread &t; bool &done; ~Joiner() { if (!done && t.joinable()) t.join(); } } joiner{side, side_joined};
 
@@ -565,6 +710,7 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
         if (g->name_index_ok) g->num2id = table.direct();
     } else if (const int wrc = resolve_walks(*stp, g, tm, err, err_cap)) {
         side.join();
+        side_copy.join();
         delete g;
         return wrc;
     }
@@ -572,6 +718,8 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
     // ---- what the side thread made meanwhile
     side.join();
     side_joined = true;
+    side_copy.join();
+    if (copy_rc) side_rc = 1;
     if (side_rc == 1) { delete g; return fail(err, err_cap, PHI_HOST_ERR_INVALID, "out of memory"); }
     if (side_rc == 3) {
         const std::string nm(g->name_arena.data() + g->name_off[(size_t)side_sorted]);
@@ -590,6 +738,10 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
         tm.lap("wait for the walk text's consumer");
         g->state = stp;
         stp = nullptr;
+    } else {
+        g->state = stp;
+        stp = nullptr;
+        g->let_state_go();
     }
     *out = g;
     return PHI_HOST_OK;
@@ -769,8 +921,7 @@ int phi_graph_resolve_walks(phi_graph *g, char *err, int err_cap)
     if (!g || !g->state) return fail(err, err_cap, PHI_HOST_ERR_INVALID, "the walks of this graph are resolved already");
     StageTimer tm;
     const int rc = resolve_walks(*g->state, g, tm, err, err_cap);
-    delete g->state;
-    g->state = nullptr;
+    g->let_state_go();
     return rc;
 }
 int phi_graph_set_walk_off(phi_graph *g, const int64_t *walk_off)
@@ -778,8 +929,7 @@ int phi_graph_set_walk_off(phi_graph *g, const int64_t *walk_off)
     if (!g || !g->state || !walk_off) return PHI_HOST_ERR_INVALID;
     const size_t n = g->state->walks.size();
     g->walk_off.assign(walk_off, walk_off + n + 1);
-    delete g->state;                                   // (the mapping of the file goes with it)
-    g->state = nullptr;
+    g->let_state_go();
     return PHI_HOST_OK;
 }
 

@@ -635,6 +635,19 @@ static int run(const Options &o)
                 n_chunks.load(), (long long)chunk_bytes, n_chunks >= 2 && pinned ? ", pinned" : "", n_dev, (long long)host_parsed_bases, realtime(),
                 o.detached ? "; teardown detached" : "");
         g_marks.print();
+        // what the peak is made of: the mapped GFA file's own pages count as resident (RssFile / RssShmem), anonymous memory is the rest
+        if (FILE *fp = fopen("/proc/self/status", "r")) {
+            char line[256];
+            long hwm = -1, anon = -1, file = -1, shm = -1;
+            while (fgets(line, sizeof line, fp)) {
+                if (!strncmp(line, "VmHWM:", 6)) hwm = atol(line + 6);
+                else if (!strncmp(line, "RssAnon:", 8)) anon = atol(line + 8);
+                else if (!strncmp(line, "RssFile:", 8)) file = atol(line + 8);
+                else if (!strncmp(line, "RssShmem:", 9)) shm = atol(line + 9);
+            }
+            fclose(fp);
+            fprintf(stderr, "[phi timing] main: resident now: anonymous %.3f GB, mapped files %.3f GB (the GFA among them); peak %.3f GB\n", anon / 1048576.0, (file + shm) / 1048576.0, hwm / 1048576.0);
+        }
     }
     if (!res.optimal) {
         // the reference returns only what model.optimize() proved (ILP_index.cpp:1418); here that can only fall short when

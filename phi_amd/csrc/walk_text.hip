@@ -308,8 +308,11 @@ int phi_walk_text_resolve(phi_ctx *c, const char *prefix, int32_t prefix_n, cons
         HIPCHK(hipGetLastError());
         tm.lap("names -> vertices");
     }
-    // the text has served
-    if (W.d_text.p) { (void)hipFree(W.d_text.p); W.d_text = DevBuf{}; }
+    // The text has served.  Its buffer stays with the context (the next upload takes it again; phi_walk_text_upload(ctx, NULL, 0),
+    // PHI_WALK_TEXT_FREE=1 or the context's end let it go): the driver hands freed device memory out again only once it has
+    // cleared it, and with these 10 GB freed here phi_solve's large allocations waited 0.25 s at config 5 (solve 0.50 -> 0.75 s,
+    // four runs of each: profiles/README.md r04i).
+    if (getenv("PHI_WALK_TEXT_FREE") && W.d_text.p) { (void)hipFree(W.d_text.p); W.d_text = DevBuf{}; }
     W.ready = false;
     tm.lap("text let go");
     *irregular = flag;

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--runs", type=int, default=2)
     ap.add_argument("--out", default=None)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--gap", type=float, default=4.0, help="seconds between runs: the driver clears the 65 GB of HBM the last process gave back before it hands "
+                    "them out again, and a process that starts within a second of the last one's end waits ~1 s in one of its large allocations "
+                    "(r04i: PHI_TIMING_ALLOC=1 shows one hipMalloc of 11.4 GB taking 0.26 ms or 1 s, in alternate runs 1 s apart)")
     args = ap.parse_args()
     sys.path.insert(0, ROOT)
     import bench
@@ -55,7 +58,7 @@ def main():
         phi = os.path.join(ROOT, "phi_amd", "PHI")
         runs = []
         for i in range(args.runs):
-            time.sleep(1.0)                                    # (one process per run since round 4: when the command returns its 65 GB of HBM are free)
+            time.sleep(args.gap)
             t_spawn = time.time()
             t0 = time.perf_counter()
             r = subprocess.run([phi, "-g", gfa, "-r", rd, "-o", fa], capture_output=True, text=True, env=dict(os.environ, PHI_TIMING="1"))
@@ -64,14 +67,16 @@ def main():
             log = [l for l in r.stderr.splitlines() if not l.startswith("syn")]
             rec = {"rc": r.returncode, "wall_s": dt, "spawn_to_fasta_closed_s": info.get("fasta_closed_epoch", t_spawn + dt) - t_spawn,
                    "stages_s": {k: v for k, v in stages.items() if k != "detail"}, "detail_ms": stages.get("detail", {}),
-                   "log": [l for l in log if not l.startswith("[phi timing] main: stage")][-60:]}
+                   "log": [l for l in log if not l.startswith("[phi timing] main: stage")][-160:]}
             for l in log:
                 if "Real time" in l:
                     rec["phi_line"] = l
+                if "resident now" in l:
+                    rec["resident"] = l.split("main: ", 1)[1]
                 if l.startswith("Recombined haplotypes"):
                     rec["recombined"] = l[:300]
             runs.append(rec)
-            print(json.dumps({k: rec.get(k) for k in ("rc", "wall_s", "spawn_to_fasta_closed_s", "phi_line", "stages_s")}), flush=True)
+            print(json.dumps({k: rec.get(k) for k in ("rc", "wall_s", "spawn_to_fasta_closed_s", "phi_line", "resident", "stages_s")}), flush=True)
             if r.returncode != 0:
                 print(r.stderr[-3000:])
                 break

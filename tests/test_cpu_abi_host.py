@@ -521,3 +521,48 @@ def test_gzip_inputs_plain_block_and_concatenated(built, oracle, tmp_path, monke
     for name in ("seq_off", "adj_off", "adj", "walk_off", "walk_vtx", "top_order_map"):
         assert np.array_equal(getattr(g1, name), getattr(g2, name)), name
     assert bytes(g1.seq_concat) == bytes(g2.seq_concat) and list(g1.hap_id2name) == list(g2.hap_id2name)
+
+
+@pytest.mark.parametrize("env", [{"PHI_GFA_SLICE": "64"}, {"PHI_GFA_SLICE": "5000", "PHI_HOST_THREADS": "3"}, {"PHI_GFA_NAMES_SERIAL": "1"}])
+def test_host_gfa_reader_slices_and_name_entry(built, monkeypatch, env):
+    """The reader cuts the text fine among short lines and coarse among long ones, and enters <prefix><number> segment names
+    on all threads at once: whatever the cuts, and with the names entered one by one instead, the graph is the same."""
+    from phi_amd import ilp_index as H
+    path = os.path.join(DATA, "MHC_4.gfa.gz")
+    want = H.Graph(path)
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    g = H.Graph(path)
+    assert g.hap_id2name == want.hap_id2name and g.seg_names == want.seg_names
+    for f in ("seq_off", "seq_concat", "adj_off", "adj", "walk_off", "walk_vtx", "top_order_map"):
+        assert np.array_equal(getattr(g, f), getattr(want, f)), f
+
+
+def test_deferred_walks_resolved_by_the_host_after_all(built, tmp_path):
+    """phi_gfa_read_deferred + phi_graph_resolve_walks == phi_gfa_read (what a caller does when the walk text is not of the
+    kind the device takes); the walk texts it hands out are the W-lines' walk fields (tags included: the device cuts them)."""
+    from phi_amd import ilp_index as H
+    import ctypes as C
+    for name in ("test.gfa", "MHC_4.gfa.gz"):
+        path = os.path.join(DATA, name)
+        want = H.Graph(path)
+        g = H.DeferredGraph(path)
+        assert g.walk_off is None and g.num_walks == want.num_walks
+        texts = g.walk_texts()
+        assert len(texts) == want.num_walks
+        for (addr, n), h in zip(texts, range(want.num_walks)):
+            txt = C.string_at(addr, n).decode()
+            assert txt.count(">") + txt.count("<") == want.walk_off[h + 1] - want.walk_off[h]
+        g.resolve_on_host()
+        for f in ("seq_off", "seq_concat", "adj_off", "adj", "walk_off", "walk_vtx", "top_order_map"):
+            assert np.array_equal(getattr(g, f), getattr(want, f)), f
+        assert g.hap_id2name == want.hap_id2name
+    # a walk error comes out of the deferred resolution as it does out of phi_gfa_read
+    p = tmp_path / "rev.gfa"
+    p.write_text("S\ts1\tACGT\nS\ts2\tGGA\nS\ts3\tTT\nL\ts1\t+\ts2\t+\t0M\nL\ts2\t+\ts3\t+\t0M\nW\ta\t0\tc\t0\t1\t>s1>s2>s3\nW\tb\t0\tc\t0\t1\t>s1<s2>s3\n")
+    with pytest.raises(H.HostError) as e1:
+        H.Graph(str(p))
+    g = H.DeferredGraph(str(p))
+    with pytest.raises(H.HostError) as e2:
+        g.resolve_on_host()
+    assert e1.value.args == e2.value.args
