@@ -16,7 +16,7 @@
  *     re-entrant either: src/main.cpp:136-140).
  *
  * Limits (PHI_ERR_UNSUPPORTED / PHI_ERR_INVALID beyond them): k <= 64 (k <= 32 on the fast 2-bit kernels; 33 .. 64 through
- * the exact byte-wise routine, and only while no k-mer covers more than 32 vertices), w <= 256, at most 512 walks,
+ * the exact byte-wise routine, and only while no k-mer covers more than 32 vertices), w <= 256, at most 1022 walks (one per lane of the largest workgroup: 513 and more run a slower instance of the dense DP kernel),
  * at most 2^32 - 64 walk entries (2.5 G solved: profiles/wide_entries.py), fewer than 2^31 minimisers of the distinct walk
  * contexts, anchors in the model and walk entries on vertices with recombination edges, at most
  * 254 out-edges and 255 recombination in-edges per vertex, no walk through a segment without

@@ -508,6 +508,99 @@ void phi_launch_class_sel_count(hipStream_t st, const uint8_t *sel, const int32_
     if (n_cls > 0) hipLaunchKernelGGL(phi_class_sel_count_kernel, dim3(grid_for(n_cls, 256)), dim3(256), 0, st, sel, cls_rec_off, n_cls, sel_cnt);
 }
 
+// ---- the anchors of the model, expanded from the SELECTED records only.
+// The generic expansion above walks every record of an entry's class and, per selected record, gathers its slot, the slot's
+// dense id and its two entry offsets from four arrays, then stores 12 bytes at a per-lane address: 62 ms for config 5's
+// 5.3 * 10^8 anchors (100 GB/s).  Here the selected records are first packed per class -- sel_off[c] .. sel_off[c + 1] into
+// sel_tri: (dense id, first entry - representative, last entry - representative), 4.5 M records = 54 MB, resident in the
+// Infinity Cache -- so that an entry costs two adjacent loads of sel_off and one 12-byte load per anchor, and a block's
+// anchors are staged in LDS and leave as whole cache lines.
+__global__ void __launch_bounds__(256) phi_class_sel_tri_kernel(const uint8_t *__restrict__ sel, const int32_t *__restrict__ cls_rec_off, int64_t n_cls,
+                                                                const int32_t *__restrict__ sel_off, const phi_ent_t *__restrict__ cls_rep,
+                                                                const uint32_t *__restrict__ rec_slot, const uint32_t *__restrict__ u_uid,
+                                                                const phi_ent_t *__restrict__ rec_e0, const phi_ent_t *__restrict__ rec_e1,
+                                                                int32_t *__restrict__ sel_tri)
+{
+    GRID_STRIDE(c, n_cls) {
+        int64_t o = sel_off[c];
+        if (sel_off[c + 1] == o) continue;
+        const int64_t rep = cls_rep[c];
+        for (int32_t r = cls_rec_off[c]; r < cls_rec_off[c + 1]; r++) {
+            if (!sel[r]) continue;
+            sel_tri[3 * o + 0] = (int32_t)u_uid[rec_slot[r]];
+            sel_tri[3 * o + 1] = (int32_t)((int64_t)rec_e0[r] - rep);
+            sel_tri[3 * o + 2] = (int32_t)((int64_t)rec_e1[r] - rep);
+            o++;
+        }
+    }
+}
+void phi_launch_class_sel_tri(hipStream_t st, const uint8_t *sel, const int32_t *cls_rec_off, int64_t n_cls, const int32_t *sel_off, const phi_ent_t *cls_rep,
+                              const uint32_t *rec_slot, const uint32_t *u_uid, const phi_ent_t *rec_e0, const phi_ent_t *rec_e1, int32_t *sel_tri)
+{
+    if (n_cls > 0)
+        hipLaunchKernelGGL(phi_class_sel_tri_kernel, dim3(grid_for(n_cls, 256)), dim3(256), 0, st, sel, cls_rec_off, n_cls, sel_off, cls_rep, rec_slot, u_uid,
+                           rec_e0, rec_e1, sel_tri);
+}
+
+#define EXP_STAGE 3072          // anchors of a block staged in LDS (36 KB); a block with more writes them directly
+__global__ void __launch_bounds__(256) phi_expand_tri_kernel(const int32_t *__restrict__ ent_cls, int64_t e_lo, int64_t e_hi,
+                                                             const int32_t *__restrict__ sel_off, const int32_t *__restrict__ sel_tri,
+                                                             const int64_t *__restrict__ block_off, uint32_t *__restrict__ out_tri)
+{
+    __shared__ int s_w[4];
+    __shared__ uint32_t s_out[EXP_STAGE * 3];
+    const int64_t base = e_lo + ((int64_t)blockIdx.x * 256 + threadIdx.x) * EXP_ITEMS;
+    int32_t lo[EXP_ITEMS], nn[EXP_ITEMS];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < EXP_ITEMS; j++) {
+        const int64_t e = base + j;
+        lo[j] = 0; nn[j] = 0;
+        if (e < e_hi) {
+            const int32_t c = ent_cls[e];
+            lo[j] = sel_off[c];
+            nn[j] = sel_off[c + 1] - lo[j];
+        }
+        cnt += nn[j];
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int v = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    if (lane == 63) s_w[wid] = v;
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < wid; i++) woff += s_w[i];
+    const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    int o = woff + v - cnt;                                       // this thread's first anchor inside the block
+    const int64_t gbase = block_off[blockIdx.x];
+    const bool staged = total <= EXP_STAGE;
+    uint32_t *dst = staged ? s_out : out_tri + 3 * gbase;
+#pragma unroll
+    for (int j = 0; j < EXP_ITEMS; j++) {
+        const uint32_t e = (uint32_t)(base + j);                  // (entries are below 2^32: phi_ent_t)
+        for (int32_t r = lo[j], re = lo[j] + nn[j]; r < re; r++, o++) {
+            const int32_t id = sel_tri[3 * (int64_t)r], d0 = sel_tri[3 * (int64_t)r + 1], d1 = sel_tri[3 * (int64_t)r + 2];
+            dst[3 * (int64_t)o + 0] = (uint32_t)id;
+            dst[3 * (int64_t)o + 1] = e + (uint32_t)d0;
+            dst[3 * (int64_t)o + 2] = e + (uint32_t)d1;
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    uint32_t *g = out_tri + 3 * gbase;
+    for (int i = threadIdx.x; i < 3 * total; i += 256) g[i] = s_out[i];
+}
+void phi_launch_expand_tri(hipStream_t st, const int32_t *ent_cls, int64_t e_lo, int64_t e_hi, const int32_t *sel_off, const int32_t *sel_tri,
+                           const int64_t *block_off, uint32_t *out_tri)
+{
+    const int64_t nb = phi_expand_num_blocks(e_hi - e_lo);
+    if (nb > 0) hipLaunchKernelGGL(phi_expand_tri_kernel, dim3((unsigned)nb), dim3(256), 0, st, ent_cls, e_lo, e_hi, sel_off, sel_tri, block_off, out_tri);
+}
+
 // sel[r] = 1 for the listed records (list of indices into the class records)
 __global__ void __launch_bounds__(256) phi_mark_list_kernel(const int32_t *__restrict__ list, const int32_t *__restrict__ through, int64_t n,
                                                             uint8_t *__restrict__ sel)

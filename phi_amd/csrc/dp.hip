@@ -31,6 +31,7 @@
 //     register prefetch "four entries ahead" made every step wait for the load it had just
 //     issued -- vmcnt counts in order -- and cost 0.67 us per step).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "phi_kernels.h"
 
 #define NEG (-(1 << 28))
@@ -101,15 +102,22 @@ template <int NW>   // waves in the workgroup
 __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
 {
     constexpr int NT = NW * 64;
+    // Sixteen waves (513..1022 walks: the workgroup is the largest the hardware runs, a walk id has 10 bits in the packed tops):
+    // the difference ring alone is 128 of the 160 KB of LDS, so the entry words come straight from HBM (no per-lane ring), the
+    // step stream is staged in shorter chunks and fewer recent steps keep their leaving states in LDS.  Slower per step; the
+    // same transitions, tie-breaks and outputs.
+    constexpr bool WORDS_IN_LDS = NW < 16;
     constexpr int WD = NW == 1 ? 64 : NW == 2 ? 32 : NW == 4 ? 16 : 4;   // per-lane ring of entry words
     constexpr int WP = WD / 2;                                           // refill period in steps
-    __shared__ int4 s_rec[2][CHK][2];
-    __shared__ unsigned long long s_mask[2][CHK][NW];
+    constexpr int CK = NW == 16 ? 32 : CHK;
+    constexpr int RG = NW == 16 ? 256 : RING;
+    __shared__ int4 s_rec[2][CK][2];
+    __shared__ unsigned long long s_mask[2][CK][NW];
     __shared__ int32_t s_d[32][NT];                 // difference ring, slot-major: bank = lane
-    __shared__ int4 s_top[RING];                    // packed tops of recent steps
+    __shared__ int4 s_top[RG];                      // packed tops of recent steps
     __shared__ unsigned long long s_red[NW > 1 ? NW : 1];
     __shared__ int32_t s_oidx[NT];
-    __shared__ uint64_t s_w[WD][NT];
+    __shared__ uint64_t s_w[WORDS_IN_LDS ? WD : 1][WORDS_IN_LDS ? NT : 1];
 
     const int h = threadIdx.x;
     const int lane = h & 63, wid = h >> 6;
@@ -127,11 +135,13 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
     uint64_t wtmp[WP];
     int64_t whi = eb;
     auto issue = [&]() {
+        if (!WORDS_IN_LDS) return;
         whi = min(ee, e + WD);
 #pragma unroll
         for (int j = 0; j < WP; j++) wtmp[j] = A.word[has_walk ? min(wl + j, ee - 1) : 0];
     };
     auto land = [&]() {
+        if (!WORDS_IN_LDS) return;
 #pragma unroll
         for (int j = 0; j < WP; j++) {
             const int64_t x = wl + j;
@@ -142,17 +152,17 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
     issue(); land();
     issue(); land();
     // per-lane values of the NEXT entry, read right after the previous one was processed
-    uint64_t nword = has_walk ? s_w[e & (WD - 1)][h] : 0;
+    uint64_t nword = !has_walk ? 0 : WORDS_IN_LDS ? s_w[e & (WD - 1)][h] : A.word[e];
     int32_t nold = 0;
 
     const int32_t n_steps = A.n_vtx;
-    const int n_chunks = (n_steps + CHK - 1) / CHK;
+    const int n_chunks = (n_steps + CK - 1) / CK;
 
     // stage chunk c of the step stream into LDS buffer c&1
     auto stage = [&](int c) {
         const int b = c & 1;
-        const int32_t s0 = c * CHK;
-        const int32_t ns = min(CHK, n_steps - s0);
+        const int32_t s0 = c * CK;
+        const int32_t ns = min(CK, n_steps - s0);
         const int4 *src = reinterpret_cast<const int4 *>(A.st_rec + (int64_t)s0 * 8);
         int4 *dst = &s_rec[b][0][0];
         for (int i = h; i < ns * 2; i += NT) dst[i] = src[i];
@@ -166,13 +176,13 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
     for (int c = 0; c < n_chunks; c++) {
         const int b = c & 1;
         if (c + 1 < n_chunks) stage(c + 1);          // lands while this chunk is processed
-        const int32_t s0 = c * CHK;
-        const int32_t ns = min(CHK, n_steps - s0);
+        const int32_t s0 = c * CK;
+        const int32_t ns = min(CK, n_steps - s0);
         // the step record travels one step ahead in registers
         int4 ra = s_rec[b][0][0], rb = s_rec[b][0][1];
         unsigned long long mk = s_mask[b][0][wid];
         for (int i = 0; i < ns; i++) {
-            const int inx = min(i + 1, CHK - 1);
+            const int inx = min(i + 1, CK - 1);
             const int4 na = s_rec[b][inx][0], nb = s_rec[b][inx][1];
             const unsigned long long nm = s_mask[b][inx][wid];
             if ((c | i) && (i & (WP - 1)) == 0) issue();
@@ -193,11 +203,11 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
                     if (val > E || (val == E && (hh < Eh || (hh == Eh && src < Esrc)))) { E = val; Eh = hh; Esrc = src; }
                 };
                 const uint32_t b0 = (uint32_t)ra.z >> 8, b1 = (uint32_t)ra.w >> 8, b2 = (uint32_t)rb.x >> 8;
-                if (n_in <= 3 && (b0 | b1 | b2) < RING) {
+                if (n_in <= 3 && (b0 | b1 | b2) < RG) {
                     // usual case: all sources in the LDS ring, the three look-ups in flight together
-                    const int4 q0 = s_top[(step - b0) & (RING - 1)];
-                    const int4 q1 = s_top[(step - b1) & (RING - 1)];
-                    const int4 q2 = s_top[(step - b2) & (RING - 1)];
+                    const int4 q0 = s_top[(step - b0) & (RG - 1)];
+                    const int4 q1 = s_top[(step - b1) & (RG - 1)];
+                    const int4 q2 = s_top[(step - b2) & (RG - 1)];
                     consider(q0, ra.z & 0xFF, step - (int32_t)b0);
                     if (n_in > 1) consider(q1, ra.w & 0xFF, step - (int32_t)b1);
                     if (n_in > 2) consider(q2, rb.x & 0xFF, step - (int32_t)b2);
@@ -206,7 +216,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
                         const int32_t p = j == 0 ? ra.z : j == 1 ? ra.w : j == 2 ? rb.x : A.in_packed[ra.y + j - 3];
                         const int32_t back = (int32_t)((uint32_t)p >> 8);
                         const int32_t src = step - back;
-                        const int4 q = back < RING ? s_top[src & (RING - 1)]
+                        const int4 q = back < RG ? s_top[src & (RG - 1)]
                                                    : reinterpret_cast<const int4 *>(A.tops)[src];
                         consider(q, p & 0xFF, src);
                     }
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
                 }
                 e++;
                 // the next entry's word and expiring slot: in flight until this lane is active again
-                nword = s_w[e & (WD - 1)][h];
+                nword = WORDS_IN_LDS ? s_w[e & (WD - 1)][h] : A.word[min(e, ee - 1)];
                 nold = s_d[s2][h];
             }
 
@@ -324,7 +334,7 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
                 }
                 if (h == 0) {
                     const int4 q = pack_tops(t1v, t1h, t1n, t2v, t2h);
-                    s_top[step & (RING - 1)] = q;
+                    s_top[step & (RG - 1)] = q;
                     reinterpret_cast<int4 *>(A.tops)[step] = q;
                 }
                 if (NW > 1) __syncthreads();             // ring entry visible to the other waves
@@ -336,19 +346,22 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_kernel(PhiDpArgs A)
     }
 }
 
-void phi_launch_dp(hipStream_t st, const PhiDpArgs &A)
-{
-    const int nw = (A.n_walks + 63) / 64;
-    if (nw <= 1) hipLaunchKernelGGL(phi_dp_kernel<1>, dim3(1), dim3(64), 0, st, A);
-    else if (nw <= 2) hipLaunchKernelGGL(phi_dp_kernel<2>, dim3(1), dim3(128), 0, st, A);
-    else if (nw <= 4) hipLaunchKernelGGL(phi_dp_kernel<4>, dim3(1), dim3(256), 0, st, A);
-    else hipLaunchKernelGGL(phi_dp_kernel<8>, dim3(1), dim3(512), 0, st, A);     // n_walks <= PHI_DP_MAX_WALKS
-}
-
 int phi_dp_num_waves(int n_walks)
 {
     const int nw = (n_walks + 63) / 64;
-    return nw <= 1 ? 1 : nw <= 2 ? 2 : nw <= 4 ? 4 : 8;
+    const int forced = getenv("PHI_DP_WAVES") ? atoi(getenv("PHI_DP_WAVES")) : 0;      // (tests: the sixteen-wave instance on few walks)
+    if (forced == 16) return 16;
+    return nw <= 1 ? 1 : nw <= 2 ? 2 : nw <= 4 ? 4 : nw <= 8 ? 8 : 16;
+}
+
+void phi_launch_dp(hipStream_t st, const PhiDpArgs &A)
+{
+    const int nw = phi_dp_num_waves(A.n_walks);          // (the step stream's masks are laid out for this many waves)
+    if (nw == 1) hipLaunchKernelGGL(phi_dp_kernel<1>, dim3(1), dim3(64), 0, st, A);
+    else if (nw == 2) hipLaunchKernelGGL(phi_dp_kernel<2>, dim3(1), dim3(128), 0, st, A);
+    else if (nw == 4) hipLaunchKernelGGL(phi_dp_kernel<4>, dim3(1), dim3(256), 0, st, A);
+    else if (nw == 8) hipLaunchKernelGGL(phi_dp_kernel<8>, dim3(1), dim3(512), 0, st, A);
+    else hipLaunchKernelGGL(phi_dp_kernel<16>, dim3(1), dim3(1024), 0, st, A);   // n_walks <= PHI_DP_MAX_WALKS
 }
 
 // One empty launch loads this translation unit's code object onto the device: the HIP runtime does that lazily, at the

@@ -429,7 +429,7 @@ void phi_ctx_destroy(phi_ctx *c)
     (void)phi_ipc_destroy(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->d_anchors, &c->d_cov_all, &c->d_cov_w, &c->d_slots, &c->d_slots2, &c->d_segs, &c->d_ctr, &c->d_vmax, &c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_seg_lo, &c->d_seg_row, &c->d_seg_S, &c->wtext.d_text, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.hit, &c->hit_extra[0], &c->hit_extra[1], &c->alt.stripes, &c->d_sp_cnt, &c->d_novlog, &c->d_novcnt, &c->d_ovlist, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
+    DevBuf *all[] = {&c->d_anchors, &c->d_cov_all, &c->d_cov_w, &c->d_slots, &c->d_slots2, &c->d_segs, &c->d_ctr, &c->d_vmax, &c->d_lane_walk, &c->d_walk_lane, &c->d_coff, &c->d_blk_ncls, &c->d_rownew, &c->d_blk_bad, &c->d_seg_lo, &c->d_seg_row, &c->d_seg_S, &c->wtext.d_text, &c->d_sel_off, &c->d_sel_tri, &c->d_blk_lo, &c->d_blk_ev, &c->d_blk_S, &c->d_row_out, &c->d_rowend, &c->d_blk_keys, &c->d_blk_carry, &c->d_cov, &c->d_cov2, &c->d_stepdiff, &c->alt.hit, &c->hit_extra[0], &c->hit_extra[1], &c->alt.stripes, &c->d_sp_cnt, &c->d_novlog, &c->d_novcnt, &c->d_ovlist, &c->d_vlen, &c->d_ent_cls, &c->d_cls_rep, &c->d_cls_left, &c->d_cls_mult, &c->d_cls_base, &c->d_cls_rec_off, &c->d_rec_cls, &c->d_rec_rel, &c->d_u_replist, &c->d_adj_off, &c->d_adj, &c->d_topo_rank, &c->d_cnt_edge, &c->d_walk_err, &c->d_sa_cnt, &c->d_sa_cur, &c->d_sa_off, &c->d_sa_idx, &c->d_seq, &c->d_seq_off, &c->d_walk_vtx, &c->d_walk_off, &c->d_topo, &c->d_in_off,
                      &c->d_in_src, &c->d_e_out, &c->d_st_rec, &c->d_st_mask, &c->d_in_packed, &c->d_word, &c->d_wwords, &c->d_wbad,
                      &c->d_wascii, &c->d_wstarts, &c->d_rec_hash, &c->d_rec_pos, &c->d_rec_slot,
                      &c->d_rec_e0, &c->d_rec_e1, &c->d_u_keys, &c->d_u_rep, &c->d_u_uid, &c->d_u_kv, &c->d_in_s, &c->d_last_walk, &c->d_rowdiag, &c->d_wpre, &c->d_hit, &c->d_sp_keys, &c->d_rbases,

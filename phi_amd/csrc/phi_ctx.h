@@ -190,6 +190,7 @@ struct phi_ctx {
 
     // ---- scratch for sketch passes and compaction
     DevBuf d_blk_cnt, d_blk_off, d_flags, d_flags2, d_list, d_list2, d_list3, d_walk_last;
+    DevBuf d_sel_off, d_sel_tri;                       // the filter's selected class records, packed per class (phi_solve: the anchors are expanded from these)
     DevBuf d_adj_off, d_adj, d_topo_rank, d_cnt_edge, d_walk_err;   // the walk-entry pass on the GPU (phi_walk_edges_kernel)
     DevBuf d_sa_cnt, d_sa_cur, d_sa_off, d_sa_idx;    // minimiser -> anchors CSR, built on the GPU
 

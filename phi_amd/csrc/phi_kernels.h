@@ -183,6 +183,10 @@ int64_t phi_expand_num_blocks(int64_t n_entries);
 void phi_launch_expand_count(hipStream_t st, const PhiExpandArgs &A);
 void phi_launch_expand_write(hipStream_t st, const PhiExpandArgs &A, int kind);
 void phi_launch_class_sel_count(hipStream_t st, const uint8_t *sel, const int32_t *cls_rec_off, int64_t n_cls, int32_t *sel_cnt);
+void phi_launch_class_sel_tri(hipStream_t st, const uint8_t *sel, const int32_t *cls_rec_off, int64_t n_cls, const int32_t *sel_off, const phi_ent_t *cls_rep,
+                              const uint32_t *rec_slot, const uint32_t *u_uid, const phi_ent_t *rec_e0, const phi_ent_t *rec_e1, int32_t *sel_tri);
+void phi_launch_expand_tri(hipStream_t st, const int32_t *ent_cls, int64_t e_lo, int64_t e_hi, const int32_t *sel_off, const int32_t *sel_tri,
+                           const int64_t *block_off, uint32_t *out_tri);
 void phi_launch_mark_list(hipStream_t st, const int32_t *list, const int32_t *through, int64_t n, uint8_t *sel);
 void phi_launch_share_count_cls(hipStream_t st, const int32_t *ent_cls, int64_t e_lo, int64_t e_hi, const int32_t *cls_rec_off,
                                 const uint32_t *rec_slot, int32_t walk, int32_t *last_walk, int32_t *n_walks_of);
@@ -233,7 +237,7 @@ void phi_launch_entry_csr(hipStream_t st, const phi_ent_t *a_e1, int64_t n_a, in
 #define PHI_DP_RING 2048        // steps whose leaving states are kept in LDS
 #define PHI_DP_NEED_ENTRY 1     // step flag: a recombination can enter this vertex
 #define PHI_DP_NEED_TOPS 2      // step flag: a recombination can leave this vertex
-#define PHI_DP_MAX_WALKS 512
+#define PHI_DP_MAX_WALKS 1022       // one walk per lane of sixteen waves; a walk id + 1 has 10 bits in the packed tops
 
 struct PhiDpArgs {
     int32_t n_vtx, n_walks;

@@ -633,9 +633,21 @@ int phi_solve_impl(phi_ctx *c)
         c->h_kept_hash.clear();
         PHICHK(phi_dev_ensure(c, c->d_anchors, (size_t)std::max<int64_t>(n_kept, 1) * 12));
         static_assert(sizeof(PhiAnchorHost) == 12, "PhiAnchorHost is the device triple");
-        if (n_kept) {
+        if (n_kept && getenv("PHI_EXPAND_GENERIC")) {               // (tests: the generic expansion, record by record)
             X.out_tri = c->d_anchors.as<uint32_t>();
             phi_launch_expand_write(c->stream, X, 1);
+        } else if (n_kept) {
+            // the selected records packed per class, then the anchors from those alone (contexts.hip)
+            PHICHK(phi_dev_ensure(c, c->d_sel_off, (size_t)(c->n_cls + 1) * 4));
+            PHICHK(phi_dev_ensure(c, c->d_sel_tri, (size_t)std::max<int64_t>(n_kept_rec, 1) * 12));
+            const int64_t nsb = phi_scan_i32_num_blocks(c->n_cls);
+            PHICHK(phi_dev_ensure(c, c->d_scan_blk, (size_t)nsb * 4));
+            PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nsb + 1) * 8));
+            phi_launch_scan_i32(c->stream, c->d_list3.as<int32_t>(), c->n_cls, c->d_sel_off.as<int32_t>(), c->d_scan_blk.as<int32_t>(), c->d_scan_blkoff.as<int64_t>());
+            phi_launch_class_sel_tri(c->stream, c->d_flags2.as<uint8_t>(), c->d_cls_rec_off.as<int32_t>(), c->n_cls, c->d_sel_off.as<int32_t>(), c->d_cls_rep.as<phi_ent_t>(),
+                                     c->d_rec_slot.as<uint32_t>(), c->d_u_uid.as<uint32_t>(), c->d_rec_e0.as<phi_ent_t>(), c->d_rec_e1.as<phi_ent_t>(), c->d_sel_tri.as<int32_t>());
+            phi_launch_expand_tri(c->stream, c->d_ent_cls.as<int32_t>(), 0, c->n_entries, c->d_sel_off.as<int32_t>(), c->d_sel_tri.as<int32_t>(),
+                                  c->d_blk_off.as<int64_t>(), c->d_anchors.as<uint32_t>());
         }
     }
     // The DP's per-anchor arrays (last entry, span), the anchors per walk and the checks on them, on the device.

@@ -491,9 +491,10 @@ def test_pooled_read_kernel_on_small_batches(oracle, ctx_factory, monkeypatch, w
         _check_against_oracle(oracle, ctx, g, reads, k, w, 1.0, 5)
 
 
-@pytest.mark.parametrize("n_walks", [70, 130, 300])
+@pytest.mark.parametrize("n_walks", [70, 130, 300, 600, 1022])
 def test_more_than_64_walks_vs_highs(oracle, ctx_factory, n_walks):
-    """lane <-> walk: more than 64 walks take the multi-wave instances of the DP kernel.  Brute
+    """lane <-> walk: more than 64 walks take the multi-wave instances of the DP kernel (600 and 1 022: the sixteen-wave
+    instance, whose entry words come from HBM and whose LDS rings are shorter).  Brute
     force is out of reach with this many labels; the objective is checked against HiGHS on the
     reference's restated -q0 program (oracle/solve_oracle.py build_milp)."""
     rng = np.random.default_rng(1000 + n_walks)
@@ -507,6 +508,18 @@ def test_more_than_64_walks_vs_highs(oracle, ctx_factory, n_walks):
     assert res["objective"] < res["n_in_model"]          # switching costs bite
     best, _, _ = m.milp_solve(time_limit=120.0)
     assert res["objective"] == best, (n_walks, res["objective"], best)
+
+
+def test_more_walks_than_the_largest_workgroup_has_lanes_are_refused(ctx_factory):
+    """1 023 walks: one more than a walk id has room for in the DP's packed tops -- PHI_ERR_UNSUPPORTED with a message, at
+    phi_set_graph (the reference has no limit: include/phi_amd.h says so)."""
+    import phi_amd
+    rng = np.random.default_rng(77)
+    g = random_graph(rng, n_sites=3, n_walks=1023, seg_len=(6, 12), alt_len=(2, 5), p_del=0.3)
+    ctx = ctx_factory(k=5, w=2, threshold=0.6, recombination=4)
+    with pytest.raises(phi_amd.PhiError) as e:
+        _set_graph(ctx, g)
+    assert "more than 1022 walks" in str(e.value)
 
 
 def test_dense_and_event_dp_agree(oracle, ctx_factory, monkeypatch):
@@ -528,6 +541,58 @@ def test_dense_and_event_dp_agree(oracle, ctx_factory, monkeypatch):
     monkeypatch.delenv("PHI_DP_DENSE")
     for R in (0, 3, 100):
         assert out[("events", R)] == out[("dense", R)], (R, out)
+
+
+@pytest.mark.parametrize("k,w,seg_len", [(9, 2, (8, 16)), (15, 8, (3, 25))])
+def test_anchors_from_packed_selected_records_equal_the_generic_expansion(oracle, ctx_factory, monkeypatch, k, w, seg_len):
+    """phi_solve expands the model's anchors from the filter's selected class records packed per class (a block's anchors
+    staged in LDS when they are at most 3 072, written directly otherwise: dense minimisers, k = 9 / w = 2, take the second
+    branch); PHI_EXPAND_GENERIC=1 walks every record of every entry's class as before.  Same anchors in the same order, and
+    the oracle's kept anchors."""
+    rng = np.random.default_rng(6100 + k)
+    g = random_graph(rng, n_sites=1500, n_walks=20, seg_len=seg_len, alt_len=(1, 12), p_del=0.2)
+    reads = mosaic_reads(rng, g, n_reads=1200, read_len=100, n_seg=5, err=0.01)
+    got = {}
+    for mode in ("packed", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("PHI_EXPAND_GENERIC", "1")
+        ctx = ctx_factory(k=k, w=w, threshold=0.8, recombination=10)
+        _set_graph(ctx, g)
+        ctx.add_reads(reads)
+        res = ctx.solve()
+        got[mode] = (ctx.kept_anchors(), res["objective"], res["n_anchors"].tolist())
+        monkeypatch.delenv("PHI_EXPAND_GENERIC", raising=False)
+        if mode == "packed":
+            _check_against_oracle(oracle, ctx, g, reads, k, w, 0.8, 10)
+    for a, b in zip(got["packed"][0], got["generic"][0]):
+        assert np.array_equal(a, b)
+    assert got["packed"][1:] == got["generic"][1:]
+    assert len(got["packed"][0][0]) > 20000
+
+
+def test_sixteen_wave_dense_dp_agrees_with_the_event_dp(oracle, ctx_factory, monkeypatch):
+    """The dense kernel's sixteen-wave instance (513..1022 walks: entry words from HBM, step stream in chunks of 32, the last
+    256 steps' leaving states in LDS and older ones from HBM) forced onto a graph of thousands of vertices and 100 walks
+    (PHI_DP_WAVES=16 lays the step masks out for sixteen waves too): the event DP's objective, a feasible path."""
+    rng = np.random.default_rng(9103)
+    g = random_graph(rng, n_sites=1500, n_walks=100, seg_len=(3, 25), alt_len=(1, 12), p_del=0.2)
+    reads = mosaic_reads(rng, g, n_reads=1200, read_len=100, n_seg=5, err=0.01)
+    k, w = 15, 8
+    out = {}
+    for R in (2, 40):
+        for mode in ("events", "dense16"):
+            if mode == "dense16":
+                monkeypatch.setenv("PHI_DP_DENSE", "1")
+                monkeypatch.setenv("PHI_DP_WAVES", "16")
+            ctx = ctx_factory(k=k, w=w, threshold=0.8, recombination=R)
+            _set_graph(ctx, g)
+            ctx.add_reads(reads)
+            res = ctx.solve()
+            assert res["optimal"] == 1
+            out[(mode, R)] = (res["objective"], res["recombination_count"])
+            monkeypatch.delenv("PHI_DP_DENSE", raising=False)
+            monkeypatch.delenv("PHI_DP_WAVES", raising=False)
+        assert out[("events", R)][0] == out[("dense16", R)][0], (R, out)
 
 
 @pytest.mark.parametrize("seed,n_walks", [(1, 60), (2, 33), (3, 100), (4, 200), (5, 256)])
