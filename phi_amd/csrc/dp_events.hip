@@ -227,6 +227,12 @@ void phi_launch_scan_u8(hipStream_t st, const uint8_t *cnt, int64_t n, int32_t *
 //   32 B  G : byte a (1..30) = #{weight-1 anchors of the walk inside [entry - a, entry]}, byte 0 = 0,
 //             byte 31 = out-edge index of the entry (255: the walk ends here)
 // overflow: more than 255 anchors end inside the window (the DP then counts from the CSR).
+// The anchors an event looks at -- those ending on the 30 entries up to it (G, End) and on the 31 from it (SB) -- are ONE range
+// of the list sorted by last entry, and the ranges of a block's 256 consecutive events overlap almost entirely: the block loads
+// the union once, coalesced, into LDS (last entry; span | weight << 7) and every event counts from there.  (Round 3: every
+// event walked its ranges in global memory, three dependent loads per anchor and 24 anchors per event at config 5: 30 ms per
+// DP run.)  A block whose union is longer than the stage (events far apart along chain vertices) reads global memory as before.
+#define EVF_STAGE 6144
 __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const phi_ent_t *__restrict__ ev_e, int64_t n_ev,
                                                                 const int32_t *__restrict__ walk_vtx,
                                                                 const int32_t *__restrict__ cvtx,
@@ -239,8 +245,14 @@ __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const phi_ent_t 
                                                                 const int32_t *__restrict__ wpre, int64_t n_entries,
                                                                 uint4 *__restrict__ ev)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ev; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t e = ev_e[i];
+    __shared__ uint32_t s_e1[EVF_STAGE];
+    __shared__ uint8_t s_sw[EVF_STAGE];
+    __shared__ int64_t s_rng[2];
+    const int64_t n_blocks = (n_ev + 255) / 256;
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int64_t i = blk * 256 + threadIdx.x;
+        const bool in = i < n_ev;
+        const int64_t e = ev_e[in ? i : n_ev - 1];
         // walk of e: last h with walk_off[h] <= e.  Events are in entry order: nearly every wave lies inside one walk --
         // found once, for the wave's first event, on the scalar unit; the lanes search for themselves only when the wave
         // straddles walks (eight dependent loads per event otherwise, for 2.4 * 10^8 events per DP run at chromosome scale)
@@ -261,47 +273,69 @@ __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const phi_ent_t 
             }
         }
         const int64_t eb = walk_off[lo];
-        unsigned long long w[4] = {0, 0, 0, 0};
-        int total = 0;
         const int64_t x0 = e - 29 > eb ? e - 29 : eb;
+        const int64_t xe = e + 31 < n_entries ? e + 31 : n_entries;
         // the dp anchors are sorted by their last entry: those ending on the entries x0 .. e are ONE range of the list (two
-        // loads of the CSR instead of two per entry of the window)
-        const int64_t g_hi = g_off[e + 1];
-        for (int64_t g = g_off[x0]; g < g_hi; g++) {
-            if (!a_weight[g]) continue;
-            const int a = (int)(e - ((int64_t)a_e1[g] - g_span[g]));      // age a run needs to contain this anchor
-            if (a > 30) continue;
-            total++;
-            const unsigned long long one = 1ull << (8 * (a & 7));
-            if ((a >> 3) == 0) w[0] += one; else if ((a >> 3) == 1) w[1] += one; else if ((a >> 3) == 2) w[2] += one; else w[3] += one;
-        }
-        const bool ovf = total > 255;
-        // byte-wise inclusive prefix sums across the four words
-        unsigned long long carry = 0;
+        // loads of the CSR instead of two per entry of the window), those ending on e .. e + 30 another
+        const int64_t g_lo = g_off[x0], g_e = g_off[e], g_hi = g_off[e + 1], g_fe = g_off[xe];
+        if (threadIdx.x == 0) s_rng[0] = g_lo;                 // (both bounds grow with the event)
+        if (i == (n_ev < blk * 256 + 256 ? n_ev : blk * 256 + 256) - 1) s_rng[1] = g_fe;
+        __syncthreads();
+        const int64_t gb = s_rng[0], ge = s_rng[1];
+        const bool staged = ge - gb <= EVF_STAGE;
+        if (staged)
+            for (int64_t j = threadIdx.x; j < ge - gb; j += 256) {
+                s_e1[j] = a_e1[gb + j];
+                s_sw[j] = (uint8_t)(g_span[gb + j] | (a_weight[gb + j] ? 0x80 : 0));
+            }
+        __syncthreads();
+        if (in) {
+            unsigned long long w[4] = {0, 0, 0, 0};
+            int total = 0;
+            int32_t sb_extra = 0;
+            auto count = [&](int a) {                          // age a run needs to contain this anchor
+                if (a > 30) return;
+                total++;
+                const unsigned long long one = 1ull << (8 * (a & 7));
+                if ((a >> 3) == 0) w[0] += one; else if ((a >> 3) == 1) w[1] += one; else if ((a >> 3) == 2) w[2] += one; else w[3] += one;
+            };
+            const uint32_t e32 = (uint32_t)e;
+            if (staged) {
+                for (int64_t g = g_lo - gb; g < g_hi - gb; g++) {
+                    const uint32_t sw = s_sw[g];
+                    if (sw & 0x80) count((int)(e32 - (s_e1[g] - (sw & 0x7F))));
+                }
+                for (int64_t g = g_e - gb; g < g_fe - gb; g++) {
+                    const uint32_t sw = s_sw[g];
+                    sb_extra += (sw & 0x80) && (int64_t)s_e1[g] - (int64_t)(sw & 0x7F) < e;
+                }
+            } else {
+                for (int64_t g = g_lo; g < g_hi; g++)
+                    if (a_weight[g]) count((int)(e - ((int64_t)a_e1[g] - g_span[g])));
+                for (int64_t g = g_e; g < g_fe; g++) sb_extra += a_weight[g] && (int64_t)a_e1[g] - g_span[g] < e;
+            }
+            const bool ovf = total > 255;
+            // byte-wise inclusive prefix sums across the four words
+            unsigned long long carry = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            w[q] = w[q] * 0x0101010101010101ull + carry * 0x0101010101010101ull;
-            carry = w[q] >> 56;
+            for (int q = 0; q < 4; q++) {
+                w[q] = w[q] * 0x0101010101010101ull + carry * 0x0101010101010101ull;
+                carry = w[q] >> 56;
+            }
+            w[3] = (w[3] & 0x00FFFFFFFFFFFFFFull) | ((unsigned long long)e_out[e] << 56);
+            // End and SB count from the walk's first entry (anchors of earlier walks have both begun and ended before it):
+            // keys E - SB stay within the score range whatever the number of walks
+            const int32_t base = wpre[g_off[eb]];
+            uint4 A;
+            A.x = (uint32_t)cvtx[walk_vtx[e]] | (ovf ? 0x80000000u : 0u);
+            A.y = (uint32_t)e;
+            A.z = (uint32_t)(wpre[g_hi] - base);
+            A.w = (uint32_t)(wpre[g_e] - base + sb_extra);
+            ev[i * 3 + 0] = A;
+            ev[i * 3 + 1] = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
+            ev[i * 3 + 2] = make_uint4((uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32));
         }
-        w[3] = (w[3] & 0x00FFFFFFFFFFFFFFull) | ((unsigned long long)e_out[e] << 56);
-        // End and SB count from the walk's first entry (anchors of earlier walks have both begun and ended before it):
-        // keys E - SB stay within the score range whatever the number of walks
-        const int64_t g_e = g_off[e];
-        const int32_t base = wpre[g_off[eb]];
-        int32_t sb = wpre[g_e] - base;
-        {
-            const int64_t xe = e + 31 < n_entries ? e + 31 : n_entries;
-            const int64_t g_fe = g_off[xe];
-            for (int64_t g = g_e; g < g_fe; g++) sb += a_weight[g] && (int64_t)a_e1[g] - g_span[g] < e;
-        }
-        uint4 A;
-        A.x = (uint32_t)cvtx[walk_vtx[e]] | (ovf ? 0x80000000u : 0u);
-        A.y = (uint32_t)e;
-        A.z = (uint32_t)(wpre[g_hi] - base);
-        A.w = (uint32_t)sb;
-        ev[i * 3 + 0] = A;
-        ev[i * 3 + 1] = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
-        ev[i * 3 + 2] = make_uint4((uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32));
+        __syncthreads();                                       // (the stage is refilled for the next block of events)
     }
 }
 
@@ -310,7 +344,7 @@ void phi_launch_dp_event_fill(hipStream_t st, const PhiDpEventArgs &A, const uin
 {
     if (A.n_ev <= 0) return;
     int64_t nb = (A.n_ev + 255) / 256;
-    if (nb > 8192) nb = 8192;
+    if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(phi_dp_event_fill_kernel, dim3((unsigned)nb), dim3(256), 0, st, A.ev_e, A.n_ev, walk_vtx, cvtx,
                        A.walk_off, A.n_walks, e_out, A.g_off, A.g_span, A.a_weight, a_e1, wpre, n_entries,
                        reinterpret_cast<uint4 *>(A.ev));
@@ -1005,6 +1039,45 @@ __global__ void __launch_bounds__(256) phi_cut_clean_kernel(const int32_t *__res
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= n_entries; e += (int64_t)gridDim.x * blockDim.x)
         clean[e] = e < n_entries && cov_excl[e + 1] == 0;
 }
+// The same flags without counting: a cut before e is split by an anchor iff some anchor ending at x >= e has span > x - e,
+// and spans are below PHI_RCAP, so x <= e + 30.  A block takes a tile of entries, looks through the anchors ending on the
+// tile and the 30 entries behind it (the dp anchors are sorted by last entry: g_off is their CSR) and marks in LDS the
+// entries each one covers; what is left unmarked is clean.  (The counting version -- two atomics per anchor into a difference
+// array, a prefix sum over all entries, a pass for the flags -- took 36 ms at config 5; nothing else read the counts.)
+#define CUT_TILE 4096
+__global__ void __launch_bounds__(256) phi_cut_clean_direct_kernel(const int64_t *__restrict__ g_off, const uint8_t *__restrict__ g_span, int64_t n_entries,
+                                                                   int32_t *__restrict__ clean)
+{
+    __shared__ uint8_t s_dirty[CUT_TILE];
+    const int64_t n_tiles = (n_entries + 1 + CUT_TILE - 1) / CUT_TILE;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t e0 = t * CUT_TILE;
+        for (int i = threadIdx.x; i < CUT_TILE / 4; i += 256) reinterpret_cast<uint32_t *>(s_dirty)[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < CUT_TILE + PHI_RCAP - 1; i += 256) {
+            const int64_t x = e0 + i;
+            if (x >= n_entries) break;
+            const int64_t lo = g_off[x], hi = g_off[x + 1];
+            int m = 0;
+            for (int64_t g = lo; g < hi; g++) m = max(m, (int)g_span[g]);
+            // the entries e with x - m < e <= x, inside the tile
+            for (int64_t e = max(e0, x - m + 1); e <= x && e < e0 + CUT_TILE; e++) s_dirty[e - e0] = 1;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < CUT_TILE; i += 256) {
+            const int64_t e = e0 + i;
+            if (e <= n_entries) clean[e] = e < n_entries && !s_dirty[i];
+        }
+        __syncthreads();
+    }
+}
+void phi_launch_cut_clean_direct(hipStream_t st, const int64_t *g_off, const uint8_t *g_span, int64_t n_entries, int32_t *clean)
+{
+    int64_t nb = (n_entries + 1 + CUT_TILE - 1) / CUT_TILE;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(phi_cut_clean_direct_kernel, dim3((unsigned)nb), dim3(256), 0, st, g_off, g_span, n_entries, clean);
+}
+
 // Between two consecutive events of a walk (entries l < p on compact steps a < b) the walk only runs along chain
 // vertices: a cut before any step in (a, b] is fine for this walk iff some entry in (l, p] is clean.  Where none is,
 // the steps a+1 .. b are closed: stepdiff[a + 1] += 1, stepdiff[b + 1] -= 1.

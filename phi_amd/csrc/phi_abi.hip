@@ -40,14 +40,73 @@ int phi_hip_check(phi_ctx *c, hipError_t e, const char *what)
 #define HIPCHK(call) do { int rc_ = phi_hip_check(c, (call), #call); if (rc_) return rc_; } while (0)
 #define PHICHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
+// Large device buffers that are let go are kept for the next taker of about their size instead of going back to the driver:
+// the driver clears device memory before it hands it out again (measured on this pool: ~28 us per MB once the freed memory is
+// what the next hipMalloc gets -- 60 ms for the 2.1 GB of a DP run's prefix sums at config 5, 0.25 s of phi_solve when the 10 GB
+// of walk text were freed before it, and every allocation of a process that starts right behind another one's end), and
+// phi_set_graph's temporaries are the sizes phi_solve asks for next (4 bytes per walk entry, several times).  The pool is per
+// device, emptied when a solve is done, when a context goes, and when an allocation fails.  PHI_DEVICE_POOL=0: off.
+namespace {
+struct DevPool { std::mutex mu; std::vector<DevBuf> bufs; };
+DevPool g_pool[64];
+// (PHI_DEVICE_POOL_MIN=bytes: tests pool everything, so that every buffer comes back with an earlier owner's contents)
+const size_t POOL_MIN = getenv("PHI_DEVICE_POOL_MIN") ? (size_t)atoll(getenv("PHI_DEVICE_POOL_MIN")) : ((size_t)16 << 20);
+thread_local bool t_pool_bypass = false;
+bool pool_on()
+{
+    static const bool on = !(getenv("PHI_DEVICE_POOL") && atoi(getenv("PHI_DEVICE_POOL")) == 0);
+    return on && !t_pool_bypass;
+}
+int cur_device() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 ? d : -1; }
+bool pool_take(int dev, size_t want, DevBuf &b)
+{
+    if (dev < 0) return false;
+    DevPool &P = g_pool[dev];
+    std::lock_guard<std::mutex> lk(P.mu);
+    int best = -1;
+    for (int i = 0; i < (int)P.bufs.size(); i++)
+        if (P.bufs[(size_t)i].cap >= want && P.bufs[(size_t)i].cap <= want + want / 8 && (best < 0 || P.bufs[(size_t)i].cap < P.bufs[(size_t)best].cap)) best = i;
+    if (best < 0) return false;
+    b = P.bufs[(size_t)best];
+    P.bufs.erase(P.bufs.begin() + best);
+    return true;
+}
+}  // namespace
+void phi_pool_flush(int dev)
+{
+    if (dev < 0 || dev >= 64) return;
+    std::vector<DevBuf> v;
+    { std::lock_guard<std::mutex> lk(g_pool[dev].mu); v.swap(g_pool[dev].bufs); }
+    for (DevBuf &x : v) if (x.p) (void)hipFree(x.p);
+}
+static void dev_free(DevBuf &b)
+{
+    if (!b.p) { b.cap = 0; return; }
+    const int dev = b.cap >= POOL_MIN && pool_on() ? cur_device() : -1;
+    if (dev >= 0) {
+        (void)hipDeviceSynchronize();                      // (what hipFree does before it lets memory go: nobody still works on it)
+        std::lock_guard<std::mutex> lk(g_pool[dev].mu);
+        g_pool[dev].bufs.push_back(b);
+    } else {
+        (void)hipFree(b.p);
+    }
+    b.p = nullptr; b.cap = 0;
+}
+
 int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap && b.p) return PHI_OK;
-    if (b.p) { hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return phi_hip_check(c, e, "hipFree"); }
+    dev_free(b);
     size_t want = bytes < 256 ? 256 : bytes;
+    if (want >= POOL_MIN && pool_on() && pool_take(c->device, want, b)) return PHI_OK;
     static const bool timing = getenv("PHI_TIMING_ALLOC") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&b.p, want);
+    if (e == hipErrorOutOfMemory) {                        // what the pool holds may be what is missing
+        (void)hipGetLastError();
+        phi_pool_flush(c->device);
+        e = hipMalloc(&b.p, want);
+    }
     if (timing) {
         static std::atomic<long long> total_ns{0}, calls{0};
         const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -58,8 +117,6 @@ int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes)
     b.cap = want;
     return PHI_OK;
 }
-
-static void dev_free(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
 // (the pinned staging buffers serve phi_set_graph's uploads only: given back when it is done)
 static void stage_release(phi_ctx *c)
@@ -187,7 +244,6 @@ int phi_read_counts(phi_ctx *c, uint64_t *n_logged, uint64_t *n_emitted)
 }
 
 static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
-static void dev_free(DevBuf &b);
 
 // a device buffer that grows and KEEPS its first `keep` bytes
 static int dev_grow_keep(phi_ctx *c, DevBuf &b, size_t bytes, size_t keep)
@@ -439,6 +495,9 @@ void phi_ctx_destroy(phi_ctx *c)
                      &c->d_g_off, &c->d_g_span, &c->d_a_weight, &c->d_dmax, &c->d_bstart, &c->d_k_rec, &c->d_k_in, &c->d_cvtx, &c->d_ev_e, &c->d_ev_off, &c->d_ev,
                      &c->d_off_end, &c->d_off_start, &c->d_scan_blk, &c->d_scan_blk64, &c->d_scan_blkoff, &c->d_top,
                      &c->d_ent};
+    phi_pool_flush(c->device);
+    t_pool_bypass = true;                                  // (a context that goes gives its memory back to the driver)
+    struct Bypass { ~Bypass() { t_pool_bypass = false; } } bypass_guard;
     for (DevBuf *b : all) dev_free(*b);
     for (auto &pr : c->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->h_err) (void)hipHostFree(c->h_err);
@@ -1645,7 +1704,9 @@ int phi_solve(phi_ctx *c, phi_result *out)
     if (!c || !out) return PHI_ERR_INVALID;
     if (!c->have_graph) return phi_fail(c, PHI_ERR_STATE, "phi_solve before phi_set_graph");
     HIPCHK(hipSetDevice(c->device));
-    PHICHK(phi_solve_impl(c));
+    const int rc = phi_solve_impl(c);
+    phi_pool_flush(c->device);                              // (what the index build and this solve let go and nobody took again)
+    if (rc) return rc;
     *out = c->result;
     return PHI_OK;
 }

@@ -344,6 +344,7 @@ int phi_add_reads_device_impl(phi_ctx *c, const void *d_bases, const void *d_rea
 // helpers shared between phi_abi.hip and phi_solve.hip
 int phi_fail(phi_ctx *c, int code, const char *fmt, ...);
 int phi_dev_ensure(phi_ctx *c, DevBuf &b, size_t bytes);
+void phi_pool_flush(int device);                    // the pool of large device buffers let go (phi_abi.hip) back to the driver
 int phi_hip_check(phi_ctx *c, hipError_t e, const char *what);
 int phi_sync_check(phi_ctx *c);
 // pinned host buffer of at least `bytes` (contents are not kept)

@@ -331,6 +331,7 @@ void phi_launch_carry_resolve(hipStream_t st, const int32_t *carry, int32_t LS, 
 void phi_launch_dp_block_paths_wide(hipStream_t st, const PhiDpEventArgs &A);
 void phi_launch_cut_cov(hipStream_t st, const phi_ent_t *a_e1, const uint8_t *a_span, int64_t n_a, int32_t *diff);
 void phi_launch_cut_clean(hipStream_t st, const int32_t *cov_excl, int64_t n_entries, int32_t *clean);
+void phi_launch_cut_clean_direct(hipStream_t st, const int64_t *g_off, const uint8_t *g_span, int64_t n_entries, int32_t *clean);
 void phi_launch_cut_events(hipStream_t st, const phi_ent_t *ev_e, int64_t n_ev, const int64_t *ev_off, const int64_t *walk_off, int32_t n_walks,
                            const int32_t *walk_vtx, const int32_t *cvtx, const int32_t *ncl_excl, int32_t *stepdiff);
 void phi_launch_blk_ev(hipStream_t st, const int32_t *blk_lo, int32_t n_blk, const phi_ent_t *ev_e, const int64_t *ev_off, int32_t n_walks,

@@ -116,11 +116,15 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
         PHICHK(phi_dev_ensure(c, c->d_scan_blkoff, (size_t)(nb + 1) * 8));
     }
     int32_t *d_a = c->d_off_end.as<int32_t>(), *d_b = c->d_off_start.as<int32_t>();
-    HIPCHK(hipMemsetAsync(d_a, 0, (size_t)(ne + 3) * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->d_stepdiff.p, 0, (size_t)(nk + 2) * 4, c->stream));
-    phi_launch_cut_cov(c->stream, c->d_a_e1.as<phi_ent_t>(), c->d_g_span.as<uint8_t>(), n_dp, d_a);
-    phi_launch_scan_i32(c->stream, d_a, ne + 1, d_b, c->d_scan_blk.as<int32_t>(), c->d_scan_blkoff.as<int64_t>());     // d_b[e + 1] = anchors a cut before e splits
-    phi_launch_cut_clean(c->stream, d_b, ne, d_a);                                                                       // d_a[e] = clean
+    if (getenv("PHI_CUT_COUNTED")) {                                   // (tests: the flags from counted coverage, as until round 4)
+        HIPCHK(hipMemsetAsync(d_a, 0, (size_t)(ne + 3) * 4, c->stream));
+        phi_launch_cut_cov(c->stream, c->d_a_e1.as<phi_ent_t>(), c->d_g_span.as<uint8_t>(), n_dp, d_a);
+        phi_launch_scan_i32(c->stream, d_a, ne + 1, d_b, c->d_scan_blk.as<int32_t>(), c->d_scan_blkoff.as<int64_t>());     // d_b[e + 1] = anchors a cut before e splits
+        phi_launch_cut_clean(c->stream, d_b, ne, d_a);                                                                       // d_a[e] = clean
+    } else {
+        phi_launch_cut_clean_direct(c->stream, c->d_g_off.as<int64_t>(), c->d_g_span.as<uint8_t>(), ne, d_a);               // d_a[e] = clean
+    }
     phi_launch_scan_i32(c->stream, d_a, ne + 1, d_b, c->d_scan_blk.as<int32_t>(), c->d_scan_blkoff.as<int64_t>());     // d_b[e] = clean entries before e
     phi_launch_cut_events(c->stream, c->d_ev_e.as<phi_ent_t>(), c->n_ev, c->d_ev_off.as<int64_t>(), c->d_walk_off.as<int64_t>(), c->n_walks,
                           c->d_walk_vtx.as<int32_t>(), c->d_cvtx.as<int32_t>(), d_b, c->d_stepdiff.as<int32_t>());

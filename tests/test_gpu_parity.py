@@ -570,6 +570,30 @@ def test_anchors_from_packed_selected_records_equal_the_generic_expansion(oracle
     assert len(got["packed"][0][0]) > 20000
 
 
+@pytest.mark.parametrize("n_walks,k,w", [(20, 15, 8), (100, 15, 8), (30, 9, 2)])
+def test_cut_flags_without_counting_place_the_same_blocks(ctx_factory, monkeypatch, n_walks, k, w):
+    """Where the DP's chain may be cut: an entry no anchor reaches across.  phi_solve marks what the anchors ending on a tile of
+    entries cover (LDS, no atomics); PHI_CUT_COUNTED=1 counts coverage as before (two atomics per anchor, a prefix sum).  The same
+    flags give the same blocks (PHI_DP_BLOCK_STEPS=5: a cut wherever one is allowed), objective and path."""
+    rng = np.random.default_rng(8200 + n_walks)
+    g = random_graph(rng, n_sites=1500, n_walks=n_walks, seg_len=(3, 25), alt_len=(1, 12), p_del=0.2)
+    reads = mosaic_reads(rng, g, n_reads=1200, read_len=100, n_seg=5, err=0.01)
+    monkeypatch.setenv("PHI_DP_BLOCK_STEPS", "5")
+    got = {}
+    for mode in ("direct", "counted"):
+        if mode == "counted":
+            monkeypatch.setenv("PHI_CUT_COUNTED", "1")
+        ctx = ctx_factory(k=k, w=w, threshold=0.8, recombination=10)
+        _set_graph(ctx, g)
+        ctx.add_reads(reads)
+        res = ctx.solve()
+        st = ctx.solve_stats()
+        got[mode] = (st["n_blocks"], st["dp_mode"], res["objective"], res["path_vtx"].tolist(), res["path_hap"].tolist())
+        monkeypatch.delenv("PHI_CUT_COUNTED", raising=False)
+    assert got["direct"] == got["counted"]
+    assert (n_walks, k) != (20, 15) or got["direct"][0] > 5          # (this one is cut into blocks)
+
+
 def test_sixteen_wave_dense_dp_agrees_with_the_event_dp(oracle, ctx_factory, monkeypatch):
     """The dense kernel's sixteen-wave instance (513..1022 walks: entry words from HBM, step stream in chunks of 32, the last
     256 steps' leaving states in LDS and older ones from HBM) forced onto a graph of thousands of vertices and 100 walks
