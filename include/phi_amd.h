@@ -118,6 +118,28 @@ int phi_add_reads_text(phi_ctx *ctx, const char *text, int64_t n_bytes, int32_t 
 int phi_reads_text_end(phi_ctx *ctx, const char **pending, int64_t *n_pending, int64_t *n_taken);
 /* Introspection for the parity tests: the records the device took from the LAST piece handed to phi_add_reads_text (their
  * bases back to back and their offsets, off[0] = 0), copied to the host.  Sizes only when the buffers are too small. */
+/*
+ * Reads text that arrives BEFORE the graph is there (the command line: the reads file is read while the GFA is parsed and the
+ * index built -- seconds at chromosome scale, with the link and 288 GB of HBM idle).  A park holds pieces of the stream in
+ * device memory; it belongs to no context (its own stream and buffers), so a reader thread may fill it while phi_set_graph
+ * runs on another thread.  phi_add_reads_text_parked is phi_add_reads_text with the index-th piece as its bytes (the pieces in
+ * stream order, mixed freely with phi_add_reads_text calls); irregular text is handed back through phi_reads_text_end as ever,
+ * and the host reads the pieces still parked with phi_text_park_fetch.
+ *   phi_text_park_create / _destroy   on a device
+ *   phi_text_park_pin                 page-locks a host buffer the pieces come from (unpinned by _destroy)
+ *   phi_text_park_add                 copies n bytes to the device; returns when they are there (the host buffer is free again)
+ *   phi_text_park_bytes / _fetch      a piece's size; its bytes back on the host
+ *   phi_text_park_release             the piece's device memory is let go (after phi_add_reads_text_parked took it)
+ */
+typedef struct phi_text_park phi_text_park;
+int phi_text_park_create(int32_t device, phi_text_park **out);
+int phi_text_park_pin(phi_text_park *park, void *host, size_t bytes);
+int phi_text_park_add(phi_text_park *park, const char *text, int64_t n, int32_t *index);
+int64_t phi_text_park_bytes(phi_text_park *park, int32_t index);
+int phi_text_park_fetch(phi_text_park *park, int32_t index, char *out, int64_t cap);
+int phi_text_park_release(phi_text_park *park, int32_t index);
+void phi_text_park_destroy(phi_text_park *park);
+int phi_add_reads_text_parked(phi_ctx *ctx, phi_text_park *park, int32_t index, int32_t *irregular);
 int phi_reads_text_last_batch(phi_ctx *ctx, char *bases, int64_t cap_bases, int64_t *off, int64_t cap_reads, int64_t *n_reads,
                               int64_t *n_bases);
 /* For a stream whose chunks go to SEVERAL contexts in turn (one per GPU): hands out the bytes this context holds

@@ -105,6 +105,12 @@ class Context:
         self._chk(self._L.phi_add_reads_text(self._h, _ptr(buf), len(buf), C.byref(irr)))
         return bool(irr.value)
 
+    def add_reads_text_parked(self, park, index):
+        """add_reads_text with the index-th piece of a TextPark as its bytes."""
+        irr = C.c_int32()
+        self._chk(self._L.phi_add_reads_text_parked(self._h, park._h, index, C.byref(irr)))
+        return bool(irr.value)
+
     def reads_text_end(self):
         """(bytes handed over but not taken, stream bytes taken as whole records)."""
         p, n, t = C.c_void_p(), C.c_int64(), C.c_int64()
@@ -324,3 +330,48 @@ class Context:
         n, ms, b = C.c_int64(), C.c_double(), C.c_int64()
         self._chk(self._L.phi_prof_read(self._h, C.byref(n), C.byref(ms), C.byref(b)))
         return n.value, ms.value, b.value
+
+
+class TextPark:
+    """Pieces of a reads text in device memory before any context wants them (include/phi_amd.h phi_text_park_*)."""
+
+    def __init__(self, device=0):
+        self._L = _capi.load()
+        self._h = C.c_void_p()
+        rc = self._L.phi_text_park_create(device, C.byref(self._h))
+        if rc:
+            raise PhiError(rc, "phi_text_park_create failed")
+
+    def add(self, text):
+        buf = np.frombuffer(text, np.uint8) if not isinstance(text, np.ndarray) else text
+        idx = C.c_int32()
+        rc = self._L.phi_text_park_add(self._h, _ptr(buf), len(buf), C.byref(idx))
+        if rc:
+            raise PhiError(rc, "phi_text_park_add failed")
+        return idx.value
+
+    def fetch(self, index):
+        n = self._L.phi_text_park_bytes(self._h, index)
+        if n < 0:
+            raise PhiError(-1, "no such piece")
+        out = np.zeros(n, np.uint8)
+        rc = self._L.phi_text_park_fetch(self._h, index, _ptr(out), n)
+        if rc:
+            raise PhiError(rc, "phi_text_park_fetch failed")
+        return out.tobytes()
+
+    def release(self, index):
+        rc = self._L.phi_text_park_release(self._h, index)
+        if rc:
+            raise PhiError(rc, "phi_text_park_release failed")
+
+    def close(self):
+        if self._h:
+            self._L.phi_text_park_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -139,9 +139,9 @@ struct Options {
 };
 
 // ---- the queue of raw text chunks between the reader thread and the device thread(s)
-struct Chunk { char *text = nullptr; int64_t n = 0; };
+struct Chunk { char *text = nullptr; int64_t n = 0; int32_t parked = -1; };      // parked >= 0: the bytes wait in device memory (phi_text_park_*), no host buffer
 struct ChunkQueue {
-    std::vector<Chunk> buf;
+    std::deque<Chunk> buf;                                    // (a deque: entries for parked pieces are added while others are in use)
     std::mutex mu;
     std::condition_variable cv;
     std::deque<int> q_free, q_full;                           // buffer indices; a full entry with n == 0 ends the stream
@@ -154,22 +154,31 @@ struct ChunkQueue {
         if (buf[(size_t)s].n > 0) q_full.pop_front();
         return s;
     }
+    Chunk *at(int s) { std::lock_guard<std::mutex> lk(mu); return &buf[(size_t)s]; }      // (entries never move; the deque's index may, while one is added)
     void give_free(int s)
     {
-        { std::lock_guard<std::mutex> lk(mu); q_free.push_back(s); }
+        { std::lock_guard<std::mutex> lk(mu); if (buf[(size_t)s].text) q_free.push_back(s); }
         cv.notify_all();
     }
 };
 
 // the rest of the stream for the host reader: blocks straight from the queue (phi_reads_stream_open_blocks)
-struct QueueBlocks { ChunkQueue *q; int held = -1; };
+struct QueueBlocks { ChunkQueue *q; int held = -1; phi_text_park *park = nullptr; std::vector<char> fetched; };
 static int64_t next_block_from_queue(void *user, const char **block)
 {
     QueueBlocks *qb = (QueueBlocks *)user;
     if (qb->held >= 0) { qb->q->give_free(qb->held); qb->held = -1; }
     const int s = qb->q->take_full();
-    const Chunk &c = qb->q->buf[(size_t)s];
+    const Chunk &c = *qb->q->at(s);
     if (c.n <= 0) return c.n;                                 // 0: the end; negative: the reader thread failed
+    if (c.parked >= 0) {
+        // a piece that went to device memory before the graph was there: its bytes come back for the host reader
+        qb->fetched.resize((size_t)c.n);
+        if (phi_text_park_fetch(qb->park, c.parked, qb->fetched.data(), c.n) != PHI_OK) return -1;
+        (void)phi_text_park_release(qb->park, c.parked);
+        *block = qb->fetched.data();
+        return c.n;
+    }
     qb->held = s;
     *block = c.text;
     return c.n;
@@ -249,14 +258,25 @@ static int run(const Options &o)
     }
     char rerr[512] = "";
     std::future<int> f_reads;
+    // reads text parked in device memory until the index is built (the reader thread's side of it is in start_reads below)
+    phi_text_park *park = nullptr;
+    std::atomic<bool> graph_ready{false}, park_go{false};      // the GFA is parsed (parking may begin) / the index is built (it ends)
+    bool park_on = false, park_pinned = false;                // (the reader thread's; main reads them after the stream has ended)
+    int64_t parked_bytes = 0;
+    const int64_t park_limit = getenv("PHI_TEXT_PARK_MAX") ? atoll(getenv("PHI_TEXT_PARK_MAX")) : ((int64_t)96 << 30);
+    if (devices.size() == 1 && !(getenv("PHI_TEXT_PARK") && atoi(getenv("PHI_TEXT_PARK")) == 0)) {
+        struct stat st;
+        const int64_t least = getenv("PHI_TEXT_PARK_MIN") ? atoll(getenv("PHI_TEXT_PARK_MIN")) : ((int64_t)256 << 20);
+        park_on = stat(reads_file.c_str(), &st) == 0 && S_ISREG(st.st_mode) && (int64_t)st.st_size >= least;
+    }
     auto start_reads = [&]() {
       f_reads = std::async(std::launch::async, [&, rf = reads_file]() {
         Stage st("reads file -> text chunks [thread]");
         phi_text_stream *ts = nullptr;
         int r = phi_text_stream_open(rf.c_str(), &ts, rerr, sizeof rerr);
+        int slot = -1;
         for (;;) {
-            int slot;
-            {
+            if (slot < 0) {
                 std::unique_lock<std::mutex> lk(Q.mu);
                 Q.cv.wait(lk, [&] { return !Q.q_free.empty() || Q.stop; });
                 if (Q.stop) break;
@@ -267,12 +287,42 @@ static int run(const Options &o)
                 n = phi_text_stream_read(ts, Q.buf[(size_t)slot].text, chunk_bytes, rerr, sizeof rerr);
                 if (n < 0) { r = (int)n; }
             } else n = r;
+            // While the graph is still being read and indexed the link and the HBM are idle: the chunk goes to device memory
+            // now (phi_text_park_*), the host buffer is free for the next one at once, and when the index is there the reads
+            // stage finds the text where the records are found anyway.  (One GPU; large files; until the index is built.)
+            if (n > 0 && park_on && !graph_ready.load() && !park_go.load()) {
+                // the GFA is still being read (all host threads, all of the memory bandwidth): chunks stay in their host buffers
+                // as long as there is another one to read into; with the last one in hand, wait for the GFA or for a taker
+                std::unique_lock<std::mutex> lk(Q.mu);
+                Q.cv.wait(lk, [&] { return park_go.load() || graph_ready.load() || !Q.q_free.empty() || Q.stop; });
+            }
+            if (n > 0 && park_on && park_go.load() && !graph_ready.load() && parked_bytes + n <= park_limit) {
+                bool ok = true;
+                if (!park) {
+                    ok = phi_text_park_create(devices[0], &park) == PHI_OK;
+                    for (auto &b : Q.buf) if (ok && b.text && phi_text_park_pin(park, b.text, (size_t)chunk_bytes) != PHI_OK) ok = false;
+                    if (ok) park_pinned = true;
+                }
+                int32_t idx = -1;
+                if (ok && phi_text_park_add(park, Q.buf[(size_t)slot].text, n, &idx) == PHI_OK) {
+                    parked_bytes += n;
+                    {
+                        std::lock_guard<std::mutex> lk(Q.mu);
+                        Q.buf.push_back(Chunk{nullptr, n, idx});
+                        Q.q_full.push_back((int)Q.buf.size() - 1);
+                    }
+                    Q.cv.notify_all();
+                    continue;                                 // (the same host buffer takes the next chunk)
+                }
+                park_on = false;                              // no room or no device yet: the usual way from here on
+            }
             Q.buf[(size_t)slot].n = n;                        // 0 ends the stream, a negative value ends it as failed
             {
                 std::lock_guard<std::mutex> lk(Q.mu);
                 Q.q_full.push_back(slot);
             }
             Q.cv.notify_all();
+            slot = -1;
             if (n <= 0) break;
         }
         if (ts) phi_text_stream_close(ts);
@@ -320,6 +370,8 @@ static int run(const Options &o)
             r = phi_gfa_read(gfa_file.c_str(), &g, err, sizeof err);
         if (r != PHI_HOST_OK) return gfa_failed();
     }
+    park_go = true;                                           // (the reads text may go to device memory from here on: see start_reads)
+    Q.cv.notify_all();
     if (defer_walks) {
         Stage st("walks");
         bool on_device = false;
@@ -392,6 +444,8 @@ static int run(const Options &o)
                 return r;
             })) return 1;
     }
+    graph_ready = true;                                       // (the reader thread stops parking chunks: they are taken as they come now)
+    Q.cv.notify_all();
     // The exchange of a multi-GPU run: the library's RCCL all-reduce.  PHI_EXCHANGE=peers takes the peer-mapped OR-gather
     // instead (one kernel per GPU, no RCCL: made for hit vectors of a few MB, every MHC-sized graph) -- opt-in until a run on
     // two or more GPUs has compared the two bit for bit: its cross-GPU loads have only ever run between contexts on ONE GPU.
@@ -446,7 +500,7 @@ static int run(const Options &o)
     // the host reader over `prefix` + the rest of the queue -> phi_add_reads on this GPU (under turn_mu)
     auto finish_on_host = [&](phi_ctx *cx, const char *prefix, int64_t n_prefix, bool rest_of_queue, int64_t stream_offset) -> int {
         Stage st("host reader (kseq state machine)");
-        QueueBlocks qb{&Q, -1};
+        QueueBlocks qb{&Q, -1, park, {}};
         phi_reads_stream *rs = nullptr;
         if (phi_reads_stream_open_blocks(prefix, n_prefix, rest_of_queue ? next_block_from_queue : nullptr, &qb, stream_offset, &rs, rerr, sizeof rerr) != PHI_HOST_OK) return PHI_ERR_INVALID;
         const int64_t cap_b = std::max<int64_t>((int64_t)1 << 20, std::min<int64_t>(chunk_bytes, (int64_t)64 << 20)), cap_r = cap_b / 32 + 1024;
@@ -474,7 +528,7 @@ static int run(const Options &o)
                     std::unique_lock<std::mutex> turn(turn_mu);
                     if (stream_done || failed) break;
                     const int slot = Q.take_full();
-                    Chunk &cb = Q.buf[(size_t)slot];
+                    Chunk &cb = *Q.at(slot);
                     if (cb.n <= 0) {
                         // the end of the stream (left in the queue for the other GPUs): what is still unfinished is the file's
                         // last record, whose end only the end of the file shows -- the host reader's
@@ -492,13 +546,19 @@ static int run(const Options &o)
                         // a file of more than one chunk: pin the buffers, so that the device copy of every further
                         // chunk is a direct DMA (pinning takes milliseconds: not worth it for a single chunk)
                         std::call_once(pin_once, [&]() {
+                            if (park_pinned) return;           // (the reader thread pinned them when it began to park chunks)
                             registered = true;
                             for (auto &b : Q.buf) if (phi_host_register(cx, b.text, (size_t)chunk_bytes) != PHI_OK) pinned = false;
                         });
                     stream_fed += cb.n;
                     int32_t irr_carry = 0, irr = 0;
                     if (n_dev > 1 && !carry.empty()) r = phi_add_reads_text(cx, carry.data(), (int64_t)carry.size(), &irr_carry);
-                    if (!r && !irr_carry) r = phi_add_reads_text(cx, cb.text, cb.n, &irr);
+                    if (!r && !irr_carry) {
+                        if (cb.parked >= 0) {
+                            r = phi_add_reads_text_parked(cx, park, cb.parked, &irr);
+                            if (!r) (void)phi_text_park_release(park, cb.parked);
+                        } else r = phi_add_reads_text(cx, cb.text, cb.n, &irr);
+                    }
                     if (!r && (irr_carry || irr)) {
                         // not one of the two regular layouts: the exact state machine takes the stream from the first byte not taken
                         stream_done = true;
@@ -631,6 +691,7 @@ static int run(const Options &o)
     fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB\n", "main", realtime() - t0_real, cputime(),
             peakrss() / 1024.0 / 1024.0 / 1024.0);
     if (timing) {
+        if (parked_bytes) fprintf(stderr, "[phi timing] main: %lld bytes of the reads text waited in device memory for the index\n", (long long)parked_bytes);
         fprintf(stderr, "[phi timing] main: %d text chunk(s) of up to %lld bytes%s on %d GPU(s); %lld bases through the host reader; FASTA closed at epoch %.6f%s\n",
                 n_chunks.load(), (long long)chunk_bytes, n_chunks >= 2 && pinned ? ", pinned" : "", n_dev, (long long)host_parsed_bases, realtime(),
                 o.detached ? "; teardown detached" : "");
@@ -660,8 +721,9 @@ static int run(const Options &o)
     }   // jobs
     if (getenv("PHI_FULL_TEARDOWN")) {                        // (leak checks: give everything back in order)
         stop_reads();
+        if (park) phi_text_park_destroy(park);                 // (unpins the chunk buffers it pinned)
         for (auto &cb : Q.buf) {
-            if (registered) (void)phi_host_unregister(ctx, cb.text);
+            if (registered && cb.text) (void)phi_host_unregister(ctx, cb.text);
             free(cb.text);
         }
         phi_graph_free(g);

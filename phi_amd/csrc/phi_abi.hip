@@ -4,6 +4,7 @@
 // that needs one returns PHI_ERR_DEVICE.
 #include <chrono>
 #include <atomic>
+#include <deque>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -1449,7 +1450,7 @@ int phi_reads_text_begin(phi_ctx *c, int64_t max_chunk_bytes)
     T.carry_cap = carry; T.chunk_cap = chunk; T.line_cap = line_cap;
     T.active = true; T.irregular = false; T.started = false; T.mode = 0;
     T.fed = 0; T.taken = 0; T.slot = 0; T.carry_len = 0; T.carry_at = carry; T.h_carry.clear();
-    T.last_slot = -1; T.why = 0; T.first_bad = 0; T.detached = false;
+    T.last_slot = -1; T.why = 0; T.first_bad = 0; T.detached = false; T.carry_stale = false;
     return PHI_OK;
 }
 
@@ -1463,23 +1464,37 @@ static int text_replay_last(phi_ctx *c, uint32_t err)
     return replay_if_full(c, err, T.bases[T.last_slot].p, T.last_uniform ? nullptr : T.roff[T.last_slot].p, T.last_reads, T.last_bases);
 }
 
-static int text_piece(phi_ctx *c, const char *p, uint32_t m, int32_t *irregular)
+// the carry's host copy, when the pieces came from device memory (parked text: nobody had their bytes on the host)
+static int text_carry_to_host(phi_ctx *c)
+{
+    auto &T = c->text;
+    if (!T.carry_stale) return PHI_OK;
+    T.h_carry.resize(T.carry_len);
+    if (T.carry_len) HIPCHK(phi_copy_sync(c, T.h_carry.data(), T.text[T.slot].as<uint8_t>() + T.carry_at, T.carry_len, hipMemcpyDeviceToHost));
+    T.carry_stale = false;
+    return PHI_OK;
+}
+
+// one piece of the stream: m bytes at p (host memory) -- or at d_src (device memory, p = NULL; first = the piece's first byte)
+static int text_piece(phi_ctx *c, const char *p, uint32_t m, int32_t *irregular, const void *d_src = nullptr, char first = 0)
 {
     auto &T = c->text;
     T.dbg_reads = 0; T.dbg_bases = 0;
+    if (p) first = p[0];
     if (!T.started) {
         T.started = true;
         // the layout is decided by the first byte of the stream; text before the first header is the host reader's business
-        if (p[0] == '@') T.mode = 1;
-        else if (p[0] == '>') T.mode = 0;
+        if (first == '@') T.mode = 1;
+        else if (first == '>') T.mode = 0;
         else { T.irregular = true; T.why = PHI_TEXT_IRREGULAR_LAYOUT; T.first_bad = 0; *irregular = 1; return PHI_OK; }
     }
+    if (p) PHICHK(text_carry_to_host(c));
     if (T.detached) { T.h_carry.clear(); T.detached = false; }
     const int slot = T.slot ^ 1;
     const uint32_t C = T.carry_cap, start = C - T.carry_len, end = C + m;
     uint8_t *buf = T.text[slot].as<uint8_t>();
     // chunk i + 1 crosses the link while chunk i is sketched: the copy runs on aux_stream, everything else on `stream`
-    HIPCHK(hipMemcpyAsync(buf + C, p, m, hipMemcpyHostToDevice, c->aux_stream));
+    HIPCHK(hipMemcpyAsync(buf + C, p ? (const void *)p : d_src, m, p ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->aux_stream));
     HIPCHK(hipEventRecord(T.ev_copy, c->aux_stream));
     if (T.carry_len)
         HIPCHK(hipMemcpyAsync(buf + start, T.text[T.slot].as<uint8_t>() + T.carry_at, T.carry_len, hipMemcpyDeviceToDevice, c->stream));
@@ -1515,7 +1530,8 @@ static int text_piece(phi_ctx *c, const char *p, uint32_t m, int32_t *irregular)
         T.dbg_slot = slot; T.dbg_reads = (int64_t)S.n_rec; T.dbg_bases = (int64_t)S.n_bases;
     }
     // the bytes not taken, on the host as well: the last `tail` bytes of (carry before + this chunk)
-    if (tail <= m) T.h_carry.assign(p + m - tail, p + m);
+    if (!p) T.carry_stale = true;                            // (fetched from the device when somebody asks: text_carry_to_host)
+    else if (tail <= m) T.h_carry.assign(p + m - tail, p + m);
     else {
         const size_t keep = tail - m;                        // of the carry before
         T.h_carry.erase(T.h_carry.begin(), T.h_carry.end() - (ptrdiff_t)keep);
@@ -1551,6 +1567,132 @@ int phi_add_reads_text(phi_ctx *c, const char *text, int64_t n_bytes, int32_t *i
     return PHI_OK;
 }
 
+/* Text that arrives before the graph is there waits in device memory (include/phi_amd.h): a park is no part of any context's
+ * state -- its own stream, its own buffers --, so that a reader thread fills it while phi_set_graph runs on another. */
+struct phi_text_park {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    struct Piece { DevBuf d; int64_t n = 0; char first = 0; };
+    std::deque<Piece> pieces;                                  // (a deque: references stay valid while pieces are added)
+    std::vector<DevBuf> spare;                                 // buffers of released pieces
+    std::vector<void *> pinned;
+};
+
+int phi_text_park_create(int32_t device, phi_text_park **out)
+{
+    if (!out) return PHI_ERR_INVALID;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return PHI_ERR_DEVICE;
+    phi_text_park *p = new phi_text_park();
+    p->device = device;
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { delete p; return PHI_ERR_DEVICE; }
+    *out = p;
+    return PHI_OK;
+}
+
+int phi_text_park_pin(phi_text_park *p, void *host, size_t bytes)
+{
+    if (!p || !host) return PHI_ERR_INVALID;
+    if (hipSetDevice(p->device) != hipSuccess || hipHostRegister(host, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return PHI_ERR_DEVICE; }
+    p->pinned.push_back(host);
+    return PHI_OK;
+}
+
+int phi_text_park_add(phi_text_park *p, const char *text, int64_t n, int32_t *index)
+{
+    if (!p || !text || n <= 0 || !index) return PHI_ERR_INVALID;
+    if (hipSetDevice(p->device) != hipSuccess) return PHI_ERR_DEVICE;
+    phi_text_park::Piece pc;
+    const size_t want = (size_t)n + 64;
+    {
+        // a buffer a released piece left behind, if one is large enough (pieces are of one size but the last)
+        std::lock_guard<std::mutex> lk(p->mu);
+        for (size_t i = 0; i < p->spare.size(); i++)
+            if (p->spare[i].cap >= want) { pc.d = p->spare[i]; p->spare.erase(p->spare.begin() + (ptrdiff_t)i); break; }
+    }
+    if (!pc.d.p) {
+        if (hipMalloc(&pc.d.p, want) != hipSuccess) { (void)hipGetLastError(); return PHI_ERR_NOMEM; }
+        pc.d.cap = want;
+    }
+    pc.n = n; pc.first = text[0];
+    if (hipMemcpyAsync(pc.d.p, text, (size_t)n, hipMemcpyHostToDevice, p->stream) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFree(pc.d.p); return PHI_ERR_DEVICE;
+    }
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->pieces.push_back(pc);
+    *index = (int32_t)p->pieces.size() - 1;
+    return PHI_OK;
+}
+
+static phi_text_park::Piece *park_piece(phi_text_park *p, int32_t index)
+{
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> lk(p->mu);
+    return index >= 0 && (size_t)index < p->pieces.size() && p->pieces[(size_t)index].d.p ? &p->pieces[(size_t)index] : nullptr;
+}
+
+int64_t phi_text_park_bytes(phi_text_park *p, int32_t index) { phi_text_park::Piece *pc = park_piece(p, index); return pc ? pc->n : -1; }
+
+int phi_text_park_fetch(phi_text_park *p, int32_t index, char *out, int64_t cap)
+{
+    phi_text_park::Piece *pc = park_piece(p, index);
+    if (!pc || !out || cap < pc->n) return PHI_ERR_INVALID;
+    if (hipSetDevice(p->device) != hipSuccess) return PHI_ERR_DEVICE;
+    if (hipMemcpyAsync(out, pc->d.p, (size_t)pc->n, hipMemcpyDeviceToHost, p->stream) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) { (void)hipGetLastError(); return PHI_ERR_DEVICE; }
+    return PHI_OK;
+}
+
+int phi_text_park_release(phi_text_park *p, int32_t index)
+{
+    phi_text_park::Piece *pc = park_piece(p, index);
+    if (!pc) return PHI_ERR_INVALID;
+    // The buffer stays with the park (the next piece takes it; phi_text_park_destroy frees them all): a hipFree per piece would
+    // wait for the device each time -- between the chunks of a stream whose sketches are meant to overlap -- and 165 of them at
+    // the end of config 5's reads are time inside whatever runs next.
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->spare.push_back(pc->d);
+    pc->d = DevBuf{};
+    return PHI_OK;
+}
+
+void phi_text_park_destroy(phi_text_park *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (auto &pc : p->pieces) if (pc.d.p) (void)hipFree(pc.d.p);
+    for (auto &d : p->spare) if (d.p) (void)hipFree(d.p);
+    for (void *h : p->pinned) (void)hipHostUnregister(h);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int phi_add_reads_text_parked(phi_ctx *c, phi_text_park *p, int32_t index, int32_t *irregular)
+{
+    if (!c || !irregular) return PHI_ERR_INVALID;
+    *irregular = 0;
+    phi_text_park::Piece *pc = park_piece(p, index);
+    if (!pc || p->device != c->device) return phi_fail(c, PHI_ERR_INVALID, "phi_add_reads_text_parked: no such piece on this context's device");
+    auto &T = c->text;
+    if (!T.active) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads_text_parked before phi_reads_text_begin");
+    if (T.irregular) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads_text_parked after an irregular chunk: finish the stream on the host reader");
+    HIPCHK(hipSetDevice(c->device));
+    for (int64_t at = 0; at < pc->n; ) {
+        const uint32_t m = (uint32_t)std::min<int64_t>(pc->n - at, T.chunk_cap);
+        PHICHK(text_piece(c, nullptr, m, irregular, pc->d.as<char>() + at, pc->first));      // (the first byte matters to the stream's first piece only)
+        if (*irregular) {
+            // as phi_add_reads_text: what the device has not taken = the carry + the rest of this piece, handed back by phi_reads_text_end
+            PHICHK(text_carry_to_host(c));
+            const size_t had = T.h_carry.size();
+            T.h_carry.resize(had + (size_t)(pc->n - at));
+            HIPCHK(phi_copy_sync(c, T.h_carry.data() + had, pc->d.as<char>() + at, (size_t)(pc->n - at), hipMemcpyDeviceToHost));
+            break;
+        }
+        at += m;
+    }
+    return PHI_OK;
+}
+
 int phi_reads_text_last_batch(phi_ctx *c, char *bases, int64_t cap_bases, int64_t *off, int64_t cap_reads, int64_t *n_reads, int64_t *n_bases)
 {
     if (!c || !n_reads || !n_bases) return PHI_ERR_INVALID;
@@ -1569,6 +1711,8 @@ int phi_reads_text_detach_carry(phi_ctx *c, const char **bytes, int64_t *n)
     if (!c || !bytes || !n) return PHI_ERR_INVALID;
     auto &T = c->text;
     if (!T.active || T.irregular) return phi_fail(c, PHI_ERR_STATE, "phi_reads_text_detach_carry: no regular text stream is open");
+    HIPCHK(hipSetDevice(c->device));
+    PHICHK(text_carry_to_host(c));
     *bytes = T.h_carry.data(); *n = (int64_t)T.h_carry.size();
     T.carry_len = 0; T.detached = true;                       // (the host copy is dropped by the next piece: the pointer stays valid until then)
     return PHI_OK;
@@ -1586,6 +1730,7 @@ int phi_reads_text_end(phi_ctx *c, const char **pending, int64_t *n_pending, int
     PHICHK(text_replay_last(c, err));
     T.last_slot = -1;
     T.active = false;
+    if (!T.irregular) PHICHK(text_carry_to_host(c));
     if (T.detached) { T.h_carry.clear(); T.detached = false; }      // (handed out already)
     if (pending) *pending = T.h_carry.data();
     if (n_pending) *n_pending = (int64_t)T.h_carry.size();

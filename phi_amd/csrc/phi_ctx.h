@@ -171,6 +171,7 @@ struct phi_ctx {
     // ---- reads as raw text (phi_add_reads_text, reads_text.hip): the device finds the records
     struct PhiTextStream {
         bool active = false, irregular = false, started = false, detached = false;
+        bool carry_stale = false;                     // the carry is on the device only (pieces from parked text): h_carry is made when asked for
         int mode = 0;                                 // 0 FASTA, 1 FASTQ with four lines per record
         int64_t fed = 0, taken = 0;                   // stream bytes handed over / taken as whole records
         uint32_t carry_cap = 0, chunk_cap = 0, line_cap = 0;

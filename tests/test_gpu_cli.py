@@ -177,6 +177,40 @@ def test_cli_streams_reads_in_chunks(tmp_path):
         assert (tmp_path / (name + ".fa")).read_text().split("\n")[1:] == (tmp_path / "one.fa").read_text().split("\n")[1:]
 
 
+def test_cli_parks_the_reads_text_in_device_memory_until_the_index_is_built(tmp_path):
+    """One GPU, a large reads file: the chunks the reader thread has read before phi_set_graph is done wait in device memory
+    (phi_text_park_*) instead of the reader waiting for a free buffer.  With PHI_TEXT_PARK_MIN=1 the fixture's 5.4 MB take that
+    way in chunks of 100 kB: every log line and the FASTA are those of the run without (PHI_TEXT_PARK=0); a file that turns
+    irregular half-way has its parked chunks fetched back for the exact host reader."""
+    import gzip
+    args = ["-t8", "-g", os.path.join(DATA, "MHC_4.gfa.gz"), "-r", os.path.join(DATA, "CHM13_reads.fq.gz")]
+    plain = _run_cli(args + ["-o", str(tmp_path / "plain.fa")], tmp_path, env={"PHI_TIMING": "1", "PHI_TEXT_PARK": "0", "PHI_READ_CHUNK": "100000"})
+    parked = _run_cli(args + ["-o", str(tmp_path / "parked.fa")], tmp_path, env={"PHI_TIMING": "1", "PHI_TEXT_PARK_MIN": "1", "PHI_READ_CHUNK": "100000"})
+    assert plain.returncode == 0 and parked.returncode == 0, plain.stderr + parked.stderr
+    assert "waited in device memory" not in plain.stderr
+    m = re.search(r"main: (\d+) bytes of the reads text waited in device memory for the index", parked.stderr)
+    assert m and int(m.group(1)) >= 1_000_000, parked.stderr[-2000:]
+
+    def lines(log):
+        return [re.sub(r"^\[M::[^\]]*\] ", "", l) for l in log.splitlines()
+                if not (l.startswith("[phi timing]") or "Real time" in l or "CMD:" in l or "written to" in l)]
+    assert lines(plain.stderr) == lines(parked.stderr)
+    assert "; 0 bases through the host reader" in parked.stderr
+    assert (tmp_path / "plain.fa").read_text().split("\n")[1:] == (tmp_path / "parked.fa").read_text().split("\n")[1:]
+    # irregular from the middle on: the parked chunks behind the irregular one come back to the host
+    text = gzip.open(os.path.join(DATA, "CHM13_reads.fq.gz"), "rb").read()
+    recs = text.split(b"\n")
+    mid = (len(recs) // 8) * 4
+    wrapped = recs[:mid] + [recs[mid], recs[mid + 1][:70], recs[mid + 1][70:], recs[mid + 2], recs[mid + 3][:70], recs[mid + 3][70:]] + recs[mid + 4:]
+    (tmp_path / "wrapped.fq").write_bytes(b"\n".join(wrapped))
+    r = _run_cli(["-t8", "-g", os.path.join(DATA, "MHC_4.gfa.gz"), "-r", str(tmp_path / "wrapped.fq"), "-o", str(tmp_path / "wrapped.fa")], tmp_path,
+                 env={"PHI_TIMING": "1", "PHI_TEXT_PARK_MIN": "1", "PHI_READ_CHUNK": "100000"})
+    assert r.returncode == 0, r.stderr
+    assert "host reader from the first byte not taken" in r.stderr and "waited in device memory" in r.stderr
+    assert [l for l in lines(r.stderr) if "Loaded graph" not in l] == [l for l in lines(plain.stderr) if "Loaded graph" not in l]
+    assert (tmp_path / "wrapped.fa").read_text().split("\n")[1:] == (tmp_path / "plain.fa").read_text().split("\n")[1:]
+
+
 def test_cli_errors(tmp_path):
     r = _run_cli([], tmp_path)
     assert r.returncode == 1 and r.stderr.startswith("Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta>")

@@ -31,7 +31,7 @@ def _records(bases, off):
     return [raw[off[i]:off[i + 1]] for i in range(len(off) - 1)]
 
 
-def split_on_device(ctx, text, call_bytes, max_chunk=None, totals_only=False):
+def split_on_device(ctx, text, call_bytes, max_chunk=None, totals_only=False, park=None):
     """Records of `text` with the device taking what it can, in calls of call_bytes.  Returns (records, bytes the
     device took, went irregular)."""
     from phi_amd import ilp_index as H
@@ -39,8 +39,16 @@ def split_on_device(ctx, text, call_bytes, max_chunk=None, totals_only=False):
     ctx.reads_text_begin(max_chunk or max(call_bytes, 64))
     recs = []
     irregular, rest_at = False, len(text)
-    for i in range(0, len(text), call_bytes):
-        if ctx.add_reads_text(text[i:i + call_bytes]):
+    for j, i in enumerate(range(0, len(text), call_bytes)):
+        if park is not None and j % 3 != 2:
+            # the piece waits in device memory first (phi_text_park_*): two of three pieces, the third from the host
+            idx = park.add(text[i:i + call_bytes])
+            assert park.fetch(idx) == text[i:i + call_bytes]
+            irr = ctx.add_reads_text_parked(park, idx)
+            park.release(idx)
+        else:
+            irr = ctx.add_reads_text(text[i:i + call_bytes])
+        if irr:
             irregular, rest_at = True, i + call_bytes
             break
         recs += _records(*ctx.reads_text_last_batch())
@@ -78,6 +86,35 @@ def test_kseq_golden_vectors_through_the_device_splitter(ctx):
             assert got == want, (case["text_hex"], call, irregular)
             n_regular += not irregular
     assert n_regular > 20
+
+
+def test_parked_pieces_are_taken_as_host_pieces_are(ctx):
+    """phi_add_reads_text_parked: the piece's bytes are in device memory already (a park filled before the graph was there) --
+    the same records, the same bytes handed back at the end or at irregular text (fetched from the device then: nobody has
+    them on the host), pieces from the park and from the host mixed in one stream.  The reference's kseq vectors and random
+    texts with anomalies, in calls of many sizes."""
+    from phi_amd.context import TextPark
+    park = TextPark(0)
+    gold = json.load(open(os.path.join(GOLDEN, "kseq_vectors.json")))
+    n_regular = 0
+    for case in gold["texts"]:
+        text = bytes.fromhex(case["text_hex"])
+        want = [bytes.fromhex(s) for _, s in case["records"]]
+        if not text:
+            continue
+        for call in (len(text), 1, 3, 7, 16, 64):
+            got, taken, irregular = split_on_device(ctx, text, call, max_chunk=max(64, call), park=park)
+            assert got == want, (case["text_hex"], call, irregular)
+            n_regular += not irregular
+    assert n_regular > 20
+    rng = np.random.default_rng(77)
+    for _ in range(120):
+        text = _random_text(rng)
+        want = kseq_records(text)
+        call = int(rng.choice([len(text), 64, 200, 1000, int(rng.integers(1, 5000))]))
+        got, taken, irregular = split_on_device(ctx, text, max(call, 1), max_chunk=max(64, call), park=park)
+        assert got == want, (text[:300], call, irregular)
+    park.close()
 
 
 def test_block_boundary_vectors_through_the_device_splitter(ctx):
