@@ -4,6 +4,7 @@
 // that needs one returns PHI_ERR_DEVICE.
 #include <chrono>
 #include <atomic>
+#include <memory>
 #include <deque>
 #include <stdarg.h>
 #include <stdio.h>
@@ -1030,41 +1031,67 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     for (int32_t u = 0; u < n_vtx; u++)
         for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) cont_total[u] += cnt_edge[x];
 
-    // ---- DP step stream (dp.hip): per step the live in-edges as (steps back, out-edge index)
-    std::vector<int32_t> st_rec((size_t)n_vtx * 8, 0), in_packed;
+    // ---- DP step stream (dp.hip): per step the live in-edges as (steps back, out-edge index).  All host threads: the records
+    //      are 32 bytes per vertex (268 MB at chromosome scale, first touched by whoever writes them), the in-edges of a vertex
+    //      are gathered with an atomic cursor and then sorted, so that the stream does not depend on who came first.
+    std::unique_ptr<int32_t[]> st_rec_buf(new int32_t[(size_t)n_vtx * 8]);
+    int32_t *const st_rec = st_rec_buf.get();
+    const size_t st_rec_n = (size_t)n_vtx * 8;
+    std::vector<int32_t> in_packed;
     {
         // live in-edges of v: (u, x) with some walk on u continuing along another edge than x
         std::vector<int32_t> live_cnt(n_vtx + 1, 0);
         std::vector<uint8_t> tops(n_vtx, 0);
-        for (int32_t u = 0; u < n_vtx; u++)
-            for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++)
-                if (cont_total[u] - cnt_edge[x] > 0) {
-                    const int64_t back = (int64_t)topo_rank[adj[x]] - topo_rank[u];
-                    if (back >= (1 << 23)) return phi_fail(c, PHI_ERR_UNSUPPORTED, "edge spans more than 2^23 topological steps");
-                    live_cnt[adj[x] + 1]++;
-                    tops[u] = 1;
-                }
+        PhiHostError perr;
+        const int64_t VCH = 1 << 16;
+        phi_parallel_chunks(n_vtx, VCH, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t u = lo; u < hi; u++)
+                for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++)
+                    if (cont_total[u] - cnt_edge[x] > 0) {
+                        const int64_t back = (int64_t)topo_rank[adj[x]] - topo_rank[u];
+                        if (back >= (1 << 23)) { perr.set(PHI_ERR_UNSUPPORTED, "edge spans more than 2^23 topological steps"); return; }
+                        __atomic_fetch_add(&live_cnt[(size_t)adj[x] + 1], 1, __ATOMIC_RELAXED);
+                        tops[u] = 1;
+                    }
+        });
+        if (perr.failed()) return phi_fail(c, perr.code, "%s", perr.msg.c_str());
         for (int32_t v = 0; v < n_vtx; v++) live_cnt[v + 1] += live_cnt[v];
         std::vector<int32_t> live(std::max<int32_t>(live_cnt[n_vtx], 1)), cur(live_cnt.begin(), live_cnt.end() - 1);
-        for (int32_t u = 0; u < n_vtx; u++)
-            for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++)
-                if (cont_total[u] - cnt_edge[x] > 0) {
-                    const int64_t back = (int64_t)topo_rank[adj[x]] - topo_rank[u];
-                    live[cur[adj[x]]++] = (int32_t)(back << 8) | (int32_t)(x - adj_off[u]);
-                }
+        phi_parallel_chunks(n_vtx, VCH, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t u = lo; u < hi; u++)
+                for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++)
+                    if (cont_total[u] - cnt_edge[x] > 0) {
+                        const int64_t back = (int64_t)topo_rank[adj[x]] - topo_rank[u];
+                        live[(size_t)__atomic_fetch_add(&cur[(size_t)adj[x]], 1, __ATOMIC_RELAXED)] = (int32_t)(back << 8) | (int32_t)(x - adj_off[u]);
+                    }
+        });
+        // the in-edges beyond the third of a step go to in_packed: where, from the counts
+        std::vector<int64_t> extra_off((size_t)n_vtx + 1, 0);
         for (int32_t s = 0; s < n_vtx; s++) {
             const int32_t v = c->h_topo[s];
-            int32_t *r = &st_rec[(size_t)s * 8];
             const int n_in = live_cnt[v + 1] - live_cnt[v];
             if (n_in > 255) return phi_fail(c, PHI_ERR_UNSUPPORTED, "vertex %d has more than 255 in-edges", v);
-            r[0] = (n_in ? PHI_DP_NEED_ENTRY : 0) | (tops[v] ? PHI_DP_NEED_TOPS : 0) | (n_in << 8);
-            r[1] = (int32_t)in_packed.size();
-            for (int j = 0; j < n_in; j++) {
-                if (j < 3) r[2 + j] = live[live_cnt[v] + j];
-                else in_packed.push_back(live[live_cnt[v] + j]);
-            }
-            r[5] = v;
+            extra_off[(size_t)s + 1] = extra_off[(size_t)s] + std::max(0, n_in - 3);
         }
+        if (extra_off[(size_t)n_vtx] > INT32_MAX) return phi_fail(c, PHI_ERR_UNSUPPORTED, "more than 2^31 recombination in-edges");
+        in_packed.assign((size_t)extra_off[(size_t)n_vtx], 0);
+        phi_parallel_chunks(n_vtx, VCH, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t s = lo; s < hi; s++) {
+                const int32_t v = c->h_topo[(size_t)s];
+                int32_t *r = &st_rec[(size_t)s * 8];
+                const int n_in = live_cnt[v + 1] - live_cnt[v];
+                int32_t *in = live.data() + live_cnt[v];
+                if (n_in > 1) std::sort(in, in + n_in);
+                r[0] = (n_in ? PHI_DP_NEED_ENTRY : 0) | (tops[v] ? PHI_DP_NEED_TOPS : 0) | (n_in << 8);
+                r[1] = (int32_t)extra_off[(size_t)s];
+                r[2] = r[3] = r[4] = 0;
+                for (int j = 0; j < n_in; j++) {
+                    if (j < 3) r[2 + j] = in[j];
+                    else in_packed[(size_t)extra_off[(size_t)s] + (size_t)(j - 3)] = in[j];
+                }
+                r[5] = v; r[6] = 0; r[7] = 0;
+            }
+        });
     }
 
     tm.lap("  dense step records");
@@ -1079,13 +1106,27 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             lane_only[walk_first(h)] = 1;
             lane_only[walk_last(h)] = 1;
         }
-        c->h_cstep.assign(n_vtx, -1);
-        c->h_kstep.clear();
-        for (int32_t s = 0; s < n_vtx; s++)
-            if ((st_rec[(size_t)s * 8] & 3) || lane_only[c->h_topo[s]]) {
-                c->h_cstep[s] = (int32_t)c->h_kstep.size();
-                c->h_kstep.push_back(s);
-            }
+        {
+            // the compact steps, numbered in step order: counted per chunk of steps, then written, by all threads
+            const int64_t SCH = 1 << 16, n_sch = ((int64_t)n_vtx + SCH - 1) / SCH;
+            std::vector<int32_t> ch_cnt((size_t)n_sch + 1, 0);
+            c->h_cstep.resize((size_t)n_vtx);
+            auto keeps = [&](int64_t s_) { return (st_rec[(size_t)s_ * 8] & 3) || lane_only[(size_t)c->h_topo[(size_t)s_]]; };
+            phi_parallel_chunks(n_vtx, SCH, [&](int64_t lo, int64_t hi, int) {
+                int32_t n = 0;
+                for (int64_t s_ = lo; s_ < hi; s_++) n += keeps(s_);
+                ch_cnt[(size_t)(lo / SCH) + 1] = n;
+            });
+            for (int64_t i = 0; i < n_sch; i++) ch_cnt[(size_t)i + 1] += ch_cnt[(size_t)i];
+            c->h_kstep.resize((size_t)ch_cnt[(size_t)n_sch]);
+            phi_parallel_chunks(n_vtx, SCH, [&](int64_t lo, int64_t hi, int) {
+                int32_t k_ = ch_cnt[(size_t)(lo / SCH)];
+                for (int64_t s_ = lo; s_ < hi; s_++) {
+                    if (keeps(s_)) { c->h_cstep[(size_t)s_] = k_; c->h_kstep[(size_t)k_++] = (int32_t)s_; }
+                    else c->h_cstep[(size_t)s_] = -1;
+                }
+            });
+        }
         c->n_k = (int32_t)c->h_kstep.size();
         k_rec.assign((size_t)c->n_k * 8, 0); k_in.clear(); cvtx.assign(n_vtx, 0);
         for (int32_t k = 0; k < c->n_k; k++) {
@@ -1125,7 +1166,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
             for (int32_t k = 0; k < c->n_k; k++) { n_tops += (k_rec[(size_t)k * 8] & PHI_DP_NEED_TOPS) != 0; n_entry += (k_rec[(size_t)k * 8] & PHI_DP_NEED_ENTRY) != 0; }
             fprintf(stderr, "[phi timing] set_graph: %d compact steps: %lld with TOPS, %lld with ENTRY, %lld pairs\n", c->n_k, (long long)n_tops, (long long)n_entry, (long long)n_pairs);
         }
-        for (int32_t v = 0; v < n_vtx; v++) cvtx[v] = c->h_cstep[topo_rank[v]];
+        phi_parallel_chunks(n_vtx, 1 << 16, [&](int64_t lo, int64_t hi, int) { for (int64_t v = lo; v < hi; v++) cvtx[(size_t)v] = c->h_cstep[(size_t)topo_rank[v]]; });
         tm.lap("  compact records");
         // where the chain of steps may be cut (dp_events.hip, blocks in parallel): not between the two steps of a pair,
         // and only where no recombination edge of this or a later step comes from before the cut
@@ -1162,7 +1203,7 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
     // ---- device copies of what the host pass made
     c->dp_dense_ready = want_masks;
     if (want_masks) {                                          // the every-vertex stream serves dp.hip only
-        PHICHK(upload(c, c->d_st_rec, st_rec.data(), st_rec.size()));
+        PHICHK(upload(c, c->d_st_rec, st_rec, st_rec_n));
         PHICHK(upload(c, c->d_in_packed, in_packed.data(), in_packed.size()));
     }
     // events of every walk: its entries on the compact steps
