@@ -46,6 +46,7 @@
 #include <condition_variable>
 #include <deque>
 #include <future>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -675,9 +676,9 @@ static int run(const Options &o)
     // ---- FASTA (:1577-1598)
     {
         Stage st("FASTA write");
-        std::vector<char> seq((size_t)(res.hap_len > 0 ? res.hap_len : 1));
-        if ((rc = phi_path_sequence(ctx, seq.data(), res.hap_len))) return die("sequence", rc);
-        if (phi_write_fasta(hap_file.c_str(), hap_name, seq.data(), res.hap_len) != PHI_HOST_OK) {
+        std::unique_ptr<char[]> seq(new char[(size_t)(res.hap_len > 0 ? res.hap_len : 1)]);      // (not zero-filled: every byte is written)
+        if ((rc = phi_path_sequence(ctx, seq.get(), res.hap_len))) return die("sequence", rc);
+        if (phi_write_fasta(hap_file.c_str(), hap_name, seq.get(), res.hap_len) != PHI_HOST_OK) {
             fprintf(stderr, "[E::%s] cannot write %s\n", "main", hap_file.c_str());
             return 1;
         }

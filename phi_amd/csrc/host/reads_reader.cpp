@@ -481,7 +481,10 @@ int phi_write_fasta(const char *path, const char *name, const char *seq, int64_t
     FILE *fp = fopen(path, "w");
     if (!fp) return PHI_HOST_ERR_IO;
     fprintf(fp, ">%s LN:%lld\n", name, (long long)len);
-    // 80-column lines, laid out in blocks of 64 K lines (5 MB) and written whole: a chromosome is 180 MB of them
+    // 80-column lines, laid out in blocks of 64 K lines (5 MB) and written whole: a chromosome is 180 MB of them.  (Round 4 tried
+    // all threads laying the lines out into a shared mapping of the file, and into blocks written with pwrite at their offsets:
+    // on tmpfs both were SLOWER than this loop, 0.19 / 0.17 against 0.15 s for 176 MB -- what costs is the file system giving
+    // the file its pages, one at a time under the file's lock.)
     const int64_t LINES = 1 << 16;
     std::vector<char> blk((size_t)(LINES * 81));
     bool ok = true;

@@ -820,21 +820,34 @@ int phi_set_graph(phi_ctx *c, int32_t n_vtx, const char *seq_concat, const int64
         return PHI_OK;
     });
 
-    // topological order from the ranks; every edge must go forward (acyclic GFA, README.md:70-75)
+    // topological order from the ranks; every edge must go forward (acyclic GFA, README.md:70-75).  All host threads: at chromosome
+    // scale these are 8.4 M + 11 M random accesses that every kernel of the index build waits for.
     c->h_topo.assign(n_vtx, -1);
-    for (int32_t v = 0; v < n_vtx; v++) {
-        const int32_t r = topo_rank[v];
-        if (r < 0 || r >= n_vtx || c->h_topo[r] != -1) return phi_fail(c, PHI_ERR_INVALID, "topo_rank is not a permutation (vertex %d): is the graph cyclic?", v);
-        c->h_topo[r] = v;
-    }
     std::vector<int64_t> indeg(n_vtx, 0);
-    for (int32_t u = 0; u < n_vtx; u++)
-        for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) {
-            const int32_t v = adj[x];
-            if (v < 0 || v >= n_vtx) return phi_fail(c, PHI_ERR_INVALID, "edge target %d out of range", v);
-            if (topo_rank[u] >= topo_rank[v]) return phi_fail(c, PHI_ERR_INVALID, "edge %d->%d goes backwards in topo_rank: graph must be acyclic", u, v);
-            indeg[v]++;
-        }
+    {
+        PhiHostError verr;
+        phi_parallel_chunks(n_vtx, 1 << 16, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t v = lo; v < hi && !verr.failed(); v++) {
+                const int32_t r = topo_rank[v];
+                int32_t none = -1;
+                if (r < 0 || r >= n_vtx || !__atomic_compare_exchange_n(&c->h_topo[(size_t)r], &none, (int32_t)v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                    verr.set(PHI_ERR_INVALID, "topo_rank is not a permutation (vertex %d): is the graph cyclic?", (int)v);
+                    return;
+                }
+            }
+        });
+        if (verr.failed()) return phi_fail(c, verr.code, "%s", verr.msg.c_str());
+        phi_parallel_chunks(n_vtx, 1 << 16, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t u = lo; u < hi && !verr.failed(); u++)
+                for (int64_t x = adj_off[u]; x < adj_off[u + 1]; x++) {
+                    const int32_t v = adj[x];
+                    if (v < 0 || v >= n_vtx) { verr.set(PHI_ERR_INVALID, "edge target %d out of range", v); return; }
+                    if (topo_rank[u] >= topo_rank[v]) { verr.set(PHI_ERR_INVALID, "edge %d->%d goes backwards in topo_rank: graph must be acyclic", (int)u, v); return; }
+                    __atomic_fetch_add(&indeg[(size_t)v], 1, __ATOMIC_RELAXED);
+                }
+        });
+        if (verr.failed()) return phi_fail(c, verr.code, "%s", verr.msg.c_str());
+    }
 
     // (the walk entries are range-checked by the first kernel that reads them: phi_walk_edges_kernel, code 4 below)
     tm.lap("validate graph, copies");
@@ -1902,12 +1915,16 @@ int phi_path_sequence(phi_ctx *c, char *buf, int64_t cap)
     if (!c || (!buf && cap > 0)) return PHI_ERR_INVALID;
     if (!c->solved) return phi_fail(c, PHI_ERR_STATE, "phi_path_sequence before phi_solve");
     if (cap < c->result.hap_len) return phi_fail(c, PHI_ERR_INVALID, "buffer too small: need %lld bytes", (long long)c->result.hap_len);
-    int64_t o = 0;
-    for (int32_t v : c->h_path_vtx) {
-        const int64_t len = c->h_seq_off[v + 1] - c->h_seq_off[v];
-        memcpy(buf + o, c->h_seq.data() + c->h_seq_off[v], (size_t)len);      // original case, :1580
-        o += len;
-    }
+    // (where every vertex of the path lands, then the copies by all host threads: 5.8 M vertices and 176 MB at chromosome scale)
+    const int64_t np = (int64_t)c->h_path_vtx.size();
+    std::vector<int64_t> at((size_t)np + 1, 0);
+    for (int64_t i = 0; i < np; i++) { const int32_t v = c->h_path_vtx[(size_t)i]; at[(size_t)i + 1] = at[(size_t)i] + (c->h_seq_off[v + 1] - c->h_seq_off[v]); }
+    phi_parallel_chunks(np, 1 << 15, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; i++) {
+            const int32_t v = c->h_path_vtx[(size_t)i];
+            memcpy(buf + at[(size_t)i], c->h_seq.data() + c->h_seq_off[v], (size_t)(at[(size_t)i + 1] - at[(size_t)i]));      // original case, :1580
+        }
+    });
     return PHI_OK;
 }
 
