@@ -342,10 +342,13 @@ static int run(const Options &o)
     // knows where they are -- while it still enters the segment names --, and the device resolves them (phi_walk_text_*): at
     // chromosome scale the walks are 96% of the file.  Text the device path does not take (reverse steps, names of another form:
     // walk_text.hip) is resolved by the host after all, with the reference's rules.  Small files (PHI_WALK_TEXT_MIN bytes of
-    // walk text, default 32 MB) and multi-GPU runs (every GPU needs the walks) stay with the host.
+    // walk text, default 1 GB) and multi-GPU runs (every GPU needs the walks) stay with the host.
     phi_graph *g = nullptr;
     struct WalkText { std::shared_future<int> *ctx_ready; std::vector<phi_ctx *> *ctxs; int64_t min_bytes; int64_t bytes = 0; int rc = 0; bool sent = false; } wt{&f_ctx, &ctxs, 0};
-    wt.min_bytes = getenv("PHI_WALK_TEXT_MIN") ? atoll(getenv("PHI_WALK_TEXT_MIN")) : ((int64_t)32 << 20);
+    // (1 GB: the host threads resolve 70 MB of walk text -- a 49-walk MHC graph -- in 10 ms, hidden behind the 0.1 s the HIP runtime
+    //  takes to start, while the device path has to wait for that start before its first byte moves: measured at C2, 32 MB as
+    //  the threshold cost every process 40 ms)
+    wt.min_bytes = getenv("PHI_WALK_TEXT_MIN") ? atoll(getenv("PHI_WALK_TEXT_MIN")) : ((int64_t)1 << 30);
     const bool defer_walks = n_dev == 1 && !(getenv("PHI_WALKS") && !strcmp(getenv("PHI_WALKS"), "host"));
     auto gfa_failed = [&]() {
         if (err[0] == 'E') fprintf(stderr, "%s\n", err);            // walk error text of ILP_index.cpp:105

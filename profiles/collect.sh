@@ -60,7 +60,7 @@ json.dump(res, open(f"{out}/sketch_kernel_counters_C3_C4_C5s.json", "w"), indent
 print(json.dumps(res, indent=1)[:3000])
 P
 # 4. the other configurations (bench lines only)
-for cfg in C3 C4 C1syn; do
+for cfg in C3 C4 C1syn C2r C3r; do
   timeout -k 10 300 python3 $B --config $cfg --steps 100 --warmup 10 --no-cpu-baseline --no-extra-legs --job-repeats 3 > $out/bench_line_$cfg.json 2> $out/bench_line_$cfg.err
 done
 timeout -k 10 300 python3 $B --config C5s --steps 5 --warmup 1 --no-cpu-baseline --no-extra-legs > $out/bench_line_C5s.json 2> $out/bench_line_C5s.err
@@ -69,5 +69,5 @@ timeout -k 10 600 python3 $B --config C5 --scaling strong --steps 3 --warmup 1 -
 head -8 $out/kernel_stats.csv | cut -c1-140
 cat $out/bench_line.json
 # 5. config 5 at its stated size from FILES (20 GB on the RAM disk): process start -> closed FASTA with its stage table
-timeout -k 10 900 python3 $GRAFT_REPO_ROOT/profiles/c5_files.py --config C5 --out $out/c5_files.json > $out/c5_files.log 2>&1
+timeout -k 10 900 python3 $GRAFT_REPO_ROOT/profiles/c5_files.py --config C5 --runs 5 --out $out/c5_files.json > $out/c5_files.log 2>&1
 tail -2 $out/c5_files.log | cut -c1-600

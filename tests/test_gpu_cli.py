@@ -211,6 +211,23 @@ def test_cli_parks_the_reads_text_in_device_memory_until_the_index_is_built(tmp_
     assert (tmp_path / "wrapped.fa").read_text().split("\n")[1:] == (tmp_path / "plain.fa").read_text().split("\n")[1:]
 
 
+def test_cli_resolves_the_walks_on_the_device(tmp_path):
+    """PHI_WALK_TEXT_MIN=1: the command line leaves the W-lines as text, uploads them from the reader's callback thread and has
+    the device resolve them (the default takes this path from 1 GB of walk text on); log and FASTA of the run that resolves
+    them on the host (PHI_WALKS=host)."""
+    args = ["-t8", "-g", os.path.join(DATA, "MHC_4.gfa.gz"), "-r", os.path.join(DATA, "CHM13_reads.fq.gz")]
+    host = _run_cli(args + ["-o", str(tmp_path / "host.fa")], tmp_path, env={"PHI_TIMING": "1", "PHI_WALKS": "host"})
+    dev = _run_cli(args + ["-o", str(tmp_path / "dev.fa")], tmp_path, env={"PHI_TIMING": "1", "PHI_WALK_TEXT_MIN": "1"})
+    assert host.returncode == 0 and dev.returncode == 0, host.stderr + dev.stderr
+    assert "resolved on the device" in dev.stderr and "resolved on the device" not in host.stderr
+
+    def lines(log):
+        return [re.sub(r"^\[M::[^\]]*\] ", "", l) for l in log.splitlines()
+                if not (l.startswith("[phi timing]") or l.startswith("[phi]") or "Real time" in l or "CMD:" in l or "written to" in l)]
+    assert lines(host.stderr) == lines(dev.stderr)
+    assert (tmp_path / "host.fa").read_text().split("\n")[1:] == (tmp_path / "dev.fa").read_text().split("\n")[1:]
+
+
 def test_cli_errors(tmp_path):
     r = _run_cli([], tmp_path)
     assert r.returncode == 1 and r.stderr.startswith("Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta>")
