@@ -543,11 +543,19 @@ void phi_launch_class_sel_tri(hipStream_t st, const uint8_t *sel, const int32_t 
 }
 
 #define EXP_STAGE 3072          // anchors of a block staged in LDS (36 KB); a block with more writes them directly
+// What the DP needs of every anchor beside the triple -- its last entry and its span in edges --, the anchors per walk and the
+// two things that would make the device path unusable (an anchor inside one vertex is no dp anchor; a span of PHI_RCAP edges or
+// more) are made here as the anchors are written, not by a second pass over 6 GB of triples (phi_anchor_prep_kernel: 17 ms at
+// config 5).  prep[0] += anchors with e1 <= e0, prep[1] |= 2 for a span >= PHI_RCAP; walk_cnt[h] += anchors whose first entry
+// lies in walk h.  (That the list is sorted by last entry is checked by phi_sorted_u32_kernel on the 4-byte array.)
+struct PhiExpandPrep { phi_ent_t *a_e1; uint8_t *a_span; const int64_t *walk_off; int32_t n_walks; unsigned long long *walk_cnt, *prep; };
 __global__ void __launch_bounds__(256) phi_expand_tri_kernel(const int32_t *__restrict__ ent_cls, int64_t e_lo, int64_t e_hi,
                                                              const int32_t *__restrict__ sel_off, const int32_t *__restrict__ sel_tri,
-                                                             const int64_t *__restrict__ block_off, uint32_t *__restrict__ out_tri)
+                                                             const int64_t *__restrict__ block_off, uint32_t *__restrict__ out_tri, PhiExpandPrep P)
 {
     __shared__ int s_w[4];
+    __shared__ int s_h[2];                                        // walk of the block's first entry; anchors outside it
+    __shared__ long long s_wr[2];
     __shared__ uint32_t s_out[EXP_STAGE * 3];
     const int64_t base = e_lo + ((int64_t)blockIdx.x * 256 + threadIdx.x) * EXP_ITEMS;
     int32_t lo[EXP_ITEMS], nn[EXP_ITEMS];
@@ -562,6 +570,12 @@ __global__ void __launch_bounds__(256) phi_expand_tri_kernel(const int32_t *__re
             nn[j] = sel_off[c + 1] - lo[j];
         }
         cnt += nn[j];
+    }
+    if (threadIdx.x == 0 && P.a_e1) {
+        int l = 0, h = P.n_walks;                                 // last walk with walk_off <= the block's first entry
+        while (h - l > 1) { const int mid = (l + h) >> 1; if (P.walk_off[mid] <= base) l = mid; else h = mid; }
+        s_h[0] = l; s_h[1] = 0;
+        s_wr[0] = P.walk_off[l]; s_wr[1] = P.walk_off[l + 1];
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int v = cnt;
@@ -579,26 +593,60 @@ __global__ void __launch_bounds__(256) phi_expand_tri_kernel(const int32_t *__re
     const int64_t gbase = block_off[blockIdx.x];
     const bool staged = total <= EXP_STAGE;
     uint32_t *dst = staged ? s_out : out_tri + 3 * gbase;
+    const int64_t w_lo = P.a_e1 ? s_wr[0] : 0, w_hi = P.a_e1 ? s_wr[1] : 0;
+    int n_flat = 0, n_out = 0;                                    // anchors inside one vertex; anchors that begin in another walk
+    uint32_t bad = 0;
 #pragma unroll
     for (int j = 0; j < EXP_ITEMS; j++) {
         const uint32_t e = (uint32_t)(base + j);                  // (entries are below 2^32: phi_ent_t)
         for (int32_t r = lo[j], re = lo[j] + nn[j]; r < re; r++, o++) {
             const int32_t id = sel_tri[3 * (int64_t)r], d0 = sel_tri[3 * (int64_t)r + 1], d1 = sel_tri[3 * (int64_t)r + 2];
+            const uint32_t e0 = e + (uint32_t)d0, e1 = e + (uint32_t)d1;
             dst[3 * (int64_t)o + 0] = (uint32_t)id;
-            dst[3 * (int64_t)o + 1] = e + (uint32_t)d0;
-            dst[3 * (int64_t)o + 2] = e + (uint32_t)d1;
+            dst[3 * (int64_t)o + 1] = e0;
+            dst[3 * (int64_t)o + 2] = e1;
+            if (P.a_e1) {
+                P.a_e1[gbase + o] = e1;
+                P.a_span[gbase + o] = (uint8_t)(e1 > e0 ? e1 - e0 : 0);
+                n_flat += e1 <= e0;
+                if (e1 > e0 && e1 - e0 >= PHI_RCAP) bad |= 2u;
+                if ((int64_t)e0 < w_lo || (int64_t)e0 >= w_hi) {  // (a block that straddles two walks: this anchor on its own)
+                    int l = 0, h = P.n_walks;
+                    while (h - l > 1) { const int mid = (l + h) >> 1; if (P.walk_off[mid] <= (int64_t)e0) l = mid; else h = mid; }
+                    atomicAdd(&P.walk_cnt[l], 1ull);
+                    n_out++;
+                }
+            }
         }
+    }
+    if (P.a_e1) {
+        if (bad) atomicOr(&P.prep[1], (unsigned long long)bad);
+        if (n_flat) atomicAdd(&P.prep[0], (unsigned long long)n_flat);
+        if (n_out) atomicAdd(&s_h[1], n_out);
+        __syncthreads();
+        if (threadIdx.x == 0 && total - s_h[1] > 0) atomicAdd(&P.walk_cnt[s_h[0]], (unsigned long long)(total - s_h[1]));
     }
     if (!staged) return;
     __syncthreads();
     uint32_t *g = out_tri + 3 * gbase;
     for (int i = threadIdx.x; i < 3 * total; i += 256) g[i] = s_out[i];
 }
+// out |= 1 when a[i] < a[i - 1] somewhere
+__global__ void __launch_bounds__(256) phi_sorted_u32_kernel(const uint32_t *__restrict__ a, int64_t n, unsigned long long *__restrict__ out)
+{
+    bool badv = false;
+    GRID_STRIDE(i, n) if (i > 0 && a[i] < a[i - 1]) badv = true;
+    if (__ballot(badv) && (threadIdx.x & 63) == 0) atomicOr(out, 1ull);
+}
 void phi_launch_expand_tri(hipStream_t st, const int32_t *ent_cls, int64_t e_lo, int64_t e_hi, const int32_t *sel_off, const int32_t *sel_tri,
-                           const int64_t *block_off, uint32_t *out_tri)
+                           const int64_t *block_off, uint32_t *out_tri, phi_ent_t *a_e1, uint8_t *a_span, const int64_t *walk_off, int32_t n_walks,
+                           unsigned long long *walk_cnt, unsigned long long *prep, int64_t n_anchors)
 {
     const int64_t nb = phi_expand_num_blocks(e_hi - e_lo);
-    if (nb > 0) hipLaunchKernelGGL(phi_expand_tri_kernel, dim3((unsigned)nb), dim3(256), 0, st, ent_cls, e_lo, e_hi, sel_off, sel_tri, block_off, out_tri);
+    if (nb <= 0) return;
+    PhiExpandPrep P{a_e1, a_span, walk_off, n_walks, walk_cnt, prep};
+    hipLaunchKernelGGL(phi_expand_tri_kernel, dim3((unsigned)nb), dim3(256), 0, st, ent_cls, e_lo, e_hi, sel_off, sel_tri, block_off, out_tri, P);
+    if (a_e1 && n_anchors > 1) hipLaunchKernelGGL(phi_sorted_u32_kernel, dim3(grid_for(n_anchors, 256)), dim3(256), 0, st, a_e1, n_anchors, prep + 1);
 }
 
 // sel[r] = 1 for the listed records (list of indices into the class records)

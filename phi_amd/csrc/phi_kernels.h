@@ -185,8 +185,10 @@ void phi_launch_expand_write(hipStream_t st, const PhiExpandArgs &A, int kind);
 void phi_launch_class_sel_count(hipStream_t st, const uint8_t *sel, const int32_t *cls_rec_off, int64_t n_cls, int32_t *sel_cnt);
 void phi_launch_class_sel_tri(hipStream_t st, const uint8_t *sel, const int32_t *cls_rec_off, int64_t n_cls, const int32_t *sel_off, const phi_ent_t *cls_rep,
                               const uint32_t *rec_slot, const uint32_t *u_uid, const phi_ent_t *rec_e0, const phi_ent_t *rec_e1, int32_t *sel_tri);
+// (a_e1 != NULL: the DP's per-anchor arrays, the anchors per walk and the checks of phi_launch_anchor_prep are made on the way)
 void phi_launch_expand_tri(hipStream_t st, const int32_t *ent_cls, int64_t e_lo, int64_t e_hi, const int32_t *sel_off, const int32_t *sel_tri,
-                           const int64_t *block_off, uint32_t *out_tri);
+                           const int64_t *block_off, uint32_t *out_tri, phi_ent_t *a_e1, uint8_t *a_span, const int64_t *walk_off, int32_t n_walks,
+                           unsigned long long *walk_cnt, unsigned long long *prep, int64_t n_anchors);
 void phi_launch_mark_list(hipStream_t st, const int32_t *list, const int32_t *through, int64_t n, uint8_t *sel);
 void phi_launch_share_count_cls(hipStream_t st, const int32_t *ent_cls, int64_t e_lo, int64_t e_hi, const int32_t *cls_rec_off,
                                 const uint32_t *rec_slot, int32_t walk, int32_t *last_walk, int32_t *n_walks_of);

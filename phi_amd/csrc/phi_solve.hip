@@ -605,6 +605,7 @@ int phi_solve_impl(phi_ctx *c)
     PHICHK(phi_dev_ensure(c, c->d_flags2, (size_t)std::max<int64_t>(n_matched, 1)));
     phi_launch_kept_flags(c->stream, F, n_matched, c->d_flags.as<uint8_t>(), c->d_flags2.as<uint8_t>());
     int64_t n_kept_rec = 0, n_kept = 0;
+    bool anchors_prepped = false;
     PHICHK(phi_compact(c, c->d_flags.as<uint8_t>(), n_matched, c->d_list, &n_kept_rec));
     tm.lap("filter kernels");
     // The kept class records are expanded into the anchors of the model: every walk entry of a record's class
@@ -637,6 +638,11 @@ int phi_solve_impl(phi_ctx *c)
         c->h_kept_hash.clear();
         PHICHK(phi_dev_ensure(c, c->d_anchors, (size_t)std::max<int64_t>(n_kept, 1) * 12));
         static_assert(sizeof(PhiAnchorHost) == 12, "PhiAnchorHost is the device triple");
+        // (the DP's per-anchor arrays and the counters of the anchor checks: the packed expansion fills them on its way)
+        PHICHK(phi_dev_ensure(c, c->d_a_e1, (size_t)std::max<int64_t>(n_kept, 1) * 4));
+        PHICHK(phi_dev_ensure(c, c->d_g_span, (size_t)std::max<int64_t>(n_kept, 1)));
+        PHICHK(phi_dev_ensure(c, c->d_ctr, (size_t)(nw + 8) * 8));
+        HIPCHK(hipMemsetAsync(c->d_ctr.p, 0, (size_t)(nw + 8) * 8, c->stream));
         if (n_kept && getenv("PHI_EXPAND_GENERIC")) {               // (tests: the generic expansion, record by record)
             X.out_tri = c->d_anchors.as<uint32_t>();
             phi_launch_expand_write(c->stream, X, 1);
@@ -650,8 +656,11 @@ int phi_solve_impl(phi_ctx *c)
             phi_launch_scan_i32(c->stream, c->d_list3.as<int32_t>(), c->n_cls, c->d_sel_off.as<int32_t>(), c->d_scan_blk.as<int32_t>(), c->d_scan_blkoff.as<int64_t>());
             phi_launch_class_sel_tri(c->stream, c->d_flags2.as<uint8_t>(), c->d_cls_rec_off.as<int32_t>(), c->n_cls, c->d_sel_off.as<int32_t>(), c->d_cls_rep.as<phi_ent_t>(),
                                      c->d_rec_slot.as<uint32_t>(), c->d_u_uid.as<uint32_t>(), c->d_rec_e0.as<phi_ent_t>(), c->d_rec_e1.as<phi_ent_t>(), c->d_sel_tri.as<int32_t>());
+            unsigned long long *d_ctr = c->d_ctr.as<unsigned long long>();
             phi_launch_expand_tri(c->stream, c->d_ent_cls.as<int32_t>(), 0, c->n_entries, c->d_sel_off.as<int32_t>(), c->d_sel_tri.as<int32_t>(),
-                                  c->d_blk_off.as<int64_t>(), c->d_anchors.as<uint32_t>());
+                                  c->d_blk_off.as<int64_t>(), c->d_anchors.as<uint32_t>(), c->d_a_e1.as<phi_ent_t>(), c->d_g_span.as<uint8_t>(),
+                                  c->d_walk_off.as<int64_t>(), nw, d_ctr + 8, d_ctr, n_kept);
+            anchors_prepped = true;
         }
     }
     // The DP's per-anchor arrays (last entry, span), the anchors per walk and the checks on them, on the device.
@@ -660,12 +669,9 @@ int phi_solve_impl(phi_ctx *c)
     const uint32_t *d_tri = c->d_anchors.as<uint32_t>();
     bool dev = false;
     {
-        PHICHK(phi_dev_ensure(c, c->d_a_e1, (size_t)std::max<int64_t>(n_kept, 1) * 4));
-        PHICHK(phi_dev_ensure(c, c->d_g_span, (size_t)std::max<int64_t>(n_kept, 1)));
-        PHICHK(phi_dev_ensure(c, c->d_ctr, (size_t)(nw + 8) * 8));
-        HIPCHK(hipMemsetAsync(c->d_ctr.p, 0, (size_t)(nw + 8) * 8, c->stream));
         unsigned long long *d_ctr = c->d_ctr.as<unsigned long long>();
-        phi_launch_anchor_prep(c->stream, d_tri, n_kept, c->d_walk_off.as<int64_t>(), nw, c->d_a_e1.as<phi_ent_t>(), c->d_g_span.as<uint8_t>(), d_ctr + 8, d_ctr);
+        if (!anchors_prepped)
+            phi_launch_anchor_prep(c->stream, d_tri, n_kept, c->d_walk_off.as<int64_t>(), nw, c->d_a_e1.as<phi_ent_t>(), c->d_g_span.as<uint8_t>(), d_ctr + 8, d_ctr);
         std::vector<unsigned long long> hc((size_t)nw + 8);
         HIPCHK(hipMemcpyAsync(hc.data(), d_ctr, hc.size() * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
