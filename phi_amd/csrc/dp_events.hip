@@ -688,13 +688,15 @@ __global__ void __launch_bounds__(NW * 64) phi_dp_events_kernel(PhiDpEventArgs A
 //            DP_SEQ writes (best scores / run starts per event, tops, entries) plus, per walk, where the run
 //            that carries the best key out of the block began -- the backtrack follows runs across blocks
 
-template <int NPW, int MODE, int P, int RINGT, int QD>
+// CK: steps of the step stream staged at a time (two chunks in LDS).  Blocks of at most 64 steps -- the class-lane blocks of a
+// chromosome-scale graph are ~18 -- take CK = 32 and a ring of 64 tops: 26 instead of 35 KB of LDS, six workgroups per CU instead of four.
+template <int NPW, int MODE, int P, int RINGT, int QD, int CK = CHK>
 __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpEventArgs A)
 {
     constexpr int D = 2 * P;
-    constexpr int PER_CHUNK = CHK / P;
-    static_assert(P % NPW == 0 && CHK % P == 0, "ring geometry");
-    __shared__ int4 s_rec[2 * CHK][2];              // step records: ring of two chunks, index = (step - k0) mod 2*CHK
+    constexpr int PER_CHUNK = CK / P;
+    static_assert(P % NPW == 0 && CK % P == 0, "ring geometry");
+    __shared__ int4 s_rec[2 * CK][2];              // step records: ring of two chunks, index = (step - k0) mod 2*CHK
     __shared__ int4 s_top[RINGT];                   // packed tops of recent steps
     __shared__ int2 s_ent[2 * P];                   // (source step, walk) of the entries of the last two periods
     __shared__ uint4 s_ev[D][3][64];
@@ -743,10 +745,10 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
         const int pw = wave - 1;
         const uint4 *evg = reinterpret_cast<const uint4 *>(A.ev);
         auto stage = [&](int c) {
-            const int32_t s0 = k0 + c * CHK;
-            const int32_t ns = min(CHK, k1 - s0);
+            const int32_t s0 = k0 + c * CK;
+            const int32_t ns = min(CK, k1 - s0);
             const int4 *src = reinterpret_cast<const int4 *>(A.k_rec + (int64_t)s0 * 8);
-            int4 *dst = &s_rec[(c & 1) * CHK][0];
+            int4 *dst = &s_rec[(c & 1) * CK][0];
             for (int i = pw * 64 + h; i < ns * 2; i += 64 * NPW) dst[i] = src[i];
         };
         stage(0);
@@ -801,7 +803,7 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
             }
             wl = max(wl, min(hi, wl + P));
             // 4. the step records of the next chunk
-            if (p % PER_CHUNK == 0 && (p / PER_CHUNK + 1) * CHK < n_steps) stage(p / PER_CHUNK + 1);
+            if (p % PER_CHUNK == 0 && (p / PER_CHUNK + 1) * CK < n_steps) stage(p / PER_CHUNK + 1);
             vprev = vi;
             __syncthreads();                         // B_{p+1}
         }
@@ -877,8 +879,8 @@ __global__ void __launch_bounds__(64 * (1 + NPW)) phi_dp_events_pc_kernel(PhiDpE
         for (int32_t r = p * P; r < r_end;) {
             const int32_t k = k0 + r;
             // records of the next two steps (past the last step: stale records, never used)
-            const int4 na = s_rec[(r + 1) & (2 * CHK - 1)][0], nb = s_rec[(r + 1) & (2 * CHK - 1)][1];
-            const int4 n2a = s_rec[(r + 2) & (2 * CHK - 1)][0], n2b = s_rec[(r + 2) & (2 * CHK - 1)][1];
+            const int4 na = s_rec[(r + 1) & (2 * CK - 1)][0], nb = s_rec[(r + 1) & (2 * CK - 1)][1];
+            const int4 n2a = s_rec[(r + 2) & (2 * CK - 1)][0], n2b = s_rec[(r + 2) & (2 * CK - 1)][1];
             // two alleles of one site (PHI_DP_PAIR: neither leaves states, no walk visits both): one iteration
             const bool pair = (ra.x & PHI_DP_PAIR) && r + 1 < r_end;
             const int32_t stepk = (int32_t)(cA.x & 0x7FFFFFFFu);    // (no event: 0xFFFFFFFF, a step no block reaches)
@@ -1477,7 +1479,9 @@ void phi_launch_dp_block_rows(hipStream_t st, const PhiDpEventArgs &A)
     //  the second pass keeps this layout, the rows go one step further:)
     // (a period of two steps instead of four halves the event ring and the result ring: 35 KB, FOUR tasks per CU; the extra
     //  barriers cost the consumer less than the fourth task gains -- C2 rows 2.8 -> 2.3 ms with their copy to the host)
-    if (A.blk_ring <= 256) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 2, 256, 8>), dim3(grid), dim3(64 * 3), 0, st, A);
+    if (A.blk_ring <= 256 && A.blk_max_len > 0 && A.blk_max_len <= 64 && !getenv("PHI_DP_ROWS_LARGE"))
+        hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 2, 64, 8, 32>), dim3(grid), dim3(64 * 3), 0, st, A);
+    else if (A.blk_ring <= 256) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 2, 256, 8>), dim3(grid), dim3(64 * 3), 0, st, A);
     else if (A.blk_ring <= 1024) hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 1024, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
     else hipLaunchKernelGGL((phi_dp_events_pc_kernel<2, DP_ROW, 4, 2048, 16>), dim3(grid), dim3(64 * 3), 0, st, A);
 }

@@ -209,7 +209,7 @@ struct phi_ctx {
     // may not sit before (a recombination edge would cross it / it would split a pair of allele steps); per solve, the cuts
     std::vector<int32_t> h_k_cut_ok;                  // [n_k + 1]: 1 = structurally a cut may sit before step k
     bool dp_blocks = false;
-    int32_t n_blk = 0, blk_ring = 1024;
+    int32_t n_blk = 0, blk_ring = 1024, blk_max_len = 0;
     std::vector<int32_t> h_blk_lo;
     DevBuf d_blk_lo, d_blk_ev, d_blk_S, d_row_out, d_rowend, d_blk_keys, d_blk_carry, d_cov, d_cov2, d_stepdiff;
     // more than 64 walks: the blocks' rows run on class lanes (dp_events.hip), regrouped per DP run

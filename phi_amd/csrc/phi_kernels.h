@@ -286,7 +286,8 @@ struct PhiDpEventArgs {
     uint32_t *err;                       // PHI_KERR_DP_QUEUE
     int32_t q_limit;                     // 0 = the kernel's queue depth; tests lower it to provoke the fallback
     // blocks of steps solved in parallel (<= 64 walks, dp_events.hip DP_ROW / DP_PATH): block b = steps [blk_lo[b], blk_lo[b+1])
-    int32_t n_blk, blk_ring;             // blk_ring: 1024 or 2048 = the longest block
+    int32_t n_blk, blk_ring;             // blk_ring: 256, 1024 or 2048 >= the longest block
+    int32_t blk_max_len;                 // the longest block in steps (0: not known)
     int32_t lane_stride;                 // row length of the per-(block, walk) tables: 64 (<= 64 walks) or 256
     const int32_t *lane_walk;            // DP_ROW on class lanes (> 64 walks): [n_blk][64] the walk that plays class lane l (-1: none)
     int32_t *rownew_out;                 // DP_ROW on class lanes: [n_blk * 65] best key of a run begun inside the block on the unit lane

@@ -179,6 +179,8 @@ static int dp_prepare_blocks(phi_ctx *c, int64_t n_dp)
     c->h_blk_lo.push_back(nk);
     c->n_blk = (int32_t)c->h_blk_lo.size() - 1;
     if (c->n_blk < 2) { c->n_blk = 0; return PHI_OK; }
+    c->blk_max_len = 0;
+    for (int32_t b = 0; b < c->n_blk; b++) c->blk_max_len = std::max(c->blk_max_len, c->h_blk_lo[(size_t)b + 1] - c->h_blk_lo[(size_t)b]);
     const size_t nbk = (size_t)c->n_blk, ls = (size_t)c->blk_ls, nrow = cls ? 65 : (size_t)(c->n_walks + 1);
     PHICHK(phi_dev_ensure(c, c->d_blk_lo, (nbk + 1) * 4));
     PHICHK(phi_dev_ensure(c, c->d_blk_ev, nbk * ls * 4));
@@ -287,7 +289,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
             // every class lane: rows of its transfer matrix; 3. the chain over the blocks, on the device; 4. the blocks
             // again, on walk lanes, from their true entry vectors; 5. the two passes must agree
             const int32_t nb = c->n_blk;
-            A.n_blk = nb; A.blk_ring = c->blk_ring; A.blk_lo = c->d_blk_lo.as<int32_t>(); A.blk_ev = c->d_blk_ev.as<int32_t>(); A.blk_S = c->d_blk_S.as<int32_t>();
+            A.n_blk = nb; A.blk_ring = c->blk_ring; A.blk_max_len = c->blk_max_len; A.blk_lo = c->d_blk_lo.as<int32_t>(); A.blk_ev = c->d_blk_ev.as<int32_t>(); A.blk_S = c->d_blk_S.as<int32_t>();
             A.row_out = c->d_row_out.as<int32_t>(); A.rowend_out = c->d_rowend.as<int32_t>(); A.rownew_out = c->d_rownew.as<int32_t>();
             A.rowdiag_out = c->d_rowdiag.as<int32_t>();
             A.blk_keys_out = c->d_blk_keys.as<int32_t>(); A.blk_carry = c->d_blk_carry.as<int32_t>();
@@ -343,7 +345,7 @@ static int run_dp(phi_ctx *c, const std::vector<uint8_t> *wgt, DpHost &H, int64_
         } else if (c->dp_blocks) {
             // 1. every block from every entry walk (and from the walk starts inside it): rows of its transfer matrix
             const int32_t nb = c->n_blk, nwk = c->n_walks, nrow = nwk + 1;
-            A.n_blk = nb; A.blk_ring = c->blk_ring; A.blk_lo = c->d_blk_lo.as<int32_t>(); A.blk_ev = c->d_blk_ev.as<int32_t>(); A.blk_S = c->d_blk_S.as<int32_t>();
+            A.n_blk = nb; A.blk_ring = c->blk_ring; A.blk_max_len = c->blk_max_len; A.blk_lo = c->d_blk_lo.as<int32_t>(); A.blk_ev = c->d_blk_ev.as<int32_t>(); A.blk_S = c->d_blk_S.as<int32_t>();
             A.row_out = c->d_row_out.as<int32_t>(); A.rowend_out = c->d_rowend.as<int32_t>();
             A.blk_keys_out = c->d_blk_keys.as<int32_t>(); A.blk_carry = c->d_blk_carry.as<int32_t>();
             phi_launch_dp_block_rows(c->stream, A);
