@@ -1264,32 +1264,43 @@ __global__ void __launch_bounds__(256) phi_blk_classes_kernel(PhiBlkClassArgs G)
 // (its constant term) -- segments x (walks + 1) independent workgroups --, phi_seg_chain_kernel chains the segments'
 // matrices (one workgroup, segments x walks rows), and MODE 2 replays every segment from its true entry keys, in
 // parallel, writing what MODE 0 (the whole chain by one workgroup) writes.  C5: 94 671 blocks in 64 segments.
-template <int MODE>
+// U: unit vectors one workgroup of MODE 1 carries through its segment AT ONCE.  The blocks' rows are the same for every unit
+// vector of a segment (24 MB per segment at C5, read by 201 workgroups: 316 GB through the L2s per DP run), and what a
+// workgroup spends per block is latency -- two barriers, LDS atomics, dependent reads --, not arithmetic: with U chains
+// interleaved in one instruction stream a block's rows are loaded once for U of them and the barriers are shared.
+template <int MODE, int U = 1>
 __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, const int32_t *__restrict__ rows, const int32_t *__restrict__ rownew,
                                                             const int32_t *__restrict__ rowdiag, int32_t *__restrict__ blk_S,
                                                             const int32_t *__restrict__ seg_lo, int32_t *__restrict__ seg_row,
                                                             const int32_t *__restrict__ seg_S)
 {
+    static_assert(MODE == 1 || U == 1, "several unit vectors at once: the segments' matrices only");
     constexpr int NR = 65 * 64;
     constexpr int DEPTH = 4;
     // "no value" is NEGK everywhere: NEGK + a key (|key| < 2^27) and NEGK + NEGK stay below NEGK / 2 and inside int32, so a
     // maximum of sums needs no test of its operands (the loop is the longest dependent chain of an iteration: one
     // workgroup walks 10^5 blocks, 1.1 us each, and what it costs is its instruction count -- C5: 112 ms per DP run)
     constexpr int32_t NONE = NEGK;
-    __shared__ int32_t s_b1[2][64], s_b2[2][64], s_n1[2][64];  // per class: best S + d, second best, walks that reach the best
+    __shared__ int32_t s_b1[2][U][64], s_b2[2][U][64], s_n1[2][U][64];  // per class: best S + d, second best, walks that reach the best
     __shared__ int32_t s_diag[2][64], s_start[2][64], s_new[2][64];
-    __shared__ int32_t s_part[2][4][64];
+    __shared__ int32_t s_part[2][U][4][64];
     const int x = threadIdx.x, lane = x & 63, wid = __builtin_amdgcn_readfirstlane(x >> 6);
     const int32_t LS = G.lane_stride;
     const bool has_walk = x < G.n_walks;
     // the blocks this workgroup chains, the keys it starts from, whether walks may start inside
-    const int32_t seg = MODE == 0 ? 0 : MODE == 1 ? (int32_t)blockIdx.x / (G.n_walks + 1) : (int32_t)blockIdx.x;
-    const int32_t unit = MODE == 1 ? (int32_t)blockIdx.x % (G.n_walks + 1) : -1;
+    const int32_t groups = MODE == 1 ? (G.n_walks + 1 + U - 1) / U : 1;
+    const int32_t seg = MODE == 0 ? 0 : MODE == 1 ? (int32_t)blockIdx.x / groups : (int32_t)blockIdx.x;
+    const int32_t unit0 = MODE == 1 ? ((int32_t)blockIdx.x % groups) * U : -1;
     const int32_t b_lo = MODE == 0 ? 0 : seg_lo[seg], nb = MODE == 0 ? G.n_blk : seg_lo[seg + 1];
-    const bool with_starts = MODE != 1 || unit == G.n_walks;
-    int32_t S = NEGK;
-    if (MODE == 1 && x == unit) S = 0;
-    if (MODE == 2 && has_walk) S = seg_S[(int64_t)seg * LS + x];
+    int32_t S[U];
+    bool with_starts[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        with_starts[u] = MODE != 1 || unit0 + u == G.n_walks;           // (units past the last one carry nothing: all keys stay NEGK)
+        S[u] = NEGK;
+        if (MODE == 1 && x == unit0 + u) S[u] = 0;
+        if (MODE == 2 && has_walk) S[u] = seg_S[(int64_t)seg * LS + x];
+    }
     int32_t st_row[DEPTH][16], st_x[DEPTH], st_lx[DEPTH], st_dx[DEPTH];
     const int32_t *p_row = rows + wid * 64 + lane;   // + b * NR + 256 * i
     const int32_t *p_x = wid == 0 ? rows + 64 * 64 + lane : wid == 1 ? rownew + lane : rowdiag + lane;   // + b * (NR | 65 | 64): walk starts (wave 0), new-run keys (wave 1), the rows' own columns (wave 2)
@@ -1308,48 +1319,68 @@ __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, c
         constexpr int j = decltype(J)::value;
         const int p = b & 1;
         const int32_t lx = st_lx[j], dx = st_dx[j];
-        if (wid == 0) s_start[p][lane] = with_starts ? st_x[j] : NEGK;   // (lanes past the block's classes are never read)
+        if (wid == 0) s_start[p][lane] = st_x[j];                         // (lanes past the block's classes are never read)
         if (wid == 1) s_new[p][lane] = st_x[j];
         if (wid == 2) s_diag[p][lane] = st_x[j];
-        if (MODE != 1 && has_walk) blk_S[(int64_t)b * LS + x] = S;
-        const bool live = has_walk && S > NEGK / 2;
-        const int32_t v = S + dx;
-        if (live) atomicMax(&s_b1[p][lx], v);                   // (reset in the previous iteration, a barrier ago)
+        if (MODE != 1 && has_walk) blk_S[(int64_t)b * LS + x] = S[0];
+        bool live[U];
+        int32_t v[U], b1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            live[u] = has_walk && S[u] > NEGK / 2;
+            v[u] = S[u] + dx;
+            if (live[u]) atomicMax(&s_b1[p][u][lx], v[u]);               // (reset in the previous iteration, a barrier ago)
+        }
         __syncthreads();
-        const int32_t b1 = s_b1[p][lx];
-        if (live) { if (v == b1) atomicAdd(&s_n1[p][lx], 1); else atomicMax(&s_b2[p][lx], v); }
-        if (x < 64) { s_b1[p ^ 1][x] = NONE; s_b2[p ^ 1][x] = NONE; s_n1[p ^ 1][x] = 0; }   // for the next iteration (last read before this iteration's first barrier)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            b1[u] = s_b1[p][u][lx];
+            if (live[u]) { if (v[u] == b1[u]) atomicAdd(&s_n1[p][u][lx], 1); else atomicMax(&s_b2[p][u][lx], v[u]); }
+        }
+        if (x < 64) {
+#pragma unroll
+            for (int u = 0; u < U; u++) { s_b1[p ^ 1][u][x] = NONE; s_b2[p ^ 1][u][x] = NONE; s_n1[p ^ 1][u][x] = 0; }   // for the next iteration (last read before this iteration's first barrier)
+        }
         // partial maxima over this wave's classes, for class lane `lane`
-        int32_t part = NONE;
         // (branch-free: the sixteen LDS reads go out together.  Classes past the block's count have no live walk: their
         //  maximum is NONE, and NONE plus whatever lies in their rows -- keys of an earlier solve at most -- stays "no
         //  value"; the row's own column holds NEGK, see the row pass)
-        int32_t o16[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) o16[i] = s_b1[p][wid + 4 * i];
+        for (int u = 0; u < U; u++) {
+            int32_t part = NONE;
+            int32_t o16[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) part = max(part, o16[i] + st_row[j][i]);
-        s_part[p][wid][lane] = part;
+            for (int i = 0; i < 16; i++) o16[i] = s_b1[p][u][wid + 4 * i];
+#pragma unroll
+            for (int i = 0; i < 16; i++) part = max(part, o16[i] + st_row[j][i]);
+            s_part[p][u][wid][lane] = part;
+        }
         issue(J, min(b + DEPTH, nb - 1));                      // (always: the compiler can then count the loads in flight instead of draining them)
         __syncthreads();
-        int32_t best = NEGK;
-        if (has_walk) {
-            if (live) { const int32_t r = s_diag[p][lx]; if (r > NEGK / 2) best = S + r; }
-            {
-                // the best of the other walks of the class
-                const int32_t o = (live && v == b1 && s_n1[p][lx] == 1) ? s_b2[p][lx] : b1;
-                const int32_t kn = s_new[p][lx];
-                if (o > NEGK / 2 && kn > NEGK / 2 && o + kn - dx > best) best = o + kn - dx;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int32_t best = NEGK;
+            if (has_walk) {
+                if (live[u]) { const int32_t r = s_diag[p][lx]; if (r > NEGK / 2) best = S[u] + r; }
+                {
+                    // the best of the other walks of the class
+                    const int32_t o = (live[u] && v[u] == b1[u] && s_n1[p][u][lx] == 1) ? s_b2[p][u][lx] : b1[u];
+                    const int32_t kn = s_new[p][lx];
+                    if (o > NEGK / 2 && kn > NEGK / 2 && o + kn - dx > best) best = o + kn - dx;
+                }
+                const int32_t d = max(max(s_part[p][u][0][lx], s_part[p][u][1][lx]), max(s_part[p][u][2][lx], s_part[p][u][3][lx]));
+                if (d > NEGK / 2 && d - dx > best) best = d - dx;
+                if (with_starts[u]) { const int32_t r = s_start[p][lx]; if (r > NEGK / 2 && r - dx > best) best = r - dx; }
             }
-            const int32_t d = max(max(s_part[p][0][lx], s_part[p][1][lx]), max(s_part[p][2][lx], s_part[p][3][lx]));
-            if (d > NEGK / 2 && d - dx > best) best = d - dx;
-            { const int32_t r = s_start[p][lx]; if (r > NEGK / 2 && r - dx > best) best = r - dx; }
+            S[u] = best > NEGK / 2 ? best : NEGK;
         }
-        S = best > NEGK / 2 ? best : NEGK;
         // (no barrier here: the next iteration writes the other parity only, and what it reads of it was settled
         //  before this iteration's second barrier)
     };
-    if (x < 64) { s_b1[b_lo & 1][x] = NONE; s_b2[b_lo & 1][x] = NONE; s_n1[b_lo & 1][x] = 0; }
+    if (x < 64) {
+#pragma unroll
+        for (int u = 0; u < U; u++) { s_b1[b_lo & 1][u][x] = NONE; s_b2[b_lo & 1][u][x] = NONE; s_n1[b_lo & 1][u][x] = 0; }
+    }
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     issue(I0{}, min(b_lo, nb - 1));
@@ -1367,7 +1398,11 @@ __global__ void __launch_bounds__(256) phi_blk_chain_kernel(PhiBlkClassArgs G, c
     if (b < nb) step(I0{}, b);
     if (b + 1 < nb) step(I1{}, b + 1);
     if (b + 2 < nb) step(I2{}, b + 2);
-    if (MODE == 1 && has_walk) seg_row[(int64_t)blockIdx.x * LS + x] = S;      // what leaves the segment
+    if (MODE == 1 && has_walk) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (unit0 + u <= G.n_walks) seg_row[((int64_t)seg * (G.n_walks + 1) + unit0 + u) * LS + x] = S[u];      // what leaves the segment
+    }
 }
 
 // The segments' matrices chained: seg_S[g] = the keys entering segment g.  seg_row[(g * (walks + 1) + u) * LS + x] = the key
@@ -1439,7 +1474,12 @@ void phi_launch_blk_chain(hipStream_t st, const PhiBlkClassArgs &G, const int32_
 void phi_launch_blk_chain_segments(hipStream_t st, const PhiBlkClassArgs &G, const int32_t *rows, const int32_t *rownew, const int32_t *rowdiag, int32_t *blk_S,
                                    int32_t n_seg, const int32_t *d_seg_lo, int32_t *seg_row, int32_t *seg_S)
 {
-    hipLaunchKernelGGL(phi_blk_chain_kernel<1>, dim3((unsigned)n_seg * (unsigned)(G.n_walks + 1)), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S, d_seg_lo, seg_row, seg_S);
+    const int units = getenv("PHI_DP_CHAIN_UNITS") ? atoi(getenv("PHI_DP_CHAIN_UNITS")) : 3;      // unit vectors per workgroup (tests: 1, 2)
+    const unsigned nu = (unsigned)(G.n_walks + 1);
+    if (units >= 4) hipLaunchKernelGGL((phi_blk_chain_kernel<1, 4>), dim3((unsigned)n_seg * ((nu + 3) / 4)), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S, d_seg_lo, seg_row, seg_S);
+    else if (units == 3) hipLaunchKernelGGL((phi_blk_chain_kernel<1, 3>), dim3((unsigned)n_seg * ((nu + 2) / 3)), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S, d_seg_lo, seg_row, seg_S);
+    else if (units == 2) hipLaunchKernelGGL((phi_blk_chain_kernel<1, 2>), dim3((unsigned)n_seg * ((nu + 1) / 2)), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S, d_seg_lo, seg_row, seg_S);
+    else hipLaunchKernelGGL((phi_blk_chain_kernel<1, 1>), dim3((unsigned)n_seg * nu), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S, d_seg_lo, seg_row, seg_S);
     hipLaunchKernelGGL(phi_seg_chain_kernel, dim3(1), dim3(256), 0, st, n_seg, G.n_walks, G.lane_stride, seg_row, seg_S);
     hipLaunchKernelGGL(phi_blk_chain_kernel<2>, dim3((unsigned)n_seg), dim3(256), 0, st, G, rows, rownew, rowdiag, blk_S, d_seg_lo, seg_row, seg_S);
 }

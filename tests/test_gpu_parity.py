@@ -1606,8 +1606,11 @@ def test_dp_blocks_on_class_lanes_equal_the_whole_chain(oracle, ctx_factory, mon
         a, b = out["blocks"], out["whole"]
         # the chain over the blocks cut into segments (unit rows in parallel, segment chain, replay): 3 segments, and as many as
         # there are blocks -- field for field what the one-workgroup chain gives
-        for n_seg in ("3", "100000"):
+        # ... with three unit vectors per workgroup (the default), and with one, two and four
+        for n_seg, units in (("3", None), ("100000", None), ("3", "1"), ("5", "2"), ("3", "4")):
             monkeypatch.setenv("PHI_DP_CHAIN_SEGMENTS", n_seg)
+            if units is not None:
+                monkeypatch.setenv("PHI_DP_CHAIN_UNITS", units)
             if block_steps is not None:
                 monkeypatch.setenv("PHI_DP_BLOCK_STEPS", block_steps)
             ctx = ctx_factory(k=k, w=w, threshold=1.0, recombination=R)
@@ -1617,6 +1620,7 @@ def test_dp_blocks_on_class_lanes_equal_the_whole_chain(oracle, ctx_factory, mon
             sres = ctx.solve()
             sinfo = ctx.solve_stats()
             monkeypatch.delenv("PHI_DP_CHAIN_SEGMENTS")
+            monkeypatch.delenv("PHI_DP_CHAIN_UNITS", raising=False)
             monkeypatch.delenv("PHI_DP_BLOCK_STEPS", raising=False)
             for key in a:
                 if isinstance(a[key], np.ndarray):
