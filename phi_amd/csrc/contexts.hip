@@ -542,7 +542,7 @@ void phi_launch_class_sel_tri(hipStream_t st, const uint8_t *sel, const int32_t 
                            rec_e0, rec_e1, sel_tri);
 }
 
-#define EXP_STAGE 3072          // anchors of a block staged in LDS (36 KB); a block with more writes them directly
+#define EXP_STAGE 1536          // anchors of a block staged in LDS (18 KB: eight workgroups per CU); a block with more writes them directly
 // What the DP needs of every anchor beside the triple -- its last entry and its span in edges --, the anchors per walk and the
 // two things that would make the device path unusable (an anchor inside one vertex is no dp anchor; a span of PHI_RCAP edges or
 // more) are made here as the anchors are written, not by a second pass over 6 GB of triples (phi_anchor_prep_kernel: 17 ms at

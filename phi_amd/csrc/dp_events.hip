@@ -232,7 +232,9 @@ void phi_launch_scan_u8(hipStream_t st, const uint8_t *cnt, int64_t n, int32_t *
 // the union once, coalesced, into LDS (last entry; span | weight << 7) and every event counts from there.  (Round 3: every
 // event walked its ranges in global memory, three dependent loads per anchor and 24 anchors per event at config 5: 30 ms per
 // DP run.)  A block whose union is longer than the stage (events far apart along chain vertices) reads global memory as before.
-#define EVF_STAGE 6144
+// (3 072 entries = 15 KB: ten workgroups per CU; with 6 144 -- five -- the kernel took 19-21 instead of 15.6 ms at config 5, with 1 024
+//  too many blocks fell back to global memory: 18.8)
+#define EVF_STAGE 3072
 __global__ void __launch_bounds__(256) phi_dp_event_fill_kernel(const phi_ent_t *__restrict__ ev_e, int64_t n_ev,
                                                                 const int32_t *__restrict__ walk_vtx,
                                                                 const int32_t *__restrict__ cvtx,

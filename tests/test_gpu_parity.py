@@ -546,7 +546,7 @@ def test_dense_and_event_dp_agree(oracle, ctx_factory, monkeypatch):
 @pytest.mark.parametrize("k,w,seg_len", [(9, 2, (8, 16)), (15, 8, (3, 25))])
 def test_anchors_from_packed_selected_records_equal_the_generic_expansion(oracle, ctx_factory, monkeypatch, k, w, seg_len):
     """phi_solve expands the model's anchors from the filter's selected class records packed per class (a block's anchors
-    staged in LDS when they are at most 3 072, written directly otherwise: dense minimisers, k = 9 / w = 2, take the second
+    staged in LDS when they are at most 1 536, written directly otherwise: dense minimisers, k = 9 / w = 2, take the second
     branch); PHI_EXPAND_GENERIC=1 walks every record of every entry's class as before.  Same anchors in the same order, and
     the oracle's kept anchors."""
     rng = np.random.default_rng(6100 + k)
