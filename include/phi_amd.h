@@ -128,6 +128,8 @@ int phi_reads_text_end(phi_ctx *ctx, const char **pending, int64_t *n_pending, i
  *   phi_text_park_create / _destroy   on a device
  *   phi_text_park_pin                 page-locks a host buffer the pieces come from (unpinned by _destroy)
  *   phi_text_park_add                 copies n bytes to the device; returns when they are there (the host buffer is free again)
+ *   phi_text_park_add_async / _wait   the same in two halves: the copy is issued / the host buffer may be written again (the next
+ *                                     chunk is read into another buffer meanwhile)
  *   phi_text_park_bytes / _fetch      a piece's size; its bytes back on the host
  *   phi_text_park_release             the piece's device memory is let go (after phi_add_reads_text_parked took it)
  */
@@ -135,6 +137,8 @@ typedef struct phi_text_park phi_text_park;
 int phi_text_park_create(int32_t device, phi_text_park **out);
 int phi_text_park_pin(phi_text_park *park, void *host, size_t bytes);
 int phi_text_park_add(phi_text_park *park, const char *text, int64_t n, int32_t *index);
+int phi_text_park_add_async(phi_text_park *park, const char *text, int64_t n, int32_t *index);
+int phi_text_park_wait(phi_text_park *park, int32_t index);
 int64_t phi_text_park_bytes(phi_text_park *park, int32_t index);
 int phi_text_park_fetch(phi_text_park *park, int32_t index, char *out, int64_t cap);
 int phi_text_park_release(phi_text_park *park, int32_t index);

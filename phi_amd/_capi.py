@@ -24,7 +24,7 @@ SYMBOLS = [
     "phi_host_register", "phi_host_unregister", "phi_set_solve_budget", "phi_device_synchronize", "phi_walk_text_upload", "phi_walk_text_resolve", "phi_walk_entries",
     "phi_index_stats", "phi_solve_stats", "phi_comm_unique_id", "phi_comm_init", "phi_comm_info", "phi_comm_allreduce_hits", "phi_comm_exchange", "phi_comm_destroy",
     "phi_reads_text_begin", "phi_add_reads_text", "phi_reads_text_end", "phi_reads_text_detach_carry", "phi_reads_text_last_batch",
-    "phi_text_park_create", "phi_text_park_pin", "phi_text_park_add", "phi_text_park_bytes", "phi_text_park_fetch", "phi_text_park_release", "phi_text_park_destroy",
+    "phi_text_park_create", "phi_text_park_pin", "phi_text_park_add", "phi_text_park_add_async", "phi_text_park_wait", "phi_text_park_bytes", "phi_text_park_fetch", "phi_text_park_release", "phi_text_park_destroy",
     "phi_add_reads_text_parked",
     "phi_peers_create", "phi_peers_join", "phi_peers_allreduce_hits", "phi_peers_exchange", "phi_peers_destroy",
     "phi_ipc_unique_id", "phi_ipc_init", "phi_ipc_info", "phi_ipc_allreduce_hits", "phi_ipc_flush", "phi_ipc_exchange", "phi_ipc_check", "phi_ipc_destroy",
@@ -86,6 +86,8 @@ def load():
     L.phi_text_park_create.argtypes = [i32, C.POINTER(vp)]
     L.phi_text_park_pin.argtypes = [vp, vp, C.c_size_t]
     L.phi_text_park_add.argtypes = [vp, vp, i64, C.POINTER(i32)]
+    L.phi_text_park_add_async.argtypes = [vp, vp, i64, C.POINTER(i32)]
+    L.phi_text_park_wait.argtypes = [vp, i32]
     L.phi_text_park_bytes.argtypes = [vp, i32]
     L.phi_text_park_bytes.restype = i64
     L.phi_text_park_fetch.argtypes = [vp, i32, vp, i64]

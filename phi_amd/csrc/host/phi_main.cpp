@@ -275,7 +275,8 @@ static int run(const Options &o)
         Stage st("reads file -> text chunks [thread]");
         phi_text_stream *ts = nullptr;
         int r = phi_text_stream_open(rf.c_str(), &ts, rerr, sizeof rerr);
-        int slot = -1;
+        int slot = -1, fly_slot = -1;
+        int32_t fly_idx = -1;
         for (;;) {
             if (slot < 0) {
                 std::unique_lock<std::mutex> lk(Q.mu);
@@ -293,9 +294,10 @@ static int run(const Options &o)
             // stage finds the text where the records are found anyway.  (One GPU; large files; until the index is built.)
             if (n > 0 && park_on && !graph_ready.load() && !park_go.load()) {
                 // the GFA is still being read (all host threads, all of the memory bandwidth): chunks stay in their host buffers
-                // as long as there is another one to read into; with the last one in hand, wait for the GFA or for a taker
+                // as long as two more are free (parking needs two: one is read into while the other's copy is on its way); with
+                // fewer, wait with this chunk in hand for the GFA or for a taker
                 std::unique_lock<std::mutex> lk(Q.mu);
-                Q.cv.wait(lk, [&] { return park_go.load() || graph_ready.load() || !Q.q_free.empty() || Q.stop; });
+                Q.cv.wait(lk, [&] { return park_go.load() || graph_ready.load() || Q.q_free.size() >= 2 || Q.stop; });
             }
             if (n > 0 && park_on && park_go.load() && !graph_ready.load() && parked_bytes + n <= park_limit) {
                 bool ok = true;
@@ -305,7 +307,7 @@ static int run(const Options &o)
                     if (ok) park_pinned = true;
                 }
                 int32_t idx = -1;
-                if (ok && phi_text_park_add(park, Q.buf[(size_t)slot].text, n, &idx) == PHI_OK) {
+                if (ok && phi_text_park_add_async(park, Q.buf[(size_t)slot].text, n, &idx) == PHI_OK) {
                     parked_bytes += n;
                     {
                         std::lock_guard<std::mutex> lk(Q.mu);
@@ -313,10 +315,16 @@ static int run(const Options &o)
                         Q.q_full.push_back((int)Q.buf.size() - 1);
                     }
                     Q.cv.notify_all();
-                    continue;                                 // (the same host buffer takes the next chunk)
+                    // this buffer is the copy engine's until its copy has landed: the next chunk is read into another one
+                    // meanwhile, and the buffer of the copy before -- done by now -- goes back to the free ones
+                    if (fly_slot >= 0) { (void)phi_text_park_wait(park, fly_idx); Q.give_free(fly_slot); }
+                    fly_slot = slot; fly_idx = idx;
+                    slot = -1;
+                    continue;
                 }
                 park_on = false;                              // no room or no device yet: the usual way from here on
             }
+            if (fly_slot >= 0) { (void)phi_text_park_wait(park, fly_idx); Q.give_free(fly_slot); fly_slot = -1; }
             Q.buf[(size_t)slot].n = n;                        // 0 ends the stream, a negative value ends it as failed
             {
                 std::lock_guard<std::mutex> lk(Q.mu);
@@ -326,6 +334,7 @@ static int run(const Options &o)
             slot = -1;
             if (n <= 0) break;
         }
+        if (fly_slot >= 0) { (void)phi_text_park_wait(park, fly_idx); Q.give_free(fly_slot); }
         if (ts) phi_text_stream_close(ts);
         return r;
       });

@@ -1627,7 +1627,7 @@ struct phi_text_park {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    struct Piece { DevBuf d; int64_t n = 0; char first = 0; };
+    struct Piece { DevBuf d; int64_t n = 0; char first = 0; hipEvent_t ev = nullptr; };      // ev: the copy of the bytes has landed
     std::deque<Piece> pieces;                                  // (a deque: references stay valid while pieces are added)
     std::vector<DevBuf> spare;                                 // buffers of released pieces
     std::vector<void *> pinned;
@@ -1653,7 +1653,9 @@ int phi_text_park_pin(phi_text_park *p, void *host, size_t bytes)
     return PHI_OK;
 }
 
-int phi_text_park_add(phi_text_park *p, const char *text, int64_t n, int32_t *index)
+// the copy is ISSUED when this returns; phi_text_park_wait says when the host buffer may be written again (whoever takes the
+// piece -- phi_add_reads_text_parked, phi_text_park_fetch -- waits for it by itself)
+int phi_text_park_add_async(phi_text_park *p, const char *text, int64_t n, int32_t *index)
 {
     if (!p || !text || n <= 0 || !index) return PHI_ERR_INVALID;
     if (hipSetDevice(p->device) != hipSuccess) return PHI_ERR_DEVICE;
@@ -1670,8 +1672,11 @@ int phi_text_park_add(phi_text_park *p, const char *text, int64_t n, int32_t *in
         pc.d.cap = want;
     }
     pc.n = n; pc.first = text[0];
-    if (hipMemcpyAsync(pc.d.p, text, (size_t)n, hipMemcpyHostToDevice, p->stream) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) {
-        (void)hipGetLastError(); (void)hipFree(pc.d.p); return PHI_ERR_DEVICE;
+    if (hipEventCreateWithFlags(&pc.ev, hipEventDisableTiming) != hipSuccess ||
+        hipMemcpyAsync(pc.d.p, text, (size_t)n, hipMemcpyHostToDevice, p->stream) != hipSuccess || hipEventRecord(pc.ev, p->stream) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipStreamSynchronize(p->stream);
+        if (pc.ev) (void)hipEventDestroy(pc.ev);
+        (void)hipFree(pc.d.p); return PHI_ERR_DEVICE;
     }
     std::lock_guard<std::mutex> lk(p->mu);
     p->pieces.push_back(pc);
@@ -1686,6 +1691,20 @@ static phi_text_park::Piece *park_piece(phi_text_park *p, int32_t index)
     return index >= 0 && (size_t)index < p->pieces.size() && p->pieces[(size_t)index].d.p ? &p->pieces[(size_t)index] : nullptr;
 }
 
+int phi_text_park_wait(phi_text_park *p, int32_t index)
+{
+    phi_text_park::Piece *pc = park_piece(p, index);
+    if (!pc) return PHI_ERR_INVALID;
+    if (pc->ev && hipEventSynchronize(pc->ev) != hipSuccess) { (void)hipGetLastError(); return PHI_ERR_DEVICE; }
+    return PHI_OK;
+}
+
+int phi_text_park_add(phi_text_park *p, const char *text, int64_t n, int32_t *index)
+{
+    const int rc = phi_text_park_add_async(p, text, n, index);
+    return rc ? rc : phi_text_park_wait(p, *index);
+}
+
 int64_t phi_text_park_bytes(phi_text_park *p, int32_t index) { phi_text_park::Piece *pc = park_piece(p, index); return pc ? pc->n : -1; }
 
 int phi_text_park_fetch(phi_text_park *p, int32_t index, char *out, int64_t cap)
@@ -1693,6 +1712,7 @@ int phi_text_park_fetch(phi_text_park *p, int32_t index, char *out, int64_t cap)
     phi_text_park::Piece *pc = park_piece(p, index);
     if (!pc || !out || cap < pc->n) return PHI_ERR_INVALID;
     if (hipSetDevice(p->device) != hipSuccess) return PHI_ERR_DEVICE;
+    if (pc->ev) (void)hipEventSynchronize(pc->ev);
     if (hipMemcpyAsync(out, pc->d.p, (size_t)pc->n, hipMemcpyDeviceToHost, p->stream) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) { (void)hipGetLastError(); return PHI_ERR_DEVICE; }
     return PHI_OK;
 }
@@ -1704,6 +1724,7 @@ int phi_text_park_release(phi_text_park *p, int32_t index)
     // The buffer stays with the park (the next piece takes it; phi_text_park_destroy frees them all): a hipFree per piece would
     // wait for the device each time -- between the chunks of a stream whose sketches are meant to overlap -- and 165 of them at
     // the end of config 5's reads are time inside whatever runs next.
+    if (pc->ev) { (void)hipEventSynchronize(pc->ev); (void)hipEventDestroy(pc->ev); pc->ev = nullptr; }
     std::lock_guard<std::mutex> lk(p->mu);
     p->spare.push_back(pc->d);
     pc->d = DevBuf{};
@@ -1714,7 +1735,8 @@ void phi_text_park_destroy(phi_text_park *p)
 {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (auto &pc : p->pieces) if (pc.d.p) (void)hipFree(pc.d.p);
+    (void)hipStreamSynchronize(p->stream);
+    for (auto &pc : p->pieces) { if (pc.ev) (void)hipEventDestroy(pc.ev); if (pc.d.p) (void)hipFree(pc.d.p); }
     for (auto &d : p->spare) if (d.p) (void)hipFree(d.p);
     for (void *h : p->pinned) (void)hipHostUnregister(h);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -1731,6 +1753,7 @@ int phi_add_reads_text_parked(phi_ctx *c, phi_text_park *p, int32_t index, int32
     if (!T.active) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads_text_parked before phi_reads_text_begin");
     if (T.irregular) return phi_fail(c, PHI_ERR_STATE, "phi_add_reads_text_parked after an irregular chunk: finish the stream on the host reader");
     HIPCHK(hipSetDevice(c->device));
+    if (pc->ev) HIPCHK(hipEventSynchronize(pc->ev));          // (the piece's bytes have landed)
     for (int64_t at = 0; at < pc->n; ) {
         const uint32_t m = (uint32_t)std::min<int64_t>(pc->n - at, T.chunk_cap);
         PHICHK(text_piece(c, nullptr, m, irregular, pc->d.as<char>() + at, pc->first));      // (the first byte matters to the stream's first piece only)
