@@ -67,7 +67,9 @@ def main():
     ctx = phi_amd.Context(0)
     ctx.set_params(k=5, w=3, threshold=1.0, recombination=10)
     T._set_graph(ctx, g)
-    n = n_irr = n_dev = 0
+    n = n_irr = n_dev = n_parked = 0
+    from phi_amd.context import TextPark
+    park = TextPark(0)
     with tempfile.TemporaryDirectory() as td:
         while time.time() < t_end:
             txt = random_text(rng)
@@ -82,8 +84,16 @@ def main():
             ctx.reset_reads()
             ctx.reads_text_begin(max(64, call))
             got, irregular, rest_at = [], False, len(txt)
+            parked_mode = rng.random() < 0.5              # (half the texts: pieces through device memory first, phi_text_park_*)
             for i in range(0, len(txt), call):
-                if ctx.add_reads_text(txt[i:i + call]):
+                if parked_mode and rng.random() < 0.7:
+                    idx = park.add(txt[i:i + call])
+                    irr = ctx.add_reads_text_parked(park, idx)
+                    park.release(idx)
+                    n_parked += 1
+                else:
+                    irr = ctx.add_reads_text(txt[i:i + call])
+                if irr:
                     irregular, rest_at = True, i + call
                     break
                 got += records(*ctx.reads_text_last_batch())
@@ -94,8 +104,9 @@ def main():
             got += records(*H.reads_of_text(pending, [txt[rest_at:]] if rest_at < len(txt) else [], stream_offset=taken))
             assert got == want, (call, os.environ["PHI_TEXT_CARRY"], irregular, txt[:1500])
             n += 1; n_irr += irregular; n_dev += n_taken > 0
+    park.close()
     ctx.close()
-    print("fuzz ok:", n, "texts,", n_irr, "went irregular,", n_dev, "with records taken by the device")
+    print("fuzz ok:", n, "texts,", n_irr, "went irregular,", n_dev, "with records taken by the device;", n_parked, "pieces through the text park")
 
 
 if __name__ == "__main__":
