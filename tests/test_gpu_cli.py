@@ -228,6 +228,41 @@ def test_cli_resolves_the_walks_on_the_device(tmp_path):
     assert (tmp_path / "host.fa").read_text().split("\n")[1:] == (tmp_path / "dev.fa").read_text().split("\n")[1:]
 
 
+def test_cli_at_a_chromosome_arm_takes_the_device_walks_and_the_park_by_default(tmp_path):
+    """200 walks over 20 Mbp from FILES (the native generator: 1.0 GB of GFA, 1.3 GB of FASTQ on the RAM disk): the command
+    line resolves the W-lines on the device (0.9 GB of walk text: the threshold of 1 GB is lowered to 256 MB for the test) and,
+    by its own threshold (>= 256 MB), parks the reads text in device memory while the index is built; log and FASTA equal the
+    run with both switched off, the generator's truth walks come back."""
+    import shutil
+    import tempfile
+    from phi_amd import synth
+    gk, s_seed, n_mosaic, r_seed, cov = synth.NATIVE_CONFIGS["C5n-mid"]
+    d = tempfile.mkdtemp(prefix="phi_test_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        g = synth.NativeGraph(**gk)
+        truth = g.sample(s_seed, n_mosaic)
+        gfa, rd = os.path.join(d, "g.gfa"), os.path.join(d, "r.fq")
+        assert g.write_gfa(gfa) > (900 << 20)
+        assert g.write_reads(rd, r_seed, 0, g.n_reads(cov), fastq=True) > (256 << 20)
+        names = [f"syn{h:03d}.{h % 2}" for h in truth["walks"]]
+        g.close()
+        dflt = _run_cli(["-t16", "-g", gfa, "-r", rd, "-o", os.path.join(d, "a.fa")], tmp_path, env={"PHI_TIMING": "1", "PHI_WALK_TEXT_MIN": str(256 << 20)})
+        off = _run_cli(["-t16", "-g", gfa, "-r", rd, "-o", os.path.join(d, "b.fa")], tmp_path, env={"PHI_TIMING": "1", "PHI_WALKS": "host", "PHI_TEXT_PARK": "0"})
+        assert dflt.returncode == 0 and off.returncode == 0, dflt.stderr[-3000:] + off.stderr[-3000:]
+        assert "resolved on the device" in dflt.stderr and "waited in device memory" in dflt.stderr
+        assert "resolved on the device" not in off.stderr and "waited in device memory" not in off.stderr
+
+        def lines(log):
+            return [re.sub(r"^\[M::[^\]]*\] ", "", l) for l in log.splitlines()
+                    if not (l.startswith("[phi timing]") or l.startswith("[phi]") or "Real time" in l or "CMD:" in l or "written to" in l)]
+        assert lines(dflt.stderr) == lines(off.stderr)
+        assert open(os.path.join(d, "a.fa")).read() == open(os.path.join(d, "b.fa")).read()
+        rec = [l for l in dflt.stderr.splitlines() if l.startswith("Recombined haplotypes")][0]
+        assert re.findall(r"\((syn\d+\.\d),", rec) == names, (rec[:300], names)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def test_cli_errors(tmp_path):
     r = _run_cli([], tmp_path)
     assert r.returncode == 1 and r.stderr.startswith("Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta>")
