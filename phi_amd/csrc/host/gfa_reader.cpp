@@ -576,8 +576,10 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
         if (hazard.load()) one_thread();
     }
     tm.lap("  arcs together");
-    // (the records -- 19 M of them, 0.76 GB, at chromosome scale -- are freed with the rest of the reader's tables, on the thread that
-    //  lets the state go: freeing them here was 50 ms of this thread's time)
+    // (the records -- 19 M of them, 0.76 GB, at chromosome scale -- are freed on a thread of their own while this one waits for the side
+    //  threads below: 50 ms here; left to the thread that lets the state go they cost phi_set_graph, which runs by then, as much)
+    std::thread free_recs([&so]() { for (SliceOut &s : so) std::vector<Rec>().swap(s.recs); });
+    struct RecsJoin { std::thread &t; ~RecsJoin() { if (t.joinable()) t.join(); } } recs_join{free_recs};
     const int32_t n_seg = table.size();
     const int64_t n_walks = (int64_t)walks.size();
     stp->n_seg = n_seg;
@@ -734,6 +736,7 @@ static int gfa_read_impl(const char *path, phi_graph **out, bool defer, phi_walk
         return code;
     }
     tm.lap("wait for arrays + topological order (side thread)");
+    if (free_recs.joinable()) free_recs.join();                // (before the state changes hands)
     if (defer) {
         if (text_thread.joinable()) text_thread.join();
         tm.lap("wait for the walk text's consumer");
