@@ -164,7 +164,7 @@ struct ChunkQueue {
 };
 
 // the rest of the stream for the host reader: blocks straight from the queue (phi_reads_stream_open_blocks)
-struct QueueBlocks { ChunkQueue *q; int held = -1; phi_text_park *park = nullptr; std::vector<char> fetched; };
+struct QueueBlocks { ChunkQueue *q; int held = -1; phi_text_park *const *park = nullptr; std::vector<char> fetched; };      // park: where the park's handle will stand once the reader thread has made it
 static int64_t next_block_from_queue(void *user, const char **block)
 {
     QueueBlocks *qb = (QueueBlocks *)user;
@@ -175,8 +175,8 @@ static int64_t next_block_from_queue(void *user, const char **block)
     if (c.parked >= 0) {
         // a piece that went to device memory before the graph was there: its bytes come back for the host reader
         qb->fetched.resize((size_t)c.n);
-        if (phi_text_park_fetch(qb->park, c.parked, qb->fetched.data(), c.n) != PHI_OK) return -1;
-        (void)phi_text_park_release(qb->park, c.parked);
+        if (!qb->park || phi_text_park_fetch(*qb->park, c.parked, qb->fetched.data(), c.n) != PHI_OK) return -1;
+        (void)phi_text_park_release(*qb->park, c.parked);
         *block = qb->fetched.data();
         return c.n;
     }
@@ -262,7 +262,8 @@ static int run(const Options &o)
     // reads text parked in device memory until the index is built (the reader thread's side of it is in start_reads below)
     phi_text_park *park = nullptr;
     std::atomic<bool> graph_ready{false}, park_go{false};      // the GFA is parsed (parking may begin) / the index is built (it ends)
-    bool park_on = false, park_pinned = false;                // (the reader thread's; main reads them after the stream has ended)
+    bool park_on = false;                                     // (the reader thread's)
+    std::atomic<bool> park_pinned{false};                     // the reader thread pinned the chunk buffers (main then does not)
     int64_t parked_bytes = 0;
     const int64_t park_limit = getenv("PHI_TEXT_PARK_MAX") ? atoll(getenv("PHI_TEXT_PARK_MAX")) : ((int64_t)96 << 30);
     if (devices.size() == 1 && !(getenv("PHI_TEXT_PARK") && atoi(getenv("PHI_TEXT_PARK")) == 0)) {
@@ -513,7 +514,7 @@ static int run(const Options &o)
     // the host reader over `prefix` + the rest of the queue -> phi_add_reads on this GPU (under turn_mu)
     auto finish_on_host = [&](phi_ctx *cx, const char *prefix, int64_t n_prefix, bool rest_of_queue, int64_t stream_offset) -> int {
         Stage st("host reader (kseq state machine)");
-        QueueBlocks qb{&Q, -1, park, {}};
+        QueueBlocks qb{&Q, -1, &park, {}};
         phi_reads_stream *rs = nullptr;
         if (phi_reads_stream_open_blocks(prefix, n_prefix, rest_of_queue ? next_block_from_queue : nullptr, &qb, stream_offset, &rs, rerr, sizeof rerr) != PHI_HOST_OK) return PHI_ERR_INVALID;
         const int64_t cap_b = std::max<int64_t>((int64_t)1 << 20, std::min<int64_t>(chunk_bytes, (int64_t)64 << 20)), cap_r = cap_b / 32 + 1024;
@@ -559,9 +560,10 @@ static int run(const Options &o)
                         // a file of more than one chunk: pin the buffers, so that the device copy of every further
                         // chunk is a direct DMA (pinning takes milliseconds: not worth it for a single chunk)
                         std::call_once(pin_once, [&]() {
-                            if (park_pinned) return;           // (the reader thread pinned them when it began to park chunks)
+                            if (park_pinned.load()) return;    // (the reader thread pinned them when it began to park chunks)
                             registered = true;
-                            for (auto &b : Q.buf) if (phi_host_register(cx, b.text, (size_t)chunk_bytes) != PHI_OK) pinned = false;
+                            std::lock_guard<std::mutex> lk(Q.mu);      // (the reader thread may be adding an entry for a parked chunk)
+                            for (auto &b : Q.buf) if (b.text && phi_host_register(cx, b.text, (size_t)chunk_bytes) != PHI_OK) pinned = false;
                         });
                     stream_fed += cb.n;
                     int32_t irr_carry = 0, irr = 0;
