@@ -84,7 +84,13 @@ void phi_pool_flush(int dev)
 static void dev_free(DevBuf &b)
 {
     if (!b.p) { b.cap = 0; return; }
-    const int dev = b.cap >= POOL_MIN && pool_on() ? cur_device() : -1;
+    int dev = -1;
+    if (b.cap >= POOL_MIN && pool_on()) {
+        // (the device the buffer lives on -- not the calling thread's current one: a thread that has not chosen a device is on device 0)
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, b.p) == hipSuccess && at.device >= 0 && at.device < 64 && at.device == cur_device()) dev = at.device;
+        else (void)hipGetLastError();
+    }
     if (dev >= 0) {
         (void)hipDeviceSynchronize();                      // (what hipFree does before it lets memory go: nobody still works on it)
         std::lock_guard<std::mutex> lk(g_pool[dev].mu);
